@@ -1,0 +1,22 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+
+
+def pytest_collection_modifyitems(config, items):
+    have_ref = os.path.isdir(os.environ.get("SKG_REFERENCE_ROOT", "/root/reference"))
+    skip_ref = pytest.mark.skip(reason="reference tree not present (GPU box)")
+    for item in items:
+        if "reference" in item.keywords and not have_ref:
+            item.add_marker(skip_ref)
