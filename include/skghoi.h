@@ -1,0 +1,183 @@
+/* skghoi.h -- C ABI of the MI355X-native SKGHOI interaction-head hot path (libskghoi_hip.so).
+ *
+ * The reference (lijingzhu1/SKGHOI) has no native boundary: its interaction head is eager PyTorch.  This header is the
+ * boundary a maintainer binds instead (ctypes stub: INTEGRATION.md); every entry point names the reference code it
+ * replaces (paths relative to the reference root, HEAD = heads/adamixer_transH_spatial_r50_head.py).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  Every pointer is a DEVICE pointer unless its name ends in
+ *     _host.  All floating point is fp32, indices are int32 unless stated (int64 where the reference's result tensors
+ *     are int64).
+ *   - Nothing allocates, nothing synchronises: work is enqueued on `stream` (a hipStream_t passed as void*), workspaces
+ *     are provided by the caller.
+ *   - Return value: 0 = enqueued; < 0 = rejected argument (SKG_E_*); > 0 = hipError_t from the launch.
+ *   - Matrices are row-major; "ld" = elements between consecutive rows.  Weights keep the nn.Linear layout [out, in].
+ */
+#ifndef SKGHOI_H
+#define SKGHOI_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKG_ABI_VERSION 1
+#define SKG_E_ARG   (-1)   /* null pointer / negative size / unsupported shape            */
+#define SKG_E_ALIGN (-2)   /* pointer or leading dimension not 16-byte aligned            */
+#define SKG_E_LIMIT (-3)   /* exceeds a compiled-in limit (boxes per image, verbs, ...)   */
+
+#define SKG_MAX_DET_PER_IMAGE 1024   /* candidates per image the preprocess kernel accepts */
+#define SKG_MAX_NODES         160    /* max_human + max_object                             */
+#define SKG_SPATIAL_LD        48     /* 46 spatial features padded to a multiple of 8      */
+#define SKG_TRANSH_DIM        50     /* HEAD:686                                           */
+#define SKG_TRANSH_ENT        80     /* HEAD:690                                           */
+
+int         skg_abi_version(void);
+const char* skg_build_info(void);     /* "gfx950 <compiler> <date>" */
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Per-image metadata of the ACTIVE (non-skipped, HEAD:829) images of a batch, built on the host from (n_h, n) and
+ * uploaded once.  One record per active image.                                                                     */
+typedef struct {
+    int32_t image;      /* index of the image in the batch                                            */
+    int32_t n_h, n;     /* humans, nodes (humans first; HEAD:826, HEAD:823)                           */
+    int32_t box_off;    /* first row of this image in the packed detections [sumN_all, ...]           */
+    int32_t enc_off;    /* first row of this image's node encodings in box_head's output (HEAD:843;   */
+                        /* the reference does not advance this over skipped images)        */
+    int32_t node_off;   /* first graph-node row (active images only)                                  */
+    int32_t hum_off;    /* first human row (active images only)                                       */
+    int32_t grid_off;   /* first grid row  (n_h*n rows per image, self pairs included; HEAD:847-860)  */
+    int32_t pair_off;   /* first kept pair (x != y)                                                   */
+    int32_t out_off;    /* first scored (pair, verb) cell in the packed result arrays                 */
+    float   img_h, img_w;
+} skg_image_meta;
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * InteractionHead.preprocess (HEAD:92-151): score >= thresh -> class-wise NMS (torchvision batched_nms, coordinate
+ * trick, IoU > nms_thresh suppresses) -> descending score (ties: ascending input index) -> first max_human humans and
+ * max_object others -> humans first.  One workgroup per image.
+ *   det_off[B+1]  : row range of each image in boxes/scores/labels (train: GT boxes already prepended, HEAD:107-116)
+ *   nverbs[num_obj_classes] : number of target classes per object class (len(object_class_to_target_class[c]))
+ *   prior_pow     : exponent applied to detection scores by compute_prior_scores (HEAD:742), used only for out_count
+ *   out_index[B, max_human+max_object] : selected rows (index local to the image), humans first
+ *   out_count[B,4] : {n_h, n, L, 0}; L = number of non-zero prior cells = size of the image's scored result (HEAD:315)
+ */
+int skg_preprocess_f32(const float* boxes, const float* scores, const int64_t* labels, const int32_t* det_off, int B,
+                       int human_idx, float score_thresh, float nms_thresh, int max_human, int max_object,
+                       const int32_t* nverbs, int num_obj_classes, float prior_pow,
+                       int32_t* out_index, int32_t* out_count, void* stream);
+
+/* Gathers the selected detections into packed arrays [sumN, ...] (HEAD:144-149).  sel_off[B+1] = prefix of n. */
+int skg_pack_detections_f32(const float* boxes, const float* scores, const int64_t* labels, const int32_t* det_off,
+                            const int32_t* index, int index_ld, const int32_t* sel_off, int B,
+                            float* out_boxes, float* out_scores, int64_t* out_labels, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Pair enumeration (HEAD:847-860) fused with compute_spatial_ratio_encodings (ops.py:85-157) and the NaN scrub
+ * (HEAD:866-868).  One wavefront per active image, boxes staged in LDS.
+ *   grid_h[sumG], grid_o[sumG] : global human row / global graph-node row of each grid row
+ *   grid_pair[sumG]            : kept-pair index of the grid row, or -1 for the self pair
+ *   grid_img[sumG]             : batch index of the row's image (meta.image)
+ *   pair_h[sumP], pair_o[sumP] : global human row / graph-node row of each kept pair
+ *   pair_grid[sumP]            : grid row of each kept pair (row-major nonzero(x != y) order)
+ *   x_keep[sumP], y_keep[sumP] : int64 local indices, the reference's x_keep / y_keep (HEAD:852)
+ *   spatial[sumG, 48]          : 23 features + log(f + 1e-10); columns 46, 47 are zero                             */
+int skg_pairs_spatial_f32(const float* boxes, const skg_image_meta* meta, int n_active,
+                          int32_t* grid_h, int32_t* grid_o, int32_t* grid_pair, int32_t* grid_img,
+                          int32_t* pair_grid, int64_t* x_keep, int64_t* y_keep, int32_t* pair_h, int32_t* pair_o,
+                          float* spatial, int scrub_nan, void* stream);
+
+/* AdaptiveAvgPool2d(1) of features['3'] (HEAD:811): in [B, C, HW] -> out [B, C]. */
+int skg_global_avgpool_f32(const float* in, int B, int C, int HW, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Dense layer  C = epilogue(A x W^T + bias)  on the fp32 MFMA (v_mfma_f32_32x32x2_f32), 128x128x16 LDS tiles.
+ * Replaces every nn.Linear / MultiBranchFusion GEMM of the head (HEAD:469-474, 509-527, 635-641, 662-669, 694-701,
+ * 410-411).  The 16 branches of an MBF are one GEMM against the row-stacked fc_1/fc_2 weights [1024, in] and the
+ * column-stacked fc_3 weights [1024, 16*64] (sum over branches == K-concatenation).                                */
+typedef enum {
+    SKG_EPI_BIAS      = 0,   /* C = A W^T + bias                                                                  */
+    SKG_EPI_BIAS_RELU = 1,   /* C = relu(A W^T + bias)                                                            */
+    SKG_EPI_MUL_RELU  = 2,   /* v = A W^T + bias ; C[orow] = relu(v * (P[pi[row]] + Q[qi[row]] + mbias))          */
+    SKG_EPI_RELU_DOT  = 3,   /* v = relu(A W^T + bias) ; dot_partial[nb][row] = sum_cols v * dot_w  (HEAD:896-897) */
+    SKG_EPI_BIAS_RES_RELU = 4 /* C = res + relu(A W^T + bias)   (message + residual, HEAD:909-914, 916-925)        */
+} skg_epilogue;
+
+typedef struct {
+    const float* A;   int64_t lda;     /* [M, K]; with a_rows: row r is A + a_rows[r]*lda (a_rows[r] < 0 -> zeros)  */
+    const float* W;   int64_t ldw;     /* [N, K]                                                                    */
+    const float* bias;                 /* [N] or NULL                                                               */
+    float*       C;   int64_t ldc;     /* [M(out rows), N]; may be NULL for SKG_EPI_RELU_DOT                        */
+    int32_t M, N, K;                   /* K % 4 == 0, lda/ldw % 4 == 0                                              */
+    int32_t epilogue;                  /* skg_epilogue                                                              */
+    const int32_t* a_rows;             /* optional row gather of A                                                  */
+    const int32_t* out_rows;           /* optional row scatter of C (out_rows[r] < 0 -> row not stored)             */
+    /* SKG_EPI_MUL_RELU */
+    const float* P; const int32_t* p_idx; int64_t ldp;    /* P may be NULL only if Q is given                        */
+    const float* Q; const int32_t* q_idx; int64_t ldq;    /* optional second table                                   */
+    const float* mbias;                                   /* optional [N], added to the multiplier                   */
+    float*       C_raw; int64_t ldc_raw;                  /* optional: also store v (pre-multiplication), by row     */
+    /* SKG_EPI_RELU_DOT */
+    const float* dot_w;                /* [N]                                                                       */
+    float*       dot_partial;          /* [2*ceil(N/128), M]: one partial per 64-column slab                        */
+    /* SKG_EPI_BIAS_RES_RELU */
+    const float* res; int64_t ldres;   /* [M, N]                                                                    */
+} skg_gemm_desc;
+
+int skg_gemm_f32(const skg_gemm_desc* desc_host, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * fc_head / fc_tail input rows (HEAD:884-885): out[r] = [ enc[enc_row[r], 0:1024] | ent[ent_img[r], ent_row[r], 0:50]
+ * | zeros ] with out_ld = 1088.  ent = per-image TransH entity tables [n_img, 80, 50] (HEAD:574-580; SURVEY Q3:
+ * heads use row human_idx, tails use the node's position).                                                         */
+int skg_concat_entity_f32(const float* enc, int64_t ld_enc, const int32_t* enc_row, const float* ent,
+                          const int32_t* ent_img, const int32_t* ent_row, int rows, float* out, int64_t out_ld,
+                          void* stream);
+
+/* out[r] = relu((P[pi[r]] + Q[qi[r]] + mbias) * F[fi[r]])  over `cols` columns (read-out MBF fc_1*fc_2, HEAD:970).  */
+int skg_rows_mul_relu_f32(const float* P, const int32_t* p_idx, int64_t ldp, const float* Q, const int32_t* q_idx,
+                          int64_t ldq, const float* mbias, const float* F, const int32_t* f_idx, int64_t ldf,
+                          int rows, int cols, float* out, int64_t ldo, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Bipartite message aggregation (HEAD:897-925).  adjacency logit of grid row r = adj_bias + sum_k dot_partial[k][r].
+ *   U[h]  = sum_j softmax_j(adj[i, :])[j] * T_os[(i, j)]     (human h = (image, i); obj_to_sub pre-fc_3 rows)
+ *   V[o]  = sum_i softmax_i(adj[:, j])[i] * T_so[(i, j)]     (node  o = (image, j); sub_to_obj pre-fc_3 rows)
+ * fc_3 is linear and the softmax weights sum to 1, so  sum_j a_ij fc_3(T_ij) == fc_3(sum_j a_ij T_ij)  (DESIGN.md).
+ * One workgroup per destination row; the image's adjacency row/column lives in LDS.  adj_out[sumG] receives the
+ * logits (HEAD:897).                                                                                               */
+int skg_graph_aggregate_f32(const float* dot_partial, int n_partial, int64_t partial_ld, float adj_bias,
+                            const skg_image_meta* meta, int n_active, const int32_t* hum_img, const int32_t* node_img,
+                            int sum_h, int sum_n, const float* T_os, const float* T_so, int64_t ldt, int cols,
+                            float* U, float* V, int64_t ldu, float* adj_out, void* stream);
+
+/* out = LayerNorm(x) * gamma + beta over `cols` (= 1024) columns, eps 1e-5 (HEAD:658-659, 912-914, 923-925). */
+int skg_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, int rows, int cols,
+                      float eps, float* out, int64_t ldo, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * compute_prior_scores (HEAD:721-767) + InteractionHead.postprocess (HEAD:237-337), table driven.
+ *   logits [sumP, ld_logits]: columns 0..K-1 = box_pair_predictor, column K = box_pair_suppressor
+ *   verb_off[num_obj+1], verb_list[]: CSR of object_class_to_target_class, verbs ascending per class
+ * Per active image, cells are emitted in nonzero(prior[0]) order (pair-major, verb ascending) at meta.out_off.
+ *   out_index/out_pred int64 [L], out_scores f32 [L], out_prior f32 [2, L_total] (row 0 = human, row 1 = object),
+ *   out_weights f32 [sumP], out_object int64 [sumP], out_boxes_h/out_boxes_o f32 [sumP,4]                          */
+int skg_postprocess_f32(const float* logits, int64_t ld_logits, int K, const float* boxes, const float* scores,
+                        const int64_t* labels, const skg_image_meta* meta, int n_active, const int64_t* x_keep,
+                        const int64_t* y_keep, const int32_t* verb_off, const int32_t* verb_list, int num_obj_classes,
+                        float prior_pow, int64_t L_total, int64_t* out_index, int64_t* out_pred, float* out_scores,
+                        float* out_prior, float* out_weights, int64_t* out_object, float* out_boxes_h,
+                        float* out_boxes_o, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * TransH hyperplane scores (heads/TransH/TransH.py:56-106) for every (kept pair, relation):
+ *   w = norm(nrm[k]); h = ent[human_idx] - (ent[human_idx].w) w; t = ent[y] - (ent[y].w) w
+ *   score[p, k] = || norm(h) + norm(rel[k]) - norm(t) ||_2        (F.normalize eps 1e-12)
+ *   ent [n_active, 80, 50], rel / nrm [n_active, K, 50] (a fresh table set per image, HEAD:574-580);
+ *   scores [sumP, K].  Training only (inference discards them).  One wavefront per (image, relation).  */
+int skg_transh_scores_f32(const float* ent, const float* rel, const float* nrm, int K, int human_idx,
+                          const skg_image_meta* meta, int n_active, float* scores, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKGHOI_H */

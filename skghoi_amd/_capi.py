@@ -1,0 +1,90 @@
+"""ctypes binding of libskghoi_hip.so (include/skghoi.h).  The product has no CPU fallback: `lib()` raises if the
+shared library has not been built (python __graft_entry__.py build / make -C skghoi_amd/csrc)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libskghoi_hip.so")
+
+EPI_BIAS, EPI_BIAS_RELU, EPI_MUL_RELU, EPI_RELU_DOT, EPI_BIAS_RES_RELU = range(5)
+MAX_DET_PER_IMAGE = 1024
+MAX_NODES = 160
+SPATIAL_LD = 48
+TRANSH_DIM = 50
+TRANSH_ENT = 80
+ABI_VERSION = 1
+
+_vp = C.c_void_p
+_i32 = C.c_int32
+_i64 = C.c_int64
+_f32 = C.c_float
+
+
+class GemmDesc(C.Structure):
+    """Mirror of skg_gemm_desc."""
+    _fields_ = [("A", _vp), ("lda", _i64), ("W", _vp), ("ldw", _i64), ("bias", _vp), ("C", _vp), ("ldc", _i64),
+                ("M", _i32), ("N", _i32), ("K", _i32), ("epilogue", _i32), ("a_rows", _vp), ("out_rows", _vp),
+                ("P", _vp), ("p_idx", _vp), ("ldp", _i64), ("Q", _vp), ("q_idx", _vp), ("ldq", _i64),
+                ("mbias", _vp), ("C_raw", _vp), ("ldc_raw", _i64), ("dot_w", _vp), ("dot_partial", _vp),
+                ("res", _vp), ("ldres", _i64)]
+
+
+# numpy dtype of skg_image_meta (12 x 4 bytes)
+META_FIELDS = [("image", "i4"), ("n_h", "i4"), ("n", "i4"), ("box_off", "i4"), ("enc_off", "i4"), ("node_off", "i4"),
+               ("hum_off", "i4"), ("grid_off", "i4"), ("pair_off", "i4"), ("out_off", "i4"), ("img_h", "f4"),
+               ("img_w", "f4")]
+
+PROTOTYPES = {
+    "skg_abi_version": (C.c_int, []),
+    "skg_build_info": (C.c_char_p, []),
+    "skg_preprocess_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, C.c_int, C.c_int, _vp, C.c_int,
+                                     _f32, _vp, _vp, _vp]),
+    "skg_pack_detections_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "skg_pairs_spatial_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int,
+                                        _vp]),
+    "skg_global_avgpool_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "skg_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "skg_concat_entity_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, C.c_int, _vp, _i64, _vp]),
+    "skg_rows_mul_relu_f32": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp,
+                                        _i64, _vp]),
+    "skg_graph_aggregate_f32": (C.c_int, [_vp, C.c_int, _i64, _f32, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp,
+                                          _vp, _i64, C.c_int, _vp, _vp, _i64, _vp, _vp]),
+    "skg_layernorm_f32": (C.c_int, [_vp, _i64, _vp, _vp, C.c_int, C.c_int, _f32, _vp, _i64, _vp]),
+    "skg_postprocess_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int,
+                                      _f32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "skg_transh_scores_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
+}
+
+_LIB = None
+
+
+class SkgError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libskghoi_hip.so once; raises (never falls back) when it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.isfile(LIB_PATH):
+        raise SkgError("libskghoi_hip.so not built at %s -- run `python __graft_entry__.py` or "
+                       "`make -C skghoi_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    l = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(l, name)
+        fn.restype = res
+        fn.argtypes = args
+    if l.skg_abi_version() != ABI_VERSION:
+        raise SkgError("libskghoi_hip.so ABI %d != binding ABI %d" % (l.skg_abi_version(), ABI_VERSION))
+    _LIB = l
+    return l
+
+
+_ERR = {-1: "SKG_E_ARG (bad argument)", -2: "SKG_E_ALIGN (pointer / leading dimension not 16-byte aligned)",
+        -3: "SKG_E_LIMIT (compiled-in limit exceeded)"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SkgError("%s failed: %s" % (what, _ERR.get(rc, "hipError_t %d" % rc)))

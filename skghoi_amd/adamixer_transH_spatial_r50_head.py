@@ -1,0 +1,369 @@
+"""Drop-in replacement for the reference module `heads/adamixer_transH_spatial_r50_head.py`.
+
+Exports the same names with the same constructor keywords, forward signatures, return structures and state_dict keys
+(SURVEY.md section 8b / Appendix A), so `models/adamixer_transH_spatial_r50_models.py:25`
+
+    from adamixer_transH_spatial_r50_head import InteractionHead, GraphHead
+
+keeps working when this directory (or <repo>/heads, which re-exports it) is put on sys.path instead of the
+reference's.  The arithmetic runs in hand-written gfx950 kernels (libskghoi_hip.so, include/skghoi.h) driven by
+skghoi_amd/engine.py; there is no eager/CPU fallback -- CPU tensors or a missing library raise.
+
+Reference file:line for every class is given in its docstring (HEAD = the reference head file).
+"""
+from collections import OrderedDict
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import nn, Tensor
+from torch.nn import Module
+
+from skghoi_amd import _capi
+from skghoi_amd.engine import HeadEngine
+
+__all__ = ["InteractionHead", "GraphHead", "MultiBranchFusion", "MessageMBF", "transH_head"]
+
+
+class MultiBranchFusion(Module):
+    """Parameter container of the reference's MultiBranchFusion (HEAD:431-474): `cardinality` branches of
+    fc_1 (appearance -> sub), fc_2 (spatial -> sub), fc_3 (sub -> representation).  The engine runs the 16 branches
+    as three stacked GEMMs; calling the module directly does the same for a single (appearance, spatial) pair."""
+
+    def __init__(self, appearance_size: int, spatial_size: int, representation_size: int, cardinality: int) -> None:
+        super().__init__()
+        self.cardinality = cardinality
+        sub_repr_size = int(representation_size / cardinality)
+        assert sub_repr_size * cardinality == representation_size, \
+            "The given representation size should be divisible by cardinality"
+        self.fc_1 = nn.ModuleList([nn.Linear(appearance_size, sub_repr_size) for _ in range(cardinality)])
+        self.fc_2 = nn.ModuleList([nn.Linear(spatial_size, sub_repr_size) for _ in range(cardinality)])
+        self.fc_3 = nn.ModuleList([nn.Linear(sub_repr_size, representation_size) for _ in range(cardinality)])
+
+    def _stacked(self, dev):
+        w1 = torch.cat([l.weight for l in self.fc_1]).detach().to(dev).float().contiguous()
+        b1 = torch.cat([l.bias for l in self.fc_1]).detach().to(dev).float()
+        w2 = torch.cat([l.weight for l in self.fc_2]).detach().to(dev).float().contiguous()
+        b2 = torch.cat([l.bias for l in self.fc_2]).detach().to(dev).float()
+        w3 = torch.cat([l.weight for l in self.fc_3], dim=1).detach().to(dev).float().contiguous()
+        b3 = torch.stack([l.bias for l in self.fc_3]).sum(0).detach().to(dev).float()
+        return w1, b1, w2, b2, w3, b3
+
+    def forward(self, appearance: Tensor, spatial: Tensor) -> Tensor:
+        """HEAD:469-474 for 2-D inputs; appearance may have one row (broadcast) or as many rows as spatial."""
+        from skghoi_amd.engine import gemm
+        if appearance.device.type != "cuda":
+            raise _capi.SkgError("MultiBranchFusion runs on a HIP device only")
+        dev = spatial.device
+        w1, b1, w2, b2, w3, b3 = self._stacked(dev)
+        M = spatial.shape[0]
+        R = w3.shape[0]
+        ka = (appearance.shape[1] + 3) // 4 * 4
+        a = torch.zeros(appearance.shape[0], ka, device=dev); a[:, :appearance.shape[1]] = appearance
+        w1p = torch.zeros(w1.shape[0], ka, device=dev); w1p[:, :w1.shape[1]] = w1
+        f1 = torch.empty(appearance.shape[0], R, device=dev)
+        gemm(a, w1p, b1, f1, appearance.shape[0], R, ka, _capi.EPI_BIAS)
+        idx = (torch.zeros(M, dtype=torch.int32, device=dev) if appearance.shape[0] == 1
+               else torch.arange(M, dtype=torch.int32, device=dev))
+        s = spatial.float().contiguous()
+        t = torch.empty(M, R, device=dev)
+        gemm(s, w2, b2, t, M, R, s.shape[1], _capi.EPI_MUL_RELU, P=f1, p_idx=idx, ldp=R)
+        out = torch.empty(M, R, device=dev)
+        gemm(t, w3, b3, out, M, R, R, _capi.EPI_BIAS_RELU)
+        return out
+
+
+class MessageMBF(MultiBranchFusion):
+    """Parameter container of the reference's MessageMBF (HEAD:476-530).  The message computation itself is fused
+    into the engine's graph pass (fc_2 GEMM with fused product, aggregation before fc_3)."""
+
+    def __init__(self, appearance_size: int, spatial_size: int, representation_size: int, node_type: str,
+                 cardinality: int) -> None:
+        super().__init__(appearance_size, spatial_size, representation_size, cardinality)
+        if node_type not in ("human", "object"):
+            raise ValueError("Unknown node type \"{}\"".format(node_type))
+        self.node_type = node_type
+
+    def forward(self, *args) -> Tensor:
+        raise _capi.SkgError("MessageMBF is evaluated inside GraphHead's fused graph pass, not standalone")
+
+
+class transH_head(Module):
+    """Holds the TransH hyper-parameters (HEAD:533-556).  The reference builds a fresh random TransH per image in
+    its forward (HEAD:574-580); here the tables are drawn on the host with the identical RNG sequence
+    (skghoi_amd/transh.py) and the scores are computed by skg_transh_scores_f32."""
+
+    def __init__(self, transh_dim: int = 200, transh_p_norm: int = 2, transh_norm_flag: bool = True,
+                 human_idx: int = 49, num_object: int = 80, num_cls: int = 117) -> None:
+        super().__init__()
+        self.transh_dim = transh_dim
+        self.transh_p_norm = transh_p_norm
+        self.transh_norm_flag = transh_norm_flag
+        self.device = "cuda"
+        self.human_idx = human_idx
+        self.num_object = num_object
+        self.num_cls = num_cls
+
+
+class GraphHead(Module):
+    """Graphical model head (HEAD:586-993): same constructor, sub-module names and state_dict keys."""
+
+    def __init__(self, out_channels: int, roi_pool_size: int, node_encoding_size: int, representation_size: int,
+                 num_cls: int, human_idx: int, object_class_to_target_class: List[list], fg_iou_thresh: float = 0.5,
+                 num_iter: int = 2) -> None:
+        super().__init__()
+        self.out_channels = out_channels
+        self.roi_pool_size = roi_pool_size
+        self.node_encoding_size = node_encoding_size
+        self.representation_size = representation_size
+        self.num_cls = num_cls
+        self.human_idx = human_idx
+        self.object_class_to_target_class = object_class_to_target_class
+        self.fg_iou_thresh = fg_iou_thresh
+        self.num_iter = num_iter
+        if node_encoding_size != 1024 or representation_size != 1024:
+            # the reference hard-wires 1024 + 50 into fc_head/fc_tail and adds [.,representation] messages to
+            # [.,node_encoding] nodes (HEAD:694-701, 912-914): no other width can run there either
+            raise ValueError("node_encoding_size and representation_size must be 1024 (HEAD:694-701)")
+        self.box_head = nn.Sequential(
+            nn.Flatten(start_dim=1),
+            nn.Linear(out_channels * roi_pool_size ** 2, node_encoding_size), nn.ReLU(),
+            nn.Linear(node_encoding_size, node_encoding_size), nn.ReLU())
+        self.adjacency = nn.Linear(representation_size, 1)
+        self.sub_to_obj = MessageMBF(node_encoding_size, 1024, representation_size, node_type="human", cardinality=16)
+        self.obj_to_sub = MessageMBF(node_encoding_size, 1024, representation_size, node_type="object", cardinality=16)
+        self.norm_h = nn.LayerNorm(node_encoding_size)
+        self.norm_o = nn.LayerNorm(node_encoding_size)
+        self.spatial_head = nn.Sequential(nn.Linear(46, 128), nn.ReLU(), nn.Linear(128, 256), nn.ReLU(),
+                                          nn.Linear(256, 1024), nn.ReLU())
+        self.attention_head = MultiBranchFusion(node_encoding_size * 2, 1024, representation_size, cardinality=16)
+        self.avg_pool = nn.AdaptiveAvgPool2d(output_size=1)
+        self.attention_head_g = MultiBranchFusion(256, 1024, representation_size, cardinality=16)
+        self.transh_head = transH_head(transh_dim=50, transh_p_norm=2, transh_norm_flag=True,
+                                       human_idx=self.human_idx, num_object=80, num_cls=self.num_cls)
+        self.fc_head = nn.Sequential(nn.Linear(1074, 1024), nn.ReLU())
+        self.fc_tail = nn.Sequential(nn.Linear(1074, 1024), nn.ReLU())
+        self._engine = None
+
+    # The engine of a stand-alone GraphHead (InteractionHead installs its own, with its predictor/suppressor).
+    def _own_engine(self):
+        if self._engine is None:
+            self._engine = HeadEngine(self, nn.Identity(), nn.Identity(), self.human_idx, self.num_cls, 0.5, 0.2,
+                                      _capi.MAX_NODES // 2, _capi.MAX_NODES // 2)
+        return self._engine
+
+    def compute_prior_scores(self, x: Tensor, y: Tensor, scores: Tensor, object_class: Tensor) -> Tensor:
+        """HEAD:721-767, dense [2, M, K] form (the fused path emits the non-zero cells directly)."""
+        dev = scores.device
+        vt = self._own_engine().verbs(dev)
+        p = 1.0 if self.training else 2.8
+        s_h = scores[x].pow(p); s_o = scores[y].pow(p)
+        cls = object_class[y].long()
+        off = vt.off.long(); flat = vt.flat.long()
+        cnt = off[cls + 1] - off[cls]
+        pair = torch.repeat_interleave(torch.arange(len(x), device=dev), cnt)
+        start = torch.repeat_interleave(off[cls], cnt)
+        within = torch.arange(len(pair), device=dev) - torch.repeat_interleave(torch.cumsum(cnt, 0) - cnt, cnt)
+        verb = flat[start + within]
+        prior = torch.zeros(2, len(x), self.num_cls, device=dev)
+        prior[0, pair, verb] = s_h[pair]
+        prior[1, pair, verb] = s_o[pair]
+        return prior
+
+    def forward(self, features: OrderedDict, image_shapes: List[Tuple[int, int]], box_features: Tensor,
+                box_coords: List[Tensor], box_labels: List[Tensor], box_scores: List[Tensor],
+                targets: Optional[List[dict]] = None):
+        """HEAD:769-993 with the reference's list-of-tensors interface (8 lists in eval, 12 in training)."""
+        if self.training:
+            assert targets is not None, "Targets should be passed during training"
+            raise NotImplementedError("training forward of GraphHead is not part of this build yet")
+        eng = self._own_engine()
+        pre = _pre_from_lists(box_coords, box_labels, box_scores, self.human_idx)
+        g = eng.graph(features["3"], image_shapes, box_features, pre, training=False)
+        return _graph_lists(self, eng, pre, g)
+
+
+def _pre_from_lists(box_coords, box_labels, box_scores, human_idx):
+    """Builds the engine's packed detection record from already-preprocessed per-image lists (HEAD:822-841)."""
+    from skghoi_amd.engine import Preprocessed
+    dev = box_coords[0].device
+    if dev.type != "cuda":
+        raise _capi.SkgError("the interaction head runs on a HIP device only (got %s)" % dev)
+    pre = Preprocessed()
+    pre.device = dev
+    pre.B = len(box_coords)
+    pre.sizes = [int(len(b)) for b in box_coords]
+    pre.boxes = torch.cat([b.reshape(-1, 4) for b in box_coords]).float().contiguous()
+    pre.labels = torch.cat(box_labels).long().contiguous()
+    pre.scores = torch.cat(box_scores).float().contiguous()
+    is_h = (pre.labels == human_idx)
+    img = torch.repeat_interleave(torch.arange(pre.B, device=dev), torch.tensor(pre.sizes, device=dev))
+    n_h = torch.zeros(pre.B, dtype=torch.int64, device=dev).index_add_(0, img, is_h.long()).cpu().numpy()
+    pre.n = np.asarray(pre.sizes, dtype=np.int64)
+    pre.n_h = n_h.astype(np.int64)
+    pre.L = None
+    off = 0
+    lab_h = pre.labels.cpu()
+    for b in range(pre.B):
+        if pre.n_h[b] > 0 and pre.n[b] > 1 and not bool(torch.all(lab_h[off:off + int(pre.n_h[b])] == human_idx)):
+            raise ValueError("Human detections are not permuted to the top")
+        off += int(pre.n[b])
+    return pre
+
+
+def _graph_lists(gh, eng, pre, g):
+    lay = g["layout"]
+    dev = pre.device
+    K = gh.num_cls
+    feats, bh, bo, oc, labels, prior = [], [], [], [], [], []
+    a = 0
+    pf = g.get("pair_features")
+    for b in range(lay.n_visit):
+        if lay.skipped[b]:
+            feats.append(torch.zeros(0, 2 * gh.representation_size, device=dev))
+            bh.append(torch.zeros(0, 4, device=dev)); bo.append(torch.zeros(0, 4, device=dev))
+            oc.append(torch.zeros(0, device=dev, dtype=torch.int64))
+            prior.append(torch.zeros(2, 0, K, device=dev)); labels.append(torch.zeros(0, K, device=dev))
+            continue
+        m = lay.meta[a]
+        p0, P = int(m["pair_off"]), int(m["n_h"]) * (int(m["n"]) - 1)
+        xk = g["x_keep"][p0:p0 + P]; yk = g["y_keep"][p0:p0 + P]
+        b0 = int(m["box_off"]); n = int(m["n"])
+        coords = pre.boxes[b0:b0 + n]; lab = pre.labels[b0:b0 + n]; sc = pre.scores[b0:b0 + n]
+        feats.append(pf[p0:p0 + P])
+        bh.append(coords[xk]); bo.append(coords[yk]); oc.append(lab[yk])
+        prior.append(gh.compute_prior_scores(xk, yk, sc, lab))
+        a += 1
+    return feats, bh, bo, oc, labels, prior, [], []
+
+
+class InteractionHead(Module):
+    """Interaction head that constructs and classifies box pairs (HEAD:29-429): same constructor keywords, forward
+    signature and result dictionaries.
+
+    Extra keyword (not in the reference, defaults reproduce it):
+      reference_quirks: bool = True -- reproduce (a) the node-offset bug on skipped images and (b) the
+        eval-mode label-list zip with skipped images in a batch > 1 (HEAD:298-310: truncated results / IndexError).
+        With False every image gets its own (possibly empty) result.
+    """
+
+    def __init__(self, box_roi_pool: Module, box_pair_head: Module, box_pair_suppressor: Module,
+                 box_pair_predictor: Module, human_idx: int, num_classes: int, box_nms_thresh: float = 0.5,
+                 box_score_thresh: float = 0.2, max_human: int = 15, max_object: int = 15,
+                 distributed: bool = False, reference_quirks: bool = True) -> None:
+        super().__init__()
+        self.box_roi_pool = box_roi_pool
+        self.box_pair_head = box_pair_head
+        self.box_pair_suppressor = box_pair_suppressor
+        self.box_pair_predictor = box_pair_predictor
+        self.num_classes = num_classes
+        self.human_idx = human_idx
+        self.box_nms_thresh = box_nms_thresh
+        self.box_score_thresh = box_score_thresh
+        self.max_human = max_human
+        self.max_object = max_object
+        self.distributed = distributed
+        self.reference_quirks = reference_quirks
+        self._engine = None
+
+    def engine(self) -> HeadEngine:
+        e = self._engine
+        if e is None or e.max_human != self.max_human or e.max_object != self.max_object \
+                or e.box_nms_thresh != float(self.box_nms_thresh) or e.box_score_thresh != float(self.box_score_thresh):
+            e = HeadEngine(self.box_pair_head, self.box_pair_predictor, self.box_pair_suppressor, self.human_idx,
+                           self.num_classes, self.box_nms_thresh, self.box_score_thresh, self.max_human,
+                           self.max_object, faithful_skip_offset=self.reference_quirks)
+            self._engine = e
+        e.faithful_skip_offset = self.reference_quirks
+        return e
+
+    # ------------------------------------------------------------------------------------------ HEAD:92-151
+    def preprocess(self, detections: List[dict], targets: List[dict], append_gt: Optional[bool] = None) -> List[dict]:
+        if append_gt is None:
+            append_gt = self.training
+        pre = self.engine().preprocess(detections, targets, append_gt, self.training)
+        return [dict(boxes=b.view(-1, 4), labels=l.view(-1), scores=s.view(-1)) for b, l, s in
+                zip(pre.boxes.split(pre.sizes), pre.labels.split(pre.sizes), pre.scores.split(pre.sizes))]
+
+    # ------------------------------------------------------------------------------------------ HEAD:237-337
+    def postprocess(self, logits_p: Tensor, logits_s: Tensor, prior: List[Tensor], boxes_h: List[Tensor],
+                    boxes_o: List[Tensor], object_class: List[Tensor], labels: List[Tensor]) -> List[dict]:
+        """List-based form kept for API compatibility (the fused forward scores on the device in one kernel)."""
+        num_boxes = [len(b) for b in boxes_h]
+        weights = torch.sigmoid(logits_s).squeeze(1).split(num_boxes)
+        scores = torch.sigmoid(logits_p).split(num_boxes)
+        if len(labels) == 0:
+            labels = [None for _ in range(len(num_boxes))]
+        results = []
+        for w, s, p, b_h, b_o, o, l in zip(weights, scores, prior, boxes_h, boxes_o, object_class, labels):
+            x, y = torch.nonzero(p[0]).unbind(1)
+            r = dict(boxes_h=b_h, boxes_o=b_o, index=x, prediction=y,
+                     scores=s[x, y] * p[:, x, y].prod(dim=0) * w[x].detach(), object=o, prior=p[:, x, y], weights=w)
+            if l is not None:
+                r["labels"] = l[x, y]
+                r["unary_labels"] = l.sum(dim=1).clamp(max=1)
+            results.append(r)
+        return results
+
+    # ------------------------------------------------------------------------------------------ HEAD:341-429
+    def forward(self, features: OrderedDict, detections: List[dict], image_shapes: List[Tuple[int, int]],
+                targets: Optional[List[dict]] = None) -> List[dict]:
+        if self.training:
+            assert targets is not None, "Targets should be passed during training"
+            raise NotImplementedError("the training step (HEAD:153-235, 933-963) is not part of this build yet")
+        eng = self.engine()
+        pre = eng.preprocess(detections, targets, False, False)
+        box_coords = list(pre.boxes.split(pre.sizes))
+        box_features = self.box_roi_pool(features, box_coords, image_shapes)
+        g = eng.graph(features["3"], image_shapes, box_features, pre, training=False)
+        lay = g["layout"]
+        if lay.n_visit == 0:
+            raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")     # HEAD:408 on an empty batch
+        dev = pre.device
+        if lay.n_active:
+            logits = eng.classify(g["pair_features"])
+            r = eng.score(logits, pre, g, False)
+            eng.last = dict(g, logits=logits)
+        else:
+            r = None
+            eng.last = dict(g)
+        return self._results(lay, r, dev)
+
+    def _empty_result(self, dev, with_labels):
+        d = dict(boxes_h=torch.zeros(0, 4, device=dev), boxes_o=torch.zeros(0, 4, device=dev),
+                 index=torch.zeros(0, dtype=torch.int64, device=dev),
+                 prediction=torch.zeros(0, dtype=torch.int64, device=dev), scores=torch.zeros(0, device=dev),
+                 object=torch.zeros(0, dtype=torch.int64, device=dev), prior=torch.zeros(2, 0, device=dev),
+                 weights=torch.zeros(0, device=dev))
+        if with_labels:
+            d["labels"] = torch.zeros(0, device=dev)
+            d["unary_labels"] = torch.zeros(0, device=dev)
+        return d
+
+    def _results(self, lay, r, dev):
+        n_skipped = int(lay.skipped[:lay.n_visit].sum())
+        quirk = self.reference_quirks and n_skipped > 0
+        # HEAD:298-310: in eval only skipped images append to the label list; postprocess then zips over it
+        n_out = min(lay.n_visit, n_skipped) if quirk else lay.n_visit
+        if quirk:
+            for b in range(n_out):
+                if not lay.skipped[b]:
+                    raise IndexError("index is out of bounds for dimension with size 0")      # HEAD:327
+        results = []
+        if r is not None:
+            ppi = [int(v) for v in lay.pairs_per_image]; cpi = [int(v) for v in lay.cells_per_image]
+            Mp, Lt = lay.sum_p, lay.sum_l
+            bh = r["boxes_h"][:Mp].split(ppi); bo = r["boxes_o"][:Mp].split(ppi)
+            ob = r["object"][:Mp].split(ppi); wt = r["weights"][:Mp].split(ppi)
+            ix = r["index"][:Lt].split(cpi); pr = r["prediction"][:Lt].split(cpi); sc = r["scores"][:Lt].split(cpi)
+            pri = r["prior"][:, :Lt].split(cpi, dim=1)
+        a = 0
+        for b in range(n_out):
+            if lay.skipped[b]:
+                results.append(self._empty_result(dev, with_labels=quirk))
+                continue
+            results.append(dict(boxes_h=bh[a], boxes_o=bo[a], index=ix[a], prediction=pr[a], scores=sc[a],
+                                object=ob[a], prior=pri[a], weights=wt[a]))
+            a += 1
+        return results

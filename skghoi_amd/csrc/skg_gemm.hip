@@ -1,0 +1,223 @@
+// skg_gemm.hip -- fp32 dense layer on the CDNA4 matrix cores:  C = epilogue(A x W^T + bias).
+//
+// Replaces every nn.Linear of the interaction head and, with row-/column-stacked branch weights, the 16-branch
+// MultiBranchFusion / MessageMBF GEMMs (reference heads/adamixer_transH_spatial_r50_head.py:469-474, 509-527).
+//
+// Design (gfx950):
+//   * v_mfma_f32_32x32x2_f32: exact fp32 (bit-for-bit an fmaf chain), the only MFMA that meets the 1e-4 logit parity
+//     bar without splitting operands; peak 157 TFLOP/s = the roofline this kernel is priced against.
+//   * 128x128 block tile, 4 wavefronts (2x2), each owning 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs).
+//   * K is consumed 16 at a time through a double-buffered LDS tile, rows padded to 20 dwords: every lane fetches its
+//     four consecutive k with ONE ds_read_b128 (conflict-free at stride 20: 16 lanes x 4 banks tile all 64 banks) and
+//     feeds them to four MFMAs; A and B use the same k permutation, which is all a dot product needs.
+//   * Weights stay in the nn.Linear layout [N, K]: both operands are "row = output index, k contiguous", so both are
+//     staged by the same coalesced 16-byte global loads (register staged: issue for tile t+1 before the MFMAs of tile
+//     t, ds_write after them, one barrier per tile).
+//   * blockIdx -> tile with n fastest: with the round-robin block->XCD dispatch each XCD sees N-tiles bn == xcd (mod 8),
+//     i.e. a fixed 1/8 slice of W (<= 2 MiB for N = 4096, K = 1024) that stays in its private 4 MiB L2, while the A
+//     panel of an M-tile is fetched by the 8 XCDs at about the same time (served once by HBM/Infinity Cache).
+//   * Epilogues are fused (bias, ReLU, gathered multiplier tables for the MBF fc_1*fc_2 product, residual, the
+//     adjacency row-dot) so no intermediate makes an extra trip through HBM.
+#include "skg_common.h"
+
+#define BM 128
+#define BN 128
+#define BK 16
+#define LDS_LD 20                       // BK + 4 dwords of padding
+#define A_TILE (BM * LDS_LD)
+#define B_TILE (BN * LDS_LD)
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void skg_gemm_kernel(const skg_gemm_desc d) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nbn = (d.N + BN - 1) / BN;
+    const int bn = blockIdx.x % nbn;
+    const int bm = blockIdx.x / nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    // ---- global -> register staging map: thread owns rows (lr, lr+64) x 4 consecutive k
+    const int lr = tid >> 2;
+    const int lc = (tid & 3) * 4;
+    const float* pa[2];
+    const float* pw[2];
+    bool va[2], vw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = m0 + lr + 64 * i;
+        int src = -1;
+        if (r < d.M) src = d.a_rows ? d.a_rows[r] : r;
+        va[i] = src >= 0;
+        pa[i] = d.A + (int64_t)(va[i] ? src : 0) * d.lda;       // always a readable row; masked after the load
+        const int c = n0 + lr + 64 * i;
+        vw[i] = c < d.N;
+        pw[i] = d.W + (int64_t)(vw[i] ? c : 0) * d.ldw;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int nk = (d.K + BK - 1) / BK;
+    float4 ra[2], rw[2];
+
+    auto gload = [&](int kt) {
+        const int k = kt * BK + lc;
+        const bool kin = k < d.K;
+        const int kk = kin ? k : 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float4 x = *reinterpret_cast<const float4*>(pa[i] + kk);
+            float4 w = *reinterpret_cast<const float4*>(pw[i] + kk);
+            if (!(kin && va[i])) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(kin && vw[i])) w = make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[i] = x;
+            rw[i] = w;
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* a_s = smem + buf * A_TILE;
+        float* b_s = smem + 2 * A_TILE + buf * B_TILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<float4*>(a_s + (lr + 64 * i) * LDS_LD + lc) = ra[i];
+            *reinterpret_cast<float4*>(b_s + (lr + 64 * i) * LDS_LD + lc) = rw[i];
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const float* a_s = smem + cur * A_TILE + (wr * 64 + li) * LDS_LD + 4 * lh;
+        const float* b_s = smem + 2 * A_TILE + cur * B_TILE + (wc * 64 + li) * LDS_LD + 4 * lh;
+#pragma unroll
+        for (int ks = 0; ks < BK / 8; ++ks) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const float4*>(a_s + i * 32 * LDS_LD + ks * 8);
+                b[i] = *reinterpret_cast<const float4*>(b_s + i * 32 * LDS_LD + ks * 8);
+            }
+            const float av[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
+            const float bv[2][4] = {{b[0].x, b[0].y, b[0].z, b[0].w}, {b[1].x, b[1].y, b[1].z, b[1].w}};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][t], bv[ni][t], acc[mi][ni], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    int col[2];
+    float bia[2], mb[2], dw[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        col[ni] = n0 + wc * 64 + ni * 32 + li;
+        const bool in = col[ni] < d.N;
+        bia[ni] = (in && d.bias) ? d.bias[col[ni]] : 0.f;
+        mb[ni] = (EPI == SKG_EPI_MUL_RELU && in && d.mbias) ? d.mbias[col[ni]] : 0.f;
+        dw[ni] = (EPI == SKG_EPI_RELU_DOT && in) ? d.dot_w[col[ni]] : 0.f;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const bool rin = row < d.M;
+            if (EPI == SKG_EPI_RELU_DOT) {
+                float s = 0.f;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const float v = fmaxf(acc[mi][ni][r] + bia[ni], 0.f);
+                    if (rin && col[ni] < d.N) {
+                        s += v * dw[ni];
+                        if (d.C) d.C[(int64_t)row * d.ldc + col[ni]] = v;
+                    }
+                }
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+                if (li == 0 && rin) d.dot_partial[(int64_t)(bn * 2 + wc) * d.M + row] = s;
+                continue;
+            }
+            if (!rin) continue;
+            const int orow = d.out_rows ? d.out_rows[row] : row;
+            if (EPI == SKG_EPI_MUL_RELU) {
+                const int pi = d.p_idx ? d.p_idx[row] : row;
+                const int qi = d.Q ? (d.q_idx ? d.q_idx[row] : row) : 0;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if (col[ni] >= d.N) continue;
+                    const float v = acc[mi][ni][r] + bia[ni];
+                    if (d.C_raw) d.C_raw[(int64_t)row * d.ldc_raw + col[ni]] = v;
+                    if (orow < 0) continue;
+                    float m = mb[ni];
+                    if (d.P) m += d.P[(int64_t)pi * d.ldp + col[ni]];
+                    if (d.Q) m += d.Q[(int64_t)qi * d.ldq + col[ni]];
+                    d.C[(int64_t)orow * d.ldc + col[ni]] = fmaxf(v * m, 0.f);
+                }
+                continue;
+            }
+            if (orow < 0) continue;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                if (col[ni] >= d.N) continue;
+                float v = acc[mi][ni][r] + bia[ni];
+                if (EPI == SKG_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                if (EPI == SKG_EPI_BIAS_RES_RELU) v = d.res[(int64_t)row * d.ldres + col[ni]] + fmaxf(v, 0.f);
+                d.C[(int64_t)orow * d.ldc + col[ni]] = v;
+            }
+        }
+    }
+}
+
+extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
+    if (!dh) return SKG_E_ARG;
+    const skg_gemm_desc d = *dh;
+    if (d.M < 0 || d.N <= 0 || d.K <= 0 || !d.A || !d.W) return SKG_E_ARG;
+    if (d.M == 0) return 0;
+    if ((d.K & 3) || (d.lda & 3) || (d.ldw & 3)) return SKG_E_ALIGN;
+    if (!skg_aligned16(d.A) || !skg_aligned16(d.W)) return SKG_E_ALIGN;
+    if (d.lda < d.K && !d.a_rows && d.M > 1) return SKG_E_ARG;
+    switch (d.epilogue) {
+        case SKG_EPI_BIAS: case SKG_EPI_BIAS_RELU:
+            if (!d.C) return SKG_E_ARG; break;
+        case SKG_EPI_MUL_RELU:
+            if (!d.C || (!d.P && !d.Q)) return SKG_E_ARG; break;
+        case SKG_EPI_RELU_DOT:
+            if (!d.dot_w || !d.dot_partial) return SKG_E_ARG; break;
+        case SKG_EPI_BIAS_RES_RELU:
+            if (!d.C || !d.res) return SKG_E_ARG; break;
+        default: return SKG_E_ARG;
+    }
+    const int64_t nbm = (d.M + BM - 1) / BM, nbn = (d.N + BN - 1) / BN;
+    if (nbm * nbn > 0x7fffffffLL) return SKG_E_LIMIT;
+    dim3 grid((unsigned)(nbm * nbn)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (d.epilogue) {
+        case SKG_EPI_BIAS:          hipLaunchKernelGGL(skg_gemm_kernel<SKG_EPI_BIAS>, grid, block, 0, s, d); break;
+        case SKG_EPI_BIAS_RELU:     hipLaunchKernelGGL(skg_gemm_kernel<SKG_EPI_BIAS_RELU>, grid, block, 0, s, d); break;
+        case SKG_EPI_MUL_RELU:      hipLaunchKernelGGL(skg_gemm_kernel<SKG_EPI_MUL_RELU>, grid, block, 0, s, d); break;
+        case SKG_EPI_RELU_DOT:      hipLaunchKernelGGL(skg_gemm_kernel<SKG_EPI_RELU_DOT>, grid, block, 0, s, d); break;
+        case SKG_EPI_BIAS_RES_RELU: hipLaunchKernelGGL(skg_gemm_kernel<SKG_EPI_BIAS_RES_RELU>, grid, block, 0, s, d); break;
+    }
+    return skg_launch_status();
+}

@@ -1,0 +1,199 @@
+// skg_preprocess.hip -- InteractionHead.preprocess on the device, one workgroup per image.
+//
+// Reference: heads/adamixer_transH_spatial_r50_head.py:92-151 (score filter, torchvision batched_nms, argsort,
+// top-k humans/objects, humans first) and the published torchvision algorithm for batched_nms / nms
+// (coordinate trick + greedy suppression at IoU > thr; restated in oracle/tv_boxes.py).
+//
+// Integer/compare work with fp32 IoU: compiled with -ffp-contract=off so every product and sum rounds exactly like
+// the unfused CPU arithmetic -- the selected indices are bit-exact against the oracle.
+#include "skg_common.h"
+
+#define PRE_THREADS 256
+
+__device__ __forceinline__ uint32_t skg_orderable(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // monotone: a < b  <=>  ord(a) < ord(b)
+}
+
+__global__ __launch_bounds__(PRE_THREADS) void skg_preprocess_kernel(
+    const float* __restrict__ boxes, const float* __restrict__ scores, const int64_t* __restrict__ labels,
+    const int32_t* __restrict__ det_off, int human_idx, float score_thresh, float nms_thresh, int max_human,
+    int max_object, const int32_t* __restrict__ nverbs, int num_obj_classes, float prior_pow,
+    int32_t* __restrict__ out_index, int32_t* __restrict__ out_count) {
+    __shared__ unsigned long long skey[SKG_MAX_DET_PER_IMAGE];
+    __shared__ float4 sbox[SKG_MAX_DET_PER_IMAGE];      // boxes shifted by label * (max_coord + 1), sorted order
+    __shared__ float sarea[SKG_MAX_DET_PER_IMAGE];
+    __shared__ unsigned char ssup[SKG_MAX_DET_PER_IMAGE];
+    __shared__ unsigned char shum[SKG_MAX_DET_PER_IMAGE];
+    __shared__ float sred[PRE_THREADS / 64];
+    __shared__ int ssel[SKG_MAX_NODES];
+    __shared__ int sact;
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int base = det_off[b];
+    const int n0 = det_off[b + 1] - base;
+    const int ld_out = max_human + max_object;
+
+    int npow = 1;
+    while (npow < n0) npow <<= 1;
+
+    // ---- keys: descending score, ties by ascending input index; inactive (score < thresh or NaN) sort last
+    float lmax = -INFINITY;
+    int lact = 0;
+    for (int i = tid; i < npow; i += PRE_THREADS) {
+        unsigned long long key = ~0ull;
+        if (i < n0) {
+            const float s = scores[base + i];
+            if (s >= score_thresh) {
+                key = ((unsigned long long)(~skg_orderable(s)) << 32) | (unsigned)i;
+                const float4 bx = *reinterpret_cast<const float4*>(boxes + 4 * (int64_t)(base + i));
+                lmax = fmaxf(lmax, fmaxf(fmaxf(bx.x, bx.y), fmaxf(bx.z, bx.w)));
+                ++lact;
+            }
+        }
+        skey[i] = key;
+    }
+    // max coordinate over the active boxes (boxes[active].max(), torchvision batched_nms)
+    lmax = skg_wave_max(lmax);
+    if ((tid & 63) == 0) sred[tid >> 6] = lmax;
+    __syncthreads();
+    const float max_coord = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+    // number of active candidates
+    if (tid == 0) sact = 0;
+    __syncthreads();
+    if (lact) atomicAdd(&sact, lact);
+    __syncthreads();
+    const int nact = sact;
+
+    // ---- bitonic sort of the keys (ascending)
+    for (int k = 2; k <= npow; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npow; i += PRE_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = skey[i], c = skey[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { skey[i] = c; skey[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- shifted boxes in sorted order
+    const float shift_unit = max_coord + 1.0f;
+    for (int i = tid; i < nact; i += PRE_THREADS) {
+        const int idx = (int)(skey[i] & 0xffffffffu);
+        const float4 bx = *reinterpret_cast<const float4*>(boxes + 4 * (int64_t)(base + idx));
+        const int64_t lab = labels[base + idx];
+        const float off = (float)lab * shift_unit;
+        const float4 sb = make_float4(bx.x + off, bx.y + off, bx.z + off, bx.w + off);
+        sbox[i] = sb;
+        sarea[i] = (sb.z - sb.x) * (sb.w - sb.y);
+        ssup[i] = 0;
+        shum[i] = (lab == (int64_t)human_idx) ? 1 : 0;
+    }
+    __syncthreads();
+
+    // ---- greedy NMS over the sorted candidates; selection of the first max_human humans / max_object others
+    int nh = 0, no = 0;
+    for (int i = 0; i < nact; ++i) {
+        if (nh >= max_human && no >= max_object) break;          // uniform
+        const bool sup = ssup[i] != 0;                           // uniform (LDS broadcast)
+        if (!sup) {
+            const bool hum = shum[i] != 0;
+            if (hum) { if (nh < max_human) { if (tid == 0) ssel[nh] = i; ++nh; } }
+            else     { if (no < max_object) { if (tid == 0) ssel[max_human + no] = i; ++no; } }
+            const float4 bi = sbox[i];
+            const float ai = sarea[i];
+            for (int j = i + 1 + tid; j < nact; j += PRE_THREADS) {
+                if (ssup[j]) continue;
+                const float4 bj = sbox[j];
+                const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+                const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+                const float w = fmaxf(xx2 - xx1, 0.f), h = fmaxf(yy2 - yy1, 0.f);
+                const float inter = w * h;
+                const float ovr = inter / (ai + sarea[j] - inter);
+                if (ovr > nms_thresh) ssup[j] = 1;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // ---- outputs: indices (humans first), counts, and L = number of non-zero prior cells (HEAD:315, 721-767)
+    const int n = nh + no;
+    for (int t = tid; t < ld_out; t += PRE_THREADS) {
+        int v = -1;
+        if (t < nh) v = (int)(skey[ssel[t]] & 0xffffffffu);
+        else if (t < n) v = (int)(skey[ssel[max_human + (t - nh)]] & 0xffffffffu);
+        out_index[(int64_t)b * ld_out + t] = v;
+    }
+    if (tid == 0) {
+        int L = 0;
+        if (nh > 0 && n > 1) {
+            int vtot = 0;
+            for (int t = 0; t < n; ++t) {
+                const int s = (t < nh) ? ssel[t] : ssel[max_human + (t - nh)];
+                const int64_t lab = labels[base + (int)(skey[s] & 0xffffffffu)];
+                vtot += (lab >= 0 && lab < num_obj_classes) ? nverbs[lab] : 0;
+            }
+            const int64_t hl = human_idx;
+            const int vh = (hl >= 0 && hl < num_obj_classes) ? nverbs[hl] : 0;
+            for (int t = 0; t < nh; ++t) {
+                const float s = scores[base + (int)(skey[ssel[t]] & 0xffffffffu)];
+                if (powf(s, prior_pow) != 0.f) L += vtot - vh;
+            }
+        }
+        out_count[4 * b + 0] = nh;
+        out_count[4 * b + 1] = n;
+        out_count[4 * b + 2] = L;
+        out_count[4 * b + 3] = nact;
+    }
+}
+
+extern "C" int skg_preprocess_f32(const float* boxes, const float* scores, const int64_t* labels,
+                                  const int32_t* det_off, int B, int human_idx, float score_thresh, float nms_thresh,
+                                  int max_human, int max_object, const int32_t* nverbs, int num_obj_classes,
+                                  float prior_pow, int32_t* out_index, int32_t* out_count, void* stream) {
+    if (B < 0 || !det_off || !out_index || !out_count || !nverbs) return SKG_E_ARG;
+    if (B == 0) return 0;
+    if (!boxes || !scores || !labels) return SKG_E_ARG;
+    if (max_human < 0 || max_object < 0 || max_human + max_object > SKG_MAX_NODES) return SKG_E_LIMIT;
+    if (!skg_aligned16(boxes)) return SKG_E_ALIGN;
+    hipLaunchKernelGGL(skg_preprocess_kernel, dim3(B), dim3(PRE_THREADS), 0, (hipStream_t)stream, boxes, scores,
+                       labels, det_off, human_idx, score_thresh, nms_thresh, max_human, max_object, nverbs,
+                       num_obj_classes, prior_pow, out_index, out_count);
+    return skg_launch_status();
+}
+
+__global__ void skg_pack_detections_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                           const int64_t* __restrict__ labels, const int32_t* __restrict__ det_off,
+                                           const int32_t* __restrict__ index, int index_ld,
+                                           const int32_t* __restrict__ sel_off, float* __restrict__ out_boxes,
+                                           float* __restrict__ out_scores, int64_t* __restrict__ out_labels) {
+    const int b = blockIdx.x;
+    const int n = sel_off[b + 1] - sel_off[b];
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const int src = det_off[b] + index[(int64_t)b * index_ld + t];
+        const int dst = sel_off[b] + t;
+        *reinterpret_cast<float4*>(out_boxes + 4 * (int64_t)dst) =
+            *reinterpret_cast<const float4*>(boxes + 4 * (int64_t)src);
+        out_scores[dst] = scores[src];
+        out_labels[dst] = labels[src];
+    }
+}
+
+extern "C" int skg_pack_detections_f32(const float* boxes, const float* scores, const int64_t* labels,
+                                       const int32_t* det_off, const int32_t* index, int index_ld,
+                                       const int32_t* sel_off, int B, float* out_boxes, float* out_scores,
+                                       int64_t* out_labels, void* stream) {
+    if (B < 0 || !det_off || !index || !sel_off) return SKG_E_ARG;
+    if (B == 0) return 0;
+    if (!boxes || !scores || !labels || !out_boxes || !out_scores || !out_labels) return SKG_E_ARG;
+    if (!skg_aligned16(boxes) || !skg_aligned16(out_boxes)) return SKG_E_ALIGN;
+    hipLaunchKernelGGL(skg_pack_detections_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, boxes, scores, labels,
+                       det_off, index, index_ld, sel_off, out_boxes, out_scores, out_labels);
+    return skg_launch_status();
+}

@@ -1,0 +1,422 @@
+"""Host orchestration of the interaction-head hot path on MI355X.
+
+Everything numerical runs in libskghoi_hip.so (include/skghoi.h) on the caller's current HIP stream; PyTorch only owns
+device memory.  The per-image Python loop of the reference (heads/adamixer_transH_spatial_r50_head.py:822-982) becomes a
+fixed sequence of batched launches over concatenated row spaces (skghoi_amd/layout.py):
+
+  preprocess (NMS/top-k) -> [one D2H of per-image counts] -> pack -> roi-pool (injected module) -> box_head GEMMs
+  -> pairs + 46-d spatial -> spatial_head GEMMs -> fc_head/fc_tail on UNIQUE node rows
+  -> message passing ONCE (iterations never feed back):
+        attention_head: fc_1 split into human/object halves on unique rows; fc_2 GEMM with the fc_1*fc_2*ReLU product
+        fused in its epilogue; fc_3 GEMM with the adjacency dot fused in its epilogue
+        messages: fc_2 GEMMs with fused product, softmax-weighted aggregation BEFORE fc_3 (linear), fc_3 on node rows
+        with fused ReLU + residual, LayerNorm
+  -> read-out MBFs on kept pairs -> predictor|suppressor GEMM -> prior + scoring + compaction.
+
+There is no CPU fallback: the library must be built and tensors must live on a HIP device.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi, layout, transh
+
+EPS_LN = 1e-5
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class PackedWeights:
+    """Device copies of the head's parameters in the layouts the kernels want (stacked MBF branches, padded K)."""
+
+    def __init__(self, graph_head, predictor, suppressor, device):
+        gh = graph_head
+        f32 = dict(device=device, dtype=torch.float32)
+
+        def w(p):
+            return p.detach().to(**f32).contiguous()
+
+        def pad_k(wt, mult=4, to=None):
+            k = wt.shape[1]
+            kp = to if to is not None else (k + mult - 1) // mult * mult
+            if kp == k:
+                return wt.contiguous()
+            out = torch.zeros(wt.shape[0], kp, **f32)
+            out[:, :k] = wt
+            return out
+
+        def mbf(m):
+            w1 = torch.cat([w(l.weight) for l in m.fc_1]); b1 = torch.cat([w(l.bias) for l in m.fc_1])
+            w2 = torch.cat([w(l.weight) for l in m.fc_2]); b2 = torch.cat([w(l.bias) for l in m.fc_2])
+            w3 = torch.cat([w(l.weight) for l in m.fc_3], dim=1).contiguous()
+            b3 = torch.stack([w(l.bias) for l in m.fc_3]).sum(dim=0)
+            return dict(w1=w1.contiguous(), b1=b1, w2=w2.contiguous(), b2=b2, w3=w3, b3=b3)
+
+        self.versions = versions_of(graph_head, predictor, suppressor)
+        self.device = device
+        self.K = gh.num_cls
+        self.bh1_w = pad_k(w(gh.box_head[1].weight)); self.bh1_b = w(gh.box_head[1].bias)
+        self.bh1_k = gh.box_head[1].weight.shape[1]
+        self.bh3_w = w(gh.box_head[3].weight); self.bh3_b = w(gh.box_head[3].bias)
+        self.sp0_w = pad_k(w(gh.spatial_head[0].weight), to=_capi.SPATIAL_LD); self.sp0_b = w(gh.spatial_head[0].bias)
+        self.sp2_w = w(gh.spatial_head[2].weight); self.sp2_b = w(gh.spatial_head[2].bias)
+        self.sp4_w = w(gh.spatial_head[4].weight); self.sp4_b = w(gh.spatial_head[4].bias)
+        self.fh_w = pad_k(w(gh.fc_head[0].weight), to=1088); self.fh_b = w(gh.fc_head[0].bias)
+        self.ft_w = pad_k(w(gh.fc_tail[0].weight), to=1088); self.ft_b = w(gh.fc_tail[0].bias)
+        self.att = mbf(gh.attention_head)
+        self.att_g = mbf(gh.attention_head_g)
+        self.os = mbf(gh.obj_to_sub)
+        self.so = mbf(gh.sub_to_obj)
+        self.adj_w = w(gh.adjacency.weight).reshape(-1).contiguous()
+        self.adj_b = float(gh.adjacency.bias.detach().float().cpu().item())
+        self.nh_g = w(gh.norm_h.weight); self.nh_b = w(gh.norm_h.bias)
+        self.no_g = w(gh.norm_o.weight); self.no_b = w(gh.norm_o.bias)
+        self.fused_cls = isinstance(predictor, torch.nn.Linear) and isinstance(suppressor, torch.nn.Linear) \
+            and predictor.in_features == 2048 and suppressor.in_features == 2048 and suppressor.out_features == 1 \
+            and predictor.out_features == self.K
+        if self.fused_cls:
+            self.cls_w = torch.cat([w(predictor.weight), w(suppressor.weight)]).contiguous()
+            pb = predictor.bias if predictor.bias is not None else torch.zeros(self.K)
+            sb = suppressor.bias if suppressor.bias is not None else torch.zeros(1)
+            self.cls_b = torch.cat([w(pb), w(sb)]).contiguous()
+
+
+def versions_of(graph_head, predictor, suppressor):
+    ps = list(graph_head.parameters()) + list(predictor.parameters()) + list(suppressor.parameters())
+    return tuple((p.data_ptr(), p._version) for p in ps)
+
+
+class VerbTable:
+    """CSR form of object_class_to_target_class (HEAD:629, 747-760); verbs ascending and unique per class."""
+
+    def __init__(self, o2v, K, device):
+        rows = [sorted(set(int(v) for v in r)) for r in o2v]
+        for r in rows:
+            if r and (r[0] < 0 or r[-1] >= K):
+                raise IndexError("index %d is out of bounds for dimension 1 with size %d" % (r[-1], K))
+        off = np.zeros(len(rows) + 1, np.int32)
+        off[1:] = np.cumsum([len(r) for r in rows])
+        flat = np.asarray([v for r in rows for v in r] or [0], np.int32)
+        self.num_obj = len(rows)
+        self.nverbs = torch.from_numpy(np.diff(off).astype(np.int32)).to(device)
+        self.off = torch.from_numpy(off).to(device)
+        self.flat = torch.from_numpy(flat).to(device)
+
+
+def gemm(A, W, bias, C_out, M, N, K, epilogue, lda=None, ldw=None, ldc=None, a_rows=None, out_rows=None, P=None,
+         p_idx=None, ldp=0, Q=None, q_idx=None, ldq=0, mbias=None, C_raw=None, ldc_raw=0, dot_w=None,
+         dot_partial=None, res=None, ldres=0, A_off=0, W_off=0, C_off=0):
+    """One skg_gemm_f32 launch.  *_off are element offsets into A / W / C (column sub-views)."""
+    d = _capi.GemmDesc()
+    d.A = A.data_ptr() + 4 * A_off; d.lda = lda if lda is not None else A.stride(0)
+    d.W = W.data_ptr() + 4 * W_off; d.ldw = ldw if ldw is not None else W.stride(0)
+    d.bias = _ptr(bias)
+    d.C = (C_out.data_ptr() + 4 * C_off) if C_out is not None else 0
+    d.ldc = ldc if ldc is not None else (C_out.stride(0) if C_out is not None else 0)
+    d.M, d.N, d.K, d.epilogue = M, N, K, epilogue
+    d.a_rows = _ptr(a_rows); d.out_rows = _ptr(out_rows)
+    d.P = _ptr(P); d.p_idx = _ptr(p_idx); d.ldp = ldp
+    d.Q = _ptr(Q); d.q_idx = _ptr(q_idx); d.ldq = ldq
+    d.mbias = _ptr(mbias); d.C_raw = _ptr(C_raw); d.ldc_raw = ldc_raw
+    d.dot_w = _ptr(dot_w); d.dot_partial = _ptr(dot_partial)
+    d.res = _ptr(res); d.ldres = ldres
+    _capi.check(_capi.lib().skg_gemm_f32(C.byref(d), _stream()), "skg_gemm_f32[%dx%dx%d epi %d]" % (M, N, K, epilogue))
+
+
+class Preprocessed:
+    """Packed output of InteractionHead.preprocess for a batch."""
+    pass
+
+
+class HeadEngine:
+    def __init__(self, graph_head, predictor, suppressor, human_idx, num_classes, box_nms_thresh, box_score_thresh,
+                 max_human, max_object, faithful_skip_offset=True):
+        self.gh = graph_head
+        self.predictor = predictor
+        self.suppressor = suppressor
+        self.human_idx = int(human_idx)
+        self.K = int(num_classes)
+        self.box_nms_thresh = float(box_nms_thresh)
+        self.box_score_thresh = float(box_score_thresh)
+        self.max_human = int(max_human)
+        self.max_object = int(max_object)
+        self.faithful_skip_offset = faithful_skip_offset
+        self._pw = None
+        self._vt = None
+        self.last = None          # intermediates of the last graph pass (parity tests read them)
+
+    # ------------------------------------------------------------------------------------------ caches
+    def weights(self, device):
+        v = versions_of(self.gh, self.predictor, self.suppressor)
+        if self._pw is None or self._pw.device != device or self._pw.versions != v:
+            self._pw = PackedWeights(self.gh, self.predictor, self.suppressor, device)
+        return self._pw
+
+    def verbs(self, device):
+        if self._vt is None or self._vt.off.device != device:
+            self._vt = VerbTable(self.gh.object_class_to_target_class, self.gh.num_cls, device)
+        return self._vt
+
+    # ------------------------------------------------------------------------------------------ preprocess
+    def preprocess(self, detections, targets, append_gt, training):
+        """HEAD:92-151 for the whole batch.  One D2H copy (per-image counts)."""
+        lib = _capi.lib()
+        dev = detections[0]["boxes"].device if detections else torch.device("cuda")
+        if dev.type != "cuda":
+            raise _capi.SkgError("the interaction head runs on a HIP device only (got %s)" % dev)
+        vt = self.verbs(dev)
+        B = len(detections)
+        bl, sl, ll, sizes = [], [], [], []
+        for b, det in enumerate(detections):
+            boxes, labels, scores = det["boxes"], det["labels"], det["scores"]
+            if append_gt:                                                        # HEAD:107-116
+                t = targets[b]
+                ng = t["boxes_h"].shape[0]
+                boxes = torch.cat([t["boxes_h"], t["boxes_o"], boxes])
+                scores = torch.cat([torch.ones(2 * ng, device=scores.device), scores])
+                labels = torch.cat([self.human_idx * torch.ones(ng, device=labels.device).long(), t["object"], labels])
+            bl.append(boxes.reshape(-1, 4)); sl.append(scores.reshape(-1)); ll.append(labels.reshape(-1))
+            sizes.append(int(boxes.shape[0]))
+        if max(sizes, default=0) > _capi.MAX_DET_PER_IMAGE:
+            raise _capi.SkgError("more than %d detections in one image" % _capi.MAX_DET_PER_IMAGE)
+        boxes = torch.cat(bl).float().contiguous() if B else torch.zeros(0, 4, device=dev)
+        scores = torch.cat(sl).float().contiguous() if B else torch.zeros(0, device=dev)
+        labels = torch.cat(ll).long().contiguous() if B else torch.zeros(0, dtype=torch.int64, device=dev)
+        det_off_h = np.zeros(B + 1, np.int32); det_off_h[1:] = np.cumsum(sizes)
+        det_off = torch.from_numpy(det_off_h).to(dev, non_blocking=True)
+        ld = self.max_human + self.max_object
+        index = torch.empty(B, max(ld, 1), dtype=torch.int32, device=dev)
+        count = torch.empty(B, 4, dtype=torch.int32, device=dev)
+        prior_pow = 1.0 if training else 2.8                                    # HEAD:742
+        if boxes.numel() == 0:
+            boxes = torch.zeros(1, 4, device=dev); scores = torch.zeros(1, device=dev)
+            labels = torch.zeros(1, dtype=torch.int64, device=dev)
+        _capi.check(lib.skg_preprocess_f32(boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(), det_off.data_ptr(),
+                                           B, self.human_idx, self.box_score_thresh, self.box_nms_thresh,
+                                           self.max_human, self.max_object, vt.nverbs.data_ptr(), vt.num_obj,
+                                           prior_pow, index.data_ptr(), count.data_ptr(), _stream()),
+                    "skg_preprocess_f32")
+        cnt = count.cpu().numpy()                                               # the one synchronisation point
+        pre = Preprocessed()
+        pre.device = dev
+        pre.B = B
+        pre.n_h = cnt[:, 0].astype(np.int64); pre.n = cnt[:, 1].astype(np.int64); pre.L = cnt[:, 2].astype(np.int64)
+        sel_off_h = np.zeros(B + 1, np.int32); sel_off_h[1:] = np.cumsum(pre.n)
+        total = int(sel_off_h[-1])
+        pre.boxes = torch.empty(max(total, 1), 4, device=dev)[:total]
+        pre.scores = torch.empty(max(total, 1), device=dev)[:total]
+        pre.labels = torch.empty(max(total, 1), dtype=torch.int64, device=dev)[:total]
+        pre.index = index
+        sel_off = torch.from_numpy(sel_off_h).to(dev, non_blocking=True)
+        if total:
+            _capi.check(lib.skg_pack_detections_f32(boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(),
+                                                    det_off.data_ptr(), index.data_ptr(), index.stride(0),
+                                                    sel_off.data_ptr(), B, pre.boxes.data_ptr(),
+                                                    pre.scores.data_ptr(), pre.labels.data_ptr(), _stream()),
+                        "skg_pack_detections_f32")
+        pre.sizes = [int(v) for v in pre.n]
+        return pre
+
+    # ------------------------------------------------------------------------------------------ graph head
+    def graph(self, feat3, image_shapes, pooled, pre, training=False, tables=None, want_scores=False):
+        """GraphHead.forward (HEAD:769-993) for the batch.  Returns a dict of packed device tensors + layout."""
+        lib = _capi.lib()
+        dev = pre.device
+        pw = self.weights(dev)
+        gh = self.gh
+        lay = layout.build(pre.n_h, pre.n, pre.L, image_shapes, self.human_idx,
+                           faithful_skip_offset=self.faithful_skip_offset)
+        A = lay.n_active
+        st = _stream()
+        f32 = dict(device=dev, dtype=torch.float32)
+        i32 = dict(device=dev, dtype=torch.int32)
+        out = dict(layout=lay)
+        if pooled.shape[0] != lay.sum_all:
+            raise _capi.SkgError("box_roi_pool returned %d rows for %d boxes" % (pooled.shape[0], lay.sum_all))
+        # ---- global features (HEAD:811) and box_head on every selected box (HEAD:812)
+        Bf, Cf = feat3.shape[0], feat3.shape[1]
+        feat3 = feat3.float().contiguous()
+        gfeat = torch.empty(Bf, Cf, **f32)
+        _capi.check(lib.skg_global_avgpool_f32(feat3.data_ptr(), Bf, Cf, feat3.shape[2] * feat3.shape[3],
+                                               gfeat.data_ptr(), st), "skg_global_avgpool_f32")
+        x0 = pooled.float().reshape(pooled.shape[0], -1)
+        if x0.shape[1] != pw.bh1_k:
+            raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)" % (
+                x0.shape[0], x0.shape[1], pw.bh1_k, 1024))
+        if x0.shape[1] != pw.bh1_w.shape[1] or not x0.is_contiguous():
+            xp = torch.zeros(x0.shape[0], pw.bh1_w.shape[1], **f32)
+            xp[:, :x0.shape[1]] = x0
+            x0 = xp
+        NA = lay.sum_all
+        enc1 = torch.empty(max(NA, 1), 1024, **f32)
+        enc = torch.empty(max(NA, 1), 1024, **f32)
+        if NA:
+            gemm(x0, pw.bh1_w, pw.bh1_b, enc1, NA, 1024, x0.shape[1], _capi.EPI_BIAS_RELU)
+            gemm(enc1, pw.bh3_w, pw.bh3_b, enc, NA, 1024, 1024, _capi.EPI_BIAS_RELU)
+        out["enc"] = enc[:NA]
+        out["gfeat"] = gfeat
+        if A == 0:
+            return out
+        # ---- small host-built index arrays: one upload
+        buf, offs = layout.pack_int_arrays(lay)
+        ibuf = torch.from_numpy(buf).to(dev, non_blocking=True)
+
+        def isl(name):
+            o, l = offs[name]
+            return ibuf[o:o + l]
+
+        meta = isl("meta")
+        Mh, Mn, Mg, Mp = lay.sum_h, lay.sum_n, lay.sum_g, lay.sum_p
+        # ---- TransH tables: consume the host RNG exactly like the reference
+        if tables is None:
+            ent, rel, nrm = transh.draw_batch(self.K, A, need_relations=want_scores)
+        else:
+            ent, rel, nrm = tables
+        ent_d = ent.to(dev, non_blocking=True).contiguous()
+        out["tables"] = (ent, rel, nrm)
+        # ---- pairs + spatial encoding
+        grid_h = torch.empty(Mg, **i32); grid_o = torch.empty(Mg, **i32); grid_pair = torch.empty(Mg, **i32)
+        grid_img = torch.empty(Mg, **i32); pair_grid = torch.empty(max(Mp, 1), **i32)
+        x_keep = torch.empty(max(Mp, 1), device=dev, dtype=torch.int64); y_keep = torch.empty_like(x_keep)
+        pair_h = torch.empty(max(Mp, 1), **i32); pair_o = torch.empty(max(Mp, 1), **i32)
+        sp48 = torch.empty(Mg, _capi.SPATIAL_LD, **f32)
+        _capi.check(lib.skg_pairs_spatial_f32(pre.boxes.data_ptr(), meta.data_ptr(), A, grid_h.data_ptr(),
+                                              grid_o.data_ptr(), grid_pair.data_ptr(), grid_img.data_ptr(),
+                                              pair_grid.data_ptr(), x_keep.data_ptr(), y_keep.data_ptr(),
+                                              pair_h.data_ptr(), pair_o.data_ptr(), sp48.data_ptr(), 1, st),
+                    "skg_pairs_spatial_f32")
+        out.update(x_keep=x_keep[:Mp], y_keep=y_keep[:Mp], spatial46=sp48, meta=meta, ibuf=ibuf)
+        # ---- spatial_head (HEAD:662-669, 888)
+        s1 = torch.empty(Mg, 128, **f32); s2 = torch.empty(Mg, 256, **f32); S = torch.empty(Mg, 1024, **f32)
+        gemm(sp48, pw.sp0_w, pw.sp0_b, s1, Mg, 128, _capi.SPATIAL_LD, _capi.EPI_BIAS_RELU)
+        gemm(s1, pw.sp2_w, pw.sp2_b, s2, Mg, 256, 128, _capi.EPI_BIAS_RELU)
+        gemm(s2, pw.sp4_w, pw.sp4_b, S, Mg, 1024, 256, _capi.EPI_BIAS_RELU)
+        del s1, s2
+        F2 = torch.empty(Mg, 1024, **f32)
+        if gh.num_iter > 0:
+            # ---- fc_head / fc_tail on unique rows (HEAD:884-885)
+            X = torch.empty(Mh + Mn, 1088, **f32)
+            rows = torch.cat([isl("hum_enc_row"), isl("node_enc_row")])
+            eimg = torch.cat([isl("hum_img"), isl("node_img")])
+            erow = torch.cat([isl("hum_ent_row"), isl("node_ent_row")])
+            _capi.check(lib.skg_concat_entity_f32(enc.data_ptr(), 1024, rows.data_ptr(), ent_d.data_ptr(),
+                                                  eimg.data_ptr(), erow.data_ptr(), Mh + Mn, X.data_ptr(), 1088, st),
+                        "skg_concat_entity_f32")
+            GH = torch.empty(Mh, 1024, **f32); GO = torch.empty(Mn, 1024, **f32)
+            gemm(X, pw.fh_w, pw.fh_b, GH, Mh, 1024, 1088, _capi.EPI_BIAS_RELU)
+            gemm(X, pw.ft_w, pw.ft_b, GO, Mn, 1024, 1088, _capi.EPI_BIAS_RELU, A_off=Mh * 1088)
+            # ---- attention_head fc_1, separable over [human | object] halves (HEAD:894-896)
+            A1h = torch.empty(Mh, 1024, **f32); A1o = torch.empty(Mn, 1024, **f32)
+            gemm(GH, pw.att["w1"], None, A1h, Mh, 1024, 1024, _capi.EPI_BIAS, ldw=2048)
+            gemm(GO, pw.att["w1"], None, A1o, Mn, 1024, 1024, _capi.EPI_BIAS, ldw=2048, W_off=1024)
+            # message fc_1 on node rows (HEAD:514, 524)
+            C1o = torch.empty(Mn, 1024, **f32); C1h = torch.empty(Mh, 1024, **f32)
+            gemm(GO, pw.os["w1"], pw.os["b1"], C1o, Mn, 1024, 1024, _capi.EPI_BIAS)
+            gemm(GH, pw.so["w1"], pw.so["b1"], C1h, Mh, 1024, 1024, _capi.EPI_BIAS)
+            # ---- fc_2 GEMMs over the grid rows with the fc_1*fc_2 -> ReLU product fused
+            T = torch.empty(Mg, 1024, **f32); Tos = torch.empty(Mg, 1024, **f32); Tso = torch.empty(Mg, 1024, **f32)
+            gemm(S, pw.att["w2"], pw.att["b2"], T, Mg, 1024, 1024, _capi.EPI_MUL_RELU, P=A1h, p_idx=grid_h, ldp=1024,
+                 Q=A1o, q_idx=grid_o, ldq=1024, mbias=pw.att["b1"], C_raw=F2, ldc_raw=1024)
+            gemm(S, pw.os["w2"], pw.os["b2"], Tos, Mg, 1024, 1024, _capi.EPI_MUL_RELU, P=C1o, p_idx=grid_o, ldp=1024)
+            gemm(S, pw.so["w2"], pw.so["b2"], Tso, Mg, 1024, 1024, _capi.EPI_MUL_RELU, P=C1h, p_idx=grid_h, ldp=1024)
+            # ---- attention fc_3 + ReLU + adjacency dot (HEAD:896-897)
+            n_part = 2 * ((1024 + 127) // 128)
+            part = torch.empty(n_part, Mg, **f32)
+            gemm(T, pw.att["w3"], pw.att["b3"], None, Mg, 1024, 1024, _capi.EPI_RELU_DOT, dot_w=pw.adj_w,
+                 dot_partial=part)
+            # ---- softmax-weighted aggregation before fc_3 (HEAD:907-922)
+            U = torch.empty(Mh, 1024, **f32); V = torch.empty(Mn, 1024, **f32); adj = torch.empty(Mg, **f32)
+            _capi.check(lib.skg_graph_aggregate_f32(part.data_ptr(), n_part, Mg, pw.adj_b, meta.data_ptr(), A,
+                                                    isl("hum_img").data_ptr(), isl("node_img").data_ptr(), Mh, Mn,
+                                                    Tos.data_ptr(), Tso.data_ptr(), 1024, 1024, U.data_ptr(),
+                                                    V.data_ptr(), 1024, adj.data_ptr(), st),
+                        "skg_graph_aggregate_f32")
+            del T, Tos, Tso
+            Hp = torch.empty(Mh, 1024, **f32); Op = torch.empty(Mn, 1024, **f32)
+            gemm(U, pw.os["w3"], pw.os["b3"], Hp, Mh, 1024, 1024, _capi.EPI_BIAS_RES_RELU, res=GH, ldres=1024)
+            gemm(V, pw.so["w3"], pw.so["b3"], Op, Mn, 1024, 1024, _capi.EPI_BIAS_RES_RELU, res=GO, ldres=1024)
+            h_node = torch.empty(Mh, 1024, **f32); node = torch.empty(Mn, 1024, **f32)
+            _capi.check(lib.skg_layernorm_f32(Hp.data_ptr(), 1024, pw.nh_g.data_ptr(), pw.nh_b.data_ptr(), Mh, 1024,
+                                              EPS_LN, h_node.data_ptr(), 1024, st), "skg_layernorm_f32")
+            _capi.check(lib.skg_layernorm_f32(Op.data_ptr(), 1024, pw.no_g.data_ptr(), pw.no_b.data_ptr(), Mn, 1024,
+                                              EPS_LN, node.data_ptr(), 1024, st), "skg_layernorm_f32")
+            out.update(adjacency=adj)
+        else:
+            # num_iter == 0: the raw box_head encodings reach the read-out (HEAD:843-845)
+            gemm(S, pw.att["w2"], pw.att["b2"], F2, Mg, 1024, 1024, _capi.EPI_BIAS)
+            h_node = enc.index_select(0, isl("hum_enc_row").long())
+            node = enc.index_select(0, isl("node_enc_row").long())
+        out.update(h_node=h_node, node=node)
+        # ---- read-out (HEAD:966-973)
+        PF = torch.empty(max(Mp, 1), 2048, **f32)
+        if Mp:
+            B1h = torch.empty(Mh, 1024, **f32); B1o = torch.empty(Mn, 1024, **f32)
+            gemm(h_node, pw.att["w1"], None, B1h, Mh, 1024, 1024, _capi.EPI_BIAS, ldw=2048)
+            gemm(node, pw.att["w1"], None, B1o, Mn, 1024, 1024, _capi.EPI_BIAS, ldw=2048, W_off=1024)
+            Tp = torch.empty(Mp, 1024, **f32)
+            _capi.check(lib.skg_rows_mul_relu_f32(B1h.data_ptr(), pair_h.data_ptr(), 1024, B1o.data_ptr(),
+                                                  pair_o.data_ptr(), 1024, pw.att["b1"].data_ptr(), F2.data_ptr(),
+                                                  pair_grid.data_ptr(), 1024, Mp, 1024, Tp.data_ptr(), 1024, st),
+                        "skg_rows_mul_relu_f32")
+            gemm(Tp, pw.att["w3"], pw.att["b3"], PF, Mp, 1024, 1024, _capi.EPI_BIAS_RELU, ldc=2048)
+            G1 = torch.empty(Bf, 1024, **f32)
+            gemm(gfeat, pw.att_g["w1"], pw.att_g["b1"], G1, Bf, 1024, Cf, _capi.EPI_BIAS)
+            Tg = Tp                                                              # reuse the buffer
+            gemm(S, pw.att_g["w2"], pw.att_g["b2"], Tg, Mg, 1024, 1024, _capi.EPI_MUL_RELU, P=G1, p_idx=grid_img,
+                 ldp=1024, out_rows=grid_pair)
+            gemm(Tg, pw.att_g["w3"], pw.att_g["b3"], PF, Mp, 1024, 1024, _capi.EPI_BIAS_RELU, ldc=2048, C_off=1024)
+        out["pair_features"] = PF[:Mp]
+        if want_scores:
+            sc = torch.empty(max(Mp, 1), self.K, **f32)
+            rel_d = rel.to(dev).contiguous(); nrm_d = nrm.to(dev).contiguous()
+            _capi.check(lib.skg_transh_scores_f32(ent_d.data_ptr(), rel_d.data_ptr(), nrm_d.data_ptr(), self.K,
+                                                  self.human_idx, meta.data_ptr(), A, sc.data_ptr(), st),
+                        "skg_transh_scores_f32")
+            out["transh_scores"] = sc[:Mp]
+        return out
+
+    # ------------------------------------------------------------------------------------------ classifier + scoring
+    def classify(self, pair_features):
+        """box_pair_predictor | box_pair_suppressor (HEAD:410-411) as one GEMM -> logits [P, K+1 (ld 120)]."""
+        dev = pair_features.device
+        pw = self.weights(dev)
+        Mp = pair_features.shape[0]
+        ld = (self.K + 1 + 3) // 4 * 4
+        logits = torch.empty(max(Mp, 1), ld, device=dev, dtype=torch.float32)
+        if pw.fused_cls:
+            if Mp:
+                gemm(pair_features, pw.cls_w, pw.cls_b, logits, Mp, self.K + 1, 2048, _capi.EPI_BIAS)
+        else:                       # injected modules that are not plain Linear layers are honoured as given
+            logits[:Mp, :self.K] = self.predictor(pair_features)
+            logits[:Mp, self.K:self.K + 1] = self.suppressor(pair_features)
+        return logits[:Mp]
+
+    def score(self, logits, pre, g, training):
+        """compute_prior_scores + postprocess (HEAD:721-767, 237-337) -> packed result tensors."""
+        lib = _capi.lib()
+        lay = g["layout"]
+        dev = pre.device
+        vt = self.verbs(dev)
+        Mp, Lt = lay.sum_p, lay.sum_l
+        i64 = dict(device=dev, dtype=torch.int64)
+        f32 = dict(device=dev, dtype=torch.float32)
+        r = dict(index=torch.empty(max(Lt, 1), **i64), prediction=torch.empty(max(Lt, 1), **i64),
+                 scores=torch.empty(max(Lt, 1), **f32), prior=torch.empty(2, max(Lt, 1), **f32),
+                 weights=torch.empty(max(Mp, 1), **f32), object=torch.empty(max(Mp, 1), **i64),
+                 boxes_h=torch.empty(max(Mp, 1), 4, **f32), boxes_o=torch.empty(max(Mp, 1), 4, **f32))
+        if lay.n_active and Mp:
+            _capi.check(lib.skg_postprocess_f32(
+                logits.data_ptr(), logits.stride(0), self.K, pre.boxes.data_ptr(), pre.scores.data_ptr(),
+                pre.labels.data_ptr(), g["meta"].data_ptr(), lay.n_active, g["x_keep"].data_ptr(),
+                g["y_keep"].data_ptr(), vt.off.data_ptr(), vt.flat.data_ptr(), vt.num_obj,
+                1.0 if training else 2.8, max(Lt, 1), r["index"].data_ptr(), r["prediction"].data_ptr(),
+                r["scores"].data_ptr(), r["prior"].data_ptr(), r["weights"].data_ptr(), r["object"].data_ptr(),
+                r["boxes_h"].data_ptr(), r["boxes_o"].data_ptr(), _stream()), "skg_postprocess_f32")
+        return r

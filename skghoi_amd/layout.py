@@ -1,0 +1,99 @@
+"""Host-side batch layout of the interaction-head hot path (pure numpy, no device work).
+
+From the per-image counts the preprocess kernel reports -- humans n_h, nodes n, scored cells L -- this builds the
+`skg_image_meta` records (include/skghoi.h) and the small index arrays the kernels gather through.  The reference
+walks images in a Python loop (heads/adamixer_transH_spatial_r50_head.py:822-982); here every image of the batch is laid
+out in concatenated row spaces:
+
+    boxes     : all selected detections            sum_all N     (box_off)
+    enc rows  : box_head output                    sum_all N     (enc_off -- see Q9 below)
+    nodes     : graph nodes of ACTIVE images       sum N         (node_off)
+    humans    : human nodes of ACTIVE images       sum n_h       (hum_off)
+    grid      : n_h x n rows incl. self pairs      sum n_h*n     (grid_off)
+    pairs     : kept pairs x != y                  sum n_h*(n-1) (pair_off)
+    cells     : scored (pair, verb) cells          sum L         (out_off)
+
+Reference quirks reproduced here (each can be switched off):
+  * Q9  (HEAD:829-839): a skipped image (n_h == 0 or n <= 1) does not advance the node-encoding offset, so later
+        images of the batch read the wrong rows of box_head's output.  `faithful_skip_offset=True` keeps that.
+  * zip truncation (HEAD:822): the image loop also zips over the rows of box_features, so at most sum_all N images
+        are visited.
+"""
+import numpy as np
+
+from . import _capi
+
+META_DTYPE = np.dtype(_capi.META_FIELDS)
+assert META_DTYPE.itemsize == 48
+
+
+class BatchLayout:
+    pass
+
+
+def build(n_h, n, L, image_shapes, human_idx, faithful_skip_offset=True, zip_truncation=True):
+    """n_h, n, L: int sequences of length B (L may be None -> zeros).  Returns a BatchLayout."""
+    n_h = np.asarray(n_h, dtype=np.int64); n = np.asarray(n, dtype=np.int64)
+    B = len(n)
+    L = np.zeros(B, np.int64) if L is None else np.asarray(L, dtype=np.int64)
+    lay = BatchLayout()
+    lay.B = B
+    lay.n_h = n_h; lay.n = n
+    lay.sum_all = int(n.sum())
+    lay.box_off = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    lay.n_visit = min(B, lay.sum_all) if zip_truncation else B
+    skipped = (n_h == 0) | (n <= 1)
+    lay.skipped = skipped
+    active = [b for b in range(lay.n_visit) if not skipped[b]]
+    lay.active = np.asarray(active, dtype=np.int64)
+    A = len(active)
+    lay.n_active = A
+    meta = np.zeros(A, META_DTYPE)
+    enc_counter = 0
+    node = hum = grid = pair = out = 0
+    for a, b in enumerate(active):
+        nh_, n_ = int(n_h[b]), int(n[b])
+        m = meta[a]
+        m["image"] = b; m["n_h"] = nh_; m["n"] = n_
+        m["box_off"] = lay.box_off[b]
+        m["enc_off"] = enc_counter if faithful_skip_offset else lay.box_off[b]
+        m["node_off"] = node; m["hum_off"] = hum; m["grid_off"] = grid; m["pair_off"] = pair; m["out_off"] = out
+        m["img_h"] = float(image_shapes[b][0]); m["img_w"] = float(image_shapes[b][1])
+        enc_counter += n_
+        node += n_; hum += nh_; grid += nh_ * n_; pair += nh_ * (n_ - 1); out += int(L[b])
+    lay.meta = meta
+    lay.sum_n, lay.sum_h, lay.sum_g, lay.sum_p, lay.sum_l = node, hum, grid, pair, out
+    an = meta["n"].astype(np.int64); ah = meta["n_h"].astype(np.int64)
+    ar = np.arange(A, dtype=np.int32)
+    lay.node_img = np.repeat(ar, an).astype(np.int32)            # active-image index of every graph node
+    lay.hum_img = np.repeat(ar, ah).astype(np.int32)
+    node_local = (np.arange(node, dtype=np.int64) - np.repeat(meta["node_off"].astype(np.int64), an))
+    hum_local = (np.arange(hum, dtype=np.int64) - np.repeat(meta["hum_off"].astype(np.int64), ah))
+    lay.node_enc_row = (np.repeat(meta["enc_off"].astype(np.int64), an) + node_local).astype(np.int32)
+    lay.hum_enc_row = (np.repeat(meta["enc_off"].astype(np.int64), ah) + hum_local).astype(np.int32)
+    lay.node_ent_row = node_local.astype(np.int32)               # tails are indexed by position y
+    lay.hum_ent_row = np.full(hum, human_idx, dtype=np.int32)    # heads are the constant human_idx
+    lay.pairs_per_image = (ah * (an - 1)).astype(np.int64)
+    lay.cells_per_image = np.asarray([int(L[b]) for b in active], dtype=np.int64)
+    if A and (meta["n"].max() > _capi.TRANSH_ENT or human_idx >= _capi.TRANSH_ENT or human_idx < 0):
+        # the reference indexes an 80-row embedding with y and human_idx (HEAD:570-572, 690)
+        raise IndexError("index out of range in self")
+    return lay
+
+
+def pack_int_arrays(lay):
+    """One contiguous int32 host buffer (single H2D copy) + the slices of each array inside it."""
+    parts = [("meta", lay.meta.view(np.int32).reshape(-1)), ("node_img", lay.node_img), ("hum_img", lay.hum_img),
+             ("node_enc_row", lay.node_enc_row), ("hum_enc_row", lay.hum_enc_row),
+             ("node_ent_row", lay.node_ent_row), ("hum_ent_row", lay.hum_ent_row)]
+    offs = {}
+    cur = 0
+    for k, v in parts:
+        cur = (cur + 3) & ~3                   # 16-byte align every slice
+        offs[k] = (cur, len(v))
+        cur += len(v)
+    buf = np.zeros(max(cur, 4), np.int32)
+    for k, v in parts:
+        o, l = offs[k]
+        buf[o:o + l] = v
+    return buf, offs

@@ -1,0 +1,77 @@
+"""Runs the product (HIP) interaction head on cuda:0 for a tests/cases.py case and flattens its outputs with the same
+keys as the golden fixtures / helpers.flatten_oracle."""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+import cases
+from skghoi_amd import GraphHead, InteractionHead, synth
+
+
+class CachedPool(torch.nn.Module):
+    """Stands in for MultiScaleRoIAlign: returns the cached pooled features for however many boxes were kept."""
+
+    def __init__(self, case):
+        super().__init__()
+        self.case = case
+
+    def forward(self, features, boxes, image_shapes):
+        return cases.pooled_for(self.case, sum(len(b) for b in boxes)).cuda()
+
+
+def build_head(case, reference_quirks=True):
+    cfg = case["cfg"]
+    gh = GraphHead(case["C"], case["p"], 1024, 1024, cfg["K"], cfg["human_idx"], case["o2v"],
+                   num_iter=case["num_iter"])
+    head = InteractionHead(CachedPool(case), gh, torch.nn.Linear(2048, 1), torch.nn.Linear(2048, cfg["K"]),
+                           human_idx=cfg["human_idx"], num_classes=cfg["K"], box_nms_thresh=case["box_nms_thresh"],
+                           box_score_thresh=case["box_score_thresh"], max_human=case["max_human"],
+                           max_object=case["max_object"], reference_quirks=reference_quirks)
+    head.load_state_dict(synth.make_state_dict(cfg["K"], case["C"], case["p"], seed=case["weight_seed"]))
+    return head.cuda().train(case["training"])
+
+
+def to_cuda(x):
+    if torch.is_tensor(x):
+        return x.cuda()
+    if isinstance(x, dict):
+        return {k: to_cuda(v) for k, v in x.items()}
+    if isinstance(x, list):
+        return [to_cuda(v) for v in x]
+    return x
+
+
+def run_head(case, head=None, reference_quirks=True):
+    head = head or build_head(case, reference_quirks)
+    K = case["cfg"]["K"]
+    det = to_cuda(case["detections"]); tg = to_cuda(case["targets"])
+    feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
+    out = {}
+    with torch.no_grad():
+        for b, d in enumerate(head.preprocess(det, tg)):
+            out["pre%d.boxes" % b] = d["boxes"]; out["pre%d.labels" % b] = d["labels"]; out["pre%d.scores" % b] = d["scores"]
+        torch.manual_seed(case["rng_seed"])
+        results = head(feats, det, case["shapes"], tg)
+    torch.cuda.synchronize()
+    last = head.engine().last
+    for b, r in enumerate(results):
+        for k, v in r.items():
+            out["res%d.%s" % (b, k)] = v
+    out["n_results"] = torch.tensor(len(results))
+    lay = last["layout"]
+    out["n_tables"] = torch.tensor(lay.n_active)
+    if lay.n_active:
+        out["logits_p"] = last["logits"][:, :K]; out["logits_s"] = last["logits"][:, K:K + 1]
+        out["pair_features"] = last["pair_features"]
+        ent = last["tables"][0]
+        for a in range(lay.n_active):
+            m = lay.meta[a]
+            g0, G = int(m["grid_off"]), int(m["n_h"]) * int(m["n"])
+            out["timg%d.ent" % a] = ent[a]
+            out["timg%d.spatial46" % a] = last["spatial46"][g0:g0 + G, :46]
+            out["timg%d.h_node" % a] = last["h_node"][int(m["hum_off"]):int(m["hum_off"]) + int(m["n_h"])]
+            out["timg%d.node" % a] = last["node"][int(m["node_off"]):int(m["node_off"]) + int(m["n"])]
+            if "adjacency" in last:
+                out["timg%d.adjacency" % a] = last["adjacency"][g0:g0 + G].reshape(-1, 1)
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()}

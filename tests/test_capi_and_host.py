@@ -1,0 +1,145 @@
+"""CPU tests of the C-ABI boundary and the host logic (no GPU compute):
+  * libskghoi_hip.so builds/loads and exports every symbol include/skghoi.h declares, with the ctypes mirror in sync
+  * argument validation returns SKG_E_* instead of launching
+  * batch layout (offsets, Q9 enc offset, zip truncation), TransH RNG replication, module surface / state_dict keys."""
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import helpers
+from skghoi_amd import _capi, layout, synth, transh
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.isfile(_capi.LIB_PATH):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+        __graft_entry__.build()
+    return _capi.lib()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "skghoi.h")).read()
+    declared = set(re.findall(r"\b(skg_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_capi.PROTOTYPES), declared ^ set(_capi.PROTOTYPES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.skg_abi_version() == _capi.ABI_VERSION
+    assert b"gfx950" in lib.skg_build_info()
+
+
+def test_struct_mirrors_match_header():
+    assert ctypes.sizeof(_capi.GemmDesc) == 192
+    assert layout.META_DTYPE.itemsize == 48
+    hdr = open(os.path.join(ROOT, "include", "skghoi.h")).read()
+    body = hdr[hdr.index("typedef struct {\n    int32_t image"):hdr.index("} skg_image_meta;")]
+    names = re.findall(r"(?:int32_t|float)\s+([a-z_, ]+);", body)
+    flat = [n.strip() for group in names for n in group.split(",")]
+    assert flat == [f[0] for f in _capi.META_FIELDS]
+
+
+def test_argument_validation_without_gpu(lib):
+    d = _capi.GemmDesc()
+    assert lib.skg_gemm_f32(None, None) == -1
+    d.M, d.N, d.K = 4, 4, 6
+    d.A = 16; d.W = 16; d.C = 16; d.lda = 8; d.ldw = 8; d.ldc = 4
+    assert lib.skg_gemm_f32(ctypes.byref(d), None) == -2           # K % 4 != 0
+    d.K = 8; d.A = 20
+    assert lib.skg_gemm_f32(ctypes.byref(d), None) == -2           # misaligned A
+    d.A = 16; d.epilogue = 9
+    assert lib.skg_gemm_f32(ctypes.byref(d), None) == -1
+    d.epilogue = _capi.EPI_BIAS; d.M = 0
+    assert lib.skg_gemm_f32(ctypes.byref(d), None) == 0            # empty problem: nothing launched
+    assert lib.skg_preprocess_f32(16, 16, 16, 16, 2, 49, 0.2, 0.5, 100, 100, 16, 80, 2.8, 16, 16, None) == -3
+    assert lib.skg_global_avgpool_f32(None, 0, 256, 10, None, None) == 0
+    assert lib.skg_layernorm_f32(16, 1024, 16, 16, 3, 2048, 1e-5, 16, 1024, None) == -1
+
+
+def test_layout_offsets_and_quirks():
+    shapes = [(800, 1200)] * 5
+    lay = layout.build([0, 2, 1, 3, 0], [3, 4, 1, 4, 0], [0, 10, 0, 7, 0], shapes, 49)
+    assert lay.active.tolist() == [1, 3] and lay.n_visit == 5
+    m = lay.meta
+    assert m["box_off"].tolist() == [3, 8]
+    assert m["enc_off"].tolist() == [0, 4]            # Q9: skipped images do not advance the encoding offset
+    assert m["node_off"].tolist() == [0, 4] and m["hum_off"].tolist() == [0, 2]
+    assert m["grid_off"].tolist() == [0, 8] and m["pair_off"].tolist() == [0, 6] and m["out_off"].tolist() == [0, 10]
+    assert (lay.sum_n, lay.sum_h, lay.sum_g, lay.sum_p, lay.sum_l) == (8, 5, 20, 15, 17)
+    assert lay.hum_enc_row.tolist() == [0, 1, 4, 5, 6] and lay.node_ent_row.tolist() == [0, 1, 2, 3, 0, 1, 2, 3]
+    fixed = layout.build([0, 2, 1, 3, 0], [3, 4, 1, 4, 0], None, shapes, 49, faithful_skip_offset=False)
+    assert fixed.meta["enc_off"].tolist() == [3, 8]
+    trunc = layout.build([1, 1, 1], [2, 0, 0], None, shapes[:3], 49)       # sum N = 2 < B = 3 (HEAD:822 zip)
+    assert trunc.n_visit == 2
+    buf, offs = layout.pack_int_arrays(lay)
+    o, l = offs["meta"]
+    assert l == 2 * 12 and all(v[0] % 4 == 0 for v in offs.values())
+    with pytest.raises(IndexError):
+        layout.build([1], [81], None, shapes[:1], 49)                      # TransH ent_tot = 80
+
+
+@pytest.mark.parametrize("K", [117, 24])
+def test_transh_rng_matches_reference_draw_order(K):
+    """The tables the reference drew (captured in the fixtures) are reproduced from the seed."""
+    name = "tiny" if K == 117 else "vcoco"
+    g = helpers.load_golden(name)
+    case = cases.build_case(name)
+    torch.manual_seed(case["rng_seed"])
+    ent, rel, nrm = transh.draw_batch(K, int(g["n_tables"]), need_relations=True)
+    for i in range(int(g["n_tables"])):
+        assert np.array_equal(ent[i].numpy(), g["timg%d.ent" % i])
+        assert np.array_equal(rel[i].numpy(), g["timg%d.rel_table" % i])
+        assert np.array_equal(nrm[i].numpy(), g["timg%d.norm_table" % i])
+    # skipping the relation tables must still advance the RNG identically
+    torch.manual_seed(case["rng_seed"])
+    ent2, _, _ = transh.draw_batch(K, int(g["n_tables"]), need_relations=False)
+    assert torch.equal(ent, ent2)
+
+
+def test_module_surface_and_state_dict_keys():
+    from skghoi_amd import GraphHead, InteractionHead
+    o2v = synth.hico_object_to_verb()
+    gh = GraphHead(out_channels=8, roi_pool_size=2, node_encoding_size=1024, representation_size=1024, num_cls=117,
+                   human_idx=49, object_class_to_target_class=o2v, fg_iou_thresh=0.5, num_iter=2)
+    head = InteractionHead(box_roi_pool=torch.nn.Identity(), box_pair_head=gh,
+                           box_pair_suppressor=torch.nn.Linear(2048, 1), box_pair_predictor=torch.nn.Linear(2048, 117),
+                           num_classes=117, human_idx=49, box_nms_thresh=0.5, box_score_thresh=0.2, max_human=15,
+                           max_object=15, distributed=False)
+    sd = head.state_dict()
+    want = synth.head_param_shapes(117, 8, 2)
+    assert len(sd) == 408 == len(want)
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == [(k, tuple(s)) for k, s in want]
+    assert sum(v.numel() for v in sd.values()) == sum(int(np.prod(s)) for _, s in want)
+    head.load_state_dict(synth.make_state_dict(117, 8, 2, seed=3))
+    # CPU tensors must fail loudly, never fall back
+    det = [dict(boxes=torch.zeros(2, 4), labels=torch.tensor([49, 1]), scores=torch.tensor([0.9, 0.8]))]
+    head.eval()
+    with pytest.raises(_capi.SkgError):
+        head({"3": torch.zeros(1, 256, 2, 2)}, det, [(10, 10)])
+    head.train()
+    with pytest.raises(AssertionError):
+        head({"3": torch.zeros(1, 256, 2, 2)}, det, [(10, 10)])
+    with pytest.raises(ValueError):
+        GraphHead(8, 2, 512, 1024, 117, 49, o2v)
+
+
+@pytest.mark.reference
+def test_state_dict_matches_reference_module():
+    from oracle import ref_import
+    from skghoi_amd import GraphHead, InteractionHead
+    o2v = synth.hico_object_to_verb()
+    ref = ref_import.build_reference_head(117, 49, o2v, 256, 7, 15, 15)
+    gh = GraphHead(256, 7, 1024, 1024, 117, 49, o2v)
+    head = InteractionHead(torch.nn.Identity(), gh, torch.nn.Linear(2048, 1), torch.nn.Linear(2048, 117), 49, 117)
+    a = [(k, tuple(v.shape)) for k, v in ref.state_dict().items()]
+    b = [(k, tuple(v.shape)) for k, v in head.state_dict().items()]
+    assert a == b and len(a) == 408
+    head.load_state_dict(ref.state_dict())

@@ -1,0 +1,145 @@
+"""GPU tests of the individual HIP kernels through the C ABI against plain PyTorch fp32 on the same device."""
+import numpy as np
+import pytest
+import torch
+
+from skghoi_amd import _capi
+from skghoi_amd.engine import gemm, _stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1).cuda()
+
+
+def _close(a, b, tol):
+    err = (a - b).abs().max().item()
+    assert err <= tol, "max err %.3e > %.1e" % (err, tol)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1024, 256), (40, 1024, 32), (130, 118, 2048), (300, 128, 48), (257, 1024, 1088),
+                                   (800, 1024, 1024), (513, 256, 128), (128, 128, 16), (64, 100, 12544)])
+def test_gemm_bias_relu_shapes_and_tails(M, N, K):
+    A = _rand(M, K, seed=1); W = _rand(N, K, seed=2) / np.sqrt(K); b = _rand(N, seed=3)
+    ref = torch.relu(A.double() @ W.double().t() + b.double()).float()
+    C = torch.full((M, N + 4), 7.0, device="cuda")
+    gemm(A, W, b, C, M, N, K, _capi.EPI_BIAS_RELU)
+    torch.cuda.synchronize()
+    _close(C[:, :N], ref, 2e-5)
+    assert torch.all(C[:, N:] == 7.0)                     # nothing written past N
+    C2 = torch.empty(M, N, device="cuda")
+    gemm(A, W, None, C2, M, N, K, _capi.EPI_BIAS)
+    _close(C2, (A.double() @ W.double().t()).float(), 2e-5)
+
+
+def test_gemm_identity_asymmetric_layout():
+    """A = I against an asymmetric W catches any row/col swap of the MFMA C/D map."""
+    n = 128
+    A = torch.eye(n, device="cuda")
+    W = (torch.arange(n * n, device="cuda", dtype=torch.float32).reshape(n, n) % 97) + \
+        torch.arange(n, device="cuda", dtype=torch.float32)[:, None] * 3
+    C = torch.empty(n, n, device="cuda")
+    gemm(A, W, None, C, n, n, n, _capi.EPI_BIAS)
+    torch.cuda.synchronize()
+    assert torch.equal(C, W.t().contiguous())
+
+
+def test_gemm_gather_scatter_and_column_views():
+    M, N, K = 200, 256, 64
+    src = _rand(50, K, seed=4); W = _rand(N, 2 * K, seed=5); b = _rand(N, seed=6)
+    rows = torch.randint(-1, 50, (M,), generator=torch.Generator().manual_seed(1)).int().cuda()
+    orow = torch.randperm(M, generator=torch.Generator().manual_seed(2)).int()
+    orow[::7] = -1
+    orow = orow.cuda()
+    C = torch.zeros(M, 2 * N, device="cuda")
+    gemm(src, W, b, C, M, N, K, _capi.EPI_BIAS, a_rows=rows, out_rows=orow, ldw=2 * K, W_off=K, ldc=2 * N, C_off=N)
+    torch.cuda.synchronize()
+    Ag = torch.where(rows[:, None] >= 0, src[rows.clamp(min=0).long()], torch.zeros(1, device="cuda"))
+    ref = (Ag.double() @ W[:, K:].double().t() + b.double()).float()
+    for r in range(M):
+        o = int(orow[r])
+        if o >= 0:
+            _close(C[o, N:], ref[r], 1e-5)
+    assert torch.all(C[:, :N] == 0)
+
+
+def test_gemm_mul_relu_epilogue():
+    M, N, K = 333, 1024, 256
+    A = _rand(M, K, seed=1); W = _rand(N, K, seed=2) / 16; b = _rand(N, seed=3)
+    P = _rand(17, N, seed=4); Q = _rand(29, N, seed=5); mb = _rand(N, seed=6)
+    pi = torch.randint(0, 17, (M,), generator=torch.Generator().manual_seed(3)).int().cuda()
+    qi = torch.randint(0, 29, (M,), generator=torch.Generator().manual_seed(4)).int().cuda()
+    C = torch.empty(M, N, device="cuda"); raw = torch.empty(M, N, device="cuda")
+    gemm(A, W, b, C, M, N, K, _capi.EPI_MUL_RELU, P=P, p_idx=pi, ldp=N, Q=Q, q_idx=qi, ldq=N, mbias=mb, C_raw=raw,
+         ldc_raw=N)
+    torch.cuda.synchronize()
+    v = (A.double() @ W.double().t() + b.double())
+    ref = torch.relu(v * (P[pi.long()] + Q[qi.long()] + mb).double()).float()
+    _close(raw, v.float(), 1e-5)
+    _close(C, ref, 2e-5)
+    C1 = torch.empty(M, N, device="cuda")
+    gemm(A, W, b, C1, M, N, K, _capi.EPI_MUL_RELU, P=P, p_idx=pi, ldp=N)
+    _close(C1, torch.relu(v * P[pi.long()].double()).float(), 2e-5)
+
+
+def test_gemm_relu_dot_and_residual_epilogues():
+    M, N, K = 450, 1024, 128
+    A = _rand(M, K, seed=1); W = _rand(N, K, seed=2) / 8; b = _rand(N, seed=3); dw = _rand(N, seed=4)
+    part = torch.empty(16, M, device="cuda")
+    gemm(A, W, b, None, M, N, K, _capi.EPI_RELU_DOT, dot_w=dw, dot_partial=part)
+    torch.cuda.synchronize()
+    v = torch.relu(A.double() @ W.double().t() + b.double())
+    _close(part.sum(0), (v @ dw.double()).float(), 1e-4)
+    res = _rand(M, N, seed=5)
+    C = torch.empty(M, N, device="cuda")
+    gemm(A, W, b, C, M, N, K, _capi.EPI_BIAS_RES_RELU, res=res, ldres=N)
+    _close(C, (res.double() + v).float(), 2e-5)
+
+
+def test_layernorm_avgpool_rowsmul():
+    lib = _capi.lib()
+    x = _rand(37, 1024, seed=1) * 3; g = _rand(1024, seed=2); b = _rand(1024, seed=3)
+    out = torch.empty_like(x)
+    _capi.check(lib.skg_layernorm_f32(x.data_ptr(), 1024, g.data_ptr(), b.data_ptr(), 37, 1024, 1e-5, out.data_ptr(),
+                                      1024, _stream()), "ln")
+    _close(out, torch.nn.functional.layer_norm(x, (1024,), g, b), 1e-5)
+    f = _rand(3, 256, 25, 38, seed=4)
+    o = torch.empty(3, 256, device="cuda")
+    _capi.check(lib.skg_global_avgpool_f32(f.data_ptr(), 3, 256, 25 * 38, o.data_ptr(), _stream()), "pool")
+    _close(o, f.mean(dim=(2, 3)), 1e-6)
+    P = _rand(5, 1024, seed=5); Q = _rand(7, 1024, seed=6); mb = _rand(1024, seed=7); F = _rand(11, 1024, seed=8)
+    pi = torch.tensor([0, 4, 2, 2], dtype=torch.int32).cuda(); qi = torch.tensor([6, 0, 3, 3], dtype=torch.int32).cuda()
+    fi = torch.tensor([10, 1, 1, 5], dtype=torch.int32).cuda()
+    out = torch.empty(4, 1024, device="cuda")
+    _capi.check(lib.skg_rows_mul_relu_f32(P.data_ptr(), pi.data_ptr(), 1024, Q.data_ptr(), qi.data_ptr(), 1024,
+                                          mb.data_ptr(), F.data_ptr(), fi.data_ptr(), 1024, 4, 1024, out.data_ptr(),
+                                          1024, _stream()), "rowsmul")
+    _close(out, torch.relu((P[pi.long()] + Q[qi.long()] + mb) * F[fi.long()]), 1e-6)
+
+
+def test_transh_scores_match_oracle():
+    from oracle import skg_oracle as O
+    from skghoi_amd import layout
+    lib = _capi.lib()
+    K = 24
+    torch.manual_seed(5)
+    tabs = [O.draw_transh_tables(K) for _ in range(2)]
+    lay = layout.build([2, 3], [5, 4], None, [(100, 100)] * 2, 1)
+    meta = torch.from_numpy(lay.meta.view(np.int32).reshape(-1).copy()).cuda()
+    ent = torch.stack([t[0] for t in tabs]).cuda(); rel = torch.stack([t[1] for t in tabs]).cuda()
+    nrm = torch.stack([t[2] for t in tabs]).cuda()
+    sc = torch.empty(lay.sum_p, K, device="cuda")
+    _capi.check(lib.skg_transh_scores_f32(ent.data_ptr(), rel.data_ptr(), nrm.data_ptr(), K, 1, meta.data_ptr(), 2,
+                                          sc.data_ptr(), _stream()), "transh")
+    torch.cuda.synchronize()
+    off = 0
+    for a, (nh, n) in enumerate([(2, 5), (3, 4)]):
+        x, y, xk, yk = O.pair_grid(nh, n)
+        G = nh * n
+        _, _, _, _, s = O.transh_forward(*tabs[a], torch.full((G * K,), 1), torch.arange(K).repeat(G),
+                                         y.repeat_interleave(K))
+        want = s.reshape(nh, n, K)[xk, yk]
+        _close(sc[off:off + len(xk)].cpu(), want, 2e-6)
+        off += len(xk)
