@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- images/s through the interaction head on synthetic 20-human x 20-object graphs (BASELINE.json metric).
+
+One "step" = one eval forward of InteractionHead over a batch of B cached images per GPU (preprocess/NMS -> roi-pool
+stand-in returning the HBM-resident cached box features -> graph head -> classifier -> scoring -> result dicts).
+Inputs are resident in HBM before the timed region.  N GPUs = N independent shards of images (no data-path
+collective: images are independent); value = N * B * K / max-over-ranks time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline     : dominant kernel (the fp32-MFMA GEMM) algorithmic FLOP/s from HIP-event timings of every launch
+  cpu_baseline : the CPU oracle (faithful restatement of the reference head, oracle/skg_oracle.py) timed on this
+                 box's host cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from collections import OrderedDict
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+N_H = N_O = 20
+C_FEAT, POOL = 256, 7
+
+
+class ResidentPool(torch.nn.Module):
+    """box_roi_pool stand-in: the cached AdaMixer-R50 box features, already in HBM, in the head's box order."""
+
+    def __init__(self, pooled):
+        super().__init__()
+        self.pooled = pooled
+
+    def forward(self, features, boxes, image_shapes):
+        return self.pooled
+
+
+def make_inputs(B, rank, device):
+    from skghoi_amd import synth
+    dets, pooled, feats, shapes = [], [], [], []
+    for i in range(B):
+        im = synth.make_image(1000 + rank * B + i, n_h=N_H, n_o=N_O, out_channels=C_FEAT, pool=POOL)
+        dets.append(dict(boxes=im["boxes"].to(device), labels=im["labels"].to(device), scores=im["scores"].to(device)))
+        pooled.append(im["pooled"]); feats.append(im["feat3"]); shapes.append(im["hw"])
+    pooled = torch.cat(pooled).to(device)
+    feat3 = torch.cat(feats).to(device)
+    return dets, pooled, OrderedDict((k, feat3) for k in "0123"), shapes
+
+
+def build_head(device):
+    from skghoi_amd import GraphHead, InteractionHead, synth
+    o2v = synth.hico_object_to_verb()
+    gh = GraphHead(C_FEAT, POOL, 1024, 1024, 117, 49, o2v, num_iter=2)
+    head = InteractionHead(torch.nn.Identity(), gh, torch.nn.Linear(2048, 1), torch.nn.Linear(2048, 117),
+                           human_idx=49, num_classes=117, max_human=N_H, max_object=N_O)
+    head.load_state_dict(synth.make_state_dict(117, C_FEAT, POOL, seed=0))
+    return head.to(device).eval()
+
+
+def cpu_baseline(n_images):
+    """The oracle (kind 'port': loop-for-loop restatement of the reference head, incl. its Python row loop) on the
+    host cores, same synthetic workload, batch 1 per forward like the reference's inference (utils.py:166-167)."""
+    from oracle import skg_oracle as O
+    from skghoi_amd import synth
+    sd = synth.make_state_dict(117, C_FEAT, POOL, seed=0)
+    o2v = synth.hico_object_to_verb()
+    cores = torch.get_num_threads()
+    times = []
+    with torch.no_grad():
+        for i in range(n_images + 1):
+            im = synth.make_image(1000 + i, n_h=N_H, n_o=N_O, out_channels=C_FEAT, pool=POOL)
+            det = [dict(boxes=im["boxes"], labels=im["labels"], scores=im["scores"])]
+            torch.manual_seed(i)
+            t0 = time.perf_counter()
+            O.interaction_head_forward(sd, im["feat3"], det, [im["hw"]], lambda c: im["pooled"], 117, 49, o2v,
+                                       max_human=N_H, max_object=N_O, row_loop=True)
+            dt = time.perf_counter() - t0
+            if i > 0:                       # first image = warm-up
+                times.append(dt)
+            if sum(times) > 25.0:
+                break
+    return dict(value=round(len(times) / sum(times), 4), unit="images/s", cores=cores, kind="port",
+                sample="%d images (20x20), batch 1 per forward, fp32 torch CPU, %d threads, after 1 warm-up; "
+                       "median %.3f s/image" % (len(times), cores, float(np.median(times))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if dist_on:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from skghoi_amd import engine
+    head = build_head(device)
+    dets, pooled, feats, shapes = make_inputs(args.batch, rank, device)
+    head.box_roi_pool = ResidentPool(pooled)
+
+    def step():
+        with torch.no_grad():
+            return head(feats, dets, shapes)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    torch.manual_seed(1234 + rank)
+    for _ in range(args.warmup):
+        res = step()
+    assert len(res) == args.batch and res[0]["boxes_h"].shape == (N_H * (N_H + N_O - 1), 4)
+
+    engine.GEMM_TIMER = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer, engine.GEMM_TIMER = engine.GEMM_TIMER, None
+
+    if dist_on:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_images = args.batch * args.steps * world
+    value = total_images / elapsed
+
+    # ---- roofline of the dominant kernel: per-launch HIP-event durations, grouped by kernel instance (epilogue)
+    groups = {}
+    for e0, e1, M, N, K, epi in timer:
+        g = groups.setdefault(epi, [0.0, 0.0, 0])
+        g[0] += e0.elapsed_time(e1) * 1e-3; g[1] += 2.0 * M * N * K; g[2] += 1
+    names = {0: "skg_gemm_kernel<BIAS>", 1: "skg_gemm_kernel<BIAS_RELU>", 2: "skg_gemm_kernel<MUL_RELU>",
+             3: "skg_gemm_kernel<RELU_DOT>", 4: "skg_gemm_kernel<BIAS_RES_RELU>"}
+    dom = max(groups, key=lambda k: groups[k][0])
+    t_dom, f_dom, n_dom = groups[dom]
+    t_all = sum(g[0] for g in groups.values()); f_all = sum(g[1] for g in groups.values())
+    achieved = f_dom / t_dom / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")     # HBM bytes per launch from the rocprofv3 --pmc passes
+    if os.path.isfile(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(names[dom])
+        except Exception:
+            traffic = None
+    roofline = dict(bound="mfma", kernel=names[dom], achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS,
+                    unit="TFLOP/s", frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
+                    launches=n_dom, avg_launch_ms=round(t_dom / n_dom * 1e3, 4),
+                    all_gemm_tflops=round(f_all / t_all / 1e12, 2),
+                    gemm_share_of_step=round(t_all / (elapsed if not dist_on else elapsed), 4),
+                    gflop_per_image=round(f_all / (args.batch * args.steps) / 1e9, 3))
+
+    out = OrderedDict(metric="images/sec through interaction head (20x20 pairs)", value=round(value, 2),
+                      unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                      ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
+                      vs_baseline=None, dtype="f32", data="synthetic",
+                      config=dict(workload="HICO-DET-shaped synthetic cached detections: 20 humans x 20 objects per "
+                                           "image (G=800 grid rows, P=780 pairs, K=117 verbs), eval forward of "
+                                           "InteractionHead from cached AdaMixer-R50 box features [40,256,7,7]/image",
+                                  batch_per_gpu=args.batch, images_per_step=args.batch * world,
+                                  parallelism="dp%d (independent image shards, no data-path collective)" % world),
+                      roofline=roofline)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(12)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,10 @@ from . import _capi, layout, transh
 
 EPS_LN = 1e-5
 
+# bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
+# entries are (start_event, end_event, M, N, K, epilogue).  None = no instrumentation (the default).
+GEMM_TIMER = None
+
 
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
@@ -127,7 +131,13 @@ def gemm(A, W, bias, C_out, M, N, K, epilogue, lda=None, ldw=None, ldc=None, a_r
     d.mbias = _ptr(mbias); d.C_raw = _ptr(C_raw); d.ldc_raw = ldc_raw
     d.dot_w = _ptr(dot_w); d.dot_partial = _ptr(dot_partial)
     d.res = _ptr(res); d.ldres = ldres
+    if GEMM_TIMER is not None:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     _capi.check(_capi.lib().skg_gemm_f32(C.byref(d), _stream()), "skg_gemm_f32[%dx%dx%d epi %d]" % (M, N, K, epilogue))
+    if GEMM_TIMER is not None:
+        e1.record()
+        GEMM_TIMER.append((e0, e1, M, N, K, epilogue))
 
 
 class Preprocessed:
