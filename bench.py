@@ -73,7 +73,8 @@ def cpu_baseline(n_images):
     from skghoi_amd import synth
     sd = synth.make_state_dict(117, C_FEAT, POOL, seed=0)
     o2v = synth.hico_object_to_verb()
-    cores = torch.get_num_threads()
+    cores = min(torch.get_num_threads(), 16)      # a 1-GPU box's CPU share
+    torch.set_num_threads(cores)
     times = []
     with torch.no_grad():
         for i in range(n_images + 1):

@@ -158,15 +158,26 @@ class HeadEngine:
         self.max_human = int(max_human)
         self.max_object = int(max_object)
         self.faithful_skip_offset = faithful_skip_offset
+        self.chunk_images = 64      # active images per graph chunk (RNG/GPU overlap + cache-sized intermediates)
+        self.debug = False          # keep per-chunk intermediates (spatial46, h_node, node, adjacency) in graph()
+        self._plist = None
         self._pw = None
         self._vt = None
         self.last = None          # intermediates of the last graph pass (parity tests read them)
 
     # ------------------------------------------------------------------------------------------ caches
     def weights(self, device):
-        v = versions_of(self.gh, self.predictor, self.suppressor)
-        if self._pw is None or self._pw.device != device or self._pw.versions != v:
+        """Packed weights, re-packed when any parameter was modified in place, replaced or moved."""
+        if self._plist is None:
+            self._plist = list(self.gh.parameters()) + list(self.predictor.parameters()) + \
+                list(self.suppressor.parameters())
+        sig = (sum(p._version for p in self._plist), self._plist[0].data_ptr(), self._plist[-1].data_ptr())
+        if self._pw is None or self._pw.device != device or self._pw.sig != sig:
+            self._plist = list(self.gh.parameters()) + list(self.predictor.parameters()) + \
+                list(self.suppressor.parameters())
+            sig = (sum(p._version for p in self._plist), self._plist[0].data_ptr(), self._plist[-1].data_ptr())
             self._pw = PackedWeights(self.gh, self.predictor, self.suppressor, device)
+            self._pw.sig = sig
         return self._pw
 
     def verbs(self, device):
@@ -236,17 +247,19 @@ class HeadEngine:
 
     # ------------------------------------------------------------------------------------------ graph head
     def graph(self, feat3, image_shapes, pooled, pre, training=False, tables=None, want_scores=False):
-        """GraphHead.forward (HEAD:769-993) for the batch.  Returns a dict of packed device tensors + layout."""
+        """GraphHead.forward (HEAD:769-993) for the batch.  Returns a dict of packed device tensors + layout.
+
+        The active images are processed in chunks of `self.chunk_images`: the TransH tables of chunk c are drawn on
+        the host (the reference's RNG stream, ~27k mt19937 draws per image) while the GPU is still busy with chunk
+        c-1, and the chunk-sized intermediates ([G,1024] panels) stay closer to the caches."""
         lib = _capi.lib()
         dev = pre.device
         pw = self.weights(dev)
-        gh = self.gh
         lay = layout.build(pre.n_h, pre.n, pre.L, image_shapes, self.human_idx,
                            faithful_skip_offset=self.faithful_skip_offset)
         A = lay.n_active
         st = _stream()
         f32 = dict(device=dev, dtype=torch.float32)
-        i32 = dict(device=dev, dtype=torch.int32)
         out = dict(layout=lay)
         if pooled.shape[0] != lay.sum_all:
             raise _capi.SkgError("box_roi_pool returned %d rows for %d boxes" % (pooled.shape[0], lay.sum_all))
@@ -274,8 +287,48 @@ class HeadEngine:
         out["gfeat"] = gfeat
         if A == 0:
             return out
-        # ---- small host-built index arrays: one upload
-        buf, offs = layout.pack_int_arrays(lay)
+        G1 = torch.empty(Bf, 1024, **f32)                       # attention_head_g fc_1(global) per image (HEAD:971)
+        gemm(gfeat, pw.att_g["w1"], pw.att_g["b1"], G1, Bf, 1024, Cf, _capi.EPI_BIAS)
+        Mp = lay.sum_p
+        meta_g = torch.from_numpy(lay.meta.view(np.int32).reshape(-1).copy()).to(dev, non_blocking=True)
+        x_keep = torch.empty(max(Mp, 1), device=dev, dtype=torch.int64); y_keep = torch.empty_like(x_keep)
+        PF = torch.empty(max(Mp, 1), 2048, **f32)
+        sc = torch.empty(max(Mp, 1), self.K, **f32) if want_scores else None
+        keep = {} if self.debug else None
+        tabs = []
+        step = max(int(self.chunk_images), 1)
+        for a0 in range(0, A, step):
+            ch = layout.chunk(lay, a0, min(A, a0 + step))
+
+            def draw(n, a0=a0):
+                if tables is None:
+                    t = transh.draw_batch(self.K, n, need_relations=want_scores, pin=True)
+                else:
+                    t = tuple(None if x is None else x[a0:a0 + n] for x in tables)
+                tabs.append(t)
+                return t
+
+            self._graph_chunk(ch, pw, pre, enc, G1, draw, x_keep, y_keep, PF, sc, keep)
+        out.update(x_keep=x_keep[:Mp], y_keep=y_keep[:Mp], meta=meta_g, pair_features=PF[:Mp])
+        out["tables"] = tuple(None if tabs[0][i] is None else torch.cat([t[i] for t in tabs]) for i in range(3))
+        if want_scores:
+            out["transh_scores"] = sc[:Mp]
+        if keep is not None:
+            for k, v in keep.items():
+                out[k] = torch.cat(v)
+        return out
+
+    def _graph_chunk(self, ch, pw, pre, enc, G1, draw, x_keep, y_keep, PF, sc, keep):
+        """Pairs, spatial head, message passing and read-out for the active images of one chunk."""
+        lib = _capi.lib()
+        gh = self.gh
+        dev = pre.device
+        st = _stream()
+        f32 = dict(device=dev, dtype=torch.float32)
+        i32 = dict(device=dev, dtype=torch.int32)
+        A = ch.n_active
+        Mh, Mn, Mg, Mp = ch.sum_h, ch.sum_n, ch.sum_g, ch.sum_p
+        buf, offs = layout.pack_int_arrays(ch)
         ibuf = torch.from_numpy(buf).to(dev, non_blocking=True)
 
         def isl(name):
@@ -283,32 +336,33 @@ class HeadEngine:
             return ibuf[o:o + l]
 
         meta = isl("meta")
-        Mh, Mn, Mg, Mp = lay.sum_h, lay.sum_n, lay.sum_g, lay.sum_p
-        # ---- TransH tables: consume the host RNG exactly like the reference
-        if tables is None:
-            ent, rel, nrm = transh.draw_batch(self.K, A, need_relations=want_scores)
-        else:
-            ent, rel, nrm = tables
-        ent_d = ent.to(dev, non_blocking=True).contiguous()
-        out["tables"] = (ent, rel, nrm)
-        # ---- pairs + spatial encoding
+        xk = x_keep[ch.P0:]; yk = y_keep[ch.P0:]               # global arrays, written at the chunk's pair offset
+        # ---- pairs + spatial encoding (no dependence on the TransH tables: enqueued before they are drawn)
         grid_h = torch.empty(Mg, **i32); grid_o = torch.empty(Mg, **i32); grid_pair = torch.empty(Mg, **i32)
         grid_img = torch.empty(Mg, **i32); pair_grid = torch.empty(max(Mp, 1), **i32)
-        x_keep = torch.empty(max(Mp, 1), device=dev, dtype=torch.int64); y_keep = torch.empty_like(x_keep)
         pair_h = torch.empty(max(Mp, 1), **i32); pair_o = torch.empty(max(Mp, 1), **i32)
         sp48 = torch.empty(Mg, _capi.SPATIAL_LD, **f32)
         _capi.check(lib.skg_pairs_spatial_f32(pre.boxes.data_ptr(), meta.data_ptr(), A, grid_h.data_ptr(),
                                               grid_o.data_ptr(), grid_pair.data_ptr(), grid_img.data_ptr(),
-                                              pair_grid.data_ptr(), x_keep.data_ptr(), y_keep.data_ptr(),
+                                              pair_grid.data_ptr(), xk.data_ptr(), yk.data_ptr(),
                                               pair_h.data_ptr(), pair_o.data_ptr(), sp48.data_ptr(), 1, st),
                     "skg_pairs_spatial_f32")
-        out.update(x_keep=x_keep[:Mp], y_keep=y_keep[:Mp], spatial46=sp48, meta=meta, ibuf=ibuf)
         # ---- spatial_head (HEAD:662-669, 888)
         s1 = torch.empty(Mg, 128, **f32); s2 = torch.empty(Mg, 256, **f32); S = torch.empty(Mg, 1024, **f32)
         gemm(sp48, pw.sp0_w, pw.sp0_b, s1, Mg, 128, _capi.SPATIAL_LD, _capi.EPI_BIAS_RELU)
         gemm(s1, pw.sp2_w, pw.sp2_b, s2, Mg, 256, 128, _capi.EPI_BIAS_RELU)
         gemm(s2, pw.sp4_w, pw.sp4_b, S, Mg, 1024, 256, _capi.EPI_BIAS_RELU)
         del s1, s2
+        # ---- global read-out branch: attention_head_g needs only S and the image's global feature (HEAD:971-972)
+        Tg = torch.empty(max(Mp, 1), 1024, **f32)
+        if Mp:
+            gemm(S, pw.att_g["w2"], pw.att_g["b2"], Tg, Mg, 1024, 1024, _capi.EPI_MUL_RELU, P=G1, p_idx=grid_img,
+                 ldp=1024, out_rows=grid_pair)
+            gemm(Tg, pw.att_g["w3"], pw.att_g["b3"], PF, Mp, 1024, 1024, _capi.EPI_BIAS_RELU, ldc=2048,
+                 C_off=ch.P0 * 2048 + 1024)
+        # ---- TransH tables: consume the host RNG exactly like the reference while the GPU works
+        ent, rel, nrm = draw(A)
+        ent_d = ent.to(dev, non_blocking=True)
         F2 = torch.empty(Mg, 1024, **f32)
         if gh.num_iter > 0:
             # ---- fc_head / fc_tail on unique rows (HEAD:884-885)
@@ -357,40 +411,34 @@ class HeadEngine:
                                               EPS_LN, h_node.data_ptr(), 1024, st), "skg_layernorm_f32")
             _capi.check(lib.skg_layernorm_f32(Op.data_ptr(), 1024, pw.no_g.data_ptr(), pw.no_b.data_ptr(), Mn, 1024,
                                               EPS_LN, node.data_ptr(), 1024, st), "skg_layernorm_f32")
-            out.update(adjacency=adj)
         else:
             # num_iter == 0: the raw box_head encodings reach the read-out (HEAD:843-845)
             gemm(S, pw.att["w2"], pw.att["b2"], F2, Mg, 1024, 1024, _capi.EPI_BIAS)
             h_node = enc.index_select(0, isl("hum_enc_row").long())
             node = enc.index_select(0, isl("node_enc_row").long())
-        out.update(h_node=h_node, node=node)
-        # ---- read-out (HEAD:966-973)
-        PF = torch.empty(max(Mp, 1), 2048, **f32)
+            adj = None
+        # ---- read-out attention_head on the kept pairs (HEAD:966-970)
         if Mp:
             B1h = torch.empty(Mh, 1024, **f32); B1o = torch.empty(Mn, 1024, **f32)
             gemm(h_node, pw.att["w1"], None, B1h, Mh, 1024, 1024, _capi.EPI_BIAS, ldw=2048)
             gemm(node, pw.att["w1"], None, B1o, Mn, 1024, 1024, _capi.EPI_BIAS, ldw=2048, W_off=1024)
-            Tp = torch.empty(Mp, 1024, **f32)
+            Tp = Tg                                              # the global branch has consumed this buffer
             _capi.check(lib.skg_rows_mul_relu_f32(B1h.data_ptr(), pair_h.data_ptr(), 1024, B1o.data_ptr(),
                                                   pair_o.data_ptr(), 1024, pw.att["b1"].data_ptr(), F2.data_ptr(),
                                                   pair_grid.data_ptr(), 1024, Mp, 1024, Tp.data_ptr(), 1024, st),
                         "skg_rows_mul_relu_f32")
-            gemm(Tp, pw.att["w3"], pw.att["b3"], PF, Mp, 1024, 1024, _capi.EPI_BIAS_RELU, ldc=2048)
-            G1 = torch.empty(Bf, 1024, **f32)
-            gemm(gfeat, pw.att_g["w1"], pw.att_g["b1"], G1, Bf, 1024, Cf, _capi.EPI_BIAS)
-            Tg = Tp                                                              # reuse the buffer
-            gemm(S, pw.att_g["w2"], pw.att_g["b2"], Tg, Mg, 1024, 1024, _capi.EPI_MUL_RELU, P=G1, p_idx=grid_img,
-                 ldp=1024, out_rows=grid_pair)
-            gemm(Tg, pw.att_g["w3"], pw.att_g["b3"], PF, Mp, 1024, 1024, _capi.EPI_BIAS_RELU, ldc=2048, C_off=1024)
-        out["pair_features"] = PF[:Mp]
-        if want_scores:
-            sc = torch.empty(max(Mp, 1), self.K, **f32)
-            rel_d = rel.to(dev).contiguous(); nrm_d = nrm.to(dev).contiguous()
+            gemm(Tp, pw.att["w3"], pw.att["b3"], PF, Mp, 1024, 1024, _capi.EPI_BIAS_RELU, ldc=2048,
+                 C_off=ch.P0 * 2048)
+        if sc is not None:
+            rel_d = rel.to(dev, non_blocking=True); nrm_d = nrm.to(dev, non_blocking=True)
             _capi.check(lib.skg_transh_scores_f32(ent_d.data_ptr(), rel_d.data_ptr(), nrm_d.data_ptr(), self.K,
-                                                  self.human_idx, meta.data_ptr(), A, sc.data_ptr(), st),
-                        "skg_transh_scores_f32")
-            out["transh_scores"] = sc[:Mp]
-        return out
+                                                  self.human_idx, meta.data_ptr(), A,
+                                                  sc.data_ptr() + 4 * ch.P0 * self.K, st), "skg_transh_scores_f32")
+        if keep is not None:
+            keep.setdefault("spatial46", []).append(sp48)
+            keep.setdefault("h_node", []).append(h_node); keep.setdefault("node", []).append(node)
+            if adj is not None:
+                keep.setdefault("adjacency", []).append(adj)
 
     # ------------------------------------------------------------------------------------------ classifier + scoring
     def classify(self, pair_features):

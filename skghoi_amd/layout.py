@@ -81,6 +81,34 @@ def build(n_h, n, L, image_shapes, human_idx, faithful_skip_offset=True, zip_tru
     return lay
 
 
+class ChunkLayout:
+    pass
+
+
+def chunk(lay, a0, a1):
+    """Sub-layout of active images [a0, a1): node / human / grid / pair offsets are rebased to the chunk (the graph
+    stage works on chunk-local workspaces), box_off / enc_off / image / out_off stay global.  P0 / G0 are the global
+    offsets of the chunk's first kept pair / grid row (outputs are written through views starting there)."""
+    ch = ChunkLayout()
+    meta = lay.meta[a0:a1].copy()
+    ch.P0 = int(meta["pair_off"][0]); ch.G0 = int(meta["grid_off"][0])
+    ch.N0 = int(meta["node_off"][0]); ch.H0 = int(meta["hum_off"][0])
+    meta["pair_off"] -= ch.P0; meta["grid_off"] -= ch.G0; meta["node_off"] -= ch.N0; meta["hum_off"] -= ch.H0
+    ch.meta = meta
+    ch.a0, ch.a1 = a0, a1
+    ch.n_active = a1 - a0
+    an = meta["n"].astype(np.int64); ah = meta["n_h"].astype(np.int64)
+    ch.sum_n = int(an.sum()); ch.sum_h = int(ah.sum())
+    ch.sum_g = int((an * ah).sum()); ch.sum_p = int((ah * (an - 1)).sum())
+    ch.node_img = (lay.node_img[ch.N0:ch.N0 + ch.sum_n] - a0).astype(np.int32)
+    ch.hum_img = (lay.hum_img[ch.H0:ch.H0 + ch.sum_h] - a0).astype(np.int32)
+    ch.node_enc_row = lay.node_enc_row[ch.N0:ch.N0 + ch.sum_n]
+    ch.hum_enc_row = lay.hum_enc_row[ch.H0:ch.H0 + ch.sum_h]
+    ch.node_ent_row = lay.node_ent_row[ch.N0:ch.N0 + ch.sum_n]
+    ch.hum_ent_row = lay.hum_ent_row[ch.H0:ch.H0 + ch.sum_h]
+    return ch
+
+
 def pack_int_arrays(lay):
     """One contiguous int32 host buffer (single H2D copy) + the slices of each array inside it."""
     parts = [("meta", lay.meta.view(np.int32).reshape(-1)), ("node_img", lay.node_img), ("hum_img", lay.hum_img),

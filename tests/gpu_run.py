@@ -48,6 +48,9 @@ def run_head(case, head=None, reference_quirks=True):
     det = to_cuda(case["detections"]); tg = to_cuda(case["targets"])
     feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
     out = {}
+    head.engine().debug = True
+    if "chunk_images" in case:
+        head.engine().chunk_images = case["chunk_images"]
     with torch.no_grad():
         for b, d in enumerate(head.preprocess(det, tg)):
             out["pre%d.boxes" % b] = d["boxes"]; out["pre%d.labels" % b] = d["labels"]; out["pre%d.scores" % b] = d["scores"]

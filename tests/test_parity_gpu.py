@@ -67,6 +67,16 @@ def test_head_matches_oracle_with_fresh_rng(name):
     _check(got, want, name)
 
 
+@pytest.mark.parametrize("chunk", [1, 2])
+def test_chunked_graph_pass_is_equivalent(chunk):
+    """The graph stage walks the active images in chunks (RNG / GPU overlap): any chunking gives the same result."""
+    for name in ("ragged3", "vcoco"):
+        case = cases.build_case(name)
+        case["chunk_images"] = chunk
+        got = gpu_run.run_head(case)
+        _check(got, helpers.load_golden(name), name)
+
+
 def test_eval_skip_quirk_and_sane_mode():
     case = cases.build_case("skips_raise")
     with pytest.raises(IndexError):
@@ -84,6 +94,7 @@ def test_full_size_properties():
     case["detections"] = [dict(boxes=i["boxes"], labels=i["labels"], scores=i["scores"]) for i in imgs]
     case["feat3"] = torch.cat([i["feat3"] for i in imgs]); case["shapes"] = [i["hw"] for i in imgs]
     head = gpu_run.build_head(case)
+    case["chunk_images"] = 3
     got = gpu_run.run_head(case, head=head)
     assert int(got["n_results"]) == 8
     single = dict(case); single["detections"] = case["detections"][:1]; single["feat3"] = case["feat3"][:1]
