@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunk", type=int, default=0, help="override HeadEngine.chunk_images")
+    ap.add_argument("--gemm-table", action="store_true", help="per-shape GEMM timing table on stderr")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,6 +119,8 @@ def main():
     head = build_head(device)
     dets, pooled, feats, shapes = make_inputs(args.batch, rank, device)
     head.box_roi_pool = ResidentPool(pooled)
+    if args.chunk:
+        head.engine().chunk_images = args.chunk
 
     def step():
         with torch.no_grad():
@@ -154,6 +158,14 @@ def main():
     for e0, e1, M, N, K, epi in timer:
         g = groups.setdefault(epi, [0.0, 0.0, 0])
         g[0] += e0.elapsed_time(e1) * 1e-3; g[1] += 2.0 * M * N * K; g[2] += 1
+    if args.gemm_table and rank == 0:
+        tab = {}
+        for e0, e1, M, N, K, epi in timer:
+            g = tab.setdefault((M, N, K, epi), [0.0, 0])
+            g[0] += e0.elapsed_time(e1); g[1] += 1
+        for (M, N, K, epi), (ms, n) in sorted(tab.items(), key=lambda kv: -kv[1][0]):
+            print("M=%7d N=%5d K=%6d epi=%d  n=%3d  total %8.3f ms  avg %7.3f ms  %6.1f TFLOP/s" % (
+                M, N, K, epi, n, ms, ms / n, 2.0 * M * N * K * n / ms / 1e9), file=sys.stderr)
     names = {0: "skg_gemm_kernel<BIAS>", 1: "skg_gemm_kernel<BIAS_RELU>", 2: "skg_gemm_kernel<MUL_RELU>",
              3: "skg_gemm_kernel<RELU_DOT>", 4: "skg_gemm_kernel<BIAS_RES_RELU>"}
     dom = max(groups, key=lambda k: groups[k][0])

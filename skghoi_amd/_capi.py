@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libskghoi_hip.so")
+LIB_PATH = os.environ.get("SKG_LIB") or os.path.join(_HERE, "csrc", "libskghoi_hip.so")   # SKG_LIB: kernel A/B builds
 
 EPI_BIAS, EPI_BIAS_RELU, EPI_MUL_RELU, EPI_RELU_DOT, EPI_BIAS_RES_RELU = range(5)
 MAX_DET_PER_IMAGE = 1024

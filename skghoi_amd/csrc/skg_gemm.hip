@@ -22,13 +22,19 @@
 
 #define BM 128
 #define BN 128
-#define BK 16
-#define LDS_LD 20                       // BK + 4 dwords of padding
+#ifndef SKG_BK
+#define SKG_BK 16
+#endif
+#ifndef SKG_MINW
+#define SKG_MINW 2
+#endif
+#define BK SKG_BK
+#define LDS_LD (BK + 4)                 // + 4 dwords of padding: conflict-free ds_read_b128 at strides 20 and 36
 #define A_TILE (BM * LDS_LD)
 #define B_TILE (BN * LDS_LD)
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void skg_gemm_kernel(const skg_gemm_desc d) {
+__global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_kernel(const skg_gemm_desc d) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
 
     const int tid = threadIdx.x;
@@ -43,19 +49,22 @@ __global__ __launch_bounds__(256, 2) void skg_gemm_kernel(const skg_gemm_desc d)
     const int m0 = bm * BM, n0 = bn * BN;
 
     // ---- global -> register staging map: thread owns rows (lr, lr+64) x 4 consecutive k
-    const int lr = tid >> 2;
-    const int lc = (tid & 3) * 4;
-    const float* pa[2];
-    const float* pw[2];
-    bool va[2], vw[2];
+    constexpr int TPR = BK / 4;                  // threads per tile row (float4 each)
+    constexpr int RPP = 256 / TPR;               // rows per staging pass
+    constexpr int NPASS = BM / RPP;
+    const int lr = tid / TPR;
+    const int lc = (tid % TPR) * 4;
+    const float* pa[NPASS];
+    const float* pw[NPASS];
+    bool va[NPASS], vw[NPASS];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = m0 + lr + 64 * i;
+    for (int i = 0; i < NPASS; ++i) {
+        const int r = m0 + lr + RPP * i;
         int src = -1;
         if (r < d.M) src = d.a_rows ? d.a_rows[r] : r;
         va[i] = src >= 0;
         pa[i] = d.A + (int64_t)(va[i] ? src : 0) * d.lda;       // always a readable row; masked after the load
-        const int c = n0 + lr + 64 * i;
+        const int c = n0 + lr + RPP * i;
         vw[i] = c < d.N;
         pw[i] = d.W + (int64_t)(vw[i] ? c : 0) * d.ldw;
     }
@@ -69,49 +78,62 @@ __global__ __launch_bounds__(256, 2) void skg_gemm_kernel(const skg_gemm_desc d)
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     const int nk = (d.K + BK - 1) / BK;
-    float4 ra[2], rw[2];
+    float4 ra[NPASS], rw[NPASS];
 
+    // Loads are unconditional (addresses are clamped to readable rows / k); rows past M or N and the K tail are
+    // zeroed with selects when the tile is written to LDS, AFTER the MFMAs of the current tile.  (A select next to the
+    // load makes hipcc branch around it and wait vmcnt(0) per load, which serialises the whole prefetch.)
     auto gload = [&](int kt) {
         const int k = kt * BK + lc;
-        const bool kin = k < d.K;
-        const int kk = kin ? k : 0;
+        const int kk = (k < d.K) ? k : 0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float4 x = *reinterpret_cast<const float4*>(pa[i] + kk);
-            float4 w = *reinterpret_cast<const float4*>(pw[i] + kk);
-            if (!(kin && va[i])) x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!(kin && vw[i])) w = make_float4(0.f, 0.f, 0.f, 0.f);
-            ra[i] = x;
-            rw[i] = w;
+        for (int i = 0; i < NPASS; ++i) {
+            ra[i] = *reinterpret_cast<const float4*>(pa[i] + kk);
+            rw[i] = *reinterpret_cast<const float4*>(pw[i] + kk);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, int kt) {
         float* a_s = smem + buf * A_TILE;
         float* b_s = smem + 2 * A_TILE + buf * B_TILE;
+        const bool kin = kt * BK + lc < d.K;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<float4*>(a_s + (lr + 64 * i) * LDS_LD + lc) = ra[i];
-            *reinterpret_cast<float4*>(b_s + (lr + 64 * i) * LDS_LD + lc) = rw[i];
+        for (int i = 0; i < NPASS; ++i) {
+            const bool ma = kin && va[i], mw = kin && vw[i];
+            const float4 x = ra[i], w = rw[i];
+            *reinterpret_cast<float4*>(a_s + (lr + RPP * i) * LDS_LD + lc) =
+                make_float4(ma ? x.x : 0.f, ma ? x.y : 0.f, ma ? x.z : 0.f, ma ? x.w : 0.f);
+            *reinterpret_cast<float4*>(b_s + (lr + RPP * i) * LDS_LD + lc) =
+                make_float4(mw ? w.x : 0.f, mw ? w.y : 0.f, mw ? w.z : 0.f, mw ? w.w : 0.f);
         }
     };
 
     gload(0);
-    lstore(0);
+    lstore(0, 0);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
+#if !defined(SKG_ABL) || SKG_ABL == 1
         if (kt + 1 < nk) gload(kt + 1);
+#endif
         const float* a_s = smem + cur * A_TILE + (wr * 64 + li) * LDS_LD + 4 * lh;
         const float* b_s = smem + 2 * A_TILE + cur * B_TILE + (wc * 64 + li) * LDS_LD + 4 * lh;
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) {
             float4 a[2], b[2];
+#if defined(SKG_ABL) && (SKG_ABL == 1 || SKG_ABL == 3)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {       // ablation: operands from registers, no LDS reads
+                a[i] = make_float4(ra[0].x + i, ra[0].y, ra[1].z, ra[1].w + ks);
+                b[i] = make_float4(rw[0].x + i, rw[0].y, rw[1].z, rw[1].w + ks);
+            }
+#else
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 a[i] = *reinterpret_cast<const float4*>(a_s + i * 32 * LDS_LD + ks * 8);
                 b[i] = *reinterpret_cast<const float4*>(b_s + i * 32 * LDS_LD + ks * 8);
             }
+#endif
             const float av[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
             const float bv[2][4] = {{b[0].x, b[0].y, b[0].z, b[0].w}, {b[1].x, b[1].y, b[1].z, b[1].w}};
 #pragma unroll
@@ -122,8 +144,14 @@ __global__ __launch_bounds__(256, 2) void skg_gemm_kernel(const skg_gemm_desc d)
                     for (int ni = 0; ni < 2; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][t], bv[ni][t], acc[mi][ni], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);              // keep the staging writes (and their vmcnt wait) below the MFMAs
+#if !defined(SKG_ABL)
+        if (kt + 1 < nk) lstore(cur ^ 1, kt + 1);
         __syncthreads();
+#elif SKG_ABL == 1
+        if (kt + 1 < nk) lstore(cur ^ 1, kt + 1);
+        __syncthreads();
+#endif
     }
 
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
