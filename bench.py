@@ -167,7 +167,7 @@ def main():
             print("M=%7d N=%5d K=%6d epi=%d  n=%3d  total %8.3f ms  avg %7.3f ms  %6.1f TFLOP/s" % (
                 M, N, K, epi, n, ms, ms / n, 2.0 * M * N * K * n / ms / 1e9), file=sys.stderr)
     names = {0: "skg_gemm_kernel<BIAS>", 1: "skg_gemm_kernel<BIAS_RELU>", 2: "skg_gemm_kernel<MUL_RELU>",
-             3: "skg_gemm_kernel<RELU_DOT>", 4: "skg_gemm_kernel<BIAS_RES_RELU>"}
+             3: "skg_gemm_kernel<RELU_DOT>", 4: "skg_gemm_kernel<BIAS_RES_RELU>", 5: "skg_gemm_group_kernel"}
     dom = max(groups, key=lambda k: groups[k][0])
     t_dom, f_dom, n_dom = groups[dom]
     t_all = sum(g[0] for g in groups.values()); f_all = sum(g[1] for g in groups.values())

@@ -125,6 +125,12 @@ typedef struct {
 
 int skg_gemm_f32(const skg_gemm_desc* desc_host, void* stream);
 
+/* Up to SKG_GEMM_GROUP_MAX independent GEMMs in one launch (the node-row GEMMs of the graph: fc_head | fc_tail,
+ * the four fc_1 projections, the two message fc_3, HEAD:884-885, 894-896, 514-524); epilogues BIAS / BIAS_RELU /
+ * BIAS_RES_RELU / MUL_RELU / RELU_DOT are selected per descriptor at run time. */
+#define SKG_GEMM_GROUP_MAX 4
+int skg_gemm_group_f32(const skg_gemm_desc* descs_host, int n, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * fc_head / fc_tail input rows (HEAD:884-885): out[r] = [ enc[enc_row[r], 0:1024] | ent[ent_img[r], ent_row[r], 0:50]
  * | zeros ] with out_ld = 1088.  ent = per-image TransH entity tables [n_img, 80, 50] (HEAD:574-580; SURVEY Q3:

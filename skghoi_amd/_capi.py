@@ -13,6 +13,7 @@ SPATIAL_LD = 48
 TRANSH_DIM = 50
 TRANSH_ENT = 80
 ABI_VERSION = 1
+GEMM_GROUP_MAX = 4
 
 _vp = C.c_void_p
 _i32 = C.c_int32
@@ -44,6 +45,7 @@ PROTOTYPES = {
                                         _vp]),
     "skg_global_avgpool_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "skg_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "skg_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
     "skg_concat_entity_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, C.c_int, _vp, _i64, _vp]),
     "skg_rows_mul_relu_f32": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp,
                                         _i64, _vp]),

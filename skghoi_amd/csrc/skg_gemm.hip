@@ -33,10 +33,10 @@
 #define A_TILE (BM * LDS_LD)
 #define B_TILE (BN * LDS_LD)
 
-template <int EPI>
-__global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_kernel(const skg_gemm_desc d) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
-
+// EPI >= 0: epilogue fixed at compile time; EPI < 0: taken from the descriptor (grouped launches of small GEMMs).
+template <int EPI_T>
+__device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, const int block_id, float* smem) {
+    const int EPI = EPI_T >= 0 ? EPI_T : d.epilogue;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = tid >> 6;
@@ -44,8 +44,17 @@ __global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_kernel(const skg_gemm_
     const int li = lane & 31, lh = lane >> 5;
 
     const int nbn = (d.N + BN - 1) / BN;
-    const int bn = blockIdx.x % nbn;
-    const int bm = blockIdx.x / nbn;
+#if defined(SKG_MAP) && SKG_MAP == 1
+    // experiment: XCD pairs share an N half (4 N-tiles = 2 MiB of W at K = 1024), the A panel is read by 2 XCDs not 8
+    const int nbm_ = (d.M + BM - 1) / BM;
+    const int xcd = block_id & 7, slot = block_id >> 3;
+    const int bn = (xcd & 1) * 4 + (slot & 3);
+    const int bm = (slot >> 2) * 4 + (xcd >> 1);
+    if (bm >= nbm_) return;
+#else
+    const int bn = block_id % nbn;
+    const int bm = block_id / nbn;
+#endif
     const int m0 = bm * BM, n0 = bn * BN;
 
     // ---- global -> register staging map: thread owns rows (lr, lr+64) x 4 consecutive k
@@ -217,11 +226,31 @@ __global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_kernel(const skg_gemm_
     }
 }
 
-extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
-    if (!dh) return SKG_E_ARG;
-    const skg_gemm_desc d = *dh;
+template <int EPI>
+__global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_kernel(const skg_gemm_desc d) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
+    skg_gemm_tile<EPI>(d, blockIdx.x, smem);
+}
+
+// Several independent small GEMMs in ONE launch (node-row GEMMs with M = sum n_h or sum n fill a fraction of the 256
+// CUs each; grouped they run side by side).  Block ranges: [start[g], start[g+1]).
+struct skg_gemm_group_args {
+    skg_gemm_desc d[SKG_GEMM_GROUP_MAX];
+    int start[SKG_GEMM_GROUP_MAX + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_group_kernel(const skg_gemm_group_args g) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
+    int k = 0;
+#pragma unroll
+    for (int t = 1; t < SKG_GEMM_GROUP_MAX; ++t)
+        if (t < g.n && (int)blockIdx.x >= g.start[t]) k = t;
+    skg_gemm_tile<-1>(g.d[k], blockIdx.x - g.start[k], smem);
+}
+
+static int skg_gemm_validate(const skg_gemm_desc& d) {
     if (d.M < 0 || d.N <= 0 || d.K <= 0 || !d.A || !d.W) return SKG_E_ARG;
-    if (d.M == 0) return 0;
     if ((d.K & 3) || (d.lda & 3) || (d.ldw & 3)) return SKG_E_ALIGN;
     if (!skg_aligned16(d.A) || !skg_aligned16(d.W)) return SKG_E_ALIGN;
     if (d.lda < d.K && !d.a_rows && d.M > 1) return SKG_E_ARG;
@@ -236,9 +265,45 @@ extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
             if (!d.C || !d.res) return SKG_E_ARG; break;
         default: return SKG_E_ARG;
     }
+    return 0;
+}
+
+extern "C" int skg_gemm_group_f32(const skg_gemm_desc* descs_host, int n, void* stream) {
+    if (!descs_host || n < 1 || n > SKG_GEMM_GROUP_MAX) return SKG_E_ARG;
+    skg_gemm_group_args g;
+    g.n = 0;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rc = skg_gemm_validate(descs_host[i]);
+        if (rc) return rc;
+        if (descs_host[i].M == 0) continue;
+        const int64_t nb = (int64_t)((descs_host[i].M + BM - 1) / BM) * ((descs_host[i].N + BN - 1) / BN);
+        if (blocks + nb > 0x7fffffffLL) return SKG_E_LIMIT;
+        g.d[g.n] = descs_host[i];
+        g.start[g.n] = blocks;
+        blocks += (int)nb;
+        ++g.n;
+    }
+    if (g.n == 0) return 0;
+    for (int i = g.n; i <= SKG_GEMM_GROUP_MAX; ++i) g.start[i] = blocks;
+    hipLaunchKernelGGL(skg_gemm_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+    return skg_launch_status();
+}
+
+extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
+    if (!dh) return SKG_E_ARG;
+    const skg_gemm_desc d = *dh;
+    const int rc = skg_gemm_validate(d);
+    if (rc) return rc;
+    if (d.M == 0) return 0;
     const int64_t nbm = (d.M + BM - 1) / BM, nbn = (d.N + BN - 1) / BN;
     if (nbm * nbn > 0x7fffffffLL) return SKG_E_LIMIT;
+#if defined(SKG_MAP) && SKG_MAP == 1
+    if (nbn != 8) return SKG_E_ARG;
+    dim3 grid((unsigned)(((nbm + 3) / 4) * 4 * 8)), block(256);
+#else
     dim3 grid((unsigned)(nbm * nbn)), block(256);
+#endif
     hipStream_t s = (hipStream_t)stream;
     switch (d.epilogue) {
         case SKG_EPI_BIAS:          hipLaunchKernelGGL(skg_gemm_kernel<SKG_EPI_BIAS>, grid, block, 0, s, d); break;

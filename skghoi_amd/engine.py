@@ -114,11 +114,11 @@ class VerbTable:
         self.flat = torch.from_numpy(flat).to(device)
 
 
-def gemm(A, W, bias, C_out, M, N, K, epilogue, lda=None, ldw=None, ldc=None, a_rows=None, out_rows=None, P=None,
-         p_idx=None, ldp=0, Q=None, q_idx=None, ldq=0, mbias=None, C_raw=None, ldc_raw=0, dot_w=None,
-         dot_partial=None, res=None, ldres=0, A_off=0, W_off=0, C_off=0):
-    """One skg_gemm_f32 launch.  *_off are element offsets into A / W / C (column sub-views)."""
-    d = _capi.GemmDesc()
+def gemm_desc(A, W, bias, C_out, M, N, K, epilogue, lda=None, ldw=None, ldc=None, a_rows=None, out_rows=None, P=None,
+              p_idx=None, ldp=0, Q=None, q_idx=None, ldq=0, mbias=None, C_raw=None, ldc_raw=0, dot_w=None,
+              dot_partial=None, res=None, ldres=0, A_off=0, W_off=0, C_off=0, d=None):
+    """Fills a skg_gemm_desc.  *_off are element offsets into A / W / C (column sub-views)."""
+    d = _capi.GemmDesc() if d is None else d
     d.A = A.data_ptr() + 4 * A_off; d.lda = lda if lda is not None else A.stride(0)
     d.W = W.data_ptr() + 4 * W_off; d.ldw = ldw if ldw is not None else W.stride(0)
     d.bias = _ptr(bias)
@@ -131,6 +131,12 @@ def gemm(A, W, bias, C_out, M, N, K, epilogue, lda=None, ldw=None, ldc=None, a_r
     d.mbias = _ptr(mbias); d.C_raw = _ptr(C_raw); d.ldc_raw = ldc_raw
     d.dot_w = _ptr(dot_w); d.dot_partial = _ptr(dot_partial)
     d.res = _ptr(res); d.ldres = ldres
+    return d
+
+
+def gemm(A, W, bias, C_out, M, N, K, epilogue, **kw):
+    """One skg_gemm_f32 launch (see gemm_desc for the keywords)."""
+    d = gemm_desc(A, W, bias, C_out, M, N, K, epilogue, **kw)
     if GEMM_TIMER is not None:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -138,6 +144,23 @@ def gemm(A, W, bias, C_out, M, N, K, epilogue, lda=None, ldw=None, ldc=None, a_r
     if GEMM_TIMER is not None:
         e1.record()
         GEMM_TIMER.append((e0, e1, M, N, K, epilogue))
+
+
+def gemm_group(specs):
+    """Independent small GEMMs in one launch: specs = [(args, kwargs), ...] as for gemm()."""
+    n = len(specs)
+    arr = (_capi.GemmDesc * n)()
+    flops = 0.0
+    for i, (a, kw) in enumerate(specs):
+        gemm_desc(*a, d=arr[i], **kw)
+        flops += 2.0 * a[4] * a[5] * a[6]
+    if GEMM_TIMER is not None:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _capi.check(_capi.lib().skg_gemm_group_f32(arr, n, _stream()), "skg_gemm_group_f32[%d]" % n)
+    if GEMM_TIMER is not None:
+        e1.record()
+        GEMM_TIMER.append((e0, e1, int(flops // 2), 1, 1, 5))       # epilogue id 5 = grouped launch
 
 
 class Preprocessed:
@@ -158,7 +181,7 @@ class HeadEngine:
         self.max_human = int(max_human)
         self.max_object = int(max_object)
         self.faithful_skip_offset = faithful_skip_offset
-        self.chunk_images = 64      # active images per graph chunk (RNG/GPU overlap + cache-sized intermediates)
+        self.chunk_images = 128     # active images per graph chunk (RNG/GPU overlap + cache-sized intermediates)
         self.debug = False          # keep per-chunk intermediates (spatial46, h_node, node, adjacency) in graph()
         self._plist = None
         self._pw = None
@@ -374,16 +397,16 @@ class HeadEngine:
                                                   eimg.data_ptr(), erow.data_ptr(), Mh + Mn, X.data_ptr(), 1088, st),
                         "skg_concat_entity_f32")
             GH = torch.empty(Mh, 1024, **f32); GO = torch.empty(Mn, 1024, **f32)
-            gemm(X, pw.fh_w, pw.fh_b, GH, Mh, 1024, 1088, _capi.EPI_BIAS_RELU)
-            gemm(X, pw.ft_w, pw.ft_b, GO, Mn, 1024, 1088, _capi.EPI_BIAS_RELU, A_off=Mh * 1088)
+            gemm_group([((X, pw.fh_w, pw.fh_b, GH, Mh, 1024, 1088, _capi.EPI_BIAS_RELU), {}),
+                        ((X, pw.ft_w, pw.ft_b, GO, Mn, 1024, 1088, _capi.EPI_BIAS_RELU), dict(A_off=Mh * 1088))])
             # ---- attention_head fc_1, separable over [human | object] halves (HEAD:894-896)
             A1h = torch.empty(Mh, 1024, **f32); A1o = torch.empty(Mn, 1024, **f32)
-            gemm(GH, pw.att["w1"], None, A1h, Mh, 1024, 1024, _capi.EPI_BIAS, ldw=2048)
-            gemm(GO, pw.att["w1"], None, A1o, Mn, 1024, 1024, _capi.EPI_BIAS, ldw=2048, W_off=1024)
             # message fc_1 on node rows (HEAD:514, 524)
             C1o = torch.empty(Mn, 1024, **f32); C1h = torch.empty(Mh, 1024, **f32)
-            gemm(GO, pw.os["w1"], pw.os["b1"], C1o, Mn, 1024, 1024, _capi.EPI_BIAS)
-            gemm(GH, pw.so["w1"], pw.so["b1"], C1h, Mh, 1024, 1024, _capi.EPI_BIAS)
+            gemm_group([((GH, pw.att["w1"], None, A1h, Mh, 1024, 1024, _capi.EPI_BIAS), dict(ldw=2048)),
+                        ((GO, pw.att["w1"], None, A1o, Mn, 1024, 1024, _capi.EPI_BIAS), dict(ldw=2048, W_off=1024)),
+                        ((GO, pw.os["w1"], pw.os["b1"], C1o, Mn, 1024, 1024, _capi.EPI_BIAS), {}),
+                        ((GH, pw.so["w1"], pw.so["b1"], C1h, Mh, 1024, 1024, _capi.EPI_BIAS), {})])
             # ---- fc_2 GEMMs over the grid rows with the fc_1*fc_2 -> ReLU product fused
             T = torch.empty(Mg, 1024, **f32); Tos = torch.empty(Mg, 1024, **f32); Tso = torch.empty(Mg, 1024, **f32)
             gemm(S, pw.att["w2"], pw.att["b2"], T, Mg, 1024, 1024, _capi.EPI_MUL_RELU, P=A1h, p_idx=grid_h, ldp=1024,
@@ -404,8 +427,10 @@ class HeadEngine:
                         "skg_graph_aggregate_f32")
             del T, Tos, Tso
             Hp = torch.empty(Mh, 1024, **f32); Op = torch.empty(Mn, 1024, **f32)
-            gemm(U, pw.os["w3"], pw.os["b3"], Hp, Mh, 1024, 1024, _capi.EPI_BIAS_RES_RELU, res=GH, ldres=1024)
-            gemm(V, pw.so["w3"], pw.so["b3"], Op, Mn, 1024, 1024, _capi.EPI_BIAS_RES_RELU, res=GO, ldres=1024)
+            gemm_group([((U, pw.os["w3"], pw.os["b3"], Hp, Mh, 1024, 1024, _capi.EPI_BIAS_RES_RELU),
+                         dict(res=GH, ldres=1024)),
+                        ((V, pw.so["w3"], pw.so["b3"], Op, Mn, 1024, 1024, _capi.EPI_BIAS_RES_RELU),
+                         dict(res=GO, ldres=1024))])
             h_node = torch.empty(Mh, 1024, **f32); node = torch.empty(Mn, 1024, **f32)
             _capi.check(lib.skg_layernorm_f32(Hp.data_ptr(), 1024, pw.nh_g.data_ptr(), pw.nh_b.data_ptr(), Mh, 1024,
                                               EPS_LN, h_node.data_ptr(), 1024, st), "skg_layernorm_f32")
@@ -420,8 +445,8 @@ class HeadEngine:
         # ---- read-out attention_head on the kept pairs (HEAD:966-970)
         if Mp:
             B1h = torch.empty(Mh, 1024, **f32); B1o = torch.empty(Mn, 1024, **f32)
-            gemm(h_node, pw.att["w1"], None, B1h, Mh, 1024, 1024, _capi.EPI_BIAS, ldw=2048)
-            gemm(node, pw.att["w1"], None, B1o, Mn, 1024, 1024, _capi.EPI_BIAS, ldw=2048, W_off=1024)
+            gemm_group([((h_node, pw.att["w1"], None, B1h, Mh, 1024, 1024, _capi.EPI_BIAS), dict(ldw=2048)),
+                        ((node, pw.att["w1"], None, B1o, Mn, 1024, 1024, _capi.EPI_BIAS), dict(ldw=2048, W_off=1024))])
             Tp = Tg                                              # the global branch has consumed this buffer
             _capi.check(lib.skg_rows_mul_relu_f32(B1h.data_ptr(), pair_h.data_ptr(), 1024, B1o.data_ptr(),
                                                   pair_o.data_ptr(), 1024, pw.att["b1"].data_ptr(), F2.data_ptr(),

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from skghoi_amd import _capi
-from skghoi_amd.engine import gemm, _stream
+from skghoi_amd.engine import gemm, gemm_group, _stream
 
 pytestmark = pytest.mark.gpu
 
@@ -96,6 +96,25 @@ def test_gemm_relu_dot_and_residual_epilogues():
     C = torch.empty(M, N, device="cuda")
     gemm(A, W, b, C, M, N, K, _capi.EPI_BIAS_RES_RELU, res=res, ldres=N)
     _close(C, (res.double() + v).float(), 2e-5)
+
+
+def test_gemm_group_matches_single_launches():
+    K = 256
+    specs, refs, outs = [], [], []
+    for i, (M, N, epi) in enumerate([(70, 1024, _capi.EPI_BIAS), (300, 256, _capi.EPI_BIAS_RELU),
+                                     (129, 1024, _capi.EPI_BIAS_RES_RELU), (5, 118, _capi.EPI_BIAS)]):
+        A = _rand(M, K, seed=10 + i); W = _rand(N, K, seed=20 + i) / 16; b = _rand(N, seed=30 + i)
+        res = _rand(M, N, seed=40 + i)
+        C = torch.empty(M, N, device="cuda")
+        kw = dict(res=res, ldres=N) if epi == _capi.EPI_BIAS_RES_RELU else {}
+        specs.append(((A, W, b, C, M, N, K, epi), kw)); outs.append(C)
+        v = A.double() @ W.double().t() + b.double()
+        refs.append({_capi.EPI_BIAS: v, _capi.EPI_BIAS_RELU: torch.relu(v),
+                     _capi.EPI_BIAS_RES_RELU: res.double() + torch.relu(v)}[epi].float())
+    gemm_group(specs)
+    torch.cuda.synchronize()
+    for C, r in zip(outs, refs):
+        _close(C, r, 2e-5)
 
 
 def test_layernorm_avgpool_rowsmul():
