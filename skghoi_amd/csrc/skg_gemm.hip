@@ -33,6 +33,25 @@
 #define A_TILE (BM * LDS_LD)
 #define B_TILE (BN * LDS_LD)
 
+// g = N-tiles per group (W slice <= 2 MiB), NG = number of groups rounded up to a power of two.
+__host__ __device__ __forceinline__ void skg_gemm_map(int nbn, int K, int& g, int& NG) {
+    g = 4096 / (K > 0 ? K : 1);
+    if (g < 1) g = 1;
+    if (g > nbn) g = nbn;
+    const int ng = (nbn + g - 1) / g;
+    NG = 1;
+    while (NG < ng) NG <<= 1;
+}
+
+static inline int64_t skg_gemm_blocks(int M, int N, int K) {
+    const int64_t nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
+    int g, NG;
+    skg_gemm_map((int)nbn, K, g, NG);
+    if (NG >= 8) return nbm * nbn;
+    const int XG = 8 / NG;
+    return 8LL * g * ((nbm + XG - 1) / XG);
+}
+
 // EPI >= 0: epilogue fixed at compile time; EPI < 0: taken from the descriptor (grouped launches of small GEMMs).
 template <int EPI_T>
 __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, const int block_id, float* smem) {
@@ -43,18 +62,29 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, const int 
     const int wr = wid >> 1, wc = wid & 1;
     const int li = lane & 31, lh = lane >> 5;
 
+    // ---- block -> tile map (speed only; correctness never depends on block placement).
+    // Blocks are dealt round-robin over the 8 XCDs (observed), each XCD has a private 4 MiB L2.  The N-tiles are cut
+    // into NG groups whose W slice (g tiles x 128 x K x 4 B) fits in ~2 MiB; XG = 8 / NG XCDs serve one group and
+    // split the M-tiles between them.  Inside an XCD consecutive blocks walk the g N-tiles of ONE M-tile, so the A
+    // panel is fetched from HBM by NG XCDs (not 8) and W stays L2-resident.
     const int nbn = (d.N + BN - 1) / BN;
-#if defined(SKG_MAP) && SKG_MAP == 1
-    // experiment: XCD pairs share an N half (4 N-tiles = 2 MiB of W at K = 1024), the A panel is read by 2 XCDs not 8
-    const int nbm_ = (d.M + BM - 1) / BM;
-    const int xcd = block_id & 7, slot = block_id >> 3;
-    const int bn = (xcd & 1) * 4 + (slot & 3);
-    const int bm = (slot >> 2) * 4 + (xcd >> 1);
-    if (bm >= nbm_) return;
-#else
-    const int bn = block_id % nbn;
-    const int bm = block_id / nbn;
-#endif
+    const int nbm = (d.M + BM - 1) / BM;
+    int bm, bn;
+    {
+        int g, NG;
+        skg_gemm_map(nbn, d.K, g, NG);
+        if (NG >= 8) {
+            bn = block_id % nbn;
+            bm = block_id / nbn;
+        } else {
+            const int XG = 8 / NG;
+            const int xcd = block_id & 7, slot = block_id >> 3;
+            const int ng = xcd % NG, mg = xcd / NG;
+            bn = ng * g + slot % g;
+            bm = (slot / g) * XG + mg;
+            if (bn >= nbn || bm >= nbm) return;
+        }
+    }
     const int m0 = bm * BM, n0 = bn * BN;
 
     // ---- global -> register staging map: thread owns rows (lr, lr+64) x 4 consecutive k
@@ -277,7 +307,7 @@ extern "C" int skg_gemm_group_f32(const skg_gemm_desc* descs_host, int n, void* 
         const int rc = skg_gemm_validate(descs_host[i]);
         if (rc) return rc;
         if (descs_host[i].M == 0) continue;
-        const int64_t nb = (int64_t)((descs_host[i].M + BM - 1) / BM) * ((descs_host[i].N + BN - 1) / BN);
+        const int64_t nb = skg_gemm_blocks(descs_host[i].M, descs_host[i].N, descs_host[i].K);
         if (blocks + nb > 0x7fffffffLL) return SKG_E_LIMIT;
         g.d[g.n] = descs_host[i];
         g.start[g.n] = blocks;
@@ -296,14 +326,9 @@ extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
     const int rc = skg_gemm_validate(d);
     if (rc) return rc;
     if (d.M == 0) return 0;
-    const int64_t nbm = (d.M + BM - 1) / BM, nbn = (d.N + BN - 1) / BN;
-    if (nbm * nbn > 0x7fffffffLL) return SKG_E_LIMIT;
-#if defined(SKG_MAP) && SKG_MAP == 1
-    if (nbn != 8) return SKG_E_ARG;
-    dim3 grid((unsigned)(((nbm + 3) / 4) * 4 * 8)), block(256);
-#else
-    dim3 grid((unsigned)(nbm * nbn)), block(256);
-#endif
+    const int64_t nblk = skg_gemm_blocks(d.M, d.N, d.K);
+    if (nblk > 0x7fffffffLL) return SKG_E_LIMIT;
+    dim3 grid((unsigned)nblk), block(256);
     hipStream_t s = (hipStream_t)stream;
     switch (d.epilogue) {
         case SKG_EPI_BIAS:          hipLaunchKernelGGL(skg_gemm_kernel<SKG_EPI_BIAS>, grid, block, 0, s, d); break;
