@@ -146,11 +146,9 @@ def main():
     elapsed = time.perf_counter() - t0
     timer, engine.GEMM_TIMER = engine.GEMM_TIMER, None
 
-    if dist_on:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    total_images = args.batch * args.steps * world
+    from skghoi_amd import dist as skd
+    elapsed = skd.max_over_ranks(elapsed, device=device)
+    total_images = sum(skd.gather_counts(args.batch * args.steps, device=device))
     value = total_images / elapsed
 
     # ---- roofline of the dominant kernel: per-launch HIP-event durations, grouped by kernel instance (epilogue)
