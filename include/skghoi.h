@@ -139,6 +139,10 @@ int skg_concat_entity_f32(const float* enc, int64_t ld_enc, const int32_t* enc_r
                           const int32_t* ent_img, const int32_t* ent_row, int rows, float* out, int64_t out_ld,
                           void* stream);
 
+/* out[c, r] = in[r, c]  (rows x cols -> cols x rows, ld_out >= rows).  The backward GEMMs of the training step reuse
+ * skg_gemm_f32 (both operands k-contiguous): dA = dZ (W^T)^T needs W^T, dW = dZ^T A needs dZ^T and A^T. */
+int skg_transpose_f32(const float* in, int64_t ld_in, int rows, int cols, float* out, int64_t ld_out, void* stream);
+
 /* out[r] = relu((P[pi[r]] + Q[qi[r]] + mbias) * F[fi[r]])  over `cols` columns (read-out MBF fc_1*fc_2, HEAD:970).  */
 int skg_rows_mul_relu_f32(const float* P, const int32_t* p_idx, int64_t ldp, const float* Q, const int32_t* q_idx,
                           int64_t ldq, const float* mbias, const float* F, const int32_t* f_idx, int64_t ldf,

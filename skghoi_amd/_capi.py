@@ -46,6 +46,7 @@ PROTOTYPES = {
     "skg_global_avgpool_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "skg_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "skg_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
+    "skg_transpose_f32": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _vp, _i64, _vp]),
     "skg_concat_entity_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, C.c_int, _vp, _i64, _vp]),
     "skg_rows_mul_relu_f32": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp,
                                         _i64, _vp]),

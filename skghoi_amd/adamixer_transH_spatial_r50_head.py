@@ -175,11 +175,12 @@ class GraphHead(Module):
                 box_coords: List[Tensor], box_labels: List[Tensor], box_scores: List[Tensor],
                 targets: Optional[List[dict]] = None):
         """HEAD:769-993 with the reference's list-of-tensors interface (8 lists in eval, 12 in training)."""
-        if self.training:
-            assert targets is not None, "Targets should be passed during training"
-            raise NotImplementedError("training forward of GraphHead is not part of this build yet")
         eng = self._own_engine()
         pre = _pre_from_lists(box_coords, box_labels, box_scores, self.human_idx)
+        if self.training:
+            assert targets is not None, "Targets should be passed during training"
+            from skghoi_amd.train_graph import graph_train
+            return graph_train(eng, self, features["3"], image_shapes, box_features, pre, targets)[0]
         g = eng.graph(features["3"], image_shapes, box_features, pre, training=False)
         return _graph_lists(self, eng, pre, g)
 
@@ -311,7 +312,7 @@ class InteractionHead(Module):
                 targets: Optional[List[dict]] = None) -> List[dict]:
         if self.training:
             assert targets is not None, "Targets should be passed during training"
-            raise NotImplementedError("the training step (HEAD:153-235, 933-963) is not part of this build yet")
+            return self._forward_train(features, detections, image_shapes, targets)
         eng = self.engine()
         pre = eng.preprocess(detections, targets, False, False)
         box_coords = list(pre.boxes.split(pre.sizes))
@@ -329,6 +330,70 @@ class InteractionHead(Module):
             r = None
             eng.last = dict(g)
         return self._results(lay, r, dev)
+
+    # ------------------------------------------------------------------------------------------ training (HEAD:380-429)
+    def _forward_train(self, features, detections, image_shapes, targets):
+        from skghoi_amd.autograd import linear
+        from skghoi_amd.train_graph import graph_train
+        eng = self.engine()
+        pre = eng.preprocess(detections, targets, True, True)
+        box_coords = list(pre.boxes.split(pre.sizes))
+        box_features = self.box_roi_pool(features, box_coords, image_shapes)
+        (feats, bh, bo, oc, labels, prior, pos, neg, he, te, re, rn), lay = graph_train(
+            eng, self.box_pair_head, features["3"], image_shapes, box_features, pre, targets)
+        if len(feats) == 0:
+            raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
+        pf = torch.cat(feats)
+        if isinstance(self.box_pair_predictor, nn.Linear) and isinstance(self.box_pair_suppressor, nn.Linear):
+            logits_p = linear(pf, self.box_pair_predictor.weight, self.box_pair_predictor.bias)
+            logits_s = linear(pf, self.box_pair_suppressor.weight, self.box_pair_suppressor.bias)
+        else:
+            logits_p = self.box_pair_predictor(pf); logits_s = self.box_pair_suppressor(pf)
+        results = self.postprocess(logits_p, logits_s, prior, bh, bo, oc, labels)
+        results.append(dict(
+            hoi_loss=self.compute_interaction_classification_loss(results),
+            interactiveness_loss=self.compute_interactiveness_loss(results),
+            transH_loss=self.compute_transH_loss(pos, neg, he, re, rn, te, results)))
+        return results
+
+    def _n_p(self, n_p):
+        """HEAD:167-172: average the number of positives over the ranks (the barrier is dropped: all_reduce is
+        already a synchronising collective)."""
+        if self.distributed:
+            world_size = dist.get_world_size()
+            t = torch.as_tensor([n_p], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t)
+            n_p = (t / world_size).item()
+        return n_p
+
+    def compute_interaction_classification_loss(self, results: List[dict]) -> Tensor:
+        """HEAD:153-177."""
+        from skghoi_amd.ops import binary_focal_loss
+        labels = torch.cat([r["labels"] for r in results]); scores = torch.cat([r["scores"] for r in results])
+        n_p = self._n_p(len(torch.nonzero(labels)))
+        return binary_focal_loss(scores, labels, reduction="sum", gamma=0.2) / n_p
+
+    def compute_interactiveness_loss(self, results: List[dict]) -> Tensor:
+        """HEAD:180-205."""
+        from skghoi_amd.ops import binary_focal_loss
+        weights = torch.cat([r["weights"] for r in results]); labels = torch.cat([r["unary_labels"] for r in results])
+        n_p = self._n_p(len(torch.nonzero(labels)))
+        return binary_focal_loss(weights, labels, reduction="sum", gamma=2.0) / n_p
+
+    def compute_transH_loss(self, positive_scores, negative_scores, head, relation, relation_norm, tail,
+                            results: List[dict]) -> Tensor:
+        """HEAD:207-235 with the semantics the code intends (the committed call passes six arguments to a
+        one-argument NegativeSampling.forward and raises TypeError): NegativeSampling splits
+        score = cat[pos, neg] in halves shaped [M, 1] (heads/NegativeSampling.py:30-40, 52-56) and applies
+        MarginLoss(margin=1): mean(max(p - n, -margin)) + margin (heads/MarginLoss.py:28-36); regul_rate = 0."""
+        labels = torch.cat([r["unary_labels"] for r in results])
+        n_p = self._n_p(len(torch.nonzero(labels)))
+        score = torch.cat([torch.cat(positive_scores), torch.cat(negative_scores)])
+        half = len(score) // 2
+        p = score[:half].view(-1, half).permute(1, 0); n = score[half:].view(-1, half).permute(1, 0)
+        margin = 1.0
+        loss = torch.max(p - n, torch.tensor([-margin], device=score.device)).mean() + margin
+        return loss / n_p
 
     def _empty_result(self, dev, with_labels):
         d = dict(boxes_h=torch.zeros(0, 4, device=dev), boxes_o=torch.zeros(0, 4, device=dev),

@@ -212,3 +212,32 @@ extern "C" int skg_rows_mul_relu_f32(const float* P, const int32_t* p_idx, int64
                        q_idx, ldq, mbias, F, f_idx, ldf, cols, out, ldo);
     return skg_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------ transpose
+// out[c, r] = in[r, c] for r < rows, c < cols; out has ld_out >= rows columns, columns rows..ld_out-1 are zeroed by the
+// caller.  Used by the backward GEMMs (dA = dZ W needs W^T rows, dW = dZ^T A needs both operands k-contiguous).
+__global__ __launch_bounds__(256) void skg_transpose_kernel(const float* __restrict__ in, int64_t ld_in, int rows,
+                                                            int cols, float* __restrict__ out, int64_t ld_out) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 64 x 4
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? in[(int64_t)r * ld_in + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) out[(int64_t)c * ld_out + r] = tile[tx][i];
+    }
+}
+
+extern "C" int skg_transpose_f32(const float* in, int64_t ld_in, int rows, int cols, float* out, int64_t ld_out,
+                                 void* stream) {
+    if (rows < 0 || cols < 0) return SKG_E_ARG;
+    if (rows == 0 || cols == 0) return 0;
+    if (!in || !out || ld_in < cols || ld_out < rows) return SKG_E_ARG;
+    hipLaunchKernelGGL(skg_transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0,
+                       (hipStream_t)stream, in, ld_in, rows, cols, out, ld_out);
+    return skg_launch_status();
+}

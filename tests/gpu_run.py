@@ -51,6 +51,8 @@ def run_head(case, head=None, reference_quirks=True):
     head.engine().debug = True
     if "chunk_images" in case:
         head.engine().chunk_images = case["chunk_images"]
+    if case["training"]:
+        return _run_train(case, head, det, tg, feats)
     with torch.no_grad():
         for b, d in enumerate(head.preprocess(det, tg)):
             out["pre%d.boxes" % b] = d["boxes"]; out["pre%d.labels" % b] = d["labels"]; out["pre%d.scores" % b] = d["scores"]
@@ -78,3 +80,52 @@ def run_head(case, head=None, reference_quirks=True):
             if "adjacency" in last:
                 out["timg%d.adjacency" % a] = last["adjacency"][g0:g0 + G].reshape(-1, 1)
     return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()}
+
+
+def _run_train(case, head, det, tg, feats, backward=False):
+    """Training-mode forward (and optionally backward of the summed losses).  Captures graph_train's lists."""
+    import skghoi_amd.train_graph as tgm
+    K = case["cfg"]["K"]
+    cap = {}
+    orig = tgm.graph_train
+
+    def wrapped(*a, **k):
+        r = orig(*a, **k); cap["lists"], cap["lay"] = r; return r
+
+    tgm.graph_train = wrapped
+    try:
+        out = {}
+        for b, d in enumerate(head.preprocess(det, tg)):
+            out["pre%d.boxes" % b] = d["boxes"]; out["pre%d.labels" % b] = d["labels"]; out["pre%d.scores" % b] = d["scores"]
+        torch.manual_seed(case["rng_seed"])
+        results = head(feats, det, case["shapes"], tg)
+    finally:
+        tgm.graph_train = orig
+    losses = results[-1]
+    for b, r in enumerate(results[:-1]):
+        for k, v in r.items():
+            out["res%d.%s" % (b, k)] = v
+    out["n_results"] = torch.tensor(len(results) - 1)
+    for k, v in losses.items():
+        out[k] = v
+    feats_l, bh, bo, oc, lab, prior, pos, neg, he, te, re, rn = cap["lists"]
+    out["pair_features"] = torch.cat(feats_l)
+    for i in range(len(pos)):
+        out["timg%d.pos_scores" % i] = pos[i]; out["timg%d.neg_scores" % i] = neg[i]
+        out["timg%d.head_ent" % i] = he[i]; out["timg%d.tail_ent" % i] = te[i]
+        out["timg%d.rel" % i] = re[i]; out["timg%d.rel_norm" % i] = rn[i]
+    out["n_tables"] = torch.tensor(len(pos))
+    grads = None
+    if backward:
+        head.zero_grad()
+        sum(losses.values()).backward()
+        grads = {k: p.grad.detach().cpu().numpy() for k, p in head.named_parameters() if p.grad is not None}
+    flat = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()}
+    return (flat, grads) if backward else flat
+
+
+def run_train_with_grads(case):
+    head = build_head(case)
+    det = to_cuda(case["detections"]); tg = to_cuda(case["targets"])
+    feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
+    return _run_train(case, head, det, tg, feats, backward=True)

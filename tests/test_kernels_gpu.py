@@ -162,3 +162,31 @@ def test_transh_scores_match_oracle():
         want = s.reshape(nh, n, K)[xk, yk]
         _close(sc[off:off + len(xk)].cpu(), want, 2e-6)
         off += len(xk)
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(37, 117, 46, False), (130, 1024, 1074, True), (1, 64, 32, True),
+                                        (801, 256, 128, True)])
+def test_linear_autograd_matches_torch(M, N, K, relu):
+    from skghoi_amd.autograd import linear
+    x = _rand(M, K, seed=1).requires_grad_(True); w = (_rand(N, K, seed=2) / K ** 0.5).requires_grad_(True)
+    b = _rand(N, seed=3).requires_grad_(True)
+    g = _rand(M, N, seed=4)
+    y = linear(x, w, b, relu)
+    y.backward(g)
+    xr = x.detach().double().requires_grad_(True); wr = w.detach().double().requires_grad_(True)
+    br = b.detach().double().requires_grad_(True)
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr = torch.relu(yr) if relu else yr
+    yr.backward(g.double())
+    _close(y.detach(), yr.detach().float(), 2e-5)
+    _close(x.grad, xr.grad.float(), 5e-5)
+    _close(w.grad, wr.grad.float(), 5e-5 * max(1.0, M ** 0.5 / 4))
+    _close(b.grad, br.grad.float(), 1e-4)
+
+
+def test_transpose():
+    from skghoi_amd.autograd import transpose
+    x = _rand(70, 130, seed=9)
+    t = transpose(x, 70, 130)
+    assert t.shape == (130, 72)
+    assert torch.equal(t[:, :70], x.t()) and torch.all(t[:, 70:] == 0)

@@ -111,3 +111,37 @@ def test_full_size_properties():
         pr = got["res%d.prior" % b]
         s = got["res%d.scores" % b]
         assert np.all(s <= pr[0] * pr[1] + 1e-7) and np.all(s >= 0)
+
+
+@pytest.mark.parametrize("name", cases.TRAIN_CASES)
+def test_training_forward_matches_reference_golden(name):
+    """Rows 15-17 of SURVEY 8(a): GT association, TransH pos/neg sampling (host RNG: tables + randperm), the three
+    loss terms (TransH term per the intended semantics).  Golden = the reference's own pieces."""
+    case = cases.build_case(name)
+    got = gpu_run.run_head(case)
+    want = helpers.load_golden(name)
+    helpers.compare_flat(got, want, atol=LOGIT_TOL, rtol=1e-4, only_common=True,
+                         skip=(".spatial46", ".rel_table", ".norm_table", ".adjacency", ".h_node", ".node", ".ent"))
+    for k in ("hoi_loss", "interactiveness_loss", "transH_loss"):
+        assert abs(float(got[k]) - float(want[k])) <= 1e-5 * max(1.0, abs(float(want[k]))), k
+    for b in range(int(want["n_results"])):
+        for k in ("index", "prediction", "object", "labels", "unary_labels"):
+            assert np.array_equal(got["res%d.%s" % (b, k)], want["res%d.%s" % (b, k)]), (b, k)
+
+
+def test_training_gradients_match_oracle_autograd():
+    """Backward through the HIP GEMMs (dX, dW via skg_gemm_f32 + skg_transpose_f32) vs CPU autograd of the oracle."""
+    case = cases.build_case("train_tiny")
+    flat, grads = gpu_run.run_train_with_grads(case)
+    want, losses = helpers.oracle_train_grads(case)
+    for k in ("hoi_loss", "interactiveness_loss", "transH_loss"):
+        assert abs(float(flat[k]) - losses[k]) <= 1e-5 * max(1.0, abs(losses[k]))
+    assert set(want) == set(grads), set(want) ^ set(grads)
+    worst = 0.0
+    for k, w in want.items():
+        g = grads[k]
+        scale = max(np.abs(w).max(), 1e-6)
+        err = np.abs(g - w).max() / scale
+        worst = max(worst, err)
+        assert err <= 2e-3, "%s: rel err %.3e (|grad| max %.3e)" % (k, err, scale)
+    print("max relative gradient error %.3e over %d tensors" % (worst, len(want)))
