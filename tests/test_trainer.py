@@ -1,0 +1,86 @@
+"""Trainer shell: optimizer groups / LR schedule (CPU), and a 2-rank DDP train step of the real head (gpu; both ranks
+share the one GPU of the test box and talk over gloo -- the N>1 data path is the same code as with RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from skghoi_amd import trainer
+
+
+class _Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.backbone = nn.Linear(4, 4)
+        self.interaction_head = nn.Linear(4, 2)
+
+
+def test_optimizer_groups_and_schedule():
+    net = _Net()
+    opt = trainer.build_optimizer(net, lr=1e-4, weight_decay=1e-4)
+    assert len(opt.param_groups) == 2
+    assert opt.param_groups[0]["lr"] == 1e-4 and opt.param_groups[1]["lr"] == pytest.approx(1e-5)
+    assert all(g["weight_decay"] == 1e-4 for g in opt.param_groups)
+    assert len(opt.param_groups[0]["params"]) == 2 and len(opt.param_groups[1]["params"]) == 2
+    sch = trainer.build_scheduler(opt, milestone=6, lr_decay=0.1)
+    lrs = []
+    for _ in range(8):
+        lrs.append(opt.param_groups[0]["lr"]); opt.step(); sch.step()
+    assert lrs[:6] == [1e-4] * 6 and lrs[6] == pytest.approx(1e-5) and lrs[7] == pytest.approx(1e-5)
+    bare = trainer.build_optimizer(nn.Linear(3, 3))
+    assert len(bare.param_groups) == 1
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _ddp_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    import cases, gpu_run
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    case = cases.build_case("train_tiny")
+    # shard the two images of the case over the two ranks
+    case["detections"] = case["detections"][rank:rank + 1]; case["targets"] = case["targets"][rank:rank + 1]
+    case["feat3"] = case["feat3"][rank:rank + 1]; case["shapes"] = case["shapes"][rank:rank + 1]
+    head = gpu_run.build_head(case)
+    head.distributed = True
+    ddp = trainer.wrap_ddp(head, torch.device("cuda", 0))
+    opt = trainer.build_optimizer(ddp, lr=1e-4)
+    from collections import OrderedDict
+    feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
+    torch.manual_seed(7 + rank)
+    losses, results = trainer.train_step(ddp, opt, feats, gpu_run.to_cuda(case["detections"]), case["shapes"],
+                                         targets=gpu_run.to_cuda(case["targets"]))
+    torch.cuda.synchronize()
+    vec = torch.cat([p.detach().flatten()[:64].cpu() for p in head.parameters()])
+    q.put((rank, losses, vec.numpy(), len(results)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_ddp_train_step_on_one_gpu():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, l0, v0, n0), (r1, l1, v1, n1) = res
+    assert n0 == 1 and n1 == 1
+    for l in (l0, l1):
+        assert all(np.isfinite(v) for v in l.values()) and set(l) == {"hoi_loss", "interactiveness_loss", "transH_loss"}
+    assert np.array_equal(v0, v1)            # gradients were averaged: both replicas took the same step
