@@ -94,6 +94,56 @@ def cpu_baseline(n_images):
                        "median %.3f s/image" % (len(times), cores, float(np.median(times))))
 
 
+def train_mode(args, device, rank, world, dist_on):
+    """Secondary metric: images/s of the data-parallel training step (fp32; forward + backward on the HIP GEMMs,
+    AdamW, DDP gradient all-reduce over RCCL when world > 1).  Reference settings: batch 4 per GPU (main:158)."""
+    import torch.distributed as dist
+    from skghoi_amd import synth, trainer
+    B = args.batch if args.batch != 256 else 4
+    head = build_head(device).train()
+    head.distributed = dist_on
+    dets, pooled, feats, shapes = make_inputs(B, rank, device)
+    o2v = synth.hico_object_to_verb()
+    cpu_dets = [dict(boxes=d["boxes"].cpu(), labels=d["labels"].cpu(), scores=d["scores"].cpu()) for d in dets]
+    targets = [{k: v.to(device) for k, v in synth.make_targets(d, 49, o2v, 500 + i, n_gt=4).items()}
+               for i, d in enumerate(cpu_dets)]
+
+    class Pool(torch.nn.Module):
+        def forward(self, features, boxes, image_shapes):
+            n = sum(len(b) for b in boxes)           # GT boxes are appended in training: size follows the head
+            reps = (n + pooled.shape[0] - 1) // pooled.shape[0]
+            return pooled.repeat(reps, 1, 1, 1)[:n]
+
+    head.box_roi_pool = Pool()
+    net = trainer.wrap_ddp(head, device)
+    opt = trainer.build_optimizer(net, lr=1e-4)
+    torch.manual_seed(1234 + rank)
+    for _ in range(args.warmup):
+        losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    from skghoi_amd import dist as skd
+    elapsed = skd.max_over_ranks(time.perf_counter() - t0, device=device)
+    if rank == 0:
+        print(json.dumps(dict(metric="images/sec through the interaction-head TRAINING step (20x20 pairs)",
+                              value=round(B * world * args.steps / elapsed, 2), unit="images/s", n_gpus=world,
+                              steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
+                              higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                              config=dict(workload="train step: fwd + bwd + AdamW, NegativeSampling + MarginLoss + "
+                                                   "two focal terms, 20x20 synthetic images with GT appended",
+                                          batch_per_gpu=B, parallelism="dp%d" % world),
+                              losses=losses)))
+    if dist_on:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +153,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=0, help="override HeadEngine.chunk_images")
     ap.add_argument("--gemm-table", action="store_true", help="per-shape GEMM timing table on stderr")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="train: NegativeSampling+MarginLoss training step (fwd+bwd+AdamW), secondary metric")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,6 +166,9 @@ def main():
     if dist_on:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
+
+    if args.mode == "train":
+        return train_mode(args, device, rank, world, dist_on)
 
     from skghoi_amd import engine
     head = build_head(device)

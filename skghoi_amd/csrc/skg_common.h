@@ -15,6 +15,7 @@ static inline int skg_launch_status() {
 }
 
 static inline bool skg_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+__device__ __forceinline__ bool skg_aligned16_dev(const void* p) { return (((uintptr_t)p) & 15u) == 0; }   // null counts as aligned
 
 __device__ __forceinline__ float skg_wave_sum(float v) {
 #pragma unroll

@@ -28,6 +28,9 @@
 #ifndef SKG_MINW
 #define SKG_MINW 2
 #endif
+#ifndef SKG_USE_GLDS
+#define SKG_USE_GLDS 1
+#endif
 #define BK SKG_BK
 #define LDS_LD (BK + 4)                 // + 4 dwords of padding: conflict-free ds_read_b128 at strides 20 and 36
 #define A_TILE (BM * LDS_LD)
@@ -53,7 +56,7 @@ static inline int64_t skg_gemm_blocks(int M, int N, int K) {
 }
 
 // EPI >= 0: epilogue fixed at compile time; EPI < 0: taken from the descriptor (grouped launches of small GEMMs).
-template <int EPI_T>
+template <int EPI_T, bool GLDS>
 __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, const int block_id, float* smem) {
     const int EPI = EPI_T >= 0 ? EPI_T : d.epilogue;
     const int tid = threadIdx.x;
@@ -87,6 +90,16 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, const int 
     }
     const int m0 = bm * BM, n0 = bn * BN;
 
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int nk = (d.K + BK - 1) / BK;
+    if constexpr (!GLDS) {
     // ---- global -> register staging map: thread owns rows (lr, lr+64) x 4 consecutive k
     constexpr int TPR = BK / 4;                  // threads per tile row (float4 each)
     constexpr int RPP = 256 / TPR;               // rows per staging pass
@@ -108,15 +121,6 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, const int 
         pw[i] = d.W + (int64_t)(vw[i] ? c : 0) * d.ldw;
     }
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    const int nk = (d.K + BK - 1) / BK;
     float4 ra[NPASS], rw[NPASS];
 
     // Loads are unconditional (addresses are clamped to readable rows / k); rows past M or N and the K tail are
@@ -193,73 +197,194 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, const int 
 #endif
     }
 
-    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-    int col[2];
-    float bia[2], mb[2], dw[2];
+    } else {
+        // ---- direct-to-LDS staging (global_load_lds_dwordx4): no VGPR round trip, no ds_write, no masking.
+        // Requirements (checked by the host): K % 16 == 0, no A-row gather.  Rows past M / N are clamped to row 0:
+        // they only feed accumulators whose outputs are never stored.  The LDS image is lane-linear per wave
+        // instruction (16 rows x 64 B); bank conflicts of the ds_read_b128 fragment reads are removed by XOR-ing the
+        // 16-byte k-chunk index with (row >> 2) & 3 on the global SOURCE side and on the read side.
+        constexpr int GT = BM * BK;                                   // floats per operand tile (unpadded)
+        const int rl = lane >> 2;                                     // row inside a 16-row piece
+        const int ch = lane & 3;                                      // 16-byte chunk the lane WRITES
+        const float* ga[2];
+        const float* gw[2];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        col[ni] = n0 + wc * 64 + ni * 32 + li;
-        const bool in = col[ni] < d.N;
-        bia[ni] = (in && d.bias) ? d.bias[col[ni]] : 0.f;
-        mb[ni] = (EPI == SKG_EPI_MUL_RELU && in && d.mbias) ? d.mbias[col[ni]] : 0.f;
-        dw[ni] = (EPI == SKG_EPI_RELU_DOT && in) ? d.dot_w[col[ni]] : 0.f;
+        for (int i = 0; i < 2; ++i) {
+            const int r = wid * 32 + i * 16 + rl;                     // tile row staged by this lane
+            const int sw = (r >> 2) & 3;
+            const int ar = m0 + r, wrw = n0 + r;
+            ga[i] = d.A + (int64_t)(ar < d.M ? ar : 0) * d.lda + 4 * (ch ^ sw);
+            gw[i] = d.W + (int64_t)(wrw < d.N ? wrw : 0) * d.ldw + 4 * (ch ^ sw);
+        }
+        auto stage = [&](int buf, int kt) {
+            float* a_s = smem + buf * GT + (wid * 32) * BK;
+            float* b_s = smem + 2 * GT + buf * GT + (wid * 32) * BK;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + kt * BK),
+                                                 (__attribute__((address_space(3))) void*)(a_s + i * 16 * BK), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw[i] + kt * BK),
+                                                 (__attribute__((address_space(3))) void*)(b_s + i * 16 * BK), 16, 0, 0);
+            }
+        };
+        const int swr = (li >> 2) & 3;                                // (row >> 2) & 3 of the rows this lane READS
+        stage(0, 0);
+        __syncthreads();                                              // drains vmcnt: tile 0 has landed
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const float* a_s = smem + cur * GT + (wr * 64 + li) * BK;
+            const float* b_s = smem + 2 * GT + cur * GT + (wc * 64 + li) * BK;
+            // all fragment reads of this tile first: hipcc waits vmcnt(0) before any ds_read while an LDS-DMA is in
+            // flight, so the next tile's DMA is issued only after them and lands under the 32 MFMAs
+            float4 a[BK / 8][2], b[BK / 8][2];
+#pragma unroll
+            for (int ks = 0; ks < BK / 8; ++ks) {
+                const int co = 4 * ((2 * ks + lh) ^ swr);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[ks][i] = *reinterpret_cast<const float4*>(a_s + i * 32 * BK + co);
+                    b[ks][i] = *reinterpret_cast<const float4*>(b_s + i * 32 * BK + co);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < BK / 8; ++ks) {
+                const float av[2][4] = {{a[ks][0].x, a[ks][0].y, a[ks][0].z, a[ks][0].w},
+                                        {a[ks][1].x, a[ks][1].y, a[ks][1].z, a[ks][1].w}};
+                const float bv[2][4] = {{b[ks][0].x, b[ks][0].y, b[ks][0].z, b[ks][0].w},
+                                        {b[ks][1].x, b[ks][1].y, b[ks][1].z, b[ks][1].w}};
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][t], bv[ni][t], acc[mi][ni], 0, 0, 0);
+            }
+            __syncthreads();                                          // vmcnt(0) + barrier: next tile landed, this one free
+        }
     }
+
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5),
+    // i.e. a lane owns ONE column of 16 rows: stored directly that is 4-byte accesses.  Instead each wave transposes
+    // its accumulators through LDS (the staging tiles are dead now; 32 rows x 64 columns per pass, rows padded to 68
+    // dwords) and walks them row-wise: every lane then handles 4 consecutive columns of one row, so bias / multiplier
+    // tables / residual loads and the stores are 16-byte accesses covering 256 contiguous bytes per row.
+    constexpr int EST_LD = 68;
+    float* est = smem + wid * (32 * EST_LD);
+    const bool vec_ok = ((d.ldc & 3) == 0) && skg_aligned16_dev(d.C) && skg_aligned16_dev(d.bias) &&
+                        (EPI != SKG_EPI_MUL_RELU ||
+                         (skg_aligned16_dev(d.P) && skg_aligned16_dev(d.Q) && skg_aligned16_dev(d.mbias) &&
+                          skg_aligned16_dev(d.C_raw) && ((d.ldp | d.ldq | d.ldc_raw) & 3) == 0)) &&
+                        (EPI != SKG_EPI_BIAS_RES_RELU || (skg_aligned16_dev(d.res) && (d.ldres & 3) == 0)) &&
+                        (EPI != SKG_EPI_RELU_DOT || skg_aligned16_dev(d.dot_w));
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                est[((r & 3) + 8 * (r >> 2) + 4 * lh) * EST_LD + ni * 32 + li] = acc[mi][ni][r];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 64 + lane;
+            const int rl = idx >> 4, c4 = (idx & 15) * 4;
+            const int row = m0 + wr * 64 + mi * 32 + rl;
+            const int col = n0 + wc * 64 + c4;
+            const float4 a4 = *reinterpret_cast<const float4*>(est + rl * EST_LD + c4);
+            float v[4] = {a4.x, a4.y, a4.z, a4.w};
             const bool rin = row < d.M;
+            const bool full = vec_ok && (col + 3 < d.N);
+            float bia[4] = {0.f, 0.f, 0.f, 0.f};
+            if (d.bias) {
+                if (full) {
+                    const float4 t = *reinterpret_cast<const float4*>(d.bias + col);
+                    bia[0] = t.x; bia[1] = t.y; bia[2] = t.z; bia[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) bia[c] = (col + c < d.N) ? d.bias[col + c] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += bia[c];
+
             if (EPI == SKG_EPI_RELU_DOT) {
                 float s = 0.f;
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const float v = fmaxf(acc[mi][ni][r] + bia[ni], 0.f);
-                    if (rin && col[ni] < d.N) {
-                        s += v * dw[ni];
-                        if (d.C) d.C[(int64_t)row * d.ldc + col[ni]] = v;
-                    }
+                for (int c = 0; c < 4; ++c) {
+                    v[c] = fmaxf(v[c], 0.f);
+                    if (rin && col + c < d.N) s += v[c] * d.dot_w[col + c];
+                }
+                if (d.C && rin) {
+                    if (full) *reinterpret_cast<float4*>(d.C + (int64_t)row * d.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    else
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) if (col + c < d.N) d.C[(int64_t)row * d.ldc + col + c] = v[c];
                 }
 #pragma unroll
-                for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-                if (li == 0 && rin) d.dot_partial[(int64_t)(bn * 2 + wc) * d.M + row] = s;
+                for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);      // 16 lanes share a row
+                if ((lane & 15) == 0 && rin) d.dot_partial[(int64_t)(bn * 2 + wc) * d.M + row] = s;
                 continue;
             }
-            if (!rin) continue;
+            if (!rin || col >= d.N) continue;
             const int orow = d.out_rows ? d.out_rows[row] : row;
             if (EPI == SKG_EPI_MUL_RELU) {
+                if (d.C_raw) {
+                    if (full) *reinterpret_cast<float4*>(d.C_raw + (int64_t)row * d.ldc_raw + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    else
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) if (col + c < d.N) d.C_raw[(int64_t)row * d.ldc_raw + col + c] = v[c];
+                }
+                if (orow < 0) continue;
                 const int pi = d.p_idx ? d.p_idx[row] : row;
                 const int qi = d.Q ? (d.q_idx ? d.q_idx[row] : row) : 0;
+                float m[4] = {0.f, 0.f, 0.f, 0.f};
+                if (full) {
+                    if (d.mbias) { const float4 t = *reinterpret_cast<const float4*>(d.mbias + col); m[0] = t.x; m[1] = t.y; m[2] = t.z; m[3] = t.w; }
+                    if (d.P) { const float4 t = *reinterpret_cast<const float4*>(d.P + (int64_t)pi * d.ldp + col); m[0] += t.x; m[1] += t.y; m[2] += t.z; m[3] += t.w; }
+                    if (d.Q) { const float4 t = *reinterpret_cast<const float4*>(d.Q + (int64_t)qi * d.ldq + col); m[0] += t.x; m[1] += t.y; m[2] += t.z; m[3] += t.w; }
+                    *reinterpret_cast<float4*>(d.C + (int64_t)orow * d.ldc + col) =
+                        make_float4(fmaxf(v[0] * m[0], 0.f), fmaxf(v[1] * m[1], 0.f), fmaxf(v[2] * m[2], 0.f), fmaxf(v[3] * m[3], 0.f));
+                } else {
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    if (col[ni] >= d.N) continue;
-                    const float v = acc[mi][ni][r] + bia[ni];
-                    if (d.C_raw) d.C_raw[(int64_t)row * d.ldc_raw + col[ni]] = v;
-                    if (orow < 0) continue;
-                    float m = mb[ni];
-                    if (d.P) m += d.P[(int64_t)pi * d.ldp + col[ni]];
-                    if (d.Q) m += d.Q[(int64_t)qi * d.ldq + col[ni]];
-                    d.C[(int64_t)orow * d.ldc + col[ni]] = fmaxf(v * m, 0.f);
+                    for (int c = 0; c < 4; ++c) {
+                        if (col + c >= d.N) continue;
+                        float mm = d.mbias ? d.mbias[col + c] : 0.f;
+                        if (d.P) mm += d.P[(int64_t)pi * d.ldp + col + c];
+                        if (d.Q) mm += d.Q[(int64_t)qi * d.ldq + col + c];
+                        d.C[(int64_t)orow * d.ldc + col + c] = fmaxf(v[c] * mm, 0.f);
+                    }
                 }
                 continue;
             }
             if (orow < 0) continue;
+            if (EPI == SKG_EPI_BIAS_RELU || EPI == SKG_EPI_BIAS_RES_RELU) {
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                if (col[ni] >= d.N) continue;
-                float v = acc[mi][ni][r] + bia[ni];
-                if (EPI == SKG_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-                if (EPI == SKG_EPI_BIAS_RES_RELU) v = d.res[(int64_t)row * d.ldres + col[ni]] + fmaxf(v, 0.f);
-                d.C[(int64_t)orow * d.ldc + col[ni]] = v;
+                for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
             }
+            if (EPI == SKG_EPI_BIAS_RES_RELU) {
+                if (full) {
+                    const float4 t = *reinterpret_cast<const float4*>(d.res + (int64_t)row * d.ldres + col);
+                    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (col + c < d.N) v[c] += d.res[(int64_t)row * d.ldres + col + c];
+                }
+            }
+            if (full) *reinterpret_cast<float4*>(d.C + (int64_t)orow * d.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+            else
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (col + c < d.N) d.C[(int64_t)orow * d.ldc + col + c] = v[c];
         }
     }
 }
 
-template <int EPI>
+template <int EPI, bool GLDS>
 __global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_kernel(const skg_gemm_desc d) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
-    skg_gemm_tile<EPI>(d, blockIdx.x, smem);
+    skg_gemm_tile<EPI, GLDS>(d, blockIdx.x, smem);
 }
 
 // Several independent small GEMMs in ONE launch (node-row GEMMs with M = sum n_h or sum n fill a fraction of the 256
@@ -276,7 +401,7 @@ __global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_group_kernel(const skg
 #pragma unroll
     for (int t = 1; t < SKG_GEMM_GROUP_MAX; ++t)
         if (t < g.n && (int)blockIdx.x >= g.start[t]) k = t;
-    skg_gemm_tile<-1>(g.d[k], blockIdx.x - g.start[k], smem);
+    skg_gemm_tile<-1, false>(g.d[k], blockIdx.x - g.start[k], smem);
 }
 
 static int skg_gemm_validate(const skg_gemm_desc& d) {
@@ -330,12 +455,17 @@ extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
     if (nblk > 0x7fffffffLL) return SKG_E_LIMIT;
     dim3 grid((unsigned)nblk), block(256);
     hipStream_t s = (hipStream_t)stream;
+    const bool glds = SKG_USE_GLDS && BK == 16 && (d.K % BK) == 0 && !d.a_rows;
+#define SKG_LAUNCH(E)                                                                              \
+    if (glds) hipLaunchKernelGGL((skg_gemm_kernel<E, true>), grid, block, 0, s, d);               \
+    else hipLaunchKernelGGL((skg_gemm_kernel<E, false>), grid, block, 0, s, d);
     switch (d.epilogue) {
-        case SKG_EPI_BIAS:          hipLaunchKernelGGL(skg_gemm_kernel<SKG_EPI_BIAS>, grid, block, 0, s, d); break;
-        case SKG_EPI_BIAS_RELU:     hipLaunchKernelGGL(skg_gemm_kernel<SKG_EPI_BIAS_RELU>, grid, block, 0, s, d); break;
-        case SKG_EPI_MUL_RELU:      hipLaunchKernelGGL(skg_gemm_kernel<SKG_EPI_MUL_RELU>, grid, block, 0, s, d); break;
-        case SKG_EPI_RELU_DOT:      hipLaunchKernelGGL(skg_gemm_kernel<SKG_EPI_RELU_DOT>, grid, block, 0, s, d); break;
-        case SKG_EPI_BIAS_RES_RELU: hipLaunchKernelGGL(skg_gemm_kernel<SKG_EPI_BIAS_RES_RELU>, grid, block, 0, s, d); break;
+        case SKG_EPI_BIAS:          SKG_LAUNCH(SKG_EPI_BIAS) break;
+        case SKG_EPI_BIAS_RELU:     SKG_LAUNCH(SKG_EPI_BIAS_RELU) break;
+        case SKG_EPI_MUL_RELU:      SKG_LAUNCH(SKG_EPI_MUL_RELU) break;
+        case SKG_EPI_RELU_DOT:      SKG_LAUNCH(SKG_EPI_RELU_DOT) break;
+        case SKG_EPI_BIAS_RES_RELU: SKG_LAUNCH(SKG_EPI_BIAS_RES_RELU) break;
     }
+#undef SKG_LAUNCH
     return skg_launch_status();
 }
