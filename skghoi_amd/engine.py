@@ -163,6 +163,41 @@ def gemm_group(specs):
         GEMM_TIMER.append((e0, e1, int(flops // 2), 1, 1, 5))       # epilogue id 5 = grouped launch
 
 
+class _TableDrawer:
+    """Draws the per-image TransH tables of every chunk, in order, on a helper thread (the global CPU RNG is
+    consumed exactly as the reference does, skghoi_amd/transh.py)."""
+
+    def __init__(self, K, sizes, need_relations):
+        import threading
+        self.K, self.sizes, self.need = K, sizes, need_relations
+        self.out = [None] * len(sizes)
+        self.err = None
+        self.ready = [threading.Event() for _ in sizes]
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        try:
+            for i, n in enumerate(self.sizes):
+                self.out[i] = transh.draw_batch(self.K, n, need_relations=self.need, pin=True)
+                self.ready[i].set()
+        except BaseException as e:                 # surface the failure in the caller's thread
+            self.err = e
+            for ev in self.ready:
+                ev.set()
+
+    def get(self, i):
+        self.ready[i].wait()
+        if self.err is not None:
+            raise self.err
+        return self.out[i]
+
+    def join(self):
+        self.thread.join()
+        if self.err is not None:
+            raise self.err
+
+
 class Preprocessed:
     """Packed output of InteractionHead.preprocess for a batch."""
     pass
@@ -320,18 +355,36 @@ class HeadEngine:
         keep = {} if self.debug else None
         tabs = []
         step = max(int(self.chunk_images), 1)
-        for a0 in range(0, A, step):
-            ch = layout.chunk(lay, a0, min(A, a0 + step))
+        bounds = [(a0, min(A, a0 + step)) for a0 in range(0, A, step)]
+        # The reference's RNG stream (~27k mt19937 draws per image) is produced by a helper thread, chunk by chunk and
+        # in image order, while this thread enqueues GPU work; torch releases the GIL inside the draws.
+        drawer = None
+        if tables is None:
+            drawer = _TableDrawer(self.K, [b - a for a, b in bounds], want_scores)
+        try:
+            # software pipeline over chunks: phase A (no dependence on the TransH tables) runs `lookahead` chunks ahead
+            # of phase B, so the GPU always has queued work while the host draws the next chunk's tables
+            lookahead = 2
+            ctxs = {}
 
-            def draw(n, a0=a0):
+            def phase_a(ci):
+                a0, a1 = bounds[ci]
+                ctxs[ci] = self._chunk_phase_a(layout.chunk(lay, a0, a1), pw, pre, G1, x_keep, y_keep, PF)
+
+            for ci in range(min(lookahead, len(bounds))):
+                phase_a(ci)
+            for ci, (a0, a1) in enumerate(bounds):
                 if tables is None:
-                    t = transh.draw_batch(self.K, n, need_relations=want_scores, pin=True)
+                    t = drawer.get(ci)
                 else:
-                    t = tuple(None if x is None else x[a0:a0 + n] for x in tables)
+                    t = tuple(None if x is None else x[a0:a1] for x in tables)
                 tabs.append(t)
-                return t
-
-            self._graph_chunk(ch, pw, pre, enc, G1, draw, x_keep, y_keep, PF, sc, keep)
+                self._chunk_phase_b(ctxs.pop(ci), t, pw, pre, enc, PF, sc, keep)
+                if ci + lookahead < len(bounds):
+                    phase_a(ci + lookahead)
+        finally:
+            if drawer is not None:
+                drawer.join()
         out.update(x_keep=x_keep[:Mp], y_keep=y_keep[:Mp], meta=meta_g, pair_features=PF[:Mp])
         out["tables"] = tuple(None if tabs[0][i] is None else torch.cat([t[i] for t in tabs]) for i in range(3))
         if want_scores:
@@ -341,10 +394,10 @@ class HeadEngine:
                 out[k] = torch.cat(v)
         return out
 
-    def _graph_chunk(self, ch, pw, pre, enc, G1, draw, x_keep, y_keep, PF, sc, keep):
-        """Pairs, spatial head, message passing and read-out for the active images of one chunk."""
+    def _chunk_phase_a(self, ch, pw, pre, G1, x_keep, y_keep, PF):
+        """Pairs, spatial encoding, spatial head and the global read-out branch of one chunk: everything that does not
+        depend on the TransH tables."""
         lib = _capi.lib()
-        gh = self.gh
         dev = pre.device
         st = _stream()
         f32 = dict(device=dev, dtype=torch.float32)
@@ -383,8 +436,22 @@ class HeadEngine:
                  ldp=1024, out_rows=grid_pair)
             gemm(Tg, pw.att_g["w3"], pw.att_g["b3"], PF, Mp, 1024, 1024, _capi.EPI_BIAS_RELU, ldc=2048,
                  C_off=ch.P0 * 2048 + 1024)
-        # ---- TransH tables: consume the host RNG exactly like the reference while the GPU works
-        ent, rel, nrm = draw(A)
+        return dict(ch=ch, isl=isl, meta=meta, grid_h=grid_h, grid_o=grid_o, grid_img=grid_img, grid_pair=grid_pair,
+                    pair_grid=pair_grid, pair_h=pair_h, pair_o=pair_o, sp48=sp48, S=S, Tg=Tg, ibuf=ibuf)
+
+    def _chunk_phase_b(self, cx, tabs, pw, pre, enc, PF, sc, keep):
+        """Message passing and pair read-out of one chunk (needs the chunk's TransH entity tables)."""
+        lib = _capi.lib()
+        gh = self.gh
+        dev = pre.device
+        st = _stream()
+        f32 = dict(device=dev, dtype=torch.float32)
+        ch, isl, meta = cx["ch"], cx["isl"], cx["meta"]
+        grid_h, grid_o, pair_grid, pair_h, pair_o = cx["grid_h"], cx["grid_o"], cx["pair_grid"], cx["pair_h"], cx["pair_o"]
+        sp48, S, Tg = cx["sp48"], cx["S"], cx["Tg"]
+        A = ch.n_active
+        Mh, Mn, Mg, Mp = ch.sum_h, ch.sum_n, ch.sum_g, ch.sum_p
+        ent, rel, nrm = tabs
         ent_d = ent.to(dev, non_blocking=True)
         F2 = torch.empty(Mg, 1024, **f32)
         if gh.num_iter > 0:

@@ -49,18 +49,22 @@ def build(n_h, n, L, image_shapes, human_idx, faithful_skip_offset=True, zip_tru
     A = len(active)
     lay.n_active = A
     meta = np.zeros(A, META_DTYPE)
-    enc_counter = 0
-    node = hum = grid = pair = out = 0
-    for a, b in enumerate(active):
-        nh_, n_ = int(n_h[b]), int(n[b])
-        m = meta[a]
-        m["image"] = b; m["n_h"] = nh_; m["n"] = n_
-        m["box_off"] = lay.box_off[b]
-        m["enc_off"] = enc_counter if faithful_skip_offset else lay.box_off[b]
-        m["node_off"] = node; m["hum_off"] = hum; m["grid_off"] = grid; m["pair_off"] = pair; m["out_off"] = out
-        m["img_h"] = float(image_shapes[b][0]); m["img_w"] = float(image_shapes[b][1])
-        enc_counter += n_
-        node += n_; hum += nh_; grid += nh_ * n_; pair += nh_ * (n_ - 1); out += int(L[b])
+    act = lay.active
+    ah_ = n_h[act]; an_ = n[act]
+    shp = np.asarray([(float(s[0]), float(s[1])) for s in image_shapes], dtype=np.float32).reshape(-1, 2)
+
+    def excl(v):
+        return np.cumsum(v) - v
+
+    meta["image"] = act; meta["n_h"] = ah_; meta["n"] = an_
+    meta["box_off"] = lay.box_off[act]
+    meta["enc_off"] = excl(an_) if faithful_skip_offset else lay.box_off[act]
+    meta["node_off"] = excl(an_); meta["hum_off"] = excl(ah_)
+    meta["grid_off"] = excl(ah_ * an_); meta["pair_off"] = excl(ah_ * (an_ - 1)); meta["out_off"] = excl(L[act])
+    if A:
+        meta["img_h"] = shp[act, 0]; meta["img_w"] = shp[act, 1]
+    node = int(an_.sum()); hum = int(ah_.sum()); grid = int((ah_ * an_).sum())
+    pair = int((ah_ * (an_ - 1)).sum()); out = int(L[act].sum())
     lay.meta = meta
     lay.sum_n, lay.sum_h, lay.sum_g, lay.sum_p, lay.sum_l = node, hum, grid, pair, out
     an = meta["n"].astype(np.int64); ah = meta["n_h"].astype(np.int64)
@@ -74,7 +78,7 @@ def build(n_h, n, L, image_shapes, human_idx, faithful_skip_offset=True, zip_tru
     lay.node_ent_row = node_local.astype(np.int32)               # tails are indexed by position y
     lay.hum_ent_row = np.full(hum, human_idx, dtype=np.int32)    # heads are the constant human_idx
     lay.pairs_per_image = (ah * (an - 1)).astype(np.int64)
-    lay.cells_per_image = np.asarray([int(L[b]) for b in active], dtype=np.int64)
+    lay.cells_per_image = L[act].astype(np.int64)
     if A and (meta["n"].max() > _capi.TRANSH_ENT or human_idx >= _capi.TRANSH_ENT or human_idx < 0):
         # the reference indexes an 80-row embedding with y and human_idx (HEAD:570-572, 690)
         raise IndexError("index out of range in self")
