@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=0, help="override HeadEngine.chunk_images")
+    ap.add_argument("--no-gemm-timer", action="store_true", help="skip the per-launch HIP-event GEMM timing")
     ap.add_argument("--gemm-table", action="store_true", help="per-shape GEMM timing table on stderr")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="train: NegativeSampling+MarginLoss training step (fwd+bwd+AdamW), secondary metric")
@@ -192,14 +193,14 @@ def main():
         res = step()
     assert len(res) == args.batch and res[0]["boxes_h"].shape == (N_H * (N_H + N_O - 1), 4)
 
-    engine.GEMM_TIMER = []
+    engine.GEMM_TIMER = None if args.no_gemm_timer else []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    timer, engine.GEMM_TIMER = engine.GEMM_TIMER, None
+    timer, engine.GEMM_TIMER = (engine.GEMM_TIMER or []), None
 
     from skghoi_amd import dist as skd
     elapsed = skd.max_over_ranks(elapsed, device=device)
@@ -221,6 +222,8 @@ def main():
                 M, N, K, epi, n, ms, ms / n, 2.0 * M * N * K * n / ms / 1e9), file=sys.stderr)
     names = {0: "skg_gemm_kernel<BIAS>", 1: "skg_gemm_kernel<BIAS_RELU>", 2: "skg_gemm_kernel<MUL_RELU>",
              3: "skg_gemm_kernel<RELU_DOT>", 4: "skg_gemm_kernel<BIAS_RES_RELU>", 5: "skg_gemm_group_kernel"}
+    if not groups:
+        groups = {2: [1e-9, 0.0, 0]}
     dom = max(groups, key=lambda k: groups[k][0])
     t_dom, f_dom, n_dom = groups[dom]
     t_all = sum(g[0] for g in groups.values()); f_all = sum(g[1] for g in groups.values())
@@ -234,7 +237,7 @@ def main():
             traffic = None
     roofline = dict(bound="mfma", kernel=names[dom], achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS,
                     unit="TFLOP/s", frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
-                    launches=n_dom, avg_launch_ms=round(t_dom / n_dom * 1e3, 4),
+                    launches=n_dom, avg_launch_ms=round(t_dom / max(n_dom, 1) * 1e3, 4),
                     all_gemm_tflops=round(f_all / t_all / 1e12, 2),
                     gemm_share_of_step=round(t_all / (elapsed if not dist_on else elapsed), 4),
                     gflop_per_image=round(f_all / (args.batch * args.steps) / 1e9, 3))

@@ -28,6 +28,9 @@ EPS_LN = 1e-5
 # entries are (start_event, end_event, M, N, K, epilogue).  None = no instrumentation (the default).
 GEMM_TIMER = None
 
+import os as _os
+_PIN_TABLES = _os.environ.get("SKG_PIN_TABLES", "1") == "1"     # developer switch
+
 
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
@@ -167,9 +170,10 @@ class _TableDrawer:
     """Draws the per-image TransH tables of every chunk, in order, on a helper thread (the global CPU RNG is
     consumed exactly as the reference does, skghoi_amd/transh.py)."""
 
-    def __init__(self, K, sizes, need_relations):
+    def __init__(self, K, sizes, need_relations, slots):
         import threading
         self.K, self.sizes, self.need = K, sizes, need_relations
+        self.slots = slots
         self.out = [None] * len(sizes)
         self.err = None
         self.ready = [threading.Event() for _ in sizes]
@@ -179,7 +183,11 @@ class _TableDrawer:
     def _run(self):
         try:
             for i, n in enumerate(self.sizes):
-                self.out[i] = transh.draw_batch(self.K, n, need_relations=self.need, pin=True)
+                slot = self.slots[i % len(self.slots)]
+                if slot["event"] is not None:          # the H2D copy that last read this staging buffer
+                    slot["event"].synchronize()
+                    slot["event"] = None
+                self.out[i] = transh.draw_batch(self.K, n, need_relations=self.need, out=slot["bufs"])
                 self.ready[i].set()
         except BaseException as e:                 # surface the failure in the caller's thread
             self.err = e
@@ -219,6 +227,7 @@ class HeadEngine:
         self.chunk_images = 128     # active images per graph chunk (RNG/GPU overlap + cache-sized intermediates)
         self.debug = False          # keep per-chunk intermediates (spatial46, h_node, node, adjacency) in graph()
         self._plist = None
+        self._slots = None
         self._pw = None
         self._vt = None
         self.last = None          # intermediates of the last graph pass (parity tests read them)
@@ -237,6 +246,20 @@ class HeadEngine:
             self._pw = PackedWeights(self.gh, self.predictor, self.suppressor, device)
             self._pw.sig = sig
         return self._pw
+
+    def _table_slots(self, cap, need_relations):
+        """Persistent pinned staging buffers for the TransH tables (a ring of 4): allocating pinned memory per call
+        costs a hipHostMalloc (tens of ms) whenever the caching host allocator has no free block."""
+        ok = self._slots is not None and self._slots[0]["cap"] >= cap and \
+            (not need_relations or self._slots[0]["bufs"][1] is not None)
+        if not ok:
+            self._slots = []
+            for _ in range(4):
+                ent = torch.empty(cap, _capi.TRANSH_ENT, _capi.TRANSH_DIM, pin_memory=_PIN_TABLES)
+                rel = torch.empty(cap, self.K, _capi.TRANSH_DIM, pin_memory=_PIN_TABLES) if need_relations else None
+                nrm = torch.empty(cap, self.K, _capi.TRANSH_DIM, pin_memory=_PIN_TABLES) if need_relations else None
+                self._slots.append(dict(cap=cap, bufs=(ent, rel, nrm), event=None))
+        return self._slots
 
     def verbs(self, device):
         if self._vt is None or self._vt.off.device != device:
@@ -360,7 +383,8 @@ class HeadEngine:
         # in image order, while this thread enqueues GPU work; torch releases the GIL inside the draws.
         drawer = None
         if tables is None:
-            drawer = _TableDrawer(self.K, [b - a for a, b in bounds], want_scores)
+            drawer = _TableDrawer(self.K, [b - a for a, b in bounds], want_scores,
+                                  self._table_slots(max(b - a for a, b in bounds), want_scores))
         try:
             # software pipeline over chunks: phase A (no dependence on the TransH tables) runs `lookahead` chunks ahead
             # of phase B, so the GPU always has queued work while the host draws the next chunk's tables
@@ -378,15 +402,20 @@ class HeadEngine:
                     t = drawer.get(ci)
                 else:
                     t = tuple(None if x is None else x[a0:a1] for x in tables)
-                tabs.append(t)
+                if self.debug:
+                    tabs.append(tuple(None if x is None else x.clone() for x in t))
                 self._chunk_phase_b(ctxs.pop(ci), t, pw, pre, enc, PF, sc, keep)
+                if tables is None:                      # staging slot is free again once its H2D copies are done
+                    ev = torch.cuda.Event(); ev.record()
+                    drawer.slots[ci % len(drawer.slots)]["event"] = ev
                 if ci + lookahead < len(bounds):
                     phase_a(ci + lookahead)
         finally:
             if drawer is not None:
                 drawer.join()
         out.update(x_keep=x_keep[:Mp], y_keep=y_keep[:Mp], meta=meta_g, pair_features=PF[:Mp])
-        out["tables"] = tuple(None if tabs[0][i] is None else torch.cat([t[i] for t in tabs]) for i in range(3))
+        if tabs:
+            out["tables"] = tuple(None if tabs[0][i] is None else torch.cat([t[i] for t in tabs]) for i in range(3))
         if want_scores:
             out["transh_scores"] = sc[:Mp]
         if keep is not None:

@@ -30,11 +30,17 @@ def draw_tables(K, need_relations=False, generator=None):
     return ent, rel, nrm
 
 
-def draw_batch(K, n_images, need_relations=False, pin=False):
-    """Tables for `n_images` processed images, stacked: ent [A,80,50] (+ rel, norm [A,K,50])."""
-    ent = torch.empty(n_images, TRANSH_ENT, TRANSH_DIM, pin_memory=pin)
-    rel = torch.empty(n_images, K, TRANSH_DIM, pin_memory=pin) if need_relations else None
-    nrm = torch.empty(n_images, K, TRANSH_DIM, pin_memory=pin) if need_relations else None
+def draw_batch(K, n_images, need_relations=False, pin=False, out=None):
+    """Tables for `n_images` processed images, stacked: ent [A,80,50] (+ rel, norm [A,K,50]).
+    `out` = (ent, rel, nrm) pre-allocated (e.g. persistent pinned) buffers with at least n_images rows."""
+    if out is not None:
+        ent = out[0][:n_images]
+        rel = out[1][:n_images] if need_relations else None
+        nrm = out[2][:n_images] if need_relations else None
+    else:
+        ent = torch.empty(n_images, TRANSH_ENT, TRANSH_DIM, pin_memory=pin)
+        rel = torch.empty(n_images, K, TRANSH_DIM, pin_memory=pin) if need_relations else None
+        nrm = torch.empty(n_images, K, TRANSH_DIM, pin_memory=pin) if need_relations else None
     for a in range(n_images):
         e, r, n = draw_tables(K, need_relations)
         ent[a] = e
