@@ -96,9 +96,25 @@ def graph_train(eng, gh, feat3, image_shapes, pooled, pre, targets):
             lab = associate_with_ground_truth(coords[xk], coords[yk], targets[b], K, gh.fg_iou_thresh)
             lab_imgs.append(lab)
         n_pos = [int(torch.count_nonzero(l)) for l in lab_imgs]
+        # The global CPU RNG is advanced exactly like the reference (per image: six TransH draws, HEAD:574-580, then
+        # randperm(#negatives), HEAD:938-939).  randperm(n) consumes n-1 32-bit draws: the stream is advanced with a
+        # cheap random_() of that length and the permutation itself is computed from the saved state by worker threads
+        # with private generators, overlapped with the GPU work below (tests pin the equivalence).
+        from concurrent.futures import ThreadPoolExecutor
+
+        def _perm(state, n, m):
+            g = torch.Generator(); g.set_state(state)
+            return torch.randperm(n, generator=g)[:m]
+
+        pool = ThreadPoolExecutor(max_workers=min(8, max(A, 1)))
         for a in range(A):
-            tabs.append(transh.draw_tables(K, need_relations=True))                 # HEAD:574-580
-            perms.append(torch.randperm(lab_imgs[a].numel() - n_pos[a])[:n_pos[a]])  # HEAD:938-939
+            tabs.append(transh.draw_tables(K, need_relations=True))
+            n_neg = lab_imgs[a].numel() - n_pos[a]
+            state = torch.get_rng_state()
+            if n_neg > 1:
+                torch.empty(n_neg - 1, dtype=torch.int32).random_()
+            perms.append(pool.submit(_perm, state, n_neg, n_pos[a]))
+        pool.shutdown(wait=False)
         ent = torch.stack([t[0] for t in tabs]).to(dev); rel = torch.stack([t[1] for t in tabs]).to(dev)
         nrm = torch.stack([t[2] for t in tabs]).to(dev)
         scores_all = torch.empty(max(Mp, 1), K, device=dev)
@@ -160,7 +176,7 @@ def graph_train(eng, gh, feat3, image_shapes, pooled, pre, targets):
         tl = lab_imgs[a]
         px, py = torch.nonzero(tl).unbind(1)
         neg_xy = (tl == 0).nonzero()
-        nx, ny = neg_xy[perms[a].to(dev)].unbind(1)
+        nx, ny = neg_xy[perms[a].result().to(dev)].unbind(1)
         sk = scores_all[p0:p0 + P]
         e_a, r_a, n_a = ent[a], rel[a], nrm[a]
         hrow = e_a[gh.human_idx]
