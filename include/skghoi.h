@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SKG_ABI_VERSION 1
+#define SKG_ABI_VERSION 2
 #define SKG_E_ARG   (-1)   /* null pointer / negative size / unsupported shape            */
 #define SKG_E_ALIGN (-2)   /* pointer or leading dimension not 16-byte aligned            */
 #define SKG_E_LIMIT (-3)   /* exceeds a compiled-in limit (boxes per image, verbs, ...)   */
@@ -121,6 +121,10 @@ typedef struct {
     float*       dot_partial;          /* [2*ceil(N/128), M]: one partial per 64-column slab                        */
     /* SKG_EPI_BIAS_RES_RELU */
     const float* res; int64_t ldres;   /* [M, N]                                                                    */
+    /* split-K (BIAS / BIAS_RELU only): K is cut in split_k slices computed by separate workgroups; raw partial sums
+     * go to split_ws [split_k, M, N] and a second kernel adds them in slice order and applies the epilogue.          */
+    int32_t split_k; int32_t _pad;     /* 0 or 1 = off                                                              */
+    float*  split_ws;
 } skg_gemm_desc;
 
 int skg_gemm_f32(const skg_gemm_desc* desc_host, void* stream);

@@ -12,7 +12,7 @@ MAX_NODES = 160
 SPATIAL_LD = 48
 TRANSH_DIM = 50
 TRANSH_ENT = 80
-ABI_VERSION = 1
+ABI_VERSION = 2
 GEMM_GROUP_MAX = 4
 
 _vp = C.c_void_p
@@ -27,7 +27,7 @@ class GemmDesc(C.Structure):
                 ("M", _i32), ("N", _i32), ("K", _i32), ("epilogue", _i32), ("a_rows", _vp), ("out_rows", _vp),
                 ("P", _vp), ("p_idx", _vp), ("ldp", _i64), ("Q", _vp), ("q_idx", _vp), ("ldq", _i64),
                 ("mbias", _vp), ("C_raw", _vp), ("ldc_raw", _i64), ("dot_w", _vp), ("dot_partial", _vp),
-                ("res", _vp), ("ldres", _i64)]
+                ("res", _vp), ("ldres", _i64), ("split_k", _i32), ("_pad", _i32), ("split_ws", _vp)]
 
 
 # numpy dtype of skg_image_meta (12 x 4 bytes)

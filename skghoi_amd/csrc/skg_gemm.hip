@@ -46,7 +46,7 @@ __host__ __device__ __forceinline__ void skg_gemm_map(int nbn, int K, int& g, in
     while (NG < ng) NG <<= 1;
 }
 
-static inline int64_t skg_gemm_blocks(int M, int N, int K) {
+__host__ __device__ __forceinline__ int64_t skg_gemm_blocks(int M, int N, int K) {
     const int64_t nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
     int g, NG;
     skg_gemm_map((int)nbn, K, g, NG);
@@ -57,8 +57,20 @@ static inline int64_t skg_gemm_blocks(int M, int N, int K) {
 
 // EPI >= 0: epilogue fixed at compile time; EPI < 0: taken from the descriptor (grouped launches of small GEMMs).
 template <int EPI_T, bool GLDS>
-__device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, const int block_id, float* smem) {
+__device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_id, float* smem) {
     const int EPI = EPI_T >= 0 ? EPI_T : d.epilogue;
+    // split-K (small-M layers, e.g. box_head at batch 1: M = 40, K = 12544): slice s of the K range goes to blocks
+    // [s * tiles, (s + 1) * tiles); raw partial sums land in d.split_ws[s] and skg_splitk_reduce_kernel applies the
+    // bias / ReLU epilogue in a fixed slice order (deterministic).
+    int kt_begin = 0, kt_end = (d.K + BK - 1) / BK, split_slice = 0;
+    if (d.split_k > 1) {
+        const int tiles = (int)skg_gemm_blocks(d.M, d.N, d.K);
+        split_slice = block_id / tiles;
+        block_id -= split_slice * tiles;
+        const int per = (kt_end + d.split_k - 1) / d.split_k;
+        kt_begin = split_slice * per;
+        kt_end = kt_begin + per < kt_end ? kt_begin + per : kt_end;
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = tid >> 6;
@@ -98,7 +110,7 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, const int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    const int nk = (d.K + BK - 1) / BK;
+    const int nk = kt_end;
     if constexpr (!GLDS) {
     // ---- global -> register staging map: thread owns rows (lr, lr+64) x 4 consecutive k
     constexpr int TPR = BK / 4;                  // threads per tile row (float4 each)
@@ -150,11 +162,11 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, const int 
         }
     };
 
-    gload(0);
-    lstore(0, 0);
+    gload(kt_begin);
+    lstore(kt_begin & 1, kt_begin);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt_begin; kt < nk; ++kt) {
         const int cur = kt & 1;
 #if !defined(SKG_ABL) || SKG_ABL == 1
         if (kt + 1 < nk) gload(kt + 1);
@@ -228,9 +240,9 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, const int 
             }
         };
         const int swr = (li >> 2) & 3;                                // (row >> 2) & 3 of the rows this lane READS
-        stage(0, 0);
-        __syncthreads();                                              // drains vmcnt: tile 0 has landed
-        for (int kt = 0; kt < nk; ++kt) {
+        stage(kt_begin & 1, kt_begin);
+        __syncthreads();                                              // drains vmcnt: the first tile has landed
+        for (int kt = kt_begin; kt < nk; ++kt) {
             const int cur = kt & 1;
             const float* a_s = smem + cur * GT + (wr * 64 + li) * BK;
             const float* b_s = smem + 2 * GT + cur * GT + (wc * 64 + li) * BK;
@@ -296,6 +308,14 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, const int 
             const float4 a4 = *reinterpret_cast<const float4*>(est + rl * EST_LD + c4);
             float v[4] = {a4.x, a4.y, a4.z, a4.w};
             const bool rin = row < d.M;
+            if (d.split_k > 1) {                                      // raw partial sums, [slice][M][N], no epilogue
+                if (rin) {
+                    float* wsp = d.split_ws + ((int64_t)split_slice * d.M + row) * d.N + col;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (col + c < d.N) wsp[c] = v[c];
+                }
+                continue;
+            }
             const bool full = vec_ok && (col + 3 < d.N);
             float bia[4] = {0.f, 0.f, 0.f, 0.f};
             if (d.bias) {
@@ -404,7 +424,23 @@ __global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_group_kernel(const skg
     skg_gemm_tile<-1, false>(g.d[k], blockIdx.x - g.start[k], smem);
 }
 
+__global__ __launch_bounds__(256) void skg_splitk_reduce_kernel(const skg_gemm_desc d) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)d.M * d.N;
+    if (i >= total) return;
+    const int row = (int)(i / d.N), col = (int)(i % d.N);
+    float v = 0.f;
+    for (int s = 0; s < d.split_k; ++s) v += d.split_ws[(int64_t)s * total + i];
+    if (d.bias) v += d.bias[col];
+    if (d.epilogue == SKG_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+    const int orow = d.out_rows ? d.out_rows[row] : row;
+    if (orow >= 0) d.C[(int64_t)orow * d.ldc + col] = v;
+}
+
 static int skg_gemm_validate(const skg_gemm_desc& d) {
+    if (d.split_k > 1 && (!d.split_ws || (d.epilogue != SKG_EPI_BIAS && d.epilogue != SKG_EPI_BIAS_RELU) ||
+                          d.split_k > 64))
+        return SKG_E_ARG;
     if (d.M < 0 || d.N <= 0 || d.K <= 0 || !d.A || !d.W) return SKG_E_ARG;
     if ((d.K & 3) || (d.lda & 3) || (d.ldw & 3)) return SKG_E_ALIGN;
     if (!skg_aligned16(d.A) || !skg_aligned16(d.W)) return SKG_E_ALIGN;
@@ -431,6 +467,7 @@ extern "C" int skg_gemm_group_f32(const skg_gemm_desc* descs_host, int n, void* 
     for (int i = 0; i < n; ++i) {
         const int rc = skg_gemm_validate(descs_host[i]);
         if (rc) return rc;
+        if (descs_host[i].split_k > 1) return SKG_E_ARG;
         if (descs_host[i].M == 0) continue;
         const int64_t nb = skg_gemm_blocks(descs_host[i].M, descs_host[i].N, descs_host[i].K);
         if (blocks + nb > 0x7fffffffLL) return SKG_E_LIMIT;
@@ -451,7 +488,7 @@ extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
     const int rc = skg_gemm_validate(d);
     if (rc) return rc;
     if (d.M == 0) return 0;
-    const int64_t nblk = skg_gemm_blocks(d.M, d.N, d.K);
+    const int64_t nblk = skg_gemm_blocks(d.M, d.N, d.K) * (d.split_k > 1 ? d.split_k : 1);
     if (nblk > 0x7fffffffLL) return SKG_E_LIMIT;
     dim3 grid((unsigned)nblk), block(256);
     hipStream_t s = (hipStream_t)stream;
@@ -467,5 +504,9 @@ extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
         case SKG_EPI_BIAS_RES_RELU: SKG_LAUNCH(SKG_EPI_BIAS_RES_RELU) break;
     }
 #undef SKG_LAUNCH
+    if (d.split_k > 1) {
+        const int64_t total = (int64_t)d.M * d.N;
+        hipLaunchKernelGGL(skg_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
+    }
     return skg_launch_status();
 }

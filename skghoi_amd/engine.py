@@ -119,7 +119,7 @@ class VerbTable:
 
 def gemm_desc(A, W, bias, C_out, M, N, K, epilogue, lda=None, ldw=None, ldc=None, a_rows=None, out_rows=None, P=None,
               p_idx=None, ldp=0, Q=None, q_idx=None, ldq=0, mbias=None, C_raw=None, ldc_raw=0, dot_w=None,
-              dot_partial=None, res=None, ldres=0, A_off=0, W_off=0, C_off=0, d=None):
+              dot_partial=None, res=None, ldres=0, A_off=0, W_off=0, C_off=0, d=None, split_k=0, split_ws=None):
     """Fills a skg_gemm_desc.  *_off are element offsets into A / W / C (column sub-views)."""
     d = _capi.GemmDesc() if d is None else d
     d.A = A.data_ptr() + 4 * A_off; d.lda = lda if lda is not None else A.stride(0)
@@ -134,7 +134,17 @@ def gemm_desc(A, W, bias, C_out, M, N, K, epilogue, lda=None, ldw=None, ldc=None
     d.mbias = _ptr(mbias); d.C_raw = _ptr(C_raw); d.ldc_raw = ldc_raw
     d.dot_w = _ptr(dot_w); d.dot_partial = _ptr(dot_partial)
     d.res = _ptr(res); d.ldres = ldres
+    d.split_k = split_k; d.split_ws = _ptr(split_ws)
     return d
+
+
+def pick_split_k(M, N, K, target_blocks=1024):
+    """Split-K factor for a plain layer whose M x N tile grid would leave most of the 256 CUs idle while each
+    workgroup walks a long K (box_head: K = 12544).  Slices keep >= 16 k-tiles (256 k) each."""
+    blocks = ((M + 127) // 128) * ((N + 127) // 128)
+    if blocks >= target_blocks or K < 2048:
+        return 1
+    return int(max(1, min(-(-target_blocks // blocks), K // 256, 64)))
 
 
 def gemm(A, W, bias, C_out, M, N, K, epilogue, **kw):
@@ -362,7 +372,9 @@ class HeadEngine:
         enc1 = torch.empty(max(NA, 1), 1024, **f32)
         enc = torch.empty(max(NA, 1), 1024, **f32)
         if NA:
-            gemm(x0, pw.bh1_w, pw.bh1_b, enc1, NA, 1024, x0.shape[1], _capi.EPI_BIAS_RELU)
+            sk = pick_split_k(NA, 1024, x0.shape[1])
+            ws = torch.empty(sk, NA, 1024, **f32) if sk > 1 else None
+            gemm(x0, pw.bh1_w, pw.bh1_b, enc1, NA, 1024, x0.shape[1], _capi.EPI_BIAS_RELU, split_k=sk, split_ws=ws)
             gemm(enc1, pw.bh3_w, pw.bh3_b, enc, NA, 1024, 1024, _capi.EPI_BIAS_RELU)
         out["enc"] = enc[:NA]
         out["gfeat"] = gfeat

@@ -34,6 +34,16 @@ def test_gemm_bias_relu_shapes_and_tails(M, N, K):
     _close(C2, (A.double() @ W.double().t()).float(), 2e-5)
 
 
+@pytest.mark.parametrize("M,N,K,S", [(40, 1024, 12544, 32), (130, 118, 2048, 3), (300, 1024, 1088, 5), (64, 64, 64, 2)])
+def test_gemm_split_k(M, N, K, S):
+    A = _rand(M, K, seed=1); W = _rand(N, K, seed=2) / np.sqrt(K); b = _rand(N, seed=3)
+    ref = torch.relu(A.double() @ W.double().t() + b.double()).float()
+    C = torch.empty(M, N, device="cuda"); ws = torch.empty(S, M, N, device="cuda")
+    gemm(A, W, b, C, M, N, K, _capi.EPI_BIAS_RELU, split_k=S, split_ws=ws)
+    torch.cuda.synchronize()
+    _close(C, ref, 2e-5)
+
+
 def test_gemm_identity_asymmetric_layout():
     """A = I against an asymmetric W catches any row/col swap of the MFMA C/D map."""
     n = 128
