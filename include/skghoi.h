@@ -86,6 +86,19 @@ int skg_pairs_spatial_f32(const float* boxes, const skg_image_meta* meta, int n_
                           int32_t* pair_grid, int64_t* x_keep, int64_t* y_keep, int32_t* pair_h, int32_t* pair_o,
                           float* spatial, int scrub_nan, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * MultiScaleRoIAlign (models/adamixer_transH_spatial_r50_models.py:158-162, called at HEAD:387): the producer of the
+ * cached box features.  feats_host / H_host / W_host / scales_host are HOST arrays of n_levels entries (device
+ * pointers to [B, C, H_l, W_l] maps, their sizes and spatial scales); boxes [n_rois, 4] in image pixels, box_image
+ * [n_rois] = batch index; out [n_rois, C, pooled, pooled].  Level = clamp(floor(canonical_level + log2(sqrt(area) /
+ * canonical_scale) + 1e-6), k_min, k_max) - k_min; roi_align with aligned = False, sampling_ratio samples per bin axis
+ * (<= 0: adaptive).                                                                                                 */
+#define SKG_ROI_MAX_LEVELS 8
+int skg_roi_align_f32(const float* const* feats_host, const int32_t* H_host, const int32_t* W_host,
+                      const float* scales_host, int n_levels, int C, int k_min, int k_max, float canonical_scale,
+                      int canonical_level, const float* boxes, const int32_t* box_image, int n_rois, int pooled,
+                      int sampling, float* out, void* stream);
+
 /* AdaptiveAvgPool2d(1) of features['3'] (HEAD:811): in [B, C, HW] -> out [B, C]. */
 int skg_global_avgpool_f32(const float* in, int B, int C, int HW, float* out, void* stream);
 

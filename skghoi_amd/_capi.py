@@ -43,6 +43,8 @@ PROTOTYPES = {
     "skg_pack_detections_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "skg_pairs_spatial_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int,
                                         _vp]),
+    "skg_roi_align_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp,
+                                    C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "skg_global_avgpool_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "skg_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "skg_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
