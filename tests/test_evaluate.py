@@ -1,0 +1,82 @@
+"""HOI mapping, association, 11-point AP and the exporters against the loop-level oracle (CPU)."""
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import eval_oracle as EO
+from skghoi_amd import evaluate as ev, synth
+
+
+def _rand_boxes(rs, n):
+    xy = rs.uniform(0, 300, (n, 2)); wh = rs.uniform(20, 200, (n, 2))
+    return torch.tensor(np.concatenate([xy, xy + wh], 1), dtype=torch.float32)
+
+
+def test_hoi_lut_matches_object_to_verb():
+    lut = ev.hico_object_n_verb_to_interaction()
+    o2v = synth.hico_object_to_verb()
+    assert lut.shape == (80, 117) and int((lut >= 0).sum()) == 600 and sorted(lut[lut >= 0].tolist()) == list(range(600))
+    for o in range(80):
+        assert sorted(torch.nonzero(lut[o] >= 0).squeeze(1).tolist()) == sorted(o2v[o])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_association_matches_oracle(seed):
+    rs = np.random.RandomState(seed)
+    n_gt, n_det = rs.randint(0, 5), rs.randint(0, 12)
+    gh, go = _rand_boxes(rs, n_gt), _rand_boxes(rs, n_gt)
+    # detections = jittered copies of gt pairs + random ones
+    dh = torch.cat([gh[rs.randint(0, max(n_gt, 1), n_det // 2)] + 3 if n_gt else gh[:0], _rand_boxes(rs, n_det - (n_det // 2 if n_gt else 0))])
+    do = torch.cat([go[rs.randint(0, max(n_gt, 1), n_det // 2)] + 2 if n_gt else go[:0], _rand_boxes(rs, n_det - (n_det // 2 if n_gt else 0))])
+    sc = torch.tensor(rs.uniform(0, 1, len(dh)), dtype=torch.float32)
+    got = ev.associate_pairs(gh, go, dh, do, sc)
+    want = EO.associate(gh.numpy(), go.numpy(), dh.numpy(), do.numpy(), sc.numpy())
+    assert np.array_equal(got.numpy(), want)
+
+
+def test_ap_meter_matches_oracle_and_known_answers():
+    rs = np.random.RandomState(1)
+    m = ev.DetectionAPMeter(3, num_gt=[5, 2, 0])
+    all_s, all_c, all_l = [], [], []
+    for _ in range(4):
+        s = torch.tensor(rs.uniform(0, 1, 9)); c = torch.tensor(rs.randint(0, 3, 9)); l = torch.tensor((rs.uniform(0, 1, 9) > 0.6).astype(np.float64))
+        m.append(s, c, l); all_s.append(s); all_c.append(c); all_l.append(l)
+    ap = m.eval()
+    S, Cc, L = torch.cat(all_s).numpy(), torch.cat(all_c).numpy(), torch.cat(all_l).numpy()
+    for c, ng in enumerate([5, 2, 0]):
+        want = EO.ap_11p(S[Cc == c].tolist(), L[Cc == c].tolist(), ng)
+        assert abs(float(ap[c]) - want) < 1e-12
+    # known answers: perfect ranking with all gt found -> 1; one TP out of two gt at rank 1 -> 6/11
+    assert ev.DetectionAPMeter._ap(torch.tensor([0.9, 0.8]), torch.tensor([1., 1.]), 2, "11P") == pytest.approx(1.0)
+    assert ev.DetectionAPMeter._ap(torch.tensor([0.9, 0.8]), torch.tensor([1., 0.]), 2, "11P") == pytest.approx(6 / 11)
+
+
+def test_evaluator_and_exporters(tmp_path):
+    lut = ev.hico_object_n_verb_to_interaction()
+    o2v = synth.hico_object_to_verb()
+    bh = torch.tensor([[10., 10., 100., 200.], [300., 20., 380., 220.]]); bo = torch.tensor([[50., 60., 150., 160.], [200., 100., 320., 180.]])
+    obj = torch.tensor([3, 17])
+    idx = torch.tensor([0, 0, 1]); pred = torch.tensor([o2v[3][0], o2v[3][1], o2v[17][0]])
+    out = dict(boxes_h=bh, boxes_o=bo, index=idx, prediction=pred, scores=torch.tensor([0.9, 0.4, 0.7]), object=obj)
+    hoi0 = int(lut[3, o2v[3][0]]); hoi2 = int(lut[17, o2v[17][0]])
+    target = dict(boxes_h=torch.tensor([[12., 11., 98., 205.]]), boxes_o=torch.tensor([[52., 58., 149., 161.]]),
+                  hoi=torch.tensor([hoi0]))
+    num_gt = [0] * 600; num_gt[hoi0] = 1; num_gt[hoi2] = 1
+    e = ev.HOIEvaluator(num_gt, num_anno_train=[5 if i % 2 else 50 for i in range(600)])
+    labels = e.add(out, target)
+    assert labels.tolist() == [1.0, 0.0, 0.0]
+    s = e.summary()
+    assert s["ap"][hoi0] == pytest.approx(1.0) and s["ap"][hoi2] == 0.0 and s["full"] == pytest.approx(1 / 600)
+    assert "rare" in s and "non_rare" in s
+    cells = ev.hicodet_mat_cells([out], [2], n_images=4)
+    assert cells.shape == (600, 4) and cells[hoi0, 2].shape == (1, 9) and cells[hoi0, 0].shape == (0, 0)
+    assert cells[hoi0, 2][0, 2] == 99.0 and cells[hoi0, 2][0, 8] == pytest.approx(0.9)      # x2 - 1, score
+    res = ev.vcoco_results([out], [4711], ["hold obj"] * 117)
+    assert len(res) == 3 and res[0]["image_id"] == 4711 and res[0]["hold_agent"] == pytest.approx(0.9)
+    assert res[0]["hold_obj"][:4] == bo[0].tolist() and res[0]["sit_agent"] == 0. and res[0]["sit_instr"] == [0., 0., .1, .1, 0.]
+    ev.save_vcoco_pickle(res, str(tmp_path))
+    back = pickle.load(open(tmp_path / "vcoco_results.pkl", "rb"))
+    assert len(back) == 3 and back[1]["person_box"] == bh[0].tolist()
+    assert type(back[0]).__module__ == "cache_template" and back[0]["carry_obj"] == [0., 0., .1, .1, 0.]
