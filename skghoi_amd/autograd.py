@@ -11,11 +11,18 @@ Replaces the autograd of every nn.Linear on the interaction-head path (reference
 import torch
 
 from . import _capi
-from .engine import gemm, _stream
+from .engine import gemm, pick_split_k, _stream
 
 
 def _pad4(n):
     return (n + 3) // 4 * 4
+
+
+def _gemm_sk(A, W, bias, C, M, N, K, epi):
+    """skg_gemm_f32 with split-K when the M x N tile grid is small and K long (dW = dZ^T X has K = batch rows)."""
+    sk = pick_split_k(M, N, K)
+    ws = torch.empty(sk, M, N, device=A.device, dtype=torch.float32) if sk > 1 else None
+    gemm(A, W, bias, C, M, N, K, epi, split_k=sk, split_ws=ws)
 
 
 def transpose(x, rows, cols, ld_out=None):
@@ -48,8 +55,8 @@ class LinearFn(torch.autograd.Function):
             wp = w
         y = torch.empty(M, N, device=x.device)
         if M:
-            gemm(xp, wp, bias.float().contiguous() if bias is not None else None, y, M, N, Kp,
-                 _capi.EPI_BIAS_RELU if relu else _capi.EPI_BIAS)
+            _gemm_sk(xp, wp, bias.float().contiguous() if bias is not None else None, y, M, N, Kp,
+                     _capi.EPI_BIAS_RELU if relu else _capi.EPI_BIAS)
         ctx.relu = relu
         ctx.K = K
         ctx.has_bias = bias is not None
@@ -76,7 +83,7 @@ class LinearFn(torch.autograd.Function):
             wT = transpose(wp, N, Kp, ld_out=Np)                     # [Kp, Np]
             dxp = torch.empty(M, Kp, device=dz.device)
             if M:
-                gemm(dzp, wT, None, dxp, M, Kp, Np, _capi.EPI_BIAS)
+                _gemm_sk(dzp, wT, None, dxp, M, Kp, Np, _capi.EPI_BIAS)
             dx = dxp[:, :K]
         if ctx.needs_input_grad[1]:
             Mp = _pad4(M)
@@ -84,7 +91,7 @@ class LinearFn(torch.autograd.Function):
             xT = transpose(xp, M, Kp, ld_out=Mp)                     # [Kp, Mp]
             dwp = torch.empty(N, Kp, device=dz.device)
             if M:
-                gemm(dzT, xT, None, dwp, N, Kp, Mp, _capi.EPI_BIAS)
+                _gemm_sk(dzT, xT, None, dwp, N, Kp, Mp, _capi.EPI_BIAS)
             else:
                 dwp.zero_()
             dw = dwp[:, :K]
