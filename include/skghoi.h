@@ -204,6 +204,15 @@ int skg_postprocess_f32(const float* logits, int64_t ld_logits, int K, const flo
 int skg_transh_scores_f32(const float* ent, const float* rel, const float* nrm, int K, int human_idx,
                           const skg_image_meta* meta, int n_active, float* scores, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * GraphHead.associate_with_ground_truth (HEAD:703-719), training: labels[p, verb] = 1 where a ground-truth pair with
+ * that verb overlaps the kept pair p with min(IoU_h, IoU_o) >= thresh.  gt_* are the targets of the active images
+ * concatenated, gt_off[n_active + 1] their row ranges; labels [sumP, K] must be zero-filled; npos[n_active] receives
+ * the number of positive (pair, verb) cells per image.  One workgroup per image.                                    */
+int skg_associate_f32(const float* boxes, const skg_image_meta* meta, int n_active, const int64_t* x_keep,
+                      const int64_t* y_keep, const float* gt_h, const float* gt_o, const int64_t* gt_label,
+                      const int32_t* gt_off, int K, float thresh, float* labels, int32_t* npos, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

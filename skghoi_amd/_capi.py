@@ -57,6 +57,7 @@ PROTOTYPES = {
     "skg_layernorm_f32": (C.c_int, [_vp, _i64, _vp, _vp, C.c_int, C.c_int, _f32, _vp, _i64, _vp]),
     "skg_postprocess_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int,
                                       _f32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "skg_associate_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _f32, _vp, _vp, _vp]),
     "skg_transh_scores_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
 }
 

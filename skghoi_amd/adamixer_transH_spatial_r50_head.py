@@ -339,21 +339,53 @@ class InteractionHead(Module):
         pre = eng.preprocess(detections, targets, True, True)
         box_coords = list(pre.boxes.split(pre.sizes))
         box_features = self.box_roi_pool(features, box_coords, image_shapes)
-        (feats, bh, bo, oc, labels, prior, pos, neg, he, te, re, rn), lay = graph_train(
+        (feats, bh, bo, oc, labels, prior, pos, neg, he, te, re, rn), lay, P = graph_train(
             eng, self.box_pair_head, features["3"], image_shapes, box_features, pre, targets)
         if len(feats) == 0:
             raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
-        pf = torch.cat(feats)
+        pf = P["PF"] if P is not None else torch.cat(feats)       # skipped images contribute zero rows
         if isinstance(self.box_pair_predictor, nn.Linear) and isinstance(self.box_pair_suppressor, nn.Linear):
             logits_p = linear(pf, self.box_pair_predictor.weight, self.box_pair_predictor.bias)
             logits_s = linear(pf, self.box_pair_suppressor.weight, self.box_pair_suppressor.bias)
         else:
             logits_p = self.box_pair_predictor(pf); logits_s = self.box_pair_suppressor(pf)
-        results = self.postprocess(logits_p, logits_s, prior, bh, bo, oc, labels)
+        results = self._postprocess_packed(logits_p, logits_s, P, lay, pf.device)
         results.append(dict(
             hoi_loss=self.compute_interaction_classification_loss(results),
             interactiveness_loss=self.compute_interactiveness_loss(results),
             transH_loss=self.compute_transH_loss(pos, neg, he, re, rn, te, results)))
+        return results
+
+    def _postprocess_packed(self, logits_p, logits_s, P, lay, dev):
+        """postprocess (HEAD:237-337) for the whole training batch at once; per-image dicts are views."""
+        K = self.num_classes
+        results = []
+        if P is not None:
+            A = len(P["ppi"])
+            weights = torch.sigmoid(logits_s).squeeze(1)
+            scores = torch.sigmoid(logits_p)
+            prior, lab = P["prior"], P["labels"]
+            x, y = torch.nonzero(prior[0]).unbind(1)
+            action = scores[x, y] * prior[:, x, y].prod(dim=0) * weights[x].detach()
+            pxy = prior[:, x, y]
+            lxy = lab[x, y]
+            unary = lab.sum(dim=1).clamp(max=1)
+            cpi = torch.bincount(P["pair_img"][x], minlength=A).tolist()
+            pair_off = torch.from_numpy(lay.meta["pair_off"].astype("int64")).to(dev)
+            xl = x - pair_off[P["pair_img"][x]]
+            ppi = P["ppi"]
+            w_s, u_s = weights.split(ppi), unary.split(ppi)
+            bh_s, bo_s, ob_s = P["boxes_h"].split(ppi), P["boxes_o"].split(ppi), P["object"].split(ppi)
+            x_s, y_s, a_s, l_s = xl.split(cpi), y.split(cpi), action.split(cpi), lxy.split(cpi)
+            p_s = pxy.split(cpi, dim=1)
+        a = 0
+        for b in range(lay.n_visit):
+            if lay.skipped[b]:
+                results.append(self._empty_result(dev, with_labels=True))
+                continue
+            results.append(dict(boxes_h=bh_s[a], boxes_o=bo_s[a], index=x_s[a], prediction=y_s[a], scores=a_s[a],
+                                object=ob_s[a], prior=p_s[a], weights=w_s[a], labels=l_s[a], unary_labels=u_s[a]))
+            a += 1
         return results
 
     def _n_p(self, n_p):

@@ -149,3 +149,67 @@ extern "C" int skg_transh_scores_f32(const float* ent, const float* rel, const f
 
 extern "C" int skg_abi_version(void) { return SKG_ABI_VERSION; }
 extern "C" const char* skg_build_info(void) { return "libskghoi_hip gfx950 " __VERSION__ " " __DATE__; }
+
+// ------------------------------------------------------------------------------------------------ GT association
+// GraphHead.associate_with_ground_truth (HEAD:703-719) for every active image in one launch: labels[p, verb] = 1 where
+// min(IoU(box_h, gt_h), IoU(box_o, gt_o)) >= thresh for a ground-truth pair with that verb.  IoU as torchvision's
+// box_iou (inter / (a1 + a2 - inter), no eps); compiled without fma contraction -> same decisions as the CPU code.
+// labels must be zero-filled by the caller; npos[a] = number of non-zero labels of image a (HEAD:936, 166).
+__device__ __forceinline__ float skg_iou(const float4 a, const float4 b) {
+    const float aa = (a.z - a.x) * (a.w - a.y), ab = (b.z - b.x) * (b.w - b.y);
+    const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.f), h = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.f);
+    const float inter = w * h;
+    return inter / (aa + ab - inter);
+}
+
+__global__ __launch_bounds__(256) void skg_associate_kernel(const float* __restrict__ boxes,
+                                                            const skg_image_meta* __restrict__ meta,
+                                                            const int64_t* __restrict__ x_keep,
+                                                            const int64_t* __restrict__ y_keep,
+                                                            const float* __restrict__ gt_h,
+                                                            const float* __restrict__ gt_o,
+                                                            const int64_t* __restrict__ gt_label,
+                                                            const int32_t* __restrict__ gt_off, int K, float thresh,
+                                                            float* __restrict__ labels, int32_t* __restrict__ npos) {
+    __shared__ int sred[4];
+    const int a = blockIdx.x;
+    const skg_image_meta mt = meta[a];
+    const int P = mt.n_h * (mt.n - 1);
+    const int g0 = gt_off[a], g1 = gt_off[a + 1];
+    for (int pl = threadIdx.x; pl < P; pl += 256) {
+        const int64_t p = (int64_t)mt.pair_off + pl;
+        const float4 bh = *reinterpret_cast<const float4*>(boxes + 4 * (int64_t)(mt.box_off + (int)x_keep[p]));
+        const float4 bo = *reinterpret_cast<const float4*>(boxes + 4 * (int64_t)(mt.box_off + (int)y_keep[p]));
+        for (int g = g0; g < g1; ++g) {
+            const float ih = skg_iou(bh, *reinterpret_cast<const float4*>(gt_h + 4 * (int64_t)g));
+            const float io = skg_iou(bo, *reinterpret_cast<const float4*>(gt_o + 4 * (int64_t)g));
+            if (fminf(ih, io) >= thresh && !(ih != ih) && !(io != io)) {
+                const int64_t v = gt_label[g];
+                if (v >= 0 && v < K) labels[p * K + v] = 1.f;
+            }
+        }
+    }
+    __syncthreads();
+    int cnt = 0;
+    const int64_t base = (int64_t)mt.pair_off * K, tot = (int64_t)P * K;
+    for (int64_t i = threadIdx.x; i < tot; i += 256) cnt += labels[base + i] != 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) npos[a] = sred[0] + sred[1] + sred[2] + sred[3];
+}
+
+extern "C" int skg_associate_f32(const float* boxes, const skg_image_meta* meta, int n_active, const int64_t* x_keep,
+                                 const int64_t* y_keep, const float* gt_h, const float* gt_o, const int64_t* gt_label,
+                                 const int32_t* gt_off, int K, float thresh, float* labels, int32_t* npos,
+                                 void* stream) {
+    if (n_active < 0 || K <= 0) return SKG_E_ARG;
+    if (n_active == 0) return 0;
+    if (!boxes || !meta || !x_keep || !y_keep || !gt_h || !gt_o || !gt_label || !gt_off || !labels || !npos)
+        return SKG_E_ARG;
+    if (!skg_aligned16(boxes) || !skg_aligned16(gt_h) || !skg_aligned16(gt_o)) return SKG_E_ALIGN;
+    hipLaunchKernelGGL(skg_associate_kernel, dim3(n_active), dim3(256), 0, (hipStream_t)stream, boxes, meta, x_keep,
+                       y_keep, gt_h, gt_o, gt_label, gt_off, K, thresh, labels, npos);
+    return skg_launch_status();
+}

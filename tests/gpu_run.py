@@ -90,7 +90,7 @@ def _run_train(case, head, det, tg, feats, backward=False):
     orig = tgm.graph_train
 
     def wrapped(*a, **k):
-        r = orig(*a, **k); cap["lists"], cap["lay"] = r; return r
+        r = orig(*a, **k); cap["lists"], cap["lay"] = r[0], r[1]; return r
 
     tgm.graph_train = wrapped
     try:
