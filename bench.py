@@ -102,6 +102,7 @@ def train_mode(args, device, rank, world, dist_on):
     B = args.batch if args.batch != 256 else 4
     head = build_head(device).train()
     head.distributed = dist_on
+    head.precision = args.precision
     dets, pooled, feats, shapes = make_inputs(B, rank, device)
     o2v = synth.hico_object_to_verb()
     cpu_dets = [dict(boxes=d["boxes"].cpu(), labels=d["labels"].cpu(), scores=d["scores"].cpu()) for d in dets]
@@ -135,7 +136,8 @@ def train_mode(args, device, rank, world, dist_on):
         print(json.dumps(dict(metric="images/sec through the interaction-head TRAINING step (20x20 pairs)",
                               value=round(B * world * args.steps / elapsed, 2), unit="images/s", n_gpus=world,
                               steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
-                              higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                              higher_is_better=True, scaling="weak", vs_baseline=None,
+                              dtype="bf16" if args.precision == "bf16" else "f32", data="synthetic",
                               config=dict(workload="train step: fwd + bwd + AdamW, NegativeSampling + MarginLoss + "
                                                    "two focal terms, 20x20 synthetic images with GT appended",
                                           batch_per_gpu=B, parallelism="dp%d" % world),
@@ -154,6 +156,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="override HeadEngine.chunk_images")
     ap.add_argument("--no-gemm-timer", action="store_true", help="skip the per-launch HIP-event GEMM timing")
     ap.add_argument("--gemm-table", action="store_true", help="per-shape GEMM timing table on stderr")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32", help="training-mode GEMM operands")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="train: NegativeSampling+MarginLoss training step (fwd+bwd+AdamW), secondary metric")
     args = ap.parse_args()

@@ -156,6 +156,22 @@ int skg_concat_entity_f32(const float* enc, int64_t ld_enc, const int32_t* enc_r
                           const int32_t* ent_img, const int32_t* ent_row, int rows, float* out, int64_t out_ld,
                           void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * bf16 dense layer (training configuration "bf16"): C = act(A W^T + bias) with A [M,K], W [N,K] in bf16 (raw uint16
+ * bit patterns), fp32 accumulation on v_mfma_f32_32x32x16_bf16, bias fp32, C fp32 or bf16.  K % 64 == 0,
+ * lda / ldw % 8 == 0.  split_k > 1: fp32 partials in split_ws [split_k, M, N], reduced in slice order.              */
+typedef struct {
+    const uint16_t* A; int64_t lda;
+    const uint16_t* W; int64_t ldw;
+    const float* bias;
+    void* C; int64_t ldc;
+    int32_t M, N, K;
+    int32_t relu, out_bf16, split_k;
+    float* split_ws;
+} skg_gemm_bf16_desc;
+int skg_gemm_bf16(const skg_gemm_bf16_desc* desc_host, void* stream);
+int skg_transpose_bf16(const void* in, int64_t ld_in, int rows, int cols, void* out, int64_t ld_out, void* stream);
+
 /* out[c, r] = in[r, c]  (rows x cols -> cols x rows, ld_out >= rows).  The backward GEMMs of the training step reuse
  * skg_gemm_f32 (both operands k-contiguous): dA = dZ (W^T)^T needs W^T, dW = dZ^T A needs dZ^T and A^T. */
 int skg_transpose_f32(const float* in, int64_t ld_in, int rows, int cols, float* out, int64_t ld_out, void* stream);

@@ -30,6 +30,13 @@ class GemmDesc(C.Structure):
                 ("res", _vp), ("ldres", _i64), ("split_k", _i32), ("_pad", _i32), ("split_ws", _vp)]
 
 
+class GemmBf16Desc(C.Structure):
+    """Mirror of skg_gemm_bf16_desc."""
+    _fields_ = [("A", _vp), ("lda", _i64), ("W", _vp), ("ldw", _i64), ("bias", _vp), ("C", _vp), ("ldc", _i64),
+                ("M", _i32), ("N", _i32), ("K", _i32), ("relu", _i32), ("out_bf16", _i32), ("split_k", _i32),
+                ("split_ws", _vp)]
+
+
 # numpy dtype of skg_image_meta (12 x 4 bytes)
 META_FIELDS = [("image", "i4"), ("n_h", "i4"), ("n", "i4"), ("box_off", "i4"), ("enc_off", "i4"), ("node_off", "i4"),
                ("hum_off", "i4"), ("grid_off", "i4"), ("pair_off", "i4"), ("out_off", "i4"), ("img_h", "f4"),
@@ -48,6 +55,8 @@ PROTOTYPES = {
     "skg_global_avgpool_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "skg_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "skg_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
+    "skg_gemm_bf16": (C.c_int, [C.POINTER(GemmBf16Desc), _vp]),
+    "skg_transpose_bf16": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _vp, _i64, _vp]),
     "skg_transpose_f32": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _vp, _i64, _vp]),
     "skg_concat_entity_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, C.c_int, _vp, _i64, _vp]),
     "skg_rows_mul_relu_f32": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp,

@@ -244,6 +244,8 @@ class InteractionHead(Module):
     signature and result dictionaries.
 
     Extra keyword (not in the reference, defaults reproduce it):
+      precision: str = "fp32" -- "bf16" runs the TRAINING-mode dense layers with bf16 operands on the matrix cores
+        (fp32 accumulation, fp32 master weights / gradients / activations); inference always uses the exact fp32 path.
       reference_quirks: bool = True -- reproduce (a) the node-offset bug on skipped images and (b) the
         eval-mode label-list zip with skipped images in a batch > 1 (HEAD:298-310: truncated results / IndexError).
         With False every image gets its own (possibly empty) result.
@@ -252,7 +254,7 @@ class InteractionHead(Module):
     def __init__(self, box_roi_pool: Module, box_pair_head: Module, box_pair_suppressor: Module,
                  box_pair_predictor: Module, human_idx: int, num_classes: int, box_nms_thresh: float = 0.5,
                  box_score_thresh: float = 0.2, max_human: int = 15, max_object: int = 15,
-                 distributed: bool = False, reference_quirks: bool = True) -> None:
+                 distributed: bool = False, reference_quirks: bool = True, precision: str = "fp32") -> None:
         super().__init__()
         self.box_roi_pool = box_roi_pool
         self.box_pair_head = box_pair_head
@@ -266,6 +268,9 @@ class InteractionHead(Module):
         self.max_object = max_object
         self.distributed = distributed
         self.reference_quirks = reference_quirks
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
         self._engine = None
 
     def engine(self) -> HeadEngine:
@@ -277,6 +282,7 @@ class InteractionHead(Module):
                            self.max_object, faithful_skip_offset=self.reference_quirks)
             self._engine = e
         e.faithful_skip_offset = self.reference_quirks
+        e.precision = self.precision
         return e
 
     # ------------------------------------------------------------------------------------------ HEAD:92-151
@@ -333,8 +339,9 @@ class InteractionHead(Module):
 
     # ------------------------------------------------------------------------------------------ training (HEAD:380-429)
     def _forward_train(self, features, detections, image_shapes, targets):
-        from skghoi_amd.autograd import linear
+        from skghoi_amd import autograd as _ag
         from skghoi_amd.train_graph import graph_train
+        linear = _ag.linear_bf16 if self.precision == "bf16" else _ag.linear
         eng = self.engine()
         pre = eng.preprocess(detections, targets, True, True)
         box_coords = list(pre.boxes.split(pre.sizes))

@@ -102,3 +102,95 @@ class LinearFn(torch.autograd.Function):
 
 def linear(x, weight, bias=None, relu=False):
     return LinearFn.apply(x, weight, bias, relu)
+
+
+# ------------------------------------------------------------------------------------------------ bf16 configuration
+def _pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def gemm_bf16(A, W, bias, M, N, K, relu=False, out_dtype=torch.bfloat16):
+    """C = act(A W^T + bias) on skg_gemm_bf16 (A [M,>=K] bf16, W [N,>=K] bf16, K % 64 == 0)."""
+    import ctypes as C
+    out = torch.empty(M, N, device=A.device, dtype=out_dtype)
+    if M == 0:
+        return out
+    d = _capi.GemmBf16Desc()
+    d.A = A.data_ptr(); d.lda = A.stride(0); d.W = W.data_ptr(); d.ldw = W.stride(0)
+    d.bias = bias.data_ptr() if bias is not None else 0
+    d.C = out.data_ptr(); d.ldc = out.stride(0)
+    d.M, d.N, d.K = M, N, K
+    d.relu = int(relu); d.out_bf16 = int(out_dtype == torch.bfloat16)
+    blocks = ((M + 127) // 128) * ((N + 127) // 128)
+    sk = 1
+    if blocks < 512 and K >= 1024:
+        sk = int(max(1, min(-(-512 // blocks), K // 256, 64)))
+    ws = torch.empty(sk, M, N, device=A.device, dtype=torch.float32) if sk > 1 else None
+    d.split_k = sk; d.split_ws = ws.data_ptr() if ws is not None else 0
+    _capi.check(_capi.lib().skg_gemm_bf16(C.byref(d), _stream()), "skg_gemm_bf16[%dx%dx%d]" % (M, N, K))
+    return out
+
+
+def _bf16_padded(x, cols_to):
+    """[rows, cols] any float dtype -> contiguous bf16 [rows, cols_to] (zero padded)."""
+    r, c = x.shape
+    if c == cols_to and x.dtype == torch.bfloat16 and x.is_contiguous():
+        return x
+    out = torch.zeros(r, cols_to, device=x.device, dtype=torch.bfloat16) if c != cols_to else \
+        torch.empty(r, cols_to, device=x.device, dtype=torch.bfloat16)
+    out[:, :c] = x
+    return out
+
+
+def transpose_bf16(x, rows, cols, ld_out):
+    out = torch.zeros(cols, ld_out, device=x.device, dtype=torch.bfloat16)
+    _capi.check(_capi.lib().skg_transpose_bf16(x.data_ptr(), x.stride(0), rows, cols, out.data_ptr(), ld_out,
+                                               _stream()), "skg_transpose_bf16")
+    return out
+
+
+class LinearBf16Fn(torch.autograd.Function):
+    """Autocast-style layer: operands rounded to bf16, fp32 accumulation, bf16 activations out; parameters and their
+    gradients stay fp32 (dW is accumulated in fp32 by the kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, out_dtype=torch.float32):
+        M, K = x.shape
+        N = weight.shape[0]
+        Kp = _pad_to(K, 64)
+        xb = _bf16_padded(x, Kp); wb = _bf16_padded(weight.detach(), Kp)
+        y = gemm_bf16(xb, wb, bias.detach().float().contiguous() if bias is not None else None, M, N, Kp, relu,
+                      out_dtype=out_dtype)
+        ctx.relu, ctx.K, ctx.has_bias = relu, K, bias is not None
+        ctx.save_for_backward(xb, wb, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, wb, y = ctx.saved_tensors
+        M, Kp = xb.shape
+        N = wb.shape[0]
+        K = ctx.K
+        dz = dy
+        if ctx.relu:
+            dz = dz * (y > 0)
+        dx = dw = db = None
+        Np = _pad_to(N, 64)
+        dzb = _bf16_padded(dz, Np)
+        if ctx.needs_input_grad[0]:
+            wT = transpose_bf16(wb, N, Kp, Np)                           # [Kp, Np]
+            dx = gemm_bf16(dzb, wT, None, M, Kp, Np, out_dtype=torch.float32)[:, :K]
+        if ctx.needs_input_grad[1]:
+            Mp = _pad_to(M, 64)
+            dzT = transpose_bf16(dzb, M, N, Mp)                          # [N, Mp]
+            xT = transpose_bf16(xb, M, Kp, Mp)                           # [Kp, Mp]
+            dw = gemm_bf16(dzT, xT, None, N, Kp, Mp, out_dtype=torch.float32)[:, :K]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dz.float().sum(dim=0)
+        return dx, dw, db, None, None
+
+
+def linear_bf16(x, weight, bias=None, relu=False, out_dtype=torch.float32):
+    """bf16 operands on the matrix cores, fp32 accumulation; activations are handed on in `out_dtype` (fp32 by default:
+    the element-wise glue of the head stays in fp32)."""
+    return LinearBf16Fn.apply(x, weight, bias, relu, out_dtype)

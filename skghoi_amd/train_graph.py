@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _capi, layout, transh
-from .autograd import linear
+from . import autograd as _ag
 from .engine import _stream
 
 
@@ -64,6 +64,7 @@ def graph_train(eng, gh, feat3, image_shapes, pooled, pre, targets):
     dev = pre.device
     K = gh.num_cls
     st = _stream()
+    linear = _ag.linear_bf16 if getattr(eng, "precision", "fp32") == "bf16" else _ag.linear
     lay = layout.build(pre.n_h, pre.n, None, image_shapes, gh.human_idx,
                        faithful_skip_offset=eng.faithful_skip_offset)
     A = lay.n_active

@@ -200,3 +200,36 @@ def test_transpose():
     t = transpose(x, 70, 130)
     assert t.shape == (130, 72)
     assert torch.equal(t[:, :70], x.t()) and torch.all(t[:, 70:] == 0)
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(130, 118, 2048, False), (800, 1024, 1024, True), (40, 1024, 12544, True),
+                                        (257, 256, 64, False), (3000, 1024, 128, True)])
+def test_gemm_bf16_matches_reference(M, N, K, relu):
+    from skghoi_amd.autograd import gemm_bf16
+    A = _rand(M, K, seed=1).bfloat16(); W = (_rand(N, K, seed=2) / K ** 0.5).bfloat16(); b = _rand(N, seed=3)
+    ref = A.double() @ W.double().t() + b.double()
+    ref = torch.relu(ref) if relu else ref
+    out32 = gemm_bf16(A, W, b, M, N, K, relu, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    _close(out32, ref.float(), 2e-4)                         # exact products of bf16 operands, fp32 accumulation
+    out16 = gemm_bf16(A, W, b, M, N, K, relu)
+    assert out16.dtype == torch.bfloat16
+    _close(out16.float(), ref.float(), 2e-2)
+
+
+def test_linear_bf16_autograd_close_to_fp32():
+    from skghoi_amd.autograd import linear_bf16
+    M, N, K = 300, 117, 1074
+    x = _rand(M, K, seed=1).requires_grad_(True); w = (_rand(N, K, seed=2) / K ** 0.5).requires_grad_(True)
+    b = _rand(N, seed=3).requires_grad_(True)
+    g = _rand(M, N, seed=4)
+    y = linear_bf16(x, w, b, True)
+    y.float().backward(g)
+    xr = x.detach().double().requires_grad_(True); wr = w.detach().double().requires_grad_(True)
+    br = b.detach().double().requires_grad_(True)
+    yr = torch.relu(torch.nn.functional.linear(xr, wr, br)); yr.backward(g.double())
+    cos = torch.nn.functional.cosine_similarity
+    assert (y.float() - yr.float()).abs().max() <= 3e-2
+    assert w.grad.dtype == torch.float32 and w.grad.shape == w.shape
+    for a, r in ((x.grad, xr.grad), (w.grad, wr.grad), (b.grad, br.grad)):
+        assert cos(a.flatten().double(), r.flatten(), dim=0) > 0.999

@@ -145,3 +145,27 @@ def test_training_gradients_match_oracle_autograd():
         worst = max(worst, err)
         assert err <= 2e-3, "%s: rel err %.3e (|grad| max %.3e)" % (k, err, scale)
     print("max relative gradient error %.3e over %d tensors" % (worst, len(want)))
+
+
+def test_bf16_training_tracks_fp32():
+    """BASELINE config 3 (bf16): bf16 operands on the matrix cores, fp32 accumulation / master weights.  Losses within
+    2 % of the fp32 path, gradient direction preserved (cosine > 0.97 per large tensor, > 0.99 on average)."""
+    case = cases.build_case("train_tiny")
+    flat32, g32 = gpu_run.run_train_with_grads(case)
+    head = gpu_run.build_head(case); head.precision = "bf16"
+    from collections import OrderedDict
+    det = gpu_run.to_cuda(case["detections"]); tg = gpu_run.to_cuda(case["targets"])
+    feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
+    flat16, g16 = gpu_run._run_train(case, head, det, tg, feats, backward=True)
+    for k in ("hoi_loss", "interactiveness_loss", "transH_loss"):
+        assert abs(float(flat16[k]) - float(flat32[k])) <= 2e-2 * max(abs(float(flat32[k])), 1e-3), k
+    for b in range(int(flat32["n_results"])):
+        assert np.array_equal(flat16["res%d.index" % b], flat32["res%d.index" % b])
+    coss = []
+    for k, g in g32.items():
+        if g.size >= 65536 and np.abs(g).max() > 0:
+            a, r = g16[k].ravel().astype(np.float64), g.ravel().astype(np.float64)
+            cos = float(a @ r / (np.linalg.norm(a) * np.linalg.norm(r) + 1e-30))
+            assert cos > 0.97, "%s cosine %.4f" % (k, cos)
+            coss.append(cos)
+    assert len(coss) > 20 and float(np.mean(coss)) > 0.99
