@@ -1,5 +1,5 @@
 """Developer aid (GPU box): times skg_gemm_f32 on the hot shapes of the 20x20 workload.
-usage: python tests/gemm_microbench.py [reps]   (SKG_LIB=<path to .so> selects a kernel build)"""
+usage: python tools/gemm_microbench.py [reps]   (SKG_LIB=<path to .so> selects a kernel build)"""
 import sys
 sys.path.insert(0, "."); sys.dont_write_bytecode = True
 import torch
