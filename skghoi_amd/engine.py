@@ -66,7 +66,6 @@ class PackedWeights:
             b3 = torch.stack([w(l.bias) for l in m.fc_3]).sum(dim=0)
             return dict(w1=w1.contiguous(), b1=b1, w2=w2.contiguous(), b2=b2, w3=w3, b3=b3)
 
-        self.versions = versions_of(graph_head, predictor, suppressor)
         self.device = device
         self.K = gh.num_cls
         self.bh1_w = pad_k(w(gh.box_head[1].weight)); self.bh1_b = w(gh.box_head[1].bias)
@@ -93,11 +92,6 @@ class PackedWeights:
             pb = predictor.bias if predictor.bias is not None else torch.zeros(self.K)
             sb = suppressor.bias if suppressor.bias is not None else torch.zeros(1)
             self.cls_b = torch.cat([w(pb), w(sb)]).contiguous()
-
-
-def versions_of(graph_head, predictor, suppressor):
-    ps = list(graph_head.parameters()) + list(predictor.parameters()) + list(suppressor.parameters())
-    return tuple((p.data_ptr(), p._version) for p in ps)
 
 
 class VerbTable:
