@@ -319,6 +319,12 @@ class InteractionHead(Module):
         if self.training:
             assert targets is not None, "Targets should be passed during training"
             return self._forward_train(features, detections, image_shapes, targets)
+        if targets is not None:
+            # eval mode with targets (validation): the reference associates labels and consumes the sampling RNG
+            # whenever targets are given (HEAD:933-963); served by the training-mode graph pass without autograd,
+            # without GT boxes appended (HEAD:105-106) and with the eval score power (HEAD:742)
+            with torch.no_grad():
+                return self._forward_train(features, detections, image_shapes, targets, with_losses=False)
         eng = self.engine()
         pre = eng.preprocess(detections, targets, False, False)
         box_coords = list(pre.boxes.split(pre.sizes))
@@ -338,12 +344,12 @@ class InteractionHead(Module):
         return self._results(lay, r, dev)
 
     # ------------------------------------------------------------------------------------------ training (HEAD:380-429)
-    def _forward_train(self, features, detections, image_shapes, targets):
+    def _forward_train(self, features, detections, image_shapes, targets, with_losses=True):
         from skghoi_amd import autograd as _ag
         from skghoi_amd.train_graph import graph_train
         linear = _ag.linear_bf16 if self.precision == "bf16" else _ag.linear
         eng = self.engine()
-        pre = eng.preprocess(detections, targets, True, True)
+        pre = eng.preprocess(detections, targets, self.training, self.training)
         box_coords = list(pre.boxes.split(pre.sizes))
         box_features = self.box_roi_pool(features, box_coords, image_shapes)
         (feats, bh, bo, oc, labels, prior, pos, neg, he, te, re, rn), lay, P = graph_train(
@@ -357,6 +363,8 @@ class InteractionHead(Module):
         else:
             logits_p = self.box_pair_predictor(pf); logits_s = self.box_pair_suppressor(pf)
         results = self._postprocess_packed(logits_p, logits_s, P, lay, pf.device)
+        if not with_losses:
+            return results
         results.append(dict(
             hoi_loss=self.compute_interaction_classification_loss(results),
             interactiveness_loss=self.compute_interactiveness_loss(results),

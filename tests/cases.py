@@ -102,6 +102,10 @@ def build_case(name):
     elif name == "full15x2":
         imgs = _grid_images([(17, 18), (15, 12)], 256, 7, 49, 80, 1100)      # default top-15 truncation active
         c.update(C=256, p=7, weight_seed=0)
+    elif name == "eval_targets":
+        # eval mode WITH targets (validation): labels are associated and the sampling RNG is consumed (HEAD:933-963)
+        imgs = _grid_images([(3, 4), (2, 3)], 8, 2, 49, 80, 700)
+        c.update(eval_targets=True)
     elif name == "train_tiny":
         imgs = _grid_images([(3, 4), (2, 3)], 8, 2, 49, 80, 700)
         c.update(training=True)
@@ -112,13 +116,14 @@ def build_case(name):
     c["detections"] = [_det(i) for i in imgs]
     c["feat3"] = torch.cat([i["feat3"] for i in imgs])
     c["shapes"] = [i["hw"] for i in imgs]
-    if c["training"]:
+    if c["training"] or c.get("eval_targets"):
         c["targets"] = [synth.make_targets(d, cfg["human_idx"], c["o2v"], 900 + k, n_gt=3)
                         for k, d in enumerate(c["detections"])]
     return c
 
 
-EVAL_CASES = ["tiny", "ragged3", "skips_eval", "nanbox", "vcoco", "nms", "iter1", "iter0", "full20", "full15x2"]
+EVAL_CASES = ["tiny", "ragged3", "skips_eval", "nanbox", "vcoco", "nms", "iter1", "iter0", "full20", "full15x2",
+              "eval_targets"]
 TRAIN_CASES = ["train_tiny", "train_skips"]
 RAISING_CASES = ["skips_raise"]
 ALL_CASES = EVAL_CASES + TRAIN_CASES

@@ -49,7 +49,7 @@ def run_reference(case):
              gh.norm_o.register_forward_hook(lambda m, i, o: cap["norm_o"].append(o.detach().clone()))]
     try:
         with torch.no_grad():
-            det = head.preprocess(case["detections"], case["targets"])
+            det = head.preprocess(case["detections"], case["targets"], append_gt=case["training"])
             n_rows = sum(len(d["boxes"]) for d in det)
             pooled = cases.pooled_for(case, n_rows)
             head.box_roi_pool.pooled = pooled
@@ -61,7 +61,7 @@ def run_reference(case):
                     h1 = head.box_pair_predictor.register_forward_hook(lambda m, i, o: logits.__setitem__("p", o))
                     h2 = head.box_pair_suppressor.register_forward_hook(lambda m, i, o: logits.__setitem__("s", o))
                     h3 = head.box_pair_predictor.register_forward_pre_hook(lambda m, i: logits.__setitem__("pf", i[0]))
-                    results = head(feats, case["detections"], case["shapes"], None)
+                    results = head(feats, case["detections"], case["shapes"], case["targets"])
                     h1.remove(); h2.remove(); h3.remove()
                     out["logits_p"] = logits["p"]; out["logits_s"] = logits["s"]; out["pair_features"] = logits["pf"]
                 else:

@@ -53,6 +53,19 @@ def run_head(case, head=None, reference_quirks=True):
         head.engine().chunk_images = case["chunk_images"]
     if case["training"]:
         return _run_train(case, head, det, tg, feats)
+    if tg is not None:                       # eval with targets: only the result dicts are comparable
+        out = {}
+        with torch.no_grad():
+            for b, d in enumerate(head.preprocess(det, tg)):
+                out["pre%d.boxes" % b] = d["boxes"]; out["pre%d.labels" % b] = d["labels"]; out["pre%d.scores" % b] = d["scores"]
+            torch.manual_seed(case["rng_seed"])
+            results = head(feats, det, case["shapes"], tg)
+            after = torch.empty(4).uniform_()          # position of the host RNG after the call
+        for b, r in enumerate(results):
+            for k, v in r.items():
+                out["res%d.%s" % (b, k)] = v
+        out["n_results"] = torch.tensor(len(results)); out["rng_after"] = after
+        return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()}
     with torch.no_grad():
         for b, d in enumerate(head.preprocess(det, tg)):
             out["pre%d.boxes" % b] = d["boxes"]; out["pre%d.labels" % b] = d["labels"]; out["pre%d.scores" % b] = d["scores"]
