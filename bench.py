@@ -165,11 +165,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
+    local = local % max(torch.cuda.device_count(), 1)          # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("SKG_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; gloo only for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     if args.mode == "train":
         return train_mode(args, device, rank, world, dist_on)
