@@ -292,6 +292,69 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
                           skg_aligned16_dev(d.C_raw) && ((d.ldp | d.ldq | d.ldc_raw) & 3) == 0)) &&
                         (EPI != SKG_EPI_BIAS_RES_RELU || (skg_aligned16_dev(d.res) && (d.ldres & 3) == 0)) &&
                         (EPI != SKG_EPI_RELU_DOT || skg_aligned16_dev(d.dot_w));
+    // ---- fast path: tile entirely inside the matrix, everything 16-byte aligned, no split-K.  Column-dependent
+    // operands (bias, multiplier bias, dot weights) are loaded once per lane; rows advance by pointer increments.
+    const bool interior = vec_ok && d.split_k <= 1 && (m0 + BM <= d.M) && (n0 + BN <= d.N);
+    if (interior) {
+        const int c4 = (lane & 15) * 4, r0l = lane >> 4;
+        const int col = n0 + wc * 64 + c4;
+        float4 bia4 = make_float4(0.f, 0.f, 0.f, 0.f), mb4 = bia4, dw4 = bia4;
+        if (d.bias) bia4 = *reinterpret_cast<const float4*>(d.bias + col);
+        if (EPI == SKG_EPI_MUL_RELU && d.mbias) mb4 = *reinterpret_cast<const float4*>(d.mbias + col);
+        if (EPI == SKG_EPI_RELU_DOT) dw4 = *reinterpret_cast<const float4*>(d.dot_w + col);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    est[((r & 3) + 8 * (r >> 2) + 4 * lh) * EST_LD + ni * 32 + li] = acc[mi][ni][r];
+            const int rowb = m0 + wr * 64 + mi * 32 + r0l;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = rowb + it * 4;
+                const float4 a4 = *reinterpret_cast<const float4*>(est + (it * 4 + r0l) * EST_LD + c4);
+                float4 v = make_float4(a4.x + bia4.x, a4.y + bia4.y, a4.z + bia4.z, a4.w + bia4.w);
+                if (EPI == SKG_EPI_RELU_DOT) {
+                    v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                    float sdot = (v.x * dw4.x + v.y * dw4.y) + (v.z * dw4.z + v.w * dw4.w);
+                    if (d.C) *reinterpret_cast<float4*>(d.C + (int64_t)row * d.ldc + col) = v;
+#pragma unroll
+                    for (int off = 8; off > 0; off >>= 1) sdot += __shfl_xor(sdot, off, 64);
+                    if ((lane & 15) == 0) d.dot_partial[(int64_t)(bn * 2 + wc) * d.M + row] = sdot;
+                    continue;
+                }
+                const int orow = d.out_rows ? d.out_rows[row] : row;
+                if (EPI == SKG_EPI_MUL_RELU) {
+                    if (d.C_raw) *reinterpret_cast<float4*>(d.C_raw + (int64_t)row * d.ldc_raw + col) = v;
+                    if (orow < 0) continue;
+                    float4 m = mb4;
+                    if (d.P) {
+                        const int pi = d.p_idx ? d.p_idx[row] : row;
+                        const float4 t = *reinterpret_cast<const float4*>(d.P + (int64_t)pi * d.ldp + col);
+                        m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
+                    }
+                    if (d.Q) {
+                        const int qi = d.q_idx ? d.q_idx[row] : row;
+                        const float4 t = *reinterpret_cast<const float4*>(d.Q + (int64_t)qi * d.ldq + col);
+                        m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
+                    }
+                    *reinterpret_cast<float4*>(d.C + (int64_t)orow * d.ldc + col) =
+                        make_float4(fmaxf(v.x * m.x, 0.f), fmaxf(v.y * m.y, 0.f), fmaxf(v.z * m.z, 0.f), fmaxf(v.w * m.w, 0.f));
+                    continue;
+                }
+                if (orow < 0) continue;
+                if (EPI == SKG_EPI_BIAS_RELU || EPI == SKG_EPI_BIAS_RES_RELU)
+                    v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                if (EPI == SKG_EPI_BIAS_RES_RELU) {
+                    const float4 t = *reinterpret_cast<const float4*>(d.res + (int64_t)row * d.ldres + col);
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                *reinterpret_cast<float4*>(d.C + (int64_t)orow * d.ldc + col) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
