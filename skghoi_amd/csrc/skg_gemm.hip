@@ -55,6 +55,14 @@ __host__ __device__ __forceinline__ int64_t skg_gemm_blocks(int M, int N, int K)
     return 8LL * g * ((nbm + XG - 1) / XG);
 }
 
+// Pins a wave-uniform pointer in SGPRs so that `base + per-lane 32-bit offset` selects the saddr + voffset form.
+__device__ __forceinline__ const char* skg_uniform_ptr(const char* p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+
 // EPI >= 0: epilogue fixed at compile time; EPI < 0: taken from the descriptor (grouped launches of small GEMMs).
 template <int EPI_T, bool GLDS>
 __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_id, float* smem) {
@@ -211,31 +219,38 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
 
     } else {
         // ---- direct-to-LDS staging (global_load_lds_dwordx4): no VGPR round trip, no ds_write, no masking.
-        // Requirements (checked by the host): K % 16 == 0, no A-row gather.  Rows past M / N are clamped to row 0:
+        // Requirements (checked by the host): K % 16 == 0, no A-row gather, 128 rows x ld x 4 B < 4 GiB.  Rows past M / N are clamped:
         // they only feed accumulators whose outputs are never stored.  The LDS image is lane-linear per wave
         // instruction (16 rows x 64 B); bank conflicts of the ds_read_b128 fragment reads are removed by XOR-ing the
         // 16-byte k-chunk index with (row >> 2) & 3 on the global SOURCE side and on the read side.
         constexpr int GT = BM * BK;                                   // floats per operand tile (unpadded)
         const int rl = lane >> 2;                                     // row inside a 16-row piece
         const int ch = lane & 3;                                      // 16-byte chunk the lane WRITES
-        const float* ga[2];
-        const float* gw[2];
+        // per-lane byte offsets (32-bit) from wave-uniform bases that advance by one tile per iteration: the address
+        // arithmetic of the DMA stays on the scalar unit
+        uint32_t oa[2], ow[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = wid * 32 + i * 16 + rl;                     // tile row staged by this lane
             const int sw = (r >> 2) & 3;
             const int ar = m0 + r, wrw = n0 + r;
-            ga[i] = d.A + (int64_t)(ar < d.M ? ar : 0) * d.lda + 4 * (ch ^ sw);
-            gw[i] = d.W + (int64_t)(wrw < d.N ? wrw : 0) * d.ldw + 4 * (ch ^ sw);
+            // rows past M / N are clamped to the tile's FIRST row (offset 0, never negative: the offsets are unsigned)
+            oa[i] = (uint32_t)(((int64_t)(ar < d.M ? ar - m0 : 0) * d.lda + 4 * (ch ^ sw)) * 4);
+            ow[i] = (uint32_t)(((int64_t)(wrw < d.N ? wrw - n0 : 0) * d.ldw + 4 * (ch ^ sw)) * 4);
         }
+        const char* a_base = reinterpret_cast<const char*>(d.A + (int64_t)m0 * d.lda);
+        const char* w_base = reinterpret_cast<const char*>(d.W + (int64_t)n0 * d.ldw);
+        const int wid_u = __builtin_amdgcn_readfirstlane(wid);      // provably wave-uniform: LDS DMA bases stay scalar
         auto stage = [&](int buf, int kt) {
-            float* a_s = smem + buf * GT + (wid * 32) * BK;
-            float* b_s = smem + 2 * GT + buf * GT + (wid * 32) * BK;
+            float* a_s = smem + buf * GT + (wid_u * 32) * BK;
+            float* b_s = smem + 2 * GT + buf * GT + (wid_u * 32) * BK;
+            const char* ab = skg_uniform_ptr(a_base + (int64_t)kt * BK * 4);
+            const char* wb = skg_uniform_ptr(w_base + (int64_t)kt * BK * 4);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + kt * BK),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + oa[i]),
                                                  (__attribute__((address_space(3))) void*)(a_s + i * 16 * BK), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw[i] + kt * BK),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + ow[i]),
                                                  (__attribute__((address_space(3))) void*)(b_s + i * 16 * BK), 16, 0, 0);
             }
         };
@@ -555,7 +570,8 @@ extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
     if (nblk > 0x7fffffffLL) return SKG_E_LIMIT;
     dim3 grid((unsigned)nblk), block(256);
     hipStream_t s = (hipStream_t)stream;
-    const bool glds = SKG_USE_GLDS && BK == 16 && (d.K % BK) == 0 && !d.a_rows;
+    const bool glds = SKG_USE_GLDS && BK == 16 && (d.K % BK) == 0 && !d.a_rows &&
+                      (int64_t)BM * d.lda * 4 < 0xffffffffLL && (int64_t)BN * d.ldw * 4 < 0xffffffffLL;
 #define SKG_LAUNCH(E)                                                                              \
     if (glds) hipLaunchKernelGGL((skg_gemm_kernel<E, true>), grid, block, 0, s, d);               \
     else hipLaunchKernelGGL((skg_gemm_kernel<E, false>), grid, block, 0, s, d);
