@@ -6,18 +6,23 @@
 // Design (gfx950):
 //   * v_mfma_f32_32x32x2_f32: exact fp32 (bit-for-bit an fmaf chain), the only MFMA that meets the 1e-4 logit parity
 //     bar without splitting operands; peak 157 TFLOP/s = the roofline this kernel is priced against.
-//   * 128x128 block tile, 4 wavefronts (2x2), each owning 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs).
-//   * K is consumed 16 at a time through a double-buffered LDS tile, rows padded to 20 dwords: every lane fetches its
-//     four consecutive k with ONE ds_read_b128 (conflict-free at stride 20: 16 lanes x 4 banks tile all 64 banks) and
-//     feeds them to four MFMAs; A and B use the same k permutation, which is all a dot product needs.
-//   * Weights stay in the nn.Linear layout [N, K]: both operands are "row = output index, k contiguous", so both are
-//     staged by the same coalesced 16-byte global loads (register staged: issue for tile t+1 before the MFMAs of tile
-//     t, ds_write after them, one barrier per tile).
-//   * blockIdx -> tile with n fastest: with the round-robin block->XCD dispatch each XCD sees N-tiles bn == xcd (mod 8),
-//     i.e. a fixed 1/8 slice of W (<= 2 MiB for N = 4096, K = 1024) that stays in its private 4 MiB L2, while the A
-//     panel of an M-tile is fetched by the 8 XCDs at about the same time (served once by HBM/Infinity Cache).
-//   * Epilogues are fused (bias, ReLU, gathered multiplier tables for the MBF fc_1*fc_2 product, residual, the
-//     adjacency row-dot) so no intermediate makes an extra trip through HBM.
+//   * 128x128 block tile, 4 wavefronts (2x2), each owning 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs); K is consumed
+//     16 at a time through a double-buffered LDS tile.  Every lane fetches four consecutive k with ONE ds_read_b128
+//     and feeds them to four MFMAs; A and B use the same k permutation, which is all a dot product needs.
+//   * Weights stay in the nn.Linear layout [N, K]: both operands are "row = output index, k contiguous".
+//   * Main path (K % 16 == 0, no row gather): tiles are staged straight into LDS by global_load_lds_dwordx4 from
+//     wave-uniform scalar bases + unsigned per-lane offsets; the LDS image is lane-linear (16 rows x 64 B per wave
+//     instruction) and the 16-byte k-chunk index is XOR-ed with (row >> 2) & 3 on the global SOURCE side and on the
+//     fragment reads, which makes the reads conflict-free.  All fragment reads of a tile are issued before the DMA of
+//     the next tile (hipcc drains vmcnt before any ds_read while an LDS-DMA is in flight), one barrier per tile.
+//     Fallback path (any K % 4 == 0, gathered A rows): register staging into rows padded to 20 dwords, loads
+//     unconditional and masked only when written to LDS.
+//   * Block -> tile map: XCD groups (see skg_gemm_map) keep a <= 2 MiB W slice in each XCD's private L2 and have the A
+//     panel fetched by NG XCDs instead of 8.
+//   * Epilogue: accumulators are transposed through LDS so that every lane owns 4 consecutive columns of a row; bias,
+//     ReLU, gathered multiplier tables (MBF fc_1 * fc_2), residual and the adjacency row-dot are fused with 16-byte
+//     accesses; interior tiles take a guard-free path.  Split-K (plain epilogues) and a grouped launch cover the
+//     small-M layers.
 #include "skg_common.h"
 
 #define BM 128
@@ -176,27 +181,17 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
 
     for (int kt = kt_begin; kt < nk; ++kt) {
         const int cur = kt & 1;
-#if !defined(SKG_ABL) || SKG_ABL == 1
         if (kt + 1 < nk) gload(kt + 1);
-#endif
         const float* a_s = smem + cur * A_TILE + (wr * 64 + li) * LDS_LD + 4 * lh;
         const float* b_s = smem + 2 * A_TILE + cur * B_TILE + (wc * 64 + li) * LDS_LD + 4 * lh;
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) {
             float4 a[2], b[2];
-#if defined(SKG_ABL) && (SKG_ABL == 1 || SKG_ABL == 3)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {       // ablation: operands from registers, no LDS reads
-                a[i] = make_float4(ra[0].x + i, ra[0].y, ra[1].z, ra[1].w + ks);
-                b[i] = make_float4(rw[0].x + i, rw[0].y, rw[1].z, rw[1].w + ks);
-            }
-#else
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 a[i] = *reinterpret_cast<const float4*>(a_s + i * 32 * LDS_LD + ks * 8);
                 b[i] = *reinterpret_cast<const float4*>(b_s + i * 32 * LDS_LD + ks * 8);
             }
-#endif
             const float av[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
             const float bv[2][4] = {{b[0].x, b[0].y, b[0].z, b[0].w}, {b[1].x, b[1].y, b[1].z, b[1].w}};
 #pragma unroll
@@ -208,13 +203,8 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][t], bv[ni][t], acc[mi][ni], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);              // keep the staging writes (and their vmcnt wait) below the MFMAs
-#if !defined(SKG_ABL)
         if (kt + 1 < nk) lstore(cur ^ 1, kt + 1);
         __syncthreads();
-#elif SKG_ABL == 1
-        if (kt + 1 < nk) lstore(cur ^ 1, kt + 1);
-        __syncthreads();
-#endif
     }
 
     } else {
