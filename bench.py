@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=0, help="override HeadEngine.chunk_images")
+    ap.add_argument("--streams", type=int, default=0, help="override HeadEngine.n_streams")
     ap.add_argument("--no-gemm-timer", action="store_true", help="skip the per-launch HIP-event GEMM timing")
     ap.add_argument("--gemm-table", action="store_true", help="per-shape GEMM timing table on stderr")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32", help="training-mode GEMM operands")
@@ -185,6 +186,8 @@ def main():
     head.box_roi_pool = ResidentPool(pooled)
     if args.chunk:
         head.engine().chunk_images = args.chunk
+    if args.streams:
+        head.engine().n_streams = args.streams
 
     def step():
         with torch.no_grad():

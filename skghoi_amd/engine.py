@@ -170,6 +170,14 @@ def gemm_group(specs):
         GEMM_TIMER.append((e0, e1, int(flops // 2), 1, 1, 5))       # epilogue id 5 = grouped launch
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class _TableDrawer:
     """Draws the per-image TransH tables of every chunk, in order, on a helper thread (the global CPU RNG is
     consumed exactly as the reference does, skghoi_amd/transh.py)."""
@@ -232,6 +240,8 @@ class HeadEngine:
         self.debug = False          # keep per-chunk intermediates (spatial46, h_node, node, adjacency) in graph()
         self._plist = None
         self._slots = None
+        self._streams = None
+        self.n_streams = 1          # >1: alternate chunks over side streams (tail filling); see graph()
         self._pw = None
         self._vt = None
         self.last = None          # intermediates of the last graph pass (parity tests read them)
@@ -397,9 +407,24 @@ class HeadEngine:
             lookahead = 2
             ctxs = {}
 
+            # optional: chunks alternate between `n_streams` HIP streams so that the tail of one chunk's kernels is
+            # filled by the other chunk's (same-chunk work stays ordered on its stream)
+            main = torch.cuda.current_stream()
+            ns = max(1, int(self.n_streams)) if len(bounds) > 1 else 1
+            if ns > 1:
+                if self._streams is None or len(self._streams) < ns:
+                    self._streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+                ev0 = torch.cuda.Event(); ev0.record(main)
+                for st_ in self._streams[:ns]:
+                    st_.wait_event(ev0)
+
+            def on_stream(ci):
+                return torch.cuda.stream(self._streams[ci % ns]) if ns > 1 else _NullCtx()
+
             def phase_a(ci):
                 a0, a1 = bounds[ci]
-                ctxs[ci] = self._chunk_phase_a(layout.chunk(lay, a0, a1), pw, pre, G1, x_keep, y_keep, PF)
+                with on_stream(ci):
+                    ctxs[ci] = self._chunk_phase_a(layout.chunk(lay, a0, a1), pw, pre, G1, x_keep, y_keep, PF)
 
             for ci in range(min(lookahead, len(bounds))):
                 phase_a(ci)
@@ -410,12 +435,17 @@ class HeadEngine:
                     t = tuple(None if x is None else x[a0:a1] for x in tables)
                 if self.debug:
                     tabs.append(tuple(None if x is None else x.clone() for x in t))
-                self._chunk_phase_b(ctxs.pop(ci), t, pw, pre, enc, PF, sc, keep)
-                if tables is None:                      # staging slot is free again once its H2D copies are done
-                    ev = torch.cuda.Event(); ev.record()
-                    drawer.slots[ci % len(drawer.slots)]["event"] = ev
+                with on_stream(ci):
+                    self._chunk_phase_b(ctxs.pop(ci), t, pw, pre, enc, PF, sc, keep)
+                    if tables is None:                  # staging slot is free again once its H2D copies are done
+                        ev = torch.cuda.Event(); ev.record()
+                        drawer.slots[ci % len(drawer.slots)]["event"] = ev
                 if ci + lookahead < len(bounds):
                     phase_a(ci + lookahead)
+            if ns > 1:
+                for st_ in self._streams[:ns]:
+                    ev = torch.cuda.Event(); ev.record(st_)
+                    main.wait_event(ev)
         finally:
             if drawer is not None:
                 drawer.join()

@@ -51,6 +51,8 @@ def run_head(case, head=None, reference_quirks=True):
     head.engine().debug = True
     if "chunk_images" in case:
         head.engine().chunk_images = case["chunk_images"]
+    if "n_streams" in case:
+        head.engine().n_streams = case["n_streams"]
     if case["training"]:
         return _run_train(case, head, det, tg, feats)
     if tg is not None:                       # eval with targets: only the result dicts are comparable

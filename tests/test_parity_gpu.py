@@ -69,12 +69,14 @@ def test_head_matches_oracle_with_fresh_rng(name):
     _check(got, want, name)
 
 
-@pytest.mark.parametrize("chunk", [1, 2])
-def test_chunked_graph_pass_is_equivalent(chunk):
-    """The graph stage walks the active images in chunks (RNG / GPU overlap): any chunking gives the same result."""
+@pytest.mark.parametrize("chunk,streams", [(1, 1), (2, 1), (1, 2), (1, 3)])
+def test_chunked_graph_pass_is_equivalent(chunk, streams):
+    """The graph stage walks the active images in chunks (RNG / GPU overlap), optionally alternating over side
+    streams: any chunking / stream count gives the same result."""
     for name in ("ragged3", "vcoco"):
         case = cases.build_case(name)
         case["chunk_images"] = chunk
+        case["n_streams"] = streams
         got = gpu_run.run_head(case)
         _check(got, helpers.load_golden(name), name)
 
