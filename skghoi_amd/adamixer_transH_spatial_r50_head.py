@@ -318,6 +318,18 @@ class InteractionHead(Module):
                 targets: Optional[List[dict]] = None) -> List[dict]:
         if self.training:
             assert targets is not None, "Targets should be passed during training"
+        dev = features["3"].device
+        if dev.type != "cuda":
+            raise _capi.SkgError("the interaction head runs on a HIP device only (features on %s)" % dev)
+        for det in detections:
+            if det["boxes"].device != dev:
+                raise _capi.SkgError("detections on %s but features on %s" % (det["boxes"].device, dev))
+        with torch.cuda.device(dev):           # kernels are enqueued on the current stream OF THE INPUTS' device
+            return self._forward(features, detections, image_shapes, targets)
+
+    def _forward(self, features, detections, image_shapes, targets):
+        if self.training:
+            assert targets is not None, "Targets should be passed during training"
             return self._forward_train(features, detections, image_shapes, targets)
         if targets is not None:
             # eval mode with targets (validation): the reference associates labels and consumes the sampling RNG
