@@ -131,7 +131,7 @@ typedef struct {
     float*       C_raw; int64_t ldc_raw;                  /* optional: also store v (pre-multiplication), by row     */
     /* SKG_EPI_RELU_DOT */
     const float* dot_w;                /* [N]                                                                       */
-    float*       dot_partial;          /* [2*ceil(N/128), M]: one partial per 64-column slab                        */
+    float*       dot_partial;          /* [skg_gemm_dot_partials(desc), M]: one partial per column slab of a wave    */
     /* SKG_EPI_BIAS_RES_RELU */
     const float* res; int64_t ldres;   /* [M, N]                                                                    */
     /* split-K (BIAS / BIAS_RELU only): K is cut in split_k slices computed by separate workgroups; raw partial sums
@@ -141,6 +141,11 @@ typedef struct {
 } skg_gemm_desc;
 
 int skg_gemm_f32(const skg_gemm_desc* desc_host, void* stream);
+
+/* Number of dot_partial slabs a SKG_EPI_RELU_DOT launch of `desc_host` writes (the launcher picks 128 x 128 tiles,
+ * or 64 x 64 tiles when the grid would leave most of the 256 CUs idle; the slab is the column range of one wave).
+ * Depends on M, N, K, lda, ldw, a_rows and split_k only; < 0 on a null descriptor. */
+int skg_gemm_dot_partials(const skg_gemm_desc* desc_host);
 
 /* Up to SKG_GEMM_GROUP_MAX independent GEMMs in one launch (the node-row GEMMs of the graph: fc_head | fc_tail,
  * the four fc_1 projections, the two message fc_3, HEAD:884-885, 894-896, 514-524); epilogues BIAS / BIAS_RELU /

@@ -54,6 +54,7 @@ PROTOTYPES = {
                                     C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "skg_global_avgpool_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "skg_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "skg_gemm_dot_partials": (C.c_int, [C.POINTER(GemmDesc)]),
     "skg_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
     "skg_gemm_bf16": (C.c_int, [C.POINTER(GemmBf16Desc), _vp]),
     "skg_transpose_bf16": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _vp, _i64, _vp]),

@@ -42,8 +42,8 @@
 #define B_TILE (BN * LDS_LD)
 
 // g = N-tiles per group (W slice <= 2 MiB), NG = number of groups rounded up to a power of two.
-__host__ __device__ __forceinline__ void skg_gemm_map(int nbn, int K, int& g, int& NG) {
-    g = 4096 / (K > 0 ? K : 1);
+__host__ __device__ __forceinline__ void skg_gemm_map(int nbn, int K, int T, int& g, int& NG) {
+    g = (8192 / T) / (K > 0 ? K : 1);                    // tiles of 64*T columns whose W slice fits in ~2 MiB
     if (g < 1) g = 1;
     if (g > nbn) g = nbn;
     const int ng = (nbn + g - 1) / g;
@@ -51,10 +51,10 @@ __host__ __device__ __forceinline__ void skg_gemm_map(int nbn, int K, int& g, in
     while (NG < ng) NG <<= 1;
 }
 
-__host__ __device__ __forceinline__ int64_t skg_gemm_blocks(int M, int N, int K) {
-    const int64_t nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
+__host__ __device__ __forceinline__ int64_t skg_gemm_blocks(int M, int N, int K, int T) {
+    const int64_t nbm = (M + 64 * T - 1) / (64 * T), nbn = (N + 64 * T - 1) / (64 * T);
     int g, NG;
-    skg_gemm_map((int)nbn, K, g, NG);
+    skg_gemm_map((int)nbn, K, T, g, NG);
     if (NG >= 8) return nbm * nbn;
     const int XG = 8 / NG;
     return 8LL * g * ((nbm + XG - 1) / XG);
@@ -69,15 +69,19 @@ __device__ __forceinline__ const char* skg_uniform_ptr(const char* p) {
 }
 
 // EPI >= 0: epilogue fixed at compile time; EPI < 0: taken from the descriptor (grouped launches of small GEMMs).
-template <int EPI_T, bool GLDS>
+// T = tile scale: block tile 64T x 64T, wave tile 32T x 32T = T x T MFMA tiles (T = 2: 128 x 128, the throughput
+// shape; T = 1: 64 x 64 for small M, four times the workgroups for the same problem).
+template <int EPI_T, bool GLDS, int T>
 __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_id, float* smem) {
+    static_assert(GLDS || T == 2, "the register-staged fallback exists for the 128 x 128 tile only");
+    constexpr int TBM = 64 * T, TBN = 64 * T;
     const int EPI = EPI_T >= 0 ? EPI_T : d.epilogue;
     // split-K (small-M layers, e.g. box_head at batch 1: M = 40, K = 12544): slice s of the K range goes to blocks
     // [s * tiles, (s + 1) * tiles); raw partial sums land in d.split_ws[s] and skg_splitk_reduce_kernel applies the
     // bias / ReLU epilogue in a fixed slice order (deterministic).
     int kt_begin = 0, kt_end = (d.K + BK - 1) / BK, split_slice = 0;
     if (d.split_k > 1) {
-        const int tiles = (int)skg_gemm_blocks(d.M, d.N, d.K);
+        const int tiles = (int)skg_gemm_blocks(d.M, d.N, d.K, T);
         split_slice = block_id / tiles;
         block_id -= split_slice * tiles;
         const int per = (kt_end + d.split_k - 1) / d.split_k;
@@ -95,12 +99,12 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
     // into NG groups whose W slice (g tiles x 128 x K x 4 B) fits in ~2 MiB; XG = 8 / NG XCDs serve one group and
     // split the M-tiles between them.  Inside an XCD consecutive blocks walk the g N-tiles of ONE M-tile, so the A
     // panel is fetched from HBM by NG XCDs (not 8) and W stays L2-resident.
-    const int nbn = (d.N + BN - 1) / BN;
-    const int nbm = (d.M + BM - 1) / BM;
+    const int nbn = (d.N + TBN - 1) / TBN;
+    const int nbm = (d.M + TBM - 1) / TBM;
     int bm, bn;
     {
         int g, NG;
-        skg_gemm_map(nbn, d.K, g, NG);
+        skg_gemm_map(nbn, d.K, T, g, NG);
         if (NG >= 8) {
             bn = block_id % nbn;
             bm = block_id / nbn;
@@ -113,13 +117,13 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
             if (bn >= nbn || bm >= nbm) return;
         }
     }
-    const int m0 = bm * BM, n0 = bn * BN;
+    const int m0 = bm * TBM, n0 = bn * TBN;
 
-    f32x16 acc[2][2];
+    f32x16 acc[T][T];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < T; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < T; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
@@ -213,15 +217,15 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
         // they only feed accumulators whose outputs are never stored.  The LDS image is lane-linear per wave
         // instruction (16 rows x 64 B); bank conflicts of the ds_read_b128 fragment reads are removed by XOR-ing the
         // 16-byte k-chunk index with (row >> 2) & 3 on the global SOURCE side and on the read side.
-        constexpr int GT = BM * BK;                                   // floats per operand tile (unpadded)
+        constexpr int GT = TBM * BK;                                  // floats per operand tile (unpadded)
         const int rl = lane >> 2;                                     // row inside a 16-row piece
         const int ch = lane & 3;                                      // 16-byte chunk the lane WRITES
         // per-lane byte offsets (32-bit) from wave-uniform bases that advance by one tile per iteration: the address
         // arithmetic of the DMA stays on the scalar unit
-        uint32_t oa[2], ow[2];
+        uint32_t oa[T], ow[T];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = wid * 32 + i * 16 + rl;                     // tile row staged by this lane
+        for (int i = 0; i < T; ++i) {
+            const int r = wid * (16 * T) + i * 16 + rl;               // tile row staged by this lane
             const int sw = (r >> 2) & 3;
             const int ar = m0 + r, wrw = n0 + r;
             // rows past M / N are clamped to the tile's FIRST row (offset 0, never negative: the offsets are unsigned)
@@ -232,12 +236,12 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
         const char* w_base = reinterpret_cast<const char*>(d.W + (int64_t)n0 * d.ldw);
         const int wid_u = __builtin_amdgcn_readfirstlane(wid);      // provably wave-uniform: LDS DMA bases stay scalar
         auto stage = [&](int buf, int kt) {
-            float* a_s = smem + buf * GT + (wid_u * 32) * BK;
-            float* b_s = smem + 2 * GT + buf * GT + (wid_u * 32) * BK;
+            float* a_s = smem + buf * GT + (wid_u * 16 * T) * BK;
+            float* b_s = smem + 2 * GT + buf * GT + (wid_u * 16 * T) * BK;
             const char* ab = skg_uniform_ptr(a_base + (int64_t)kt * BK * 4);
             const char* wb = skg_uniform_ptr(w_base + (int64_t)kt * BK * 4);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < T; ++i) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + oa[i]),
                                                  (__attribute__((address_space(3))) void*)(a_s + i * 16 * BK), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + ow[i]),
@@ -249,16 +253,16 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
         __syncthreads();                                              // drains vmcnt: the first tile has landed
         for (int kt = kt_begin; kt < nk; ++kt) {
             const int cur = kt & 1;
-            const float* a_s = smem + cur * GT + (wr * 64 + li) * BK;
-            const float* b_s = smem + 2 * GT + cur * GT + (wc * 64 + li) * BK;
+            const float* a_s = smem + cur * GT + (wr * 32 * T + li) * BK;
+            const float* b_s = smem + 2 * GT + cur * GT + (wc * 32 * T + li) * BK;
             // all fragment reads of this tile first: hipcc waits vmcnt(0) before any ds_read while an LDS-DMA is in
-            // flight, so the next tile's DMA is issued only after them and lands under the 32 MFMAs
-            float4 a[BK / 8][2], b[BK / 8][2];
+            // flight, so the next tile's DMA is issued only after them and lands under the MFMAs
+            float4 a[BK / 8][T], b[BK / 8][T];
 #pragma unroll
             for (int ks = 0; ks < BK / 8; ++ks) {
                 const int co = 4 * ((2 * ks + lh) ^ swr);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < T; ++i) {
                     a[ks][i] = *reinterpret_cast<const float4*>(a_s + i * 32 * BK + co);
                     b[ks][i] = *reinterpret_cast<const float4*>(b_s + i * 32 * BK + co);
                 }
@@ -268,16 +272,18 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < BK / 8; ++ks) {
-                const float av[2][4] = {{a[ks][0].x, a[ks][0].y, a[ks][0].z, a[ks][0].w},
-                                        {a[ks][1].x, a[ks][1].y, a[ks][1].z, a[ks][1].w}};
-                const float bv[2][4] = {{b[ks][0].x, b[ks][0].y, b[ks][0].z, b[ks][0].w},
-                                        {b[ks][1].x, b[ks][1].y, b[ks][1].z, b[ks][1].w}};
+                float av[T][4], bv[T][4];
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    av[i][0] = a[ks][i].x; av[i][1] = a[ks][i].y; av[i][2] = a[ks][i].z; av[i][3] = a[ks][i].w;
+                    bv[i][0] = b[ks][i].x; bv[i][1] = b[ks][i].y; bv[i][2] = b[ks][i].z; bv[i][3] = b[ks][i].w;
+                }
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < T; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < 2; ++ni)
+                        for (int ni = 0; ni < T; ++ni)
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][t], bv[ni][t], acc[mi][ni], 0, 0, 0);
             }
             __syncthreads();                                          // vmcnt(0) + barrier: next tile landed, this one free
@@ -289,7 +295,10 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
     // its accumulators through LDS (the staging tiles are dead now; 32 rows x 64 columns per pass, rows padded to 68
     // dwords) and walks them row-wise: every lane then handles 4 consecutive columns of one row, so bias / multiplier
     // tables / residual loads and the stores are 16-byte accesses covering 256 contiguous bytes per row.
-    constexpr int EST_LD = 68;
+    constexpr int EST_LD = 32 * T + 4;              // padded row: 16-byte aligned, conflict-free transposition
+    constexpr int LPR = 8 * T;                      // lanes per row (4 columns each)
+    constexpr int RPI = 64 / LPR;                   // rows per pass of the wave
+    constexpr int NIT = 32 / RPI;                   // passes per 32-row MFMA tile
     float* est = smem + wid * (32 * EST_LD);
     const bool vec_ok = ((d.ldc & 3) == 0) && skg_aligned16_dev(d.C) && skg_aligned16_dev(d.bias) &&
                         (EPI != SKG_EPI_MUL_RELU ||
@@ -299,34 +308,34 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
                         (EPI != SKG_EPI_RELU_DOT || skg_aligned16_dev(d.dot_w));
     // ---- fast path: tile entirely inside the matrix, everything 16-byte aligned, no split-K.  Column-dependent
     // operands (bias, multiplier bias, dot weights) are loaded once per lane; rows advance by pointer increments.
-    const bool interior = vec_ok && d.split_k <= 1 && (m0 + BM <= d.M) && (n0 + BN <= d.N);
+    const bool interior = vec_ok && d.split_k <= 1 && (m0 + TBM <= d.M) && (n0 + TBN <= d.N);
     if (interior) {
-        const int c4 = (lane & 15) * 4, r0l = lane >> 4;
-        const int col = n0 + wc * 64 + c4;
+        const int c4 = (lane % LPR) * 4, r0l = lane / LPR;
+        const int col = n0 + wc * 32 * T + c4;
         float4 bia4 = make_float4(0.f, 0.f, 0.f, 0.f), mb4 = bia4, dw4 = bia4;
         if (d.bias) bia4 = *reinterpret_cast<const float4*>(d.bias + col);
         if (EPI == SKG_EPI_MUL_RELU && d.mbias) mb4 = *reinterpret_cast<const float4*>(d.mbias + col);
         if (EPI == SKG_EPI_RELU_DOT) dw4 = *reinterpret_cast<const float4*>(d.dot_w + col);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < T; ++mi) {
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < T; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     est[((r & 3) + 8 * (r >> 2) + 4 * lh) * EST_LD + ni * 32 + li] = acc[mi][ni][r];
-            const int rowb = m0 + wr * 64 + mi * 32 + r0l;
+            const int rowb = m0 + wr * 32 * T + mi * 32 + r0l;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = rowb + it * 4;
-                const float4 a4 = *reinterpret_cast<const float4*>(est + (it * 4 + r0l) * EST_LD + c4);
+            for (int it = 0; it < NIT; ++it) {
+                const int row = rowb + it * RPI;
+                const float4 a4 = *reinterpret_cast<const float4*>(est + (it * RPI + r0l) * EST_LD + c4);
                 float4 v = make_float4(a4.x + bia4.x, a4.y + bia4.y, a4.z + bia4.z, a4.w + bia4.w);
                 if (EPI == SKG_EPI_RELU_DOT) {
                     v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
                     float sdot = (v.x * dw4.x + v.y * dw4.y) + (v.z * dw4.z + v.w * dw4.w);
                     if (d.C) *reinterpret_cast<float4*>(d.C + (int64_t)row * d.ldc + col) = v;
 #pragma unroll
-                    for (int off = 8; off > 0; off >>= 1) sdot += __shfl_xor(sdot, off, 64);
-                    if ((lane & 15) == 0) d.dot_partial[(int64_t)(bn * 2 + wc) * d.M + row] = sdot;
+                    for (int off = LPR / 2; off > 0; off >>= 1) sdot += __shfl_xor(sdot, off, 64);
+                    if ((lane % LPR) == 0) d.dot_partial[(int64_t)(bn * 2 + wc) * d.M + row] = sdot;
                     continue;
                 }
                 const int orow = d.out_rows ? d.out_rows[row] : row;
@@ -361,18 +370,18 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
         return;
     }
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < T; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < T; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 est[((r & 3) + 8 * (r >> 2) + 4 * lh) * EST_LD + ni * 32 + li] = acc[mi][ni][r];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int idx = it * 64 + lane;
-            const int rl = idx >> 4, c4 = (idx & 15) * 4;
-            const int row = m0 + wr * 64 + mi * 32 + rl;
-            const int col = n0 + wc * 64 + c4;
+            const int rl = idx / LPR, c4 = (idx % LPR) * 4;
+            const int row = m0 + wr * 32 * T + mi * 32 + rl;
+            const int col = n0 + wc * 32 * T + c4;
             const float4 a4 = *reinterpret_cast<const float4*>(est + rl * EST_LD + c4);
             float v[4] = {a4.x, a4.y, a4.z, a4.w};
             const bool rin = row < d.M;
@@ -412,8 +421,8 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
                         for (int c = 0; c < 4; ++c) if (col + c < d.N) d.C[(int64_t)row * d.ldc + col + c] = v[c];
                 }
 #pragma unroll
-                for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);      // 16 lanes share a row
-                if ((lane & 15) == 0 && rin) d.dot_partial[(int64_t)(bn * 2 + wc) * d.M + row] = s;
+                for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);      // LPR lanes share a row
+                if ((lane % LPR) == 0 && rin) d.dot_partial[(int64_t)(bn * 2 + wc) * d.M + row] = s;
                 continue;
             }
             if (!rin || col >= d.N) continue;
@@ -469,10 +478,10 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
     }
 }
 
-template <int EPI, bool GLDS>
+template <int EPI, bool GLDS, int T>
 __global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_kernel(const skg_gemm_desc d) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
-    skg_gemm_tile<EPI, GLDS>(d, blockIdx.x, smem);
+    __shared__ __attribute__((aligned(16))) float smem[T == 2 ? 2 * (A_TILE + B_TILE) : 4 * 32 * 36];
+    skg_gemm_tile<EPI, GLDS, T>(d, blockIdx.x, smem);
 }
 
 // Several independent small GEMMs in ONE launch (node-row GEMMs with M = sum n_h or sum n fill a fraction of the 256
@@ -489,7 +498,7 @@ __global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_group_kernel(const skg
 #pragma unroll
     for (int t = 1; t < SKG_GEMM_GROUP_MAX; ++t)
         if (t < g.n && (int)blockIdx.x >= g.start[t]) k = t;
-    skg_gemm_tile<-1, false>(g.d[k], blockIdx.x - g.start[k], smem);
+    skg_gemm_tile<-1, false, 2>(g.d[k], blockIdx.x - g.start[k], smem);
 }
 
 __global__ __launch_bounds__(256) void skg_splitk_reduce_kernel(const skg_gemm_desc d) {
@@ -503,6 +512,20 @@ __global__ __launch_bounds__(256) void skg_splitk_reduce_kernel(const skg_gemm_d
     if (d.epilogue == SKG_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
     const int orow = d.out_rows ? d.out_rows[row] : row;
     if (orow >= 0) d.C[(int64_t)orow * d.ldc + col] = v;
+}
+
+// 64 x 64 tiles when the 128 x 128 grid would leave most CUs idle (small M: low-batch inference); needs the DMA path.
+static int skg_gemm_tile_scale(const skg_gemm_desc* d) {
+    const bool glds = SKG_USE_GLDS && BK == 16 && (d->K % BK) == 0 && !d->a_rows &&
+                      (int64_t)BM * d->lda * 4 < 0xffffffffLL && (int64_t)BN * d->ldw * 4 < 0xffffffffLL;
+    const int64_t tiles128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * (d->split_k > 1 ? d->split_k : 1);
+    return (glds && tiles128 < 384) ? 1 : 2;
+}
+
+extern "C" int skg_gemm_dot_partials(const skg_gemm_desc* dh) {
+    if (!dh) return SKG_E_ARG;
+    const int T = skg_gemm_tile_scale(dh);
+    return 2 * ((dh->N + 64 * T - 1) / (64 * T));
 }
 
 static int skg_gemm_validate(const skg_gemm_desc& d) {
@@ -537,7 +560,7 @@ extern "C" int skg_gemm_group_f32(const skg_gemm_desc* descs_host, int n, void* 
         if (rc) return rc;
         if (descs_host[i].split_k > 1) return SKG_E_ARG;
         if (descs_host[i].M == 0) continue;
-        const int64_t nb = skg_gemm_blocks(descs_host[i].M, descs_host[i].N, descs_host[i].K);
+        const int64_t nb = skg_gemm_blocks(descs_host[i].M, descs_host[i].N, descs_host[i].K, 2);
         if (blocks + nb > 0x7fffffffLL) return SKG_E_LIMIT;
         g.d[g.n] = descs_host[i];
         g.start[g.n] = blocks;
@@ -556,15 +579,17 @@ extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
     const int rc = skg_gemm_validate(d);
     if (rc) return rc;
     if (d.M == 0) return 0;
-    const int64_t nblk = skg_gemm_blocks(d.M, d.N, d.K) * (d.split_k > 1 ? d.split_k : 1);
+    const bool glds = SKG_USE_GLDS && BK == 16 && (d.K % BK) == 0 && !d.a_rows &&
+                      (int64_t)BM * d.lda * 4 < 0xffffffffLL && (int64_t)BN * d.ldw * 4 < 0xffffffffLL;
+    const int T = skg_gemm_tile_scale(&d);
+    const int64_t nblk = skg_gemm_blocks(d.M, d.N, d.K, T) * (d.split_k > 1 ? d.split_k : 1);
     if (nblk > 0x7fffffffLL) return SKG_E_LIMIT;
     dim3 grid((unsigned)nblk), block(256);
     hipStream_t s = (hipStream_t)stream;
-    const bool glds = SKG_USE_GLDS && BK == 16 && (d.K % BK) == 0 && !d.a_rows &&
-                      (int64_t)BM * d.lda * 4 < 0xffffffffLL && (int64_t)BN * d.ldw * 4 < 0xffffffffLL;
 #define SKG_LAUNCH(E)                                                                              \
-    if (glds) hipLaunchKernelGGL((skg_gemm_kernel<E, true>), grid, block, 0, s, d);               \
-    else hipLaunchKernelGGL((skg_gemm_kernel<E, false>), grid, block, 0, s, d);
+    if (glds && T == 1) hipLaunchKernelGGL((skg_gemm_kernel<E, true, 1>), grid, block, 0, s, d);  \
+    else if (glds) hipLaunchKernelGGL((skg_gemm_kernel<E, true, 2>), grid, block, 0, s, d);       \
+    else hipLaunchKernelGGL((skg_gemm_kernel<E, false, 2>), grid, block, 0, s, d);
     switch (d.epilogue) {
         case SKG_EPI_BIAS:          SKG_LAUNCH(SKG_EPI_BIAS) break;
         case SKG_EPI_BIAS_RELU:     SKG_LAUNCH(SKG_EPI_BIAS_RELU) break;

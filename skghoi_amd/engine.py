@@ -141,6 +141,16 @@ def pick_split_k(M, N, K, target_blocks=1024):
     return int(max(1, min(-(-target_blocks // blocks), K // 256, 64)))
 
 
+def dot_partials(M, N, K, lda, ldw):
+    """Slab count of the dot_partial output of an EPI_RELU_DOT launch (depends on the tile shape the launcher picks)."""
+    d = _capi.GemmDesc()
+    d.M, d.N, d.K, d.lda, d.ldw, d.epilogue = M, N, K, lda, ldw, _capi.EPI_RELU_DOT
+    n = _capi.lib().skg_gemm_dot_partials(C.byref(d))
+    if n <= 0:
+        raise _capi.SkgError("skg_gemm_dot_partials -> %d" % n)
+    return n
+
+
 def gemm(A, W, bias, C_out, M, N, K, epilogue, **kw):
     """One skg_gemm_f32 launch (see gemm_desc for the keywords)."""
     d = gemm_desc(A, W, bias, C_out, M, N, K, epilogue, **kw)
@@ -546,7 +556,7 @@ class HeadEngine:
             gemm(S, pw.os["w2"], pw.os["b2"], Tos, Mg, 1024, 1024, _capi.EPI_MUL_RELU, P=C1o, p_idx=grid_o, ldp=1024)
             gemm(S, pw.so["w2"], pw.so["b2"], Tso, Mg, 1024, 1024, _capi.EPI_MUL_RELU, P=C1h, p_idx=grid_h, ldp=1024)
             # ---- attention fc_3 + ReLU + adjacency dot (HEAD:896-897)
-            n_part = 2 * ((1024 + 127) // 128)
+            n_part = dot_partials(Mg, 1024, 1024, T.stride(0), pw.att["w3"].stride(0))
             part = torch.empty(n_part, Mg, **f32)
             gemm(T, pw.att["w3"], pw.att["b3"], None, Mg, 1024, 1024, _capi.EPI_RELU_DOT, dot_w=pw.adj_w,
                  dot_partial=part)

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from skghoi_amd import _capi
-from skghoi_amd.engine import gemm, gemm_group, _stream
+from skghoi_amd.engine import gemm, gemm_group, dot_partials, _stream
 
 pytestmark = pytest.mark.gpu
 
@@ -20,7 +20,8 @@ def _close(a, b, tol):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 1024, 256), (40, 1024, 32), (130, 118, 2048), (300, 128, 48), (257, 1024, 1088),
-                                   (800, 1024, 1024), (513, 256, 128), (128, 128, 16), (64, 100, 12544)])
+                                   (800, 1024, 1024), (513, 256, 128), (128, 128, 16), (64, 100, 12544),
+                                   (6213, 1024, 64), (12801, 516, 48), (6213, 1000, 36)])   # >= 384 tiles: 128 x 128 kernel
 def test_gemm_bias_relu_shapes_and_tails(M, N, K):
     A = _rand(M, K, seed=1); W = _rand(N, K, seed=2) / np.sqrt(K); b = _rand(N, seed=3)
     ref = torch.relu(A.double() @ W.double().t() + b.double()).float()
@@ -75,8 +76,9 @@ def test_gemm_gather_scatter_and_column_views():
     assert torch.all(C[:, :N] == 0)
 
 
-def test_gemm_mul_relu_epilogue():
-    M, N, K = 333, 1024, 256
+@pytest.mark.parametrize("M", [333, 6333])                # 64 x 64 tiles / 128 x 128 tiles
+def test_gemm_mul_relu_epilogue(M):
+    N, K = 1024, 256
     A = _rand(M, K, seed=1); W = _rand(N, K, seed=2) / 16; b = _rand(N, seed=3)
     P = _rand(17, N, seed=4); Q = _rand(29, N, seed=5); mb = _rand(N, seed=6)
     pi = torch.randint(0, 17, (M,), generator=torch.Generator().manual_seed(3)).int().cuda()
@@ -94,10 +96,11 @@ def test_gemm_mul_relu_epilogue():
     _close(C1, torch.relu(v * P[pi.long()].double()).float(), 2e-5)
 
 
-def test_gemm_relu_dot_and_residual_epilogues():
-    M, N, K = 450, 1024, 128
+@pytest.mark.parametrize("M", [450, 6200])                # 64 x 64 tiles / 128 x 128 tiles
+def test_gemm_relu_dot_and_residual_epilogues(M):
+    N, K = 1024, 128
     A = _rand(M, K, seed=1); W = _rand(N, K, seed=2) / 8; b = _rand(N, seed=3); dw = _rand(N, seed=4)
-    part = torch.empty(16, M, device="cuda")
+    part = torch.empty(dot_partials(M, N, K, K, K), M, device="cuda")
     gemm(A, W, b, None, M, N, K, _capi.EPI_RELU_DOT, dot_w=dw, dot_partial=part)
     torch.cuda.synchronize()
     v = torch.relu(A.double() @ W.double().t() + b.double())

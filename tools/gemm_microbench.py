@@ -19,7 +19,7 @@ for M, N, K, epi in shapes:
         pi = (torch.arange(M) // 40 % 1280).int().cuda(); qi = (torch.arange(M) % 2560).int().cuda()
         kw = dict(P=P, p_idx=pi, ldp=N, Q=Q, q_idx=qi, ldq=N, mbias=b, C_raw=torch.empty(M, N, device="cuda"), ldc_raw=N)
     if epi == 3:
-        kw = dict(dot_w=b, dot_partial=torch.empty(16, M, device="cuda"))
+        kw = dict(dot_w=b, dot_partial=torch.empty(64, M, device="cuda"))
     for _ in range(3):
         gemm(A, W, b, None if epi == 3 else C, M, N, K, epi, **kw)
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
