@@ -29,6 +29,8 @@ import numpy as np
 import torch
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: BF16/F16 dense MFMA peak (~2.5 PF)
+F16X2_PASSES = 3                      # fp16x2 path: h.h + h.m + m.h = three fp16 MFMA flops per useful flop
 N_H = N_O = 20
 C_FEAT, POOL = 256, 7
 
@@ -102,7 +104,8 @@ def train_mode(args, device, rank, world, dist_on):
     B = args.batch if args.batch != 256 else 4
     head = build_head(device).train()
     head.distributed = dist_on
-    head.precision = args.precision
+    head.precision = args.precision or "fp32"
+    args.precision = head.precision
     dets, pooled, feats, shapes = make_inputs(B, rank, device)
     o2v = synth.hico_object_to_verb()
     cpu_dets = [dict(boxes=d["boxes"].cpu(), labels=d["labels"].cpu(), scores=d["scores"].cpu()) for d in dets]
@@ -157,7 +160,10 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="override HeadEngine.n_streams")
     ap.add_argument("--no-gemm-timer", action="store_true", help="skip the per-launch HIP-event GEMM timing")
     ap.add_argument("--gemm-table", action="store_true", help="per-shape GEMM timing table on stderr")
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32", help="training-mode GEMM operands")
+    ap.add_argument("--precision", choices=["fp16x2", "fp32", "bf16"], default=None,
+                    help="dense-layer path.  infer: fp16x2 (default; fp32-grade split operands on the fp16 MFMA) or "
+                         "fp32 (exact fp32 MFMA).  train: fp32 (default) or bf16")
+    ap.add_argument("--no-exact-leg", action="store_true", help="skip the extra timed steps on the exact fp32 path")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="train: NegativeSampling+MarginLoss training step (fwd+bwd+AdamW), secondary metric")
     args = ap.parse_args()
@@ -184,6 +190,9 @@ def main():
     head = build_head(device)
     dets, pooled, feats, shapes = make_inputs(args.batch, rank, device)
     head.box_roi_pool = ResidentPool(pooled)
+    head.precision = args.precision or "fp16x2"
+    if head.precision == "bf16":
+        raise SystemExit("--precision bf16 is a training configuration (use --mode train)")
     if args.chunk:
         head.engine().chunk_images = args.chunk
     if args.streams:
@@ -213,6 +222,21 @@ def main():
     elapsed = time.perf_counter() - t0
     timer, engine.GEMM_TIMER = (engine.GEMM_TIMER or []), None
 
+    # ---- secondary leg, same run: the exact fp32-MFMA path (precision="fp32") on the same inputs
+    exact = None
+    if head.precision != "fp32" and not args.no_exact_leg:
+        main_precision, head.precision = head.precision, "fp32"
+        k2 = max(2, min(args.steps, 5))
+        step(); step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step()
+        barrier()
+        el2 = time.perf_counter() - t1
+        head.precision = main_precision
+        exact = (el2, k2)
+
     from skghoi_amd import dist as skd
     elapsed = skd.max_over_ranks(elapsed, device=device)
     total_images = sum(skd.gather_counts(args.batch * args.steps, device=device))
@@ -239,6 +263,10 @@ def main():
     t_dom, f_dom, n_dom = groups[dom]
     t_all = sum(g[0] for g in groups.values()); f_all = sum(g[1] for g in groups.values())
     achieved = f_dom / t_dom / 1e12
+    split = head.precision == "fp16x2"
+    peak = PEAK_F16_MFMA_TFLOPS / F16X2_PASSES if split else PEAK_F32_MFMA_TFLOPS
+    if split:
+        names = {k: v.replace(">", ", fp16x2>") if k != 5 else v for k, v in names.items()}
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")     # HBM bytes per launch from the rocprofv3 --pmc passes
     if os.path.isfile(tpath):
@@ -246,8 +274,10 @@ def main():
             traffic = json.load(open(tpath)).get(names[dom])
         except Exception:
             traffic = None
-    roofline = dict(bound="mfma", kernel=names[dom], achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS,
-                    unit="TFLOP/s", frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
+    roofline = dict(bound="mfma", kernel=names[dom], achieved=round(achieved, 2), peak=round(peak, 1),
+                    unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
+                    peak_note=("useful (2MNK) flops; peak = fp16 dense MFMA %.0f TF / %d MFMA passes per useful flop"
+                               % (PEAK_F16_MFMA_TFLOPS, F16X2_PASSES)) if split else "fp32 MFMA dense peak",
                     launches=n_dom, avg_launch_ms=round(t_dom / max(n_dom, 1) * 1e3, 4),
                     all_gemm_tflops=round(f_all / t_all / 1e12, 2),
                     gemm_share_of_step=round(t_all / (elapsed if not dist_on else elapsed), 4),
@@ -256,13 +286,19 @@ def main():
     out = OrderedDict(metric="images/sec through interaction head (20x20 pairs)", value=round(value, 2),
                       unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                       ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
-                      vs_baseline=None, dtype="f32", data="synthetic",
-                      config=dict(workload="HICO-DET-shaped synthetic cached detections: 20 humans x 20 objects per "
+                      vs_baseline=None,
+                      dtype="f32 (fp16x2 split operands, fp32 accumulate)" if split else "f32", data="synthetic",
+                      config=dict(precision=head.precision, workload="HICO-DET-shaped synthetic cached detections: 20 humans x 20 objects per "
                                            "image (G=800 grid rows, P=780 pairs, K=117 verbs), eval forward of "
                                            "InteractionHead from cached AdaMixer-R50 box features [40,256,7,7]/image",
                                   batch_per_gpu=args.batch, images_per_step=args.batch * world,
                                   parallelism="dp%d (independent image shards, no data-path collective)" % world),
                       roofline=roofline)
+    if exact is not None:
+        el2 = skd.max_over_ranks(exact[0], device=device)
+        out["exact_fp32"] = dict(value=round(args.batch * world * exact[1] / el2, 2), unit="images/s", steps=exact[1],
+                                 ms_per_step=round(el2 / exact[1] * 1e3, 3),
+                                 note="same run, same inputs, precision='fp32' (exact fp32 MFMA everywhere)")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(12)
     if rank == 0:

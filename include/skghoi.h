@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SKG_ABI_VERSION 2
+#define SKG_ABI_VERSION 3
 #define SKG_E_ARG   (-1)   /* null pointer / negative size / unsupported shape            */
 #define SKG_E_ALIGN (-2)   /* pointer or leading dimension not 16-byte aligned            */
 #define SKG_E_LIMIT (-3)   /* exceeds a compiled-in limit (boxes per image, verbs, ...)   */
@@ -136,11 +136,26 @@ typedef struct {
     const float* res; int64_t ldres;   /* [M, N]                                                                    */
     /* split-K (BIAS / BIAS_RELU only): K is cut in split_k slices computed by separate workgroups; raw partial sums
      * go to split_ws [split_k, M, N] and a second kernel adds them in slice order and applies the epilogue.          */
-    int32_t split_k; int32_t _pad;     /* 0 or 1 = off                                                              */
+    int32_t split_k;                   /* 0 or 1 = off                                                              */
+    float   w_scale;                   /* with w_split: 1 / scale given to skg_split_weights_f16x2 (a power of two)  */
     float*  split_ws;
+    /* optional: W as two fp16 planes per element (h + m, 22 significant bits) in MFMA-fragment order, made by
+     * skg_split_weights_f16x2.  When given (and K % 16 == 0, w_scale > 0) the product runs on the fp16 matrix pipe
+     * from 2-way fp16 splits of both operands (h.h + h.m + m.h, fp32 accumulation; ~2^-22 relative per product, i.e.
+     * fp32 grade); tiles whose result is not finite (fp16 range exceeded, inf / nan inputs) are recomputed with the
+     * exact fp32 loop, for which W is still required. */
+    const void* w_split;
 } skg_gemm_desc;
 
 int skg_gemm_f32(const skg_gemm_desc* desc_host, void* stream);
+
+/* Re-encodes an nn.Linear weight W [N, K] (fp32, leading dimension ldw) for skg_gemm_desc.w_split: every value of
+ * scale * W becomes h + m (two fp16), stored as 1 KiB planes [ceil(N/32)][ceil(K/16)][h|m][k half][32 rows][8 k],
+ * zero padded.  `scale` must be a power of two; choose it so that max |scale * W| lies in [2^13, 2^14) (m then stays
+ * a normal fp16 for every weight that matters) and pass 1 / scale as skg_gemm_desc.w_scale.  `out` holds
+ * skg_split_weights_bytes(N, K) bytes, 16-byte aligned. */
+int64_t skg_split_weights_bytes(int N, int K);
+int skg_split_weights_f16x2(const float* W, int N, int K, int64_t ldw, float scale, void* out, void* stream);
 
 /* Number of dot_partial slabs a SKG_EPI_RELU_DOT launch of `desc_host` writes (the launcher picks 128 x 128 tiles,
  * or 64 x 64 tiles when the grid would leave most of the 256 CUs idle; the slab is the column range of one wave).

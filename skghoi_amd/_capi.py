@@ -12,7 +12,7 @@ MAX_NODES = 160
 SPATIAL_LD = 48
 TRANSH_DIM = 50
 TRANSH_ENT = 80
-ABI_VERSION = 2
+ABI_VERSION = 3
 GEMM_GROUP_MAX = 4
 
 _vp = C.c_void_p
@@ -27,7 +27,7 @@ class GemmDesc(C.Structure):
                 ("M", _i32), ("N", _i32), ("K", _i32), ("epilogue", _i32), ("a_rows", _vp), ("out_rows", _vp),
                 ("P", _vp), ("p_idx", _vp), ("ldp", _i64), ("Q", _vp), ("q_idx", _vp), ("ldq", _i64),
                 ("mbias", _vp), ("C_raw", _vp), ("ldc_raw", _i64), ("dot_w", _vp), ("dot_partial", _vp),
-                ("res", _vp), ("ldres", _i64), ("split_k", _i32), ("_pad", _i32), ("split_ws", _vp)]
+                ("res", _vp), ("ldres", _i64), ("split_k", _i32), ("w_scale", _f32), ("split_ws", _vp), ("w_split", _vp)]
 
 
 class GemmBf16Desc(C.Structure):
@@ -55,6 +55,8 @@ PROTOTYPES = {
     "skg_global_avgpool_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "skg_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "skg_gemm_dot_partials": (C.c_int, [C.POINTER(GemmDesc)]),
+    "skg_split_weights_bytes": (C.c_int64, [C.c_int, C.c_int]),
+    "skg_split_weights_f16x2": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _f32, _vp, _vp]),
     "skg_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
     "skg_gemm_bf16": (C.c_int, [C.POINTER(GemmBf16Desc), _vp]),
     "skg_transpose_bf16": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _vp, _i64, _vp]),

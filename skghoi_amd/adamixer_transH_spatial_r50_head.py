@@ -244,8 +244,14 @@ class InteractionHead(Module):
     signature and result dictionaries.
 
     Extra keyword (not in the reference, defaults reproduce it):
-      precision: str = "fp32" -- "bf16" runs the TRAINING-mode dense layers with bf16 operands on the matrix cores
-        (fp32 accumulation, fp32 master weights / gradients / activations); inference always uses the exact fp32 path.
+      precision: str = "fp16x2" -- dense layers of the inference forward:
+        "fp16x2" (default): operands split into two fp16 numbers each (22 significant bits), three fp16-MFMA passes
+          with fp32 accumulation -- fp32-grade results (~1e-6 relative to the exact path, far inside the 1e-4 logit
+          bar) at about twice the speed of the fp32 MFMA; tiles that leave the fp16 range or contain inf / nan are
+          recomputed exactly (skghoi_amd/csrc/skg_gemm.hip).
+        "fp32": the exact fp32 MFMA (bit-for-bit an fmaf chain) everywhere.
+        "bf16": TRAINING-mode dense layers with bf16 operands (fp32 accumulation, fp32 master weights / gradients /
+          activations); inference as "fp16x2".  Training otherwise always uses the exact fp32 path.
       reference_quirks: bool = True -- reproduce (a) the node-offset bug on skipped images and (b) the
         eval-mode label-list zip with skipped images in a batch > 1 (HEAD:298-310: truncated results / IndexError).
         With False every image gets its own (possibly empty) result.
@@ -254,7 +260,7 @@ class InteractionHead(Module):
     def __init__(self, box_roi_pool: Module, box_pair_head: Module, box_pair_suppressor: Module,
                  box_pair_predictor: Module, human_idx: int, num_classes: int, box_nms_thresh: float = 0.5,
                  box_score_thresh: float = 0.2, max_human: int = 15, max_object: int = 15,
-                 distributed: bool = False, reference_quirks: bool = True, precision: str = "fp32") -> None:
+                 distributed: bool = False, reference_quirks: bool = True, precision: str = "fp16x2") -> None:
         super().__init__()
         self.box_roi_pool = box_roi_pool
         self.box_pair_head = box_pair_head
@@ -268,8 +274,8 @@ class InteractionHead(Module):
         self.max_object = max_object
         self.distributed = distributed
         self.reference_quirks = reference_quirks
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if precision not in ("fp32", "bf16", "fp16x2"):
+            raise ValueError("precision must be 'fp32', 'fp16x2' or 'bf16'")
         self.precision = precision
         self._engine = None
 

@@ -24,6 +24,11 @@
 //     accesses; interior tiles take a guard-free path.  Split-K (plain epilogues) and a grouped launch cover the
 //     small-M layers.
 #include "skg_common.h"
+#include <type_traits>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define BM 128
 #define BN 128
@@ -37,6 +42,9 @@
 #define SKG_USE_GLDS 1
 #endif
 #define BK SKG_BK
+#ifndef SKG_XNST
+#define SKG_XNST 2                      // register stages of the split-operand loop (tiles in flight)
+#endif
 #define LDS_LD (BK + 4)                 // + 4 dwords of padding: conflict-free ds_read_b128 at strides 20 and 36
 #define A_TILE (BM * LDS_LD)
 #define B_TILE (BN * LDS_LD)
@@ -71,9 +79,12 @@ __device__ __forceinline__ const char* skg_uniform_ptr(const char* p) {
 // EPI >= 0: epilogue fixed at compile time; EPI < 0: taken from the descriptor (grouped launches of small GEMMs).
 // T = tile scale: block tile 64T x 64T, wave tile 32T x 32T = T x T MFMA tiles (T = 2: 128 x 128, the throughput
 // shape; T = 1: 64 x 64 for small M, four times the workgroups for the same problem).
-template <int EPI_T, bool GLDS, int T>
+// MODE = main loop: 0 register-staged fp32 MFMA, 1 DMA-staged fp32 MFMA, 2 fp16x2-split operands on the fp16 MFMA.
+template <int EPI_T, int MODE, int T>
 __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_id, float* smem) {
-    static_assert(GLDS || T == 2, "the register-staged fallback exists for the 128 x 128 tile only");
+    static_assert(MODE == 1 || T == 2, "only the DMA-staged fp32 loop has a 64 x 64 variant");
+    constexpr bool GLDS = MODE == 1;
+    const int Kmap = d.K;
     constexpr int TBM = 64 * T, TBN = 64 * T;
     const int EPI = EPI_T >= 0 ? EPI_T : d.epilogue;
     // split-K (small-M layers, e.g. box_head at batch 1: M = 40, K = 12544): slice s of the K range goes to blocks
@@ -81,7 +92,7 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
     // bias / ReLU epilogue in a fixed slice order (deterministic).
     int kt_begin = 0, kt_end = (d.K + BK - 1) / BK, split_slice = 0;
     if (d.split_k > 1) {
-        const int tiles = (int)skg_gemm_blocks(d.M, d.N, d.K, T);
+        const int tiles = (int)skg_gemm_blocks(d.M, d.N, Kmap, T);
         split_slice = block_id / tiles;
         block_id -= split_slice * tiles;
         const int per = (kt_end + d.split_k - 1) / d.split_k;
@@ -104,7 +115,7 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
     int bm, bn;
     {
         int g, NG;
-        skg_gemm_map(nbn, d.K, T, g, NG);
+        skg_gemm_map(nbn, Kmap, T, g, NG);
         if (NG >= 8) {
             bn = block_id % nbn;
             bm = block_id / nbn;
@@ -128,7 +139,9 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     const int nk = kt_end;
-    if constexpr (!GLDS) {
+    // ---- exact fp32 loop, register staged: MODE 0, and the per-tile fallback of MODE 2
+    auto loop_exact = [&]() {
+    if constexpr (T == 2) {
     // ---- global -> register staging map: thread owns rows (lr, lr+64) x 4 consecutive k
     constexpr int TPR = BK / 4;                  // threads per tile row (float4 each)
     constexpr int RPP = 256 / TPR;               // rows per staging pass
@@ -211,6 +224,139 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
         __syncthreads();
     }
 
+    }
+    };
+    if constexpr (MODE == 0) {
+        loop_exact();
+    } else if constexpr (MODE == 2) {
+        // ---- fp32-grade result from the fp16 matrix pipe (3 MFMA passes instead of the 8 of the fp32 MFMA per 16 k).
+        // Every operand value x is carried as h + m with h = fp16(x), m = fp16(x - h): 22 significant bits, i.e.
+        // |x - h - m| <= 2^-23 |x| (2^-25 absolute once m is subnormal; the fp16 MFMA takes subnormals exactly).
+        // a.b is accumulated from h.m, m.h and h.h in the fp32 accumulator of v_mfma_f32_32x32x16_f16; the dropped
+        // m.m is <= 2^-22 |a.b|.  W comes pre-split from skg_split_weights_f16x2 -- scaled by a power of two so that its
+        // m planes stay normal, un-scaled in the epilogue (d.w_scale) -- as MFMA-fragment-ordered 1 KiB planes
+        // [n-tile 32][k-tile 16][h|m][k-half][row][8 k].  A stays fp32 in HBM (gathers and epilogue outputs
+        // unchanged), is split in registers and written to LDS in the same plane format; fragment reads are
+        // lane-linear ds_read_b128.  fp16 overflows at 65504: a tile whose accumulators come out non-finite (overflow,
+        // inf / nan inputs) is recomputed by the exact loop, so those cases behave as in fp32 arithmetic.
+        char* sm = reinterpret_cast<char*>(smem);
+        constexpr int NC = 2, NCB = NC * 1024;
+        constexpr int BUF = 8 * NCB, WOFF = 4 * NCB;                  // per buffer: A planes | W planes, 4 row tiles each
+        const int q = tid & 3, r = tid >> 2;                          // staging: rows r, r + 64; k quad q
+        const float* pa[2];
+        bool va[2];
+        uint32_t aw[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = m0 + r + 64 * i;
+            int src = -1;
+            if (row < d.M) src = d.a_rows ? d.a_rows[row] : row;
+            va[i] = src >= 0 || row >= d.M;                           // rows past M: any readable data, never stored
+            pa[i] = d.A + (int64_t)(src >= 0 ? src : 0) * d.lda + q * 4;
+            aw[i] = (uint32_t)((((r >> 5) + 2 * i) * NC) * 1024 + (q >> 1) * 512 + (r & 31) * 16 + (q & 1) * 8);
+        }
+        const int nnt = (d.N + 31) >> 5, nkt = d.K >> 4;
+        int nt = (n0 >> 5) + wid;
+        if (nt >= nnt) nt = 0;                                        // columns past N: never stored
+        const uint32_t lane16 = lane * 16;
+        const char* pw = reinterpret_cast<const char*>(d.w_split) + (int64_t)nt * nkt * NCB + lane16;
+        const uint32_t ww = (uint32_t)(WOFF + wid * NCB) + lane16;
+        // register stages: tiles kt+1 .. kt+NST are in flight while tile kt is multiplied; plain loads keep the
+        // compiler's vmcnt bookkeeping exact and barriers do not drain them
+        constexpr int NST = SKG_XNST;
+        f32x4 ra[NST][2];
+        u32x4 rw[NST][NC];
+        auto load_tile = [&](auto S, int kt) {
+            constexpr int st = decltype(S)::value;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ra[st][i] = *reinterpret_cast<const f32x4*>(pa[i] + kt * 16);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) rw[st][c] = *reinterpret_cast<const u32x4*>(pw + (int64_t)kt * NCB + c * 1024);
+        };
+        auto store_tile = [&](auto S, int buf) {
+            constexpr int st = decltype(S)::value;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                h16x2 hp[2], mp[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float x0 = va[i] ? ra[st][i][2 * e] : 0.f, x1 = va[i] ? ra[st][i][2 * e + 1] : 0.f;
+                    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;                       // round to nearest even
+                    hp[e] = h16x2{h0, h1};
+                    mp[e] = h16x2{(_Float16)(x0 - (float)h0), (_Float16)(x1 - (float)h1)};    // x - h is exact
+                }
+                char* dst = sm + buf * BUF + aw[i];
+                *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(uint32_t, hp[0]), __builtin_bit_cast(uint32_t, hp[1]));
+                *reinterpret_cast<uint2*>(dst + 1024) = make_uint2(__builtin_bit_cast(uint32_t, mp[0]), __builtin_bit_cast(uint32_t, mp[1]));
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) *reinterpret_cast<u32x4*>(sm + buf * BUF + ww + c * 1024) = rw[st][c];
+        };
+        // one k-tile: fragments of tile t out of LDS, refill the stage tile t came from with tile t + NST, 12 MFMAs,
+        // split / store tile t + 1 (next stage) into the other LDS buffer
+        auto step = [&](auto S, int t) {
+            constexpr int st = decltype(S)::value;
+            const int cur = (t - kt_begin) & 1;
+            const char* a_f = sm + cur * BUF + (2 * wr * NC) * 1024 + lane16;
+            const char* b_f = sm + cur * BUF + WOFF + (2 * wc * NC) * 1024 + lane16;
+            f16x8 a[2][NC], b[2][NC];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    a[i][c] = *reinterpret_cast<const f16x8*>(a_f + (i * NC + c) * 1024);
+                    b[i][c] = *reinterpret_cast<const f16x8*>(b_f + (i * NC + c) * 1024);
+                }
+            load_tile(S, t + NST < nk ? t + NST : nk - 1);             // unconditional (clamped): no branch in the loop body
+            // small terms first (h.m, m.h), then h.h; the four accumulators take turns
+            constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][PA[p]], b[ni][PB[p]], acc[mi][ni], 0, 0, 0);
+            store_tile(std::integral_constant<int, (st + 1) % NST>{}, cur ^ 1);      // past the end: a dead buffer
+            __syncthreads();
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1 % NST>;
+        using I2 = std::integral_constant<int, 2 % NST>;
+        load_tile(I0{}, kt_begin);
+        load_tile(I1{}, kt_begin + 1 < nk ? kt_begin + 1 : nk - 1);
+        if (NST > 2) load_tile(I2{}, kt_begin + 2 < nk ? kt_begin + 2 : nk - 1);
+        store_tile(I0{}, 0);
+        __syncthreads();
+        for (int kt = kt_begin; kt < nk; kt += NST) {
+            step(I0{}, kt);
+            if (kt + 1 >= nk) break;
+            step(I1{}, kt + 1);
+            if (NST > 2) {
+                if (kt + 2 >= nk) break;
+                step(I2{}, kt + 2);
+            }
+        }
+        // un-scale; x * 0 is nan exactly when x is inf or nan: one flag per block decides the exact re-run
+        float bad = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    bad = fmaf(acc[mi][ni][rr], 0.f, bad);
+                    acc[mi][ni][rr] *= d.w_scale;
+                }
+        if (__syncthreads_or(bad != bad)) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int rr = 0; rr < 16; ++rr) acc[mi][ni][rr] = 0.f;
+            loop_exact();
+        }
     } else {
         // ---- direct-to-LDS staging (global_load_lds_dwordx4): no VGPR round trip, no ds_write, no masking.
         // Requirements (checked by the host): K % 16 == 0, no A-row gather, 128 rows x ld x 4 B < 4 GiB.  Rows past M / N are clamped:
@@ -478,10 +624,10 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
     }
 }
 
-template <int EPI, bool GLDS, int T>
+template <int EPI, int MODE, int T>
 __global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_kernel(const skg_gemm_desc d) {
     __shared__ __attribute__((aligned(16))) float smem[T == 2 ? 2 * (A_TILE + B_TILE) : 4 * 32 * 36];
-    skg_gemm_tile<EPI, GLDS, T>(d, blockIdx.x, smem);
+    skg_gemm_tile<EPI, MODE, T>(d, blockIdx.x, smem);
 }
 
 // Several independent small GEMMs in ONE launch (node-row GEMMs with M = sum n_h or sum n fill a fraction of the 256
@@ -498,7 +644,7 @@ __global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_group_kernel(const skg
 #pragma unroll
     for (int t = 1; t < SKG_GEMM_GROUP_MAX; ++t)
         if (t < g.n && (int)blockIdx.x >= g.start[t]) k = t;
-    skg_gemm_tile<-1, false, 2>(g.d[k], blockIdx.x - g.start[k], smem);
+    skg_gemm_tile<-1, 0, 2>(g.d[k], blockIdx.x - g.start[k], smem);
 }
 
 __global__ __launch_bounds__(256) void skg_splitk_reduce_kernel(const skg_gemm_desc d) {
@@ -514,11 +660,55 @@ __global__ __launch_bounds__(256) void skg_splitk_reduce_kernel(const skg_gemm_d
     if (orow >= 0) d.C[(int64_t)orow * d.ldc + col] = v;
 }
 
+// One thread per (row, k quad) of the padded weight: writes 2 x 8 bytes in the plane format of the MODE 2 loop.
+__global__ __launch_bounds__(256) void skg_split_weights_kernel(const float* __restrict__ W, int N, int K, int64_t ldw,
+                                                                float scale, char* __restrict__ out) {
+    const int nkt = (K + 15) >> 4, nnt = (N + 31) >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)nnt * 32 * nkt * 4;
+    if (i >= total) return;
+    const int qk = (int)(i % (nkt * 4)), row = (int)(i / (nkt * 4));
+    const int kt = qk >> 2, q = qk & 3;
+    h16x2 hp[2], mp[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        float x[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int k = kt * 16 + q * 4 + 2 * e + t;
+            x[t] = (row < N && k < K) ? W[(int64_t)row * ldw + k] * scale : 0.f;      // power-of-two scale: exact
+        }
+        const _Float16 h0 = (_Float16)x[0], h1 = (_Float16)x[1];
+        hp[e] = h16x2{h0, h1};
+        mp[e] = h16x2{(_Float16)(x[0] - (float)h0), (_Float16)(x[1] - (float)h1)};
+    }
+    char* dst = out + ((int64_t)(row >> 5) * nkt + kt) * 2048 + (q >> 1) * 512 + (row & 31) * 16 + (q & 1) * 8;
+    *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(uint32_t, hp[0]), __builtin_bit_cast(uint32_t, hp[1]));
+    *reinterpret_cast<uint2*>(dst + 1024) = make_uint2(__builtin_bit_cast(uint32_t, mp[0]), __builtin_bit_cast(uint32_t, mp[1]));
+}
+
+extern "C" int64_t skg_split_weights_bytes(int N, int K) {
+    if (N < 0 || K < 0) return SKG_E_ARG;
+    return (int64_t)((N + 31) >> 5) * ((K + 15) >> 4) * 2048;
+}
+
+extern "C" int skg_split_weights_f16x2(const float* W, int N, int K, int64_t ldw, float scale, void* out, void* stream) {
+    if (N < 0 || K < 0) return SKG_E_ARG;
+    if (N == 0 || K == 0) return 0;
+    int ex = 0;
+    if (!W || !out || ldw < K || !skg_aligned16(out) || !(scale > 0.f) || frexpf(scale, &ex) != 0.5f) return SKG_E_ARG;
+    const int64_t total = (int64_t)((N + 31) >> 5) * 32 * ((K + 15) >> 4) * 4;
+    hipLaunchKernelGGL(skg_split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       W, N, K, ldw, scale, reinterpret_cast<char*>(out));
+    return skg_launch_status();
+}
+
 // 64 x 64 tiles when the 128 x 128 grid would leave most CUs idle (small M: low-batch inference); needs the DMA path.
 static int skg_gemm_tile_scale(const skg_gemm_desc* d) {
     const bool glds = SKG_USE_GLDS && BK == 16 && (d->K % BK) == 0 && !d->a_rows &&
                       (int64_t)BM * d->lda * 4 < 0xffffffffLL && (int64_t)BN * d->ldw * 4 < 0xffffffffLL;
     const int64_t tiles128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * (d->split_k > 1 ? d->split_k : 1);
+    if (d->w_split && (d->K % 16) == 0 && d->w_scale > 0.f) return 2;
     return (glds && tiles128 < 384) ? 1 : 2;
 }
 
@@ -581,15 +771,17 @@ extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
     if (d.M == 0) return 0;
     const bool glds = SKG_USE_GLDS && BK == 16 && (d.K % BK) == 0 && !d.a_rows &&
                       (int64_t)BM * d.lda * 4 < 0xffffffffLL && (int64_t)BN * d.ldw * 4 < 0xffffffffLL;
-    const int T = skg_gemm_tile_scale(&d);
+    const bool split = d.w_split && (d.K % 16) == 0 && d.w_scale > 0.f;
+    const int T = split ? 2 : skg_gemm_tile_scale(&d);
     const int64_t nblk = skg_gemm_blocks(d.M, d.N, d.K, T) * (d.split_k > 1 ? d.split_k : 1);
     if (nblk > 0x7fffffffLL) return SKG_E_LIMIT;
     dim3 grid((unsigned)nblk), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define SKG_LAUNCH(E)                                                                              \
-    if (glds && T == 1) hipLaunchKernelGGL((skg_gemm_kernel<E, true, 1>), grid, block, 0, s, d);  \
-    else if (glds) hipLaunchKernelGGL((skg_gemm_kernel<E, true, 2>), grid, block, 0, s, d);       \
-    else hipLaunchKernelGGL((skg_gemm_kernel<E, false, 2>), grid, block, 0, s, d);
+    if (split) hipLaunchKernelGGL((skg_gemm_kernel<E, 2, 2>), grid, block, 0, s, d);               \
+    else if (glds && T == 1) hipLaunchKernelGGL((skg_gemm_kernel<E, 1, 1>), grid, block, 0, s, d); \
+    else if (glds) hipLaunchKernelGGL((skg_gemm_kernel<E, 1, 2>), grid, block, 0, s, d);           \
+    else hipLaunchKernelGGL((skg_gemm_kernel<E, 0, 2>), grid, block, 0, s, d);
     switch (d.epilogue) {
         case SKG_EPI_BIAS:          SKG_LAUNCH(SKG_EPI_BIAS) break;
         case SKG_EPI_BIAS_RELU:     SKG_LAUNCH(SKG_EPI_BIAS_RELU) break;

@@ -67,6 +67,7 @@ class PackedWeights:
             return dict(w1=w1.contiguous(), b1=b1, w2=w2.contiguous(), b2=b2, w3=w3, b3=b3)
 
         self.device = device
+        self.splits = SplitWeights()
         self.K = gh.num_cls
         self.bh1_w = pad_k(w(gh.box_head[1].weight)); self.bh1_b = w(gh.box_head[1].bias)
         self.bh1_k = gh.box_head[1].weight.shape[1]
@@ -111,9 +112,49 @@ class VerbTable:
         self.flat = torch.from_numpy(flat).to(device)
 
 
+_SPLITS = None       # SplitWeights in force (HeadEngine.precision == "fp16x2"), else None
+
+
+class SplitWeights:
+    """fp16x2 twins of nn.Linear weights for skg_gemm_desc.w_split, made on first use and kept with the packed
+    weights they mirror (keyed by the weight view: address, N, K, leading dimension)."""
+
+    def __init__(self):
+        self.twins = {}
+
+    def get(self, W, W_off, N, K, ldw):
+        """-> (twin bytes tensor, w_scale) for the view W.flatten()[W_off:] as [N, K] with leading dimension ldw."""
+        key = (W.data_ptr() + 4 * W_off, N, K, ldw)
+        t = self.twins.get(key)
+        if t is None:
+            lib = _capi.lib()
+            view = W.reshape(-1)[W_off:].as_strided((N, K), (ldw, 1))
+            amax = float(view.abs().max())                       # one-time host sync per weight
+            e = 13 - int(np.floor(np.log2(amax))) if np.isfinite(amax) and amax > 0 else 0
+            e = max(min(e, 100), -100)
+            twin = torch.empty(lib.skg_split_weights_bytes(N, K), dtype=torch.uint8, device=W.device)
+            _capi.check(lib.skg_split_weights_f16x2(key[0], N, K, ldw, float(2.0 ** e), twin.data_ptr(), _stream()),
+                        "skg_split_weights_f16x2")
+            t = (twin, float(2.0 ** -e), W)                       # holding W keeps its address from being reused
+            self.twins[key] = t
+        return t[0], t[1]
+
+    def __enter__(self):
+        global _SPLITS
+        self._prev = _SPLITS
+        _SPLITS = self
+        return self
+
+    def __exit__(self, *a):
+        global _SPLITS
+        _SPLITS = self._prev
+        return False
+
+
 def gemm_desc(A, W, bias, C_out, M, N, K, epilogue, lda=None, ldw=None, ldc=None, a_rows=None, out_rows=None, P=None,
               p_idx=None, ldp=0, Q=None, q_idx=None, ldq=0, mbias=None, C_raw=None, ldc_raw=0, dot_w=None,
-              dot_partial=None, res=None, ldres=0, A_off=0, W_off=0, C_off=0, d=None, split_k=0, split_ws=None):
+              dot_partial=None, res=None, ldres=0, A_off=0, W_off=0, C_off=0, d=None, split_k=0, split_ws=None,
+              w_split=None, w_scale=0.0):
     """Fills a skg_gemm_desc.  *_off are element offsets into A / W / C (column sub-views)."""
     d = _capi.GemmDesc() if d is None else d
     d.A = A.data_ptr() + 4 * A_off; d.lda = lda if lda is not None else A.stride(0)
@@ -129,6 +170,9 @@ def gemm_desc(A, W, bias, C_out, M, N, K, epilogue, lda=None, ldw=None, ldc=None
     d.dot_w = _ptr(dot_w); d.dot_partial = _ptr(dot_partial)
     d.res = _ptr(res); d.ldres = ldres
     d.split_k = split_k; d.split_ws = _ptr(split_ws)
+    if w_split is None and _SPLITS is not None and K % 16 == 0 and M > 0:
+        w_split, w_scale = _SPLITS.get(W, W_off, N, K, d.ldw)
+    d.w_split = _ptr(w_split); d.w_scale = w_scale
     return d
 
 
@@ -145,6 +189,8 @@ def dot_partials(M, N, K, lda, ldw):
     """Slab count of the dot_partial output of an EPI_RELU_DOT launch (depends on the tile shape the launcher picks)."""
     d = _capi.GemmDesc()
     d.M, d.N, d.K, d.lda, d.ldw, d.epilogue = M, N, K, lda, ldw, _capi.EPI_RELU_DOT
+    d.w_split = 1 if (_SPLITS is not None and K % 16 == 0) else 0       # only null / non-null matters here
+    d.w_scale = 1.0
     n = _capi.lib().skg_gemm_dot_partials(C.byref(d))
     if n <= 0:
         raise _capi.SkgError("skg_gemm_dot_partials -> %d" % n)
@@ -252,6 +298,7 @@ class HeadEngine:
         self._slots = None
         self._streams = None
         self.n_streams = 1          # >1: alternate chunks over side streams (tail filling); see graph()
+        self.precision = "fp16x2"   # inference GEMMs on the fp16 matrix pipe from 2-way operand splits (fp32 grade); "fp32": exact
         self._pw = None
         self._vt = None
         self.last = None          # intermediates of the last graph pass (parity tests read them)
@@ -351,7 +398,18 @@ class HeadEngine:
         return pre
 
     # ------------------------------------------------------------------------------------------ graph head
+    def _split_ctx(self, dev):
+        return self.weights(dev).splits if self.precision in ("fp16x2", "bf16") else _NullCtx()
+
     def graph(self, feat3, image_shapes, pooled, pre, training=False, tables=None, want_scores=False):
+        with self._split_ctx(pre.device):
+            return self._graph(feat3, image_shapes, pooled, pre, training, tables, want_scores)
+
+    def classify(self, pair_features):
+        with self._split_ctx(pair_features.device):
+            return self._classify(pair_features)
+
+    def _graph(self, feat3, image_shapes, pooled, pre, training=False, tables=None, want_scores=False):
         """GraphHead.forward (HEAD:769-993) for the batch.  Returns a dict of packed device tensors + layout.
 
         The active images are processed in chunks of `self.chunk_images`: the TransH tables of chunk c are drawn on
@@ -608,7 +666,7 @@ class HeadEngine:
                 keep.setdefault("adjacency", []).append(adj)
 
     # ------------------------------------------------------------------------------------------ classifier + scoring
-    def classify(self, pair_features):
+    def _classify(self, pair_features):
         """box_pair_predictor | box_pair_suppressor (HEAD:410-411) as one GEMM -> logits [P, K+1 (ld 120)]."""
         dev = pair_features.device
         pw = self.weights(dev)

@@ -20,3 +20,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "reference" in item.keywords and not have_ref:
             item.add_marker(skip_ref)
+
+
+@pytest.fixture(params=["fp32", "fp16x2"])
+def precision(request):
+    """Inference GEMM path of the heads gpu_run builds: exact fp32 MFMA, or the fp16x2 split-operand loop."""
+    import gpu_run
+    old = gpu_run.PRECISION
+    gpu_run.PRECISION = request.param
+    yield request.param
+    gpu_run.PRECISION = old

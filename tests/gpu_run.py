@@ -20,6 +20,9 @@ class CachedPool(torch.nn.Module):
         return cases.pooled_for(self.case, sum(len(b) for b in boxes)).cuda()
 
 
+PRECISION = "fp32"      # inference GEMM path of the heads built here ("fp32" exact | "fp16x2"); set by the precision fixture
+
+
 def build_head(case, reference_quirks=True):
     cfg = case["cfg"]
     gh = GraphHead(case["C"], case["p"], 1024, 1024, cfg["K"], cfg["human_idx"], case["o2v"],
@@ -27,7 +30,7 @@ def build_head(case, reference_quirks=True):
     head = InteractionHead(CachedPool(case), gh, torch.nn.Linear(2048, 1), torch.nn.Linear(2048, cfg["K"]),
                            human_idx=cfg["human_idx"], num_classes=cfg["K"], box_nms_thresh=case["box_nms_thresh"],
                            box_score_thresh=case["box_score_thresh"], max_human=case["max_human"],
-                           max_object=case["max_object"], reference_quirks=reference_quirks)
+                           max_object=case["max_object"], reference_quirks=reference_quirks, precision=PRECISION)
     head.load_state_dict(synth.make_state_dict(cfg["K"], case["C"], case["p"], seed=case["weight_seed"]))
     return head.cuda().train(case["training"])
 

@@ -4,9 +4,20 @@ import pytest
 import torch
 
 from skghoi_amd import _capi
-from skghoi_amd.engine import gemm, gemm_group, dot_partials, _stream
+from skghoi_amd.engine import SplitWeights, gemm, gemm_group, dot_partials, _stream
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["fp32", "fp16x2"])
+def gemm_mode(request):
+    """fp32: exact fp32 MFMA loops.  fp16x2: weights get a fp16x2 twin, skg_gemm_f32 takes the split-operand loop
+    whenever K % 16 == 0 (same descriptors, same epilogues, same tolerances)."""
+    if request.param == "fp16x2":
+        with SplitWeights():
+            yield request.param
+    else:
+        yield request.param
 
 
 def _rand(*shape, seed=0):
@@ -22,7 +33,7 @@ def _close(a, b, tol):
 @pytest.mark.parametrize("M,N,K", [(1, 1024, 256), (40, 1024, 32), (130, 118, 2048), (300, 128, 48), (257, 1024, 1088),
                                    (800, 1024, 1024), (513, 256, 128), (128, 128, 16), (64, 100, 12544),
                                    (6213, 1024, 64), (12801, 516, 48), (6213, 1000, 36)])   # >= 384 tiles: 128 x 128 kernel
-def test_gemm_bias_relu_shapes_and_tails(M, N, K):
+def test_gemm_bias_relu_shapes_and_tails(M, N, K, gemm_mode):
     A = _rand(M, K, seed=1); W = _rand(N, K, seed=2) / np.sqrt(K); b = _rand(N, seed=3)
     ref = torch.relu(A.double() @ W.double().t() + b.double()).float()
     C = torch.full((M, N + 4), 7.0, device="cuda")
@@ -36,7 +47,7 @@ def test_gemm_bias_relu_shapes_and_tails(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,S", [(40, 1024, 12544, 32), (130, 118, 2048, 3), (300, 1024, 1088, 5), (64, 64, 64, 2)])
-def test_gemm_split_k(M, N, K, S):
+def test_gemm_split_k(M, N, K, S, gemm_mode):
     A = _rand(M, K, seed=1); W = _rand(N, K, seed=2) / np.sqrt(K); b = _rand(N, seed=3)
     ref = torch.relu(A.double() @ W.double().t() + b.double()).float()
     C = torch.empty(M, N, device="cuda"); ws = torch.empty(S, M, N, device="cuda")
@@ -45,7 +56,7 @@ def test_gemm_split_k(M, N, K, S):
     _close(C, ref, 2e-5)
 
 
-def test_gemm_identity_asymmetric_layout():
+def test_gemm_identity_asymmetric_layout(gemm_mode):
     """A = I against an asymmetric W catches any row/col swap of the MFMA C/D map."""
     n = 128
     A = torch.eye(n, device="cuda")
@@ -57,7 +68,7 @@ def test_gemm_identity_asymmetric_layout():
     assert torch.equal(C, W.t().contiguous())
 
 
-def test_gemm_gather_scatter_and_column_views():
+def test_gemm_gather_scatter_and_column_views(gemm_mode):
     M, N, K = 200, 256, 64
     src = _rand(50, K, seed=4); W = _rand(N, 2 * K, seed=5); b = _rand(N, seed=6)
     rows = torch.randint(-1, 50, (M,), generator=torch.Generator().manual_seed(1)).int().cuda()
@@ -77,7 +88,7 @@ def test_gemm_gather_scatter_and_column_views():
 
 
 @pytest.mark.parametrize("M", [333, 6333])                # 64 x 64 tiles / 128 x 128 tiles
-def test_gemm_mul_relu_epilogue(M):
+def test_gemm_mul_relu_epilogue(M, gemm_mode):
     N, K = 1024, 256
     A = _rand(M, K, seed=1); W = _rand(N, K, seed=2) / 16; b = _rand(N, seed=3)
     P = _rand(17, N, seed=4); Q = _rand(29, N, seed=5); mb = _rand(N, seed=6)
@@ -97,7 +108,7 @@ def test_gemm_mul_relu_epilogue(M):
 
 
 @pytest.mark.parametrize("M", [450, 6200])                # 64 x 64 tiles / 128 x 128 tiles
-def test_gemm_relu_dot_and_residual_epilogues(M):
+def test_gemm_relu_dot_and_residual_epilogues(M, gemm_mode):
     N, K = 1024, 128
     A = _rand(M, K, seed=1); W = _rand(N, K, seed=2) / 8; b = _rand(N, seed=3); dw = _rand(N, seed=4)
     part = torch.empty(dot_partials(M, N, K, K, K), M, device="cuda")
@@ -111,7 +122,37 @@ def test_gemm_relu_dot_and_residual_epilogues(M):
     _close(C, (res.double() + v).float(), 2e-5)
 
 
-def test_gemm_group_matches_single_launches():
+def test_gemm_split_operands_precision_range_and_nonfinite():
+    """fp16x2 loop: h + m carries 22 significant bits (a one-hot A row returns the weights to 2^-21 relative); tiles
+    with inf / nan inputs or values beyond the fp16 range are recomputed by the exact loop and behave as in fp32."""
+    M, N, K = 160, 192, 64
+    W = _rand(N, K, seed=2) * 3
+    A = torch.zeros(M, K, device="cuda")
+    A[torch.arange(M), torch.arange(M) % K] = 1.0
+    C = torch.empty(M, N, device="cuda")
+    with SplitWeights():
+        gemm(A, W, None, C, M, N, K, _capi.EPI_BIAS)
+    torch.cuda.synchronize()
+    want = W.t()[torch.arange(M) % K].contiguous()
+    assert torch.all((C - want).abs() <= 2.0 ** -21 * want.abs())
+    A = _rand(M, K, seed=1)
+    A[3, 5] = float("inf"); A[7, 0] = float("-inf"); A[9, 63] = float("nan"); A[11, 1] = 1e38; A[12, 2] = 1e-41
+    A[140, 3] = 70000.0; A[141, 9] = -3.0e9                     # finite in fp32, beyond fp16: second M-tile
+    C0 = torch.empty(M, N, device="cuda"); C1 = torch.empty(M, N, device="cuda")
+    gemm(A, W, None, C0, M, N, K, _capi.EPI_BIAS)
+    with SplitWeights():
+        gemm(A, W, None, C1, M, N, K, _capi.EPI_BIAS)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.isnan(C0), torch.isnan(C1))
+    assert torch.equal(torch.isinf(C0), torch.isinf(C1))
+    fin = torch.isfinite(C0)
+    assert torch.isfinite(C0[140:142]).all()
+    assert torch.equal(torch.sign(C0[~fin & ~torch.isnan(C0)]), torch.sign(C1[~fin & ~torch.isnan(C0)]))
+    rel = ((C0 - C1).abs()[fin] / (C0.abs()[fin] + 1.0)).max().item()
+    assert rel < 1e-5, rel
+
+
+def test_gemm_group_matches_single_launches(gemm_mode):
     K = 256
     specs, refs, outs = [], [], []
     for i, (M, N, epi) in enumerate([(70, 1024, _capi.EPI_BIAS), (300, 256, _capi.EPI_BIAS_RELU),

@@ -46,7 +46,7 @@ def _check(got, want, name):
 
 
 @pytest.mark.parametrize("name", cases.EVAL_CASES)
-def test_head_matches_reference_golden(name):
+def test_head_matches_reference_golden(name, precision):
     case = cases.build_case(name)
     got = gpu_run.run_head(case)
     want = helpers.load_golden(name)
@@ -61,7 +61,7 @@ def test_head_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize("name", ["tiny", "ragged3", "nms", "vcoco"])
-def test_head_matches_oracle_with_fresh_rng(name):
+def test_head_matches_oracle_with_fresh_rng(name, precision):
     """Same seed -> same TransH tables on both sides (the head consumes the host RNG like the reference)."""
     case = cases.build_case(name)
     got = gpu_run.run_head(case)
@@ -89,7 +89,7 @@ def test_eval_skip_quirk_and_sane_mode():
     assert int(got["n_results"]) == 2 and got["res1.index"].size == 0 and got["res0.index"].size > 0
 
 
-def test_full_size_properties():
+def test_full_size_properties(precision):
     """BASELINE size (20 x 20, batch 8): size-independent properties -- pair order, score factorisation,
     batch-composition invariance (an image's result does not depend on its neighbours)."""
     from skghoi_amd import synth

@@ -45,7 +45,7 @@ def test_preprocess_nms_topk_bit_exact(seed):
 
 
 @pytest.mark.parametrize("seed", range(3))
-def test_random_graphs_full_head_vs_oracle(seed):
+def test_random_graphs_full_head_vs_oracle(seed, precision):
     """Random (n_h, n_o), random verb tables, overlapping boxes incl. zero-size ones: indices bit-exact, logits 1e-4."""
     rs = np.random.RandomState(200 + seed)
     case = cases.build_case("tiny")
