@@ -232,6 +232,17 @@ int skg_postprocess_f32(const float* logits, int64_t ld_logits, int K, const flo
                         float* out_boxes_o, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * HOST function (no GPU work): the TransH tables of `n_images` consecutive processed images, drawn from PyTorch's CPU
+ * generator exactly as the reference's per-image `TransH(...)` construction draws them (HEAD:574-580,
+ * heads/TransH/TransH.py:20-28: three nn.Embedding normal_ inits, then three xavier_uniform_).
+ * `torch_cpu_rng_state` = the bytes of torch.get_rng_state() (5056; other sizes are rejected), advanced in place --
+ * hand it back with torch.set_rng_state().  ent [n_images, 80, 50]; rel / nrm [n_images, K, 50] only when
+ * need_relations (their draws are skipped otherwise).  fused_affine: 1 if this PyTorch build evaluates
+ * x * (to - from) + from of uniform_ with a fused multiply-add (the binding decides by comparing against torch). */
+int skg_transh_draw_f32(void* torch_cpu_rng_state, int64_t state_bytes, int n_images, int K, int need_relations,
+                        int fused_affine, float* ent, float* rel, float* nrm);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * TransH hyperplane scores (heads/TransH/TransH.py:56-106) for every (kept pair, relation):
  *   w = norm(nrm[k]); h = ent[human_idx] - (ent[human_idx].w) w; t = ent[y] - (ent[y].w) w
  *   score[p, k] = || norm(h) + norm(rel[k]) - norm(t) ||_2        (F.normalize eps 1e-12)

@@ -54,6 +54,7 @@ PROTOTYPES = {
                                     C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "skg_global_avgpool_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "skg_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "skg_transh_draw_f32": (C.c_int, [_vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "skg_gemm_dot_partials": (C.c_int, [C.POINTER(GemmDesc)]),
     "skg_split_weights_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "skg_split_weights_f16x2": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _f32, _vp, _vp]),

@@ -104,6 +104,42 @@ def test_transh_rng_matches_reference_draw_order(K):
     assert torch.equal(ent, ent2)
 
 
+@pytest.mark.parametrize("K,need", [(117, True), (117, False), (24, True), (5, False)])
+def test_transh_native_draw_equals_torch_calls(K, need):
+    """skg_transh_draw_f32 (host C++) against the same draws made through torch: tables and generator state, from
+    generator positions inside and across Mersenne-Twister blocks, incl. a freshly seeded generator."""
+    assert transh.native_path() in (0, 1), "the native draw must be the path in use with this PyTorch build"
+    fused = transh.native_path()
+    for pre in (0, 1, 623, 624, 1000, 31431):
+        torch.manual_seed(77 + pre)
+        if pre:
+            torch.empty(pre).uniform_()
+        start = torch.get_rng_state()
+        got = transh.draw_batch(K, 3, need_relations=need)
+        after_native = torch.get_rng_state()
+        torch.set_rng_state(start)
+        transh._NATIVE = False
+        try:
+            want = transh.draw_batch(K, 3, need_relations=need)
+        finally:
+            transh._NATIVE = fused
+        assert torch.equal(after_native, torch.get_rng_state())
+        assert torch.equal(got[0], want[0])
+        if need:
+            assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+    # the reference's own construction (normal_ inits, then xavier) consumes the generator identically
+    torch.manual_seed(3)
+    e1, r1, n1 = transh.draw_tables(K, True)
+    s1 = torch.get_rng_state()
+    torch.manual_seed(3)
+    emb = [torch.nn.Embedding(transh.TRANSH_ENT, transh.TRANSH_DIM), torch.nn.Embedding(K, transh.TRANSH_DIM),
+           torch.nn.Embedding(K, transh.TRANSH_DIM)]
+    for m in emb:
+        torch.nn.init.xavier_uniform_(m.weight.data)
+    assert torch.equal(s1, torch.get_rng_state())
+    assert torch.equal(e1, emb[0].weight.data) and torch.equal(r1, emb[1].weight.data) and torch.equal(n1, emb[2].weight.data)
+
+
 def test_module_surface_and_state_dict_keys():
     from skghoi_amd import GraphHead, InteractionHead
     o2v = synth.hico_object_to_verb()
