@@ -26,7 +26,8 @@ EPS_LN = 1e-5
 
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
 # entries are (start_event, end_event, M, N, K, epilogue).  None = no instrumentation (the default).
-GEMM_TIMER = None
+GEMM_TIMER = None          # bench.py: list collecting (start event, end event, M, N, K, epilogue) per GEMM launch
+GEMM_TIMER_EPI = None      # ... restricted to these epilogue ids (None: every launch)
 
 import os as _os
 _PIN_TABLES = _os.environ.get("SKG_PIN_TABLES", "1") == "1"     # developer switch
@@ -200,11 +201,12 @@ def dot_partials(M, N, K, lda, ldw):
 def gemm(A, W, bias, C_out, M, N, K, epilogue, **kw):
     """One skg_gemm_f32 launch (see gemm_desc for the keywords)."""
     d = gemm_desc(A, W, bias, C_out, M, N, K, epilogue, **kw)
-    if GEMM_TIMER is not None:
+    timed = GEMM_TIMER is not None and (GEMM_TIMER_EPI is None or epilogue in GEMM_TIMER_EPI)
+    if timed:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
     _capi.check(_capi.lib().skg_gemm_f32(C.byref(d), _stream()), "skg_gemm_f32[%dx%dx%d epi %d]" % (M, N, K, epilogue))
-    if GEMM_TIMER is not None:
+    if timed:
         e1.record()
         GEMM_TIMER.append((e0, e1, M, N, K, epilogue))
 
@@ -217,11 +219,12 @@ def gemm_group(specs):
     for i, (a, kw) in enumerate(specs):
         gemm_desc(*a, d=arr[i], **kw)
         flops += 2.0 * a[4] * a[5] * a[6]
-    if GEMM_TIMER is not None:
+    timed = GEMM_TIMER is not None and (GEMM_TIMER_EPI is None or 5 in GEMM_TIMER_EPI)
+    if timed:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
     _capi.check(_capi.lib().skg_gemm_group_f32(arr, n, _stream()), "skg_gemm_group_f32[%d]" % n)
-    if GEMM_TIMER is not None:
+    if timed:
         e1.record()
         GEMM_TIMER.append((e0, e1, int(flops // 2), 1, 1, 5))       # epilogue id 5 = grouped launch
 
