@@ -3,20 +3,24 @@
 // Replaces every nn.Linear of the interaction head and, with row-/column-stacked branch weights, the 16-branch
 // MultiBranchFusion / MessageMBF GEMMs (reference heads/adamixer_transH_spatial_r50_head.py:469-474, 509-527).
 //
-// Design (gfx950):
-//   * v_mfma_f32_32x32x2_f32: exact fp32 (bit-for-bit an fmaf chain), the only MFMA that meets the 1e-4 logit parity
-//     bar without splitting operands; peak 157 TFLOP/s = the roofline this kernel is priced against.
-//   * 128x128 block tile, 4 wavefronts (2x2), each owning 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs); K is consumed
-//     16 at a time through a double-buffered LDS tile.  Every lane fetches four consecutive k with ONE ds_read_b128
-//     and feeds them to four MFMAs; A and B use the same k permutation, which is all a dot product needs.
-//   * Weights stay in the nn.Linear layout [N, K]: both operands are "row = output index, k contiguous".
-//   * Main path (K % 16 == 0, no row gather): tiles are staged straight into LDS by global_load_lds_dwordx4 from
-//     wave-uniform scalar bases + unsigned per-lane offsets; the LDS image is lane-linear (16 rows x 64 B per wave
-//     instruction) and the 16-byte k-chunk index is XOR-ed with (row >> 2) & 3 on the global SOURCE side and on the
-//     fragment reads, which makes the reads conflict-free.  All fragment reads of a tile are issued before the DMA of
-//     the next tile (hipcc drains vmcnt before any ds_read while an LDS-DMA is in flight), one barrier per tile.
-//     Fallback path (any K % 4 == 0, gathered A rows): register staging into rows padded to 20 dwords, loads
-//     unconditional and masked only when written to LDS.
+// Design (gfx950): 128x128 block tile, 4 wavefronts (2x2), each owning 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs); K
+// is consumed 16 at a time through a double-buffered LDS tile; weights keep the nn.Linear layout [N, K] (both operands
+// "row = output index, k contiguous").  Three main loops share the tile map and the fused epilogues:
+//   * MODE 2, fp16x2 (taken when the descriptor carries w_split): every operand value travels as h + m, two fp16
+//     numbers (22 significant bits); v_mfma_f32_32x32x16_f16 accumulates h.m + m.h + h.h in fp32 -- 3 MFMA passes per
+//     16 k against 8 of the fp32 MFMA, fp32-grade results (~2^-22 relative per product).  W is pre-split into
+//     fragment-ordered planes (skg_split_weights_f16x2), A is split in registers on its way to LDS.  Tiles that leave
+//     the fp16 range or hold inf / nan are recomputed by the exact loop.
+//   * MODE 1, exact: v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain; peak 157 TFLOP/s).  Every lane fetches four
+//     consecutive k with ONE ds_read_b128 and feeds them to four MFMAs; A and B use the same k permutation, which is
+//     all a dot product needs.  Tiles are staged straight into LDS by global_load_lds_dwordx4 from wave-uniform scalar
+//     bases + unsigned per-lane offsets; the LDS image is lane-linear (16 rows x 64 B per wave instruction) and the
+//     16-byte k-chunk index is XOR-ed with (row >> 2) & 3 on the global SOURCE side and on the fragment reads, which
+//     makes the reads conflict-free.  All fragment reads of a tile are issued before the DMA of the next tile (hipcc
+//     drains vmcnt before any ds_read while an LDS-DMA is in flight), one barrier per tile.  Needs K % 16 == 0 and no
+//     row gather; also instantiated with 64x64 tiles for grids that would leave most CUs idle.
+//   * MODE 0, exact, register staged (any K % 4 == 0, gathered A rows, grouped launches, MODE 2's fallback): rows padded
+//     to 20 dwords, loads unconditional and masked only when written to LDS.
 //   * Block -> tile map: XCD groups (see skg_gemm_map) keep a <= 2 MiB W slice in each XCD's private L2 and have the A
 //     panel fetched by NG XCDs instead of 8.
 //   * Epilogue: accumulators are transposed through LDS so that every lane owns 4 consecutive columns of a row; bias,
