@@ -651,6 +651,16 @@ __global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_group_kernel(const skg
     skg_gemm_tile<-1, 0, 2>(g.d[k], blockIdx.x - g.start[k], smem);
 }
 
+// the same with the fp16x2 loop (every descriptor of the group carries a weight twin)
+__global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_group_split_kernel(const skg_gemm_group_args g) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
+    int k = 0;
+#pragma unroll
+    for (int t = 1; t < SKG_GEMM_GROUP_MAX; ++t)
+        if (t < g.n && (int)blockIdx.x >= g.start[t]) k = t;
+    skg_gemm_tile<-1, 2, 2>(g.d[k], blockIdx.x - g.start[k], smem);
+}
+
 __global__ __launch_bounds__(256) void skg_splitk_reduce_kernel(const skg_gemm_desc d) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)d.M * d.N;
@@ -749,11 +759,13 @@ extern "C" int skg_gemm_group_f32(const skg_gemm_desc* descs_host, int n, void* 
     skg_gemm_group_args g;
     g.n = 0;
     int blocks = 0;
+    bool split = true;
     for (int i = 0; i < n; ++i) {
         const int rc = skg_gemm_validate(descs_host[i]);
         if (rc) return rc;
         if (descs_host[i].split_k > 1) return SKG_E_ARG;
         if (descs_host[i].M == 0) continue;
+        split = split && descs_host[i].w_split && (descs_host[i].K % 16) == 0 && descs_host[i].w_scale > 0.f;
         const int64_t nb = skg_gemm_blocks(descs_host[i].M, descs_host[i].N, descs_host[i].K, 2);
         if (blocks + nb > 0x7fffffffLL) return SKG_E_LIMIT;
         g.d[g.n] = descs_host[i];
@@ -763,7 +775,8 @@ extern "C" int skg_gemm_group_f32(const skg_gemm_desc* descs_host, int n, void* 
     }
     if (g.n == 0) return 0;
     for (int i = g.n; i <= SKG_GEMM_GROUP_MAX; ++i) g.start[i] = blocks;
-    hipLaunchKernelGGL(skg_gemm_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+    if (split) hipLaunchKernelGGL(skg_gemm_group_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(skg_gemm_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
     return skg_launch_status();
 }
 
