@@ -29,6 +29,7 @@
 //     small-M layers.
 #include "skg_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
@@ -47,7 +48,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #endif
 #define BK SKG_BK
 #ifndef SKG_XNST
-#define SKG_XNST 2                      // register stages of the split-operand loop (tiles in flight)
+#define SKG_XNST 4                      // register stages of the split-operand loop (tiles in flight)
 #endif
 #define LDS_LD (BK + 4)                 // + 4 dwords of padding: conflict-free ds_read_b128 at strides 20 and 36
 #define A_TILE (BM * LDS_LD)
@@ -265,8 +266,8 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
         const uint32_t lane16 = lane * 16;
         const char* pw = reinterpret_cast<const char*>(d.w_split) + (int64_t)nt * nkt * NCB + lane16;
         const uint32_t ww = (uint32_t)(WOFF + wid * NCB) + lane16;
-        // register stages: tiles kt+1 .. kt+NST are in flight while tile kt is multiplied; plain loads keep the
-        // compiler's vmcnt bookkeeping exact and barriers do not drain them
+        // register stages: NST tiles are in flight between global memory and LDS; plain loads keep the compiler's
+        // vmcnt bookkeeping exact and barriers do not drain them
         constexpr int NST = SKG_XNST;
         f32x4 ra[NST][2];
         u32x4 rw[NST][NC];
@@ -296,22 +297,29 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
 #pragma unroll
             for (int c = 0; c < NC; ++c) *reinterpret_cast<u32x4*>(sm + buf * BUF + ww + c * 1024) = rw[st][c];
         };
-        // one k-tile: fragments of tile t out of LDS, refill the stage tile t came from with tile t + NST, 12 MFMAs,
-        // split / store tile t + 1 (next stage) into the other LDS buffer
-        auto step = [&](auto S, int t) {
-            constexpr int st = decltype(S)::value;
-            const int cur = (t - kt_begin) & 1;
-            const char* a_f = sm + cur * BUF + (2 * wr * NC) * 1024 + lane16;
-            const char* b_f = sm + cur * BUF + WOFF + (2 * wc * NC) * 1024 + lane16;
-            f16x8 a[2][NC], b[2][NC];
+        // Software pipeline of one wave, per k-tile t (step index j = t - kt_begin):
+        //   fragments of tile t+1: LDS buffer (j+1)&1 -> fragment set (j+1)&1       (written in step j-1, barrier since)
+        //   12 MFMAs on tile t from fragment set j&1                                 (read in step j-1)
+        //   tile t+2: register stage (j+2)%NST -> split -> LDS buffer j&1            (its readers finished in step j-1)
+        //   tile t+2+NST: global -> the stage just freed
+        //   one barrier.
+        // Nothing a step issues is needed before the NEXT step, so LDS and global latencies hide under the MFMAs.
+        f16x8 fa[2][2][NC], fb[2][2][NC];
+        auto read_frags = [&](auto F, int buf) {
+            constexpr int fs = decltype(F)::value;
+            const char* a_f = sm + buf * BUF + (2 * wr * NC) * 1024 + lane16;
+            const char* b_f = sm + buf * BUF + WOFF + (2 * wc * NC) * 1024 + lane16;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    a[i][c] = *reinterpret_cast<const f16x8*>(a_f + (i * NC + c) * 1024);
-                    b[i][c] = *reinterpret_cast<const f16x8*>(b_f + (i * NC + c) * 1024);
+                    fa[fs][i][c] = *reinterpret_cast<const f16x8*>(a_f + (i * NC + c) * 1024);
+                    fb[fs][i][c] = *reinterpret_cast<const f16x8*>(b_f + (i * NC + c) * 1024);
                 }
-            load_tile(S, t + NST < nk ? t + NST : nk - 1);             // unconditional (clamped): no branch in the loop body
+        };
+        auto step = [&](auto J, int t) {
+            constexpr int j = decltype(J)::value;                       // step index modulo NST (NST even)
+            read_frags(std::integral_constant<int, (j + 1) & 1>{}, (j + 1) & 1);
             // small terms first (h.m, m.h), then h.h; the four accumulators take turns
             constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
 #pragma unroll
@@ -320,27 +328,42 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][PA[p]], b[ni][PB[p]], acc[mi][ni], 0, 0, 0);
-            store_tile(std::integral_constant<int, (st + 1) % NST>{}, cur ^ 1);      // past the end: a dead buffer
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[j & 1][mi][PA[p]], fb[j & 1][ni][PB[p]],
+                                                                             acc[mi][ni], 0, 0, 0);
+            using SG = std::integral_constant<int, (j + 2) % NST>;
+            store_tile(SG{}, j & 1);                                    // past the end: clamped tiles into dead buffers
+            load_tile(SG{}, t + 2 + NST < nk ? t + 2 + NST : nk - 1);   // unconditional: no branch in the loop body
             __syncthreads();
         };
+        static_assert(NST == 4, "stage / buffer / fragment-set indices below assume 4 register stages");
         using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1 % NST>;
-        using I2 = std::integral_constant<int, 2 % NST>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        auto clampk = [&](int t) { return t < nk ? t : nk - 1; };
         load_tile(I0{}, kt_begin);
-        load_tile(I1{}, kt_begin + 1 < nk ? kt_begin + 1 : nk - 1);
-        if (NST > 2) load_tile(I2{}, kt_begin + 2 < nk ? kt_begin + 2 : nk - 1);
+        load_tile(I1{}, clampk(kt_begin + 1));
+        load_tile(I2{}, clampk(kt_begin + 2));
+        load_tile(I3{}, clampk(kt_begin + 3));
         store_tile(I0{}, 0);
+        store_tile(I1{}, 1);
+        load_tile(I0{}, clampk(kt_begin + 4));
+        load_tile(I1{}, clampk(kt_begin + 5));
         __syncthreads();
-        for (int kt = kt_begin; kt < nk; kt += NST) {
+        read_frags(I0{}, 0);
+        __syncthreads();                                                // buffer 0 is rewritten by the first step
+        // groups of four steps (static indices), ONE loop exit: with early exits between the steps hipcc keeps the
+        // accumulators in fresh registers per step and copies all 64 of them back every tile
+        int kt = kt_begin;
+        for (; kt + 3 < nk; kt += 4) {
             step(I0{}, kt);
-            if (kt + 1 >= nk) break;
             step(I1{}, kt + 1);
-            if (NST > 2) {
-                if (kt + 2 >= nk) break;
-                step(I2{}, kt + 2);
-            }
+            step(I2{}, kt + 2);
+            step(I3{}, kt + 3);
         }
+        if (kt < nk) step(I0{}, kt);
+        if (kt + 1 < nk) step(I1{}, kt + 1);
+        if (kt + 2 < nk) step(I2{}, kt + 2);
         // un-scale; x * 0 is nan exactly when x is inf or nan: one flag per block decides the exact re-run
         float bad = 0.f;
 #pragma unroll
@@ -794,8 +817,9 @@ extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
     if (nblk > 0x7fffffffLL) return SKG_E_LIMIT;
     dim3 grid((unsigned)nblk), block(256);
     hipStream_t s = (hipStream_t)stream;
+    static const int dyn_lds = getenv("SKG_DEV_DYN_LDS") ? atoi(getenv("SKG_DEV_DYN_LDS")) : 0;   // developer knob: occupancy experiments
 #define SKG_LAUNCH(E)                                                                              \
-    if (split) hipLaunchKernelGGL((skg_gemm_kernel<E, 2, 2>), grid, block, 0, s, d);               \
+    if (split) hipLaunchKernelGGL((skg_gemm_kernel<E, 2, 2>), grid, block, dyn_lds, s, d);         \
     else if (glds && T == 1) hipLaunchKernelGGL((skg_gemm_kernel<E, 1, 1>), grid, block, 0, s, d); \
     else if (glds) hipLaunchKernelGGL((skg_gemm_kernel<E, 1, 2>), grid, block, 0, s, d);           \
     else hipLaunchKernelGGL((skg_gemm_kernel<E, 0, 2>), grid, block, 0, s, d);
