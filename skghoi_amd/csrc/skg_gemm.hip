@@ -29,7 +29,6 @@
 //     small-M layers.
 #include "skg_common.h"
 #include <type_traits>
-#include <stdlib.h>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
@@ -271,13 +270,17 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
         constexpr int NST = SKG_XNST;
         f32x4 ra[NST][2];
         u32x4 rw[NST][NC];
-        auto load_tile = [&](auto S, int kt) {
+        auto load_a = [&](auto S, int kt) {
             constexpr int st = decltype(S)::value;
 #pragma unroll
             for (int i = 0; i < 2; ++i) ra[st][i] = *reinterpret_cast<const f32x4*>(pa[i] + kt * 16);
+        };
+        auto load_w = [&](auto S, int kt) {
+            constexpr int st = decltype(S)::value;
 #pragma unroll
             for (int c = 0; c < NC; ++c) rw[st][c] = *reinterpret_cast<const u32x4*>(pw + (int64_t)kt * NCB + c * 1024);
         };
+        auto load_tile = [&](auto S, int kt) { load_a(S, kt); load_w(S, kt); };
         auto store_tile = [&](auto S, int buf) {
             constexpr int st = decltype(S)::value;
 #pragma unroll
@@ -332,7 +335,8 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
                                                                              acc[mi][ni], 0, 0, 0);
             using SG = std::integral_constant<int, (j + 2) % NST>;
             store_tile(SG{}, j & 1);                                    // past the end: clamped tiles into dead buffers
-            load_tile(SG{}, t + 2 + NST < nk ? t + 2 + NST : nk - 1);   // unconditional: no branch in the loop body
+            load_w(SG{}, t + 2 + NST < nk ? t + 2 + NST : nk - 1);      // unconditional: no branch in the loop body
+            load_a(SG{}, t + 2 + NST < nk ? t + 2 + NST : nk - 1);
             __syncthreads();
         };
         static_assert(NST == 4, "stage / buffer / fragment-set indices below assume 4 register stages");
@@ -817,9 +821,8 @@ extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
     if (nblk > 0x7fffffffLL) return SKG_E_LIMIT;
     dim3 grid((unsigned)nblk), block(256);
     hipStream_t s = (hipStream_t)stream;
-    static const int dyn_lds = getenv("SKG_DEV_DYN_LDS") ? atoi(getenv("SKG_DEV_DYN_LDS")) : 0;   // developer knob: occupancy experiments
 #define SKG_LAUNCH(E)                                                                              \
-    if (split) hipLaunchKernelGGL((skg_gemm_kernel<E, 2, 2>), grid, block, dyn_lds, s, d);         \
+    if (split) hipLaunchKernelGGL((skg_gemm_kernel<E, 2, 2>), grid, block, 0, s, d);               \
     else if (glds && T == 1) hipLaunchKernelGGL((skg_gemm_kernel<E, 1, 1>), grid, block, 0, s, d); \
     else if (glds) hipLaunchKernelGGL((skg_gemm_kernel<E, 1, 2>), grid, block, 0, s, d);           \
     else hipLaunchKernelGGL((skg_gemm_kernel<E, 0, 2>), grid, block, 0, s, d);
