@@ -62,6 +62,18 @@ def test_argument_validation_without_gpu(lib):
     assert lib.skg_preprocess_f32(16, 16, 16, 16, 2, 49, 0.2, 0.5, 100, 100, 16, 80, 2.8, 16, 16, None) == -3
     assert lib.skg_global_avgpool_f32(None, 0, 256, 10, None, None) == 0
     assert lib.skg_layernorm_f32(16, 1024, 16, 16, 3, 2048, 1e-5, 16, 1024, None) == -1
+    # fp16x2 weight twins: size query is pure host code; the scale must be a positive power of two
+    assert lib.skg_split_weights_bytes(1024, 1024) == 32 * 64 * 2048
+    assert lib.skg_split_weights_bytes(118, 2048) == 4 * 128 * 2048
+    assert lib.skg_split_weights_f16x2(16, 32, 32, 32, 3.0, 16, None) == -1
+    assert lib.skg_split_weights_f16x2(16, 32, 32, 16, 4.0, 16, None) == -1     # ldw < K
+    assert lib.skg_split_weights_f16x2(16, 0, 32, 32, 4.0, 16, None) == 0       # nothing to do
+    # TransH draw (host function): foreign generator-state sizes and inconsistent counters are rejected
+    blob = (ctypes.c_uint8 * 5056)()
+    ent = (ctypes.c_float * 4000)()
+    assert lib.skg_transh_draw_f32(blob, 5000, 1, 117, 0, 1, ent, None, None) == -1
+    assert lib.skg_transh_draw_f32(blob, 5056, 1, 117, 0, 1, ent, None, None) == -1      # left_ = 0 is no valid state
+    assert lib.skg_transh_draw_f32(blob, 5056, 1, 117, 1, 1, ent, None, None) == -1      # relations without buffers
 
 
 def test_layout_offsets_and_quirks():
