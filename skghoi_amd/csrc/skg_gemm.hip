@@ -493,6 +493,23 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
         if (d.bias) bia4 = *reinterpret_cast<const float4*>(d.bias + col);
         if (EPI == SKG_EPI_MUL_RELU && d.mbias) mb4 = *reinterpret_cast<const float4*>(d.mbias + col);
         if (EPI == SKG_EPI_RELU_DOT) dw4 = *reinterpret_cast<const float4*>(d.dot_w + col);
+        // row indices of the multiplier gathers / the row scatter for all rows this lane will visit, fetched up front:
+        // inside the row loop each one would sit in front of a dependent 16-byte gather, behind the previous row's stores
+        // (fp16x2 loop only: its staging registers are free here; the exact kernels would lose a wave per SIMD to them)
+        constexpr bool PRE = MODE == 2;
+        int pix[T][NIT], qix[T][NIT], oix[T][NIT];
+        auto row_indices = [&](int mi, int it) {
+            const int row = m0 + wr * 32 * T + mi * 32 + r0l + it * RPI;
+            pix[mi][it] = (EPI == SKG_EPI_MUL_RELU && d.P && d.p_idx) ? d.p_idx[row] : row;
+            qix[mi][it] = (EPI == SKG_EPI_MUL_RELU && d.Q && d.q_idx) ? d.q_idx[row] : row;
+            oix[mi][it] = (EPI != SKG_EPI_RELU_DOT && d.out_rows) ? d.out_rows[row] : row;
+        };
+        if constexpr (PRE) {
+#pragma unroll
+            for (int mi = 0; mi < T; ++mi)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) row_indices(mi, it);
+        }
 #pragma unroll
         for (int mi = 0; mi < T; ++mi) {
 #pragma unroll
@@ -504,6 +521,7 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int row = rowb + it * RPI;
+                if constexpr (!PRE) row_indices(mi, it);
                 const float4 a4 = *reinterpret_cast<const float4*>(est + (it * RPI + r0l) * EST_LD + c4);
                 float4 v = make_float4(a4.x + bia4.x, a4.y + bia4.y, a4.z + bia4.z, a4.w + bia4.w);
                 if (EPI == SKG_EPI_RELU_DOT) {
@@ -515,18 +533,18 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
                     if ((lane % LPR) == 0) d.dot_partial[(int64_t)(bn * 2 + wc) * d.M + row] = sdot;
                     continue;
                 }
-                const int orow = d.out_rows ? d.out_rows[row] : row;
+                const int orow = oix[mi][it];
                 if (EPI == SKG_EPI_MUL_RELU) {
                     if (d.C_raw) *reinterpret_cast<float4*>(d.C_raw + (int64_t)row * d.ldc_raw + col) = v;
                     if (orow < 0) continue;
                     float4 m = mb4;
                     if (d.P) {
-                        const int pi = d.p_idx ? d.p_idx[row] : row;
+                        const int pi = pix[mi][it];
                         const float4 t = *reinterpret_cast<const float4*>(d.P + (int64_t)pi * d.ldp + col);
                         m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
                     }
                     if (d.Q) {
-                        const int qi = d.q_idx ? d.q_idx[row] : row;
+                        const int qi = qix[mi][it];
                         const float4 t = *reinterpret_cast<const float4*>(d.Q + (int64_t)qi * d.ldq + col);
                         m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
                     }
