@@ -117,6 +117,27 @@ def test_full_size_properties(precision):
         assert np.all(s <= pr[0] * pr[1] + 1e-7) and np.all(s >= 0)
 
 
+@pytest.mark.parametrize("gain", [1.0, 64.0, 1.0 / 64.0])
+def test_fp16x2_tracks_exact_path_at_other_magnitudes(gain):
+    """The fp16x2 GEMM path against the exact fp32 path of the same head when activations and logits are 64x larger /
+    smaller than with the synthetic weights (box_head and classifier scaled): the deviation stays relative (<= 4e-6 of the
+    largest logit; fp32 itself reorders at ~1e-6), i.e. it rides on 22-bit operands, not on the synthetic magnitudes."""
+    case = cases.build_case("full20")
+    head = gpu_run.build_head(case)
+    with torch.no_grad():
+        head.box_pair_head.box_head[3].weight.mul_(gain); head.box_pair_head.box_head[3].bias.mul_(gain)
+        head.box_pair_predictor.weight.mul_(gain); head.box_pair_predictor.bias.mul_(gain)
+    out = {}
+    for prec in ("fp32", "fp16x2"):
+        head.precision = prec
+        out[prec] = gpu_run.run_head(case, head=head)
+    a, b = out["fp32"]["logits_p"], out["fp16x2"]["logits_p"]
+    assert np.isfinite(a).all() and np.abs(a).max() > 0
+    assert np.abs(a - b).max() <= 4e-6 * np.abs(a).max(), (np.abs(a - b).max(), np.abs(a).max())
+    for k in ("index", "prediction"):
+        assert np.array_equal(out["fp32"]["res0." + k], out["fp16x2"]["res0." + k])
+
+
 @pytest.mark.parametrize("name", cases.TRAIN_CASES)
 def test_training_forward_matches_reference_golden(name):
     """Rows 15-17 of SURVEY 8(a): GT association, TransH pos/neg sampling (host RNG: tables + randperm), the three
