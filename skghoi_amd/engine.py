@@ -241,6 +241,8 @@ class _TableDrawer:
     """Draws the per-image TransH tables of every chunk, in order, on a helper thread (the global CPU RNG is
     consumed exactly as the reference does, skghoi_amd/transh.py)."""
 
+    INLINE_IMAGES = 8
+
     def __init__(self, K, sizes, need_relations, slots):
         import threading
         self.K, self.sizes, self.need = K, sizes, need_relations
@@ -248,8 +250,12 @@ class _TableDrawer:
         self.out = [None] * len(sizes)
         self.err = None
         self.ready = [threading.Event() for _ in sizes]
-        self.thread = threading.Thread(target=self._run, daemon=True)
-        self.thread.start()
+        if sum(sizes) <= self.INLINE_IMAGES:       # a few images: the draw (20 us each) is cheaper than starting a thread
+            self.thread = None
+            self._run()
+        else:
+            self.thread = threading.Thread(target=self._run, daemon=True)
+            self.thread.start()
 
     def _run(self):
         try:
@@ -272,7 +278,8 @@ class _TableDrawer:
         return self.out[i]
 
     def join(self):
-        self.thread.join()
+        if self.thread is not None:
+            self.thread.join()
         if self.err is not None:
             raise self.err
 
@@ -401,18 +408,20 @@ class HeadEngine:
         return pre
 
     # ------------------------------------------------------------------------------------------ graph head
-    def _split_ctx(self, dev):
-        return self.weights(dev).splits if self.precision in ("fp16x2", "bf16") else _NullCtx()
+    def _split_ctx(self, pw):
+        return pw.splits if self.precision in ("fp16x2", "bf16") else _NullCtx()
 
     def graph(self, feat3, image_shapes, pooled, pre, training=False, tables=None, want_scores=False):
-        with self._split_ctx(pre.device):
-            return self._graph(feat3, image_shapes, pooled, pre, training, tables, want_scores)
+        pw = self.weights(pre.device)                 # one parameter-version check per call (408 tensors)
+        with self._split_ctx(pw):
+            return self._graph(feat3, image_shapes, pooled, pre, training, tables, want_scores, pw)
 
     def classify(self, pair_features):
-        with self._split_ctx(pair_features.device):
-            return self._classify(pair_features)
+        pw = self.weights(pair_features.device)
+        with self._split_ctx(pw):
+            return self._classify(pair_features, pw)
 
-    def _graph(self, feat3, image_shapes, pooled, pre, training=False, tables=None, want_scores=False):
+    def _graph(self, feat3, image_shapes, pooled, pre, training, tables, want_scores, pw):
         """GraphHead.forward (HEAD:769-993) for the batch.  Returns a dict of packed device tensors + layout.
 
         The active images are processed in chunks of `self.chunk_images`: the TransH tables of chunk c are drawn on
@@ -420,7 +429,6 @@ class HeadEngine:
         c-1, and the chunk-sized intermediates ([G,1024] panels) stay closer to the caches."""
         lib = _capi.lib()
         dev = pre.device
-        pw = self.weights(dev)
         lay = layout.build(pre.n_h, pre.n, pre.L, image_shapes, self.human_idx,
                            faithful_skip_offset=self.faithful_skip_offset)
         A = lay.n_active
@@ -669,10 +677,9 @@ class HeadEngine:
                 keep.setdefault("adjacency", []).append(adj)
 
     # ------------------------------------------------------------------------------------------ classifier + scoring
-    def _classify(self, pair_features):
+    def _classify(self, pair_features, pw):
         """box_pair_predictor | box_pair_suppressor (HEAD:410-411) as one GEMM -> logits [P, K+1 (ld 120)]."""
         dev = pair_features.device
-        pw = self.weights(dev)
         Mp = pair_features.shape[0]
         ld = (self.K + 1 + 3) // 4 * 4
         logits = torch.empty(max(Mp, 1), ld, device=dev, dtype=torch.float32)
