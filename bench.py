@@ -175,6 +175,8 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)          # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if world > 1:                                   # one process per GPU on one host: share the cores instead of 8 full pools
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
     if dist_on:
         import torch.distributed as dist
         backend = os.environ.get("SKG_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; gloo only for rehearsals
