@@ -32,7 +32,8 @@ def _close(a, b, tol):
 
 @pytest.mark.parametrize("M,N,K", [(1, 1024, 256), (40, 1024, 32), (130, 118, 2048), (300, 128, 48), (257, 1024, 1088),
                                    (800, 1024, 1024), (513, 256, 128), (128, 128, 16), (64, 100, 12544),
-                                   (6213, 1024, 64), (12801, 516, 48), (6213, 1000, 36)])   # >= 384 tiles: 128 x 128 kernel
+                                   (6213, 1024, 64), (12801, 516, 48), (6213, 1000, 36),   # >= 384 tiles: 128 x 128 kernel
+                                   (33000, 1024, 64), (70001, 516, 32)])                    # many rounds of workgroups per CU
 def test_gemm_bias_relu_shapes_and_tails(M, N, K, gemm_mode):
     A = _rand(M, K, seed=1); W = _rand(N, K, seed=2) / np.sqrt(K); b = _rand(N, seed=3)
     ref = torch.relu(A.double() @ W.double().t() + b.double()).float()
@@ -148,6 +149,40 @@ def test_gemm_split_operands_precision_range_and_nonfinite():
     fin = torch.isfinite(C0)
     assert torch.isfinite(C0[140:142]).all()
     assert torch.equal(torch.sign(C0[~fin & ~torch.isnan(C0)]), torch.sign(C1[~fin & ~torch.isnan(C0)]))
+    rel = ((C0 - C1).abs()[fin] / (C0.abs()[fin] + 1.0)).max().item()
+    assert rel < 1e-5, rel
+
+
+def test_gemm_large_gather_scatter_and_fallback():
+    """A grid of several thousand tiles: gathered A rows (incl. -1 = zero row), scattered output rows, a ragged N, and
+    the per-tile exact fallback of the fp16x2 loop in tiles far apart."""
+    M, N, K = 40000, 900, 64
+    src = _rand(5000, K, seed=4); W = _rand(N, K, seed=5); b = _rand(N, seed=6)
+    rows = torch.randint(-1, 5000, (M,), generator=torch.Generator().manual_seed(1)).int().cuda()
+    orow = torch.randperm(M, generator=torch.Generator().manual_seed(2)).int()
+    orow[::7] = -1
+    orow = orow.cuda()
+    C = torch.zeros(M, N, device="cuda")
+    with SplitWeights():
+        gemm(src, W, b, C, M, N, K, _capi.EPI_BIAS, a_rows=rows, out_rows=orow)
+    torch.cuda.synchronize()
+    Ag = torch.where(rows[:, None] >= 0, src[rows.clamp(min=0).long()], torch.zeros(1, device="cuda"))
+    ref = (Ag.double() @ W.double().t() + b.double()).float()
+    keep = orow >= 0
+    _close(C[orow[keep].long()], ref[keep], 1e-5)
+    untouched = torch.ones(M, dtype=torch.bool, device="cuda"); untouched[orow[keep].long()] = False
+    assert torch.all(C[untouched] == 0)
+    # fallback: values beyond fp16 / inf / nan in a few rows; columns 10 (left half) and 700 (right half) must match fp32
+    A = _rand(M, K, seed=1)
+    A[5, 3] = float("inf"); A[300, 9] = 70000.0; A[20000, 1] = float("nan"); A[39999, 63] = -1e9
+    C0 = torch.empty(M, N, device="cuda"); C1 = torch.empty(M, N, device="cuda")
+    gemm(A, W, None, C0, M, N, K, _capi.EPI_BIAS)
+    with SplitWeights():
+        gemm(A, W, None, C1, M, N, K, _capi.EPI_BIAS)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.isnan(C0), torch.isnan(C1)) and torch.equal(torch.isinf(C0), torch.isinf(C1))
+    fin = torch.isfinite(C0)
+    assert torch.isfinite(C1[300]).all() and torch.isfinite(C1[39999]).all()
     rel = ((C0 - C1).abs()[fin] / (C0.abs()[fin] + 1.0)).max().item()
     assert rel < 1e-5, rel
 
