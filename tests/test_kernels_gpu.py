@@ -33,7 +33,8 @@ def _close(a, b, tol):
 @pytest.mark.parametrize("M,N,K", [(1, 1024, 256), (40, 1024, 32), (130, 118, 2048), (300, 128, 48), (257, 1024, 1088),
                                    (800, 1024, 1024), (513, 256, 128), (128, 128, 16), (64, 100, 12544),
                                    (6213, 1024, 64), (12801, 516, 48), (6213, 1000, 36),   # >= 384 tiles: 128 x 128 kernel
-                                   (33000, 1024, 64), (70001, 516, 32)])                    # many rounds of workgroups per CU
+                                   (33000, 1024, 64), (70001, 516, 32),                     # many rounds of workgroups per CU
+                                   (130, 200, 80), (130, 200, 96), (130, 200, 112), (70, 64, 16)])  # k-tile counts 5, 6, 7, 1
 def test_gemm_bias_relu_shapes_and_tails(M, N, K, gemm_mode):
     A = _rand(M, K, seed=1); W = _rand(N, K, seed=2) / np.sqrt(K); b = _rand(N, seed=3)
     ref = torch.relu(A.double() @ W.double().t() + b.double()).float()
