@@ -113,7 +113,13 @@ class VerbTable:
         self.flat = torch.from_numpy(flat).to(device)
 
 
-_SPLITS = None       # SplitWeights in force (HeadEngine.precision == "fp16x2"), else None
+import threading as _threading
+
+_TLS = _threading.local()     # .splits: the SplitWeights in force on this thread (inside a fp16x2 engine call), else None
+
+
+def _active_splits():
+    return getattr(_TLS, "splits", None)
 
 
 class SplitWeights:
@@ -141,14 +147,12 @@ class SplitWeights:
         return t[0], t[1]
 
     def __enter__(self):
-        global _SPLITS
-        self._prev = _SPLITS
-        _SPLITS = self
+        self._prev = _active_splits()
+        _TLS.splits = self
         return self
 
     def __exit__(self, *a):
-        global _SPLITS
-        _SPLITS = self._prev
+        _TLS.splits = self._prev
         return False
 
 
@@ -171,8 +175,9 @@ def gemm_desc(A, W, bias, C_out, M, N, K, epilogue, lda=None, ldw=None, ldc=None
     d.dot_w = _ptr(dot_w); d.dot_partial = _ptr(dot_partial)
     d.res = _ptr(res); d.ldres = ldres
     d.split_k = split_k; d.split_ws = _ptr(split_ws)
-    if w_split is None and _SPLITS is not None and K % 16 == 0 and M > 0:
-        w_split, w_scale = _SPLITS.get(W, W_off, N, K, d.ldw)
+    splits = _active_splits()
+    if w_split is None and splits is not None and K % 16 == 0 and M > 0:
+        w_split, w_scale = splits.get(W, W_off, N, K, d.ldw)
     d.w_split = _ptr(w_split); d.w_scale = w_scale
     return d
 
@@ -190,7 +195,7 @@ def dot_partials(M, N, K, lda, ldw):
     """Slab count of the dot_partial output of an EPI_RELU_DOT launch (depends on the tile shape the launcher picks)."""
     d = _capi.GemmDesc()
     d.M, d.N, d.K, d.lda, d.ldw, d.epilogue = M, N, K, lda, ldw, _capi.EPI_RELU_DOT
-    d.w_split = 1 if (_SPLITS is not None and K % 16 == 0) else 0       # only null / non-null matters here
+    d.w_split = 1 if (_active_splits() is not None and K % 16 == 0) else 0       # only null / non-null matters here
     d.w_scale = 1.0
     n = _capi.lib().skg_gemm_dot_partials(C.byref(d))
     if n <= 0:
