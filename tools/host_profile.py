@@ -15,4 +15,4 @@ with torch.no_grad():
         head(feats, dets, shapes)
     torch.cuda.synchronize()
     pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr).sort_stats(sys.argv[2] if len(sys.argv) > 2 else "cumulative").print_stats(45)
