@@ -30,6 +30,8 @@ import torch
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: BF16/F16 dense MFMA peak (~2.5 PF)
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+COMPULSORY_BYTES_PER_IMAGE = 2.47e6
 F16X2_PASSES = 3                      # fp16x2 path: h.h + h.m + m.h = three fp16 MFMA flops per useful flop
 N_H = N_O = 20
 C_FEAT, POOL = 256, 7
@@ -296,6 +298,14 @@ def main():
                     all_gemm_tflops=round(f_all / t_all / 1e12, 2),
                     gemm_share_of_step=round(t_all / (elapsed / args.steps), 4),
                     gflop_per_image=round(f_all / args.batch / 1e9, 3))
+    # the north star also asks for the HBM-roofline view (it cannot bind -- ~7000 flop per compulsory byte)
+    per_gpu = value / world
+    roofline["hbm"] = dict(peak_gbs=HBM_PEAK_GBS,
+                           compulsory_frac=round(per_gpu * COMPULSORY_BYTES_PER_IMAGE / (HBM_PEAK_GBS * 1e9), 5),
+                           dominant_kernel_frac=(round(traffic / (t_dom / max(n_dom, 1)) / (HBM_PEAK_GBS * 1e9), 4)
+                                                 if traffic else None),
+                           note="compulsory = 2.47 MB per image (pooled features + TransH tables + outputs, SURVEY 8d); "
+                                "dominant kernel = measured HBM bytes per launch / launch time")
 
     out = OrderedDict(metric="images/sec through interaction head (20x20 pairs)", value=round(value, 2),
                       unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
