@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256, 2) void skg_gemm_bf16_kernel(const skg_gemm_bf
     // epilogue: transpose through LDS (fp32), then row-wise 4 columns per lane
     constexpr int EST_LD = 68;
     float* est = reinterpret_cast<float*>(smem) + wid * (32 * EST_LD);
+    const bool vec_ok = d.split_k <= 1 && (d.ldc & 3) == 0 && skg_aligned16_dev(d.C) && skg_aligned16_dev(d.bias);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -124,6 +125,24 @@ __global__ __launch_bounds__(256, 2) void skg_gemm_bf16_kernel(const skg_gemm_bf
                 float* wsp = d.split_ws + ((int64_t)slice * d.M + row) * d.N + col;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) if (col + c < d.N) wsp[c] = v[c];
+                continue;
+            }
+            if (vec_ok && col + 3 < d.N) {                            // 16-byte (fp32) / 8-byte (bf16) row segments
+                if (d.bias) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(d.bias + col);
+                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                }
+                if (d.relu) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+                }
+                if (d.out_bf16) {
+                    const uint32_t lo = (uint32_t)skg_f2bf(v[0]) | ((uint32_t)skg_f2bf(v[1]) << 16);
+                    const uint32_t hi = (uint32_t)skg_f2bf(v[2]) | ((uint32_t)skg_f2bf(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(d.C) + (int64_t)row * d.ldc + col) = make_uint2(lo, hi);
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.C) + (int64_t)row * d.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                }
                 continue;
             }
 #pragma unroll

@@ -7,11 +7,11 @@ g = torch.Generator().manual_seed(0)
 for M, N, K in [(51200, 1024, 1024), (102400, 1024, 1024), (10240, 1024, 12544), (4096, 4096, 4096), (8192, 8192, 8192)]:
     A = (torch.rand(M, K, generator=g) * 2 - 1).cuda().bfloat16(); W = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).cuda().bfloat16()
     b = torch.rand(N, generator=g).cuda()
-    for _ in range(3):
+    for _ in range(100):                 # the shader clock needs ~50 ms of load to settle
         gemm_bf16(A, W, b, M, N, K, True)
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
-    R = 10
+    R = 100
     for _ in range(R):
         gemm_bf16(A, W, b, M, N, K, True)
     e1.record(); torch.cuda.synchronize()

@@ -7,7 +7,8 @@ from skghoi_amd.engine import gemm, SplitWeights
 a = [int(x) for x in sys.argv[1:6]]
 M, N, K, epi, reps = a + [51200, 1024, 1024, 1, 300][len(a):]
 g = torch.Generator().manual_seed(0)
-A = (torch.rand(M, K, generator=g) * 2 - 1).cuda(); W = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).cuda()
+pad = int(os.environ.get("XPAD", "0"))            # extra floats per A row (leading dimension K + pad): L2 channel experiment
+A = torch.empty(M, K + pad, device="cuda"); A[:, :K] = (torch.rand(M, K, generator=g) * 2 - 1).cuda(); A = A[:, :K]; W = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).cuda()
 b = torch.rand(N, generator=g).cuda(); C = torch.empty(M, N, device="cuda")
 kw = {}
 if os.environ.get("XA"):        # every A row gathers row 0: A always cache-hot
