@@ -117,6 +117,21 @@ def test_full_size_properties(precision):
         assert np.all(s <= pr[0] * pr[1] + 1e-7) and np.all(s >= 0)
 
 
+def test_forward_is_deterministic(precision):
+    """Same inputs, same seed -> bit-identical logits and results (no atomics, fixed reduction orders), in either
+    GEMM path and independent of how the batch is cut into chunks."""
+    case = cases.build_case("ragged3")
+    head = gpu_run.build_head(case)
+    a = gpu_run.run_head(case, head=head)
+    b = gpu_run.run_head(case, head=head)
+    case2 = dict(case); case2["chunk_images"] = 1
+    c = gpu_run.run_head(case2, head=head)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    for k in ("logits_p", "logits_s"):
+        assert np.array_equal(a[k], c[k]), k
+
+
 @pytest.mark.parametrize("gain", [1.0, 64.0, 1.0 / 64.0])
 def test_fp16x2_tracks_exact_path_at_other_magnitudes(gain):
     """The fp16x2 GEMM path against the exact fp32 path of the same head when activations and logits are 64x larger /
