@@ -242,14 +242,20 @@ def main():
         main_precision, head.precision = head.precision, "fp32"
         k2 = max(2, min(args.steps, 5))
         step(); step()
+        engine.GEMM_TIMER = None if args.no_gemm_timer else []
+        engine.GEMM_TIMER_EPI = {2}
         barrier()
         t1 = time.perf_counter()
         for _ in range(k2):
             step()
         barrier()
         el2 = time.perf_counter() - t1
+        timer2, engine.GEMM_TIMER = (engine.GEMM_TIMER or []), None
+        engine.GEMM_TIMER_EPI = None
         head.precision = main_precision
-        exact = (el2, k2)
+        t_d = sum(e0.elapsed_time(e1) * 1e-3 for e0, e1, *_ in timer2)
+        f_d = sum(2.0 * M * N * K for _, _, M, N, K, _ in timer2)
+        exact = (el2, k2, (f_d / t_d / 1e12) if t_d > 0 else None, (t_d / len(timer2) * 1e3) if timer2 else None)
 
     from skghoi_amd import dist as skd
     elapsed = skd.max_over_ranks(elapsed, device=device)
@@ -323,6 +329,11 @@ def main():
         out["exact_fp32"] = dict(value=round(args.batch * world * exact[1] / el2, 2), unit="images/s", steps=exact[1],
                                  ms_per_step=round(el2 / exact[1] * 1e3, 3),
                                  note="same run, same inputs, precision='fp32' (exact fp32 MFMA everywhere)")
+        if exact[2] is not None:
+            out["exact_fp32"]["roofline"] = dict(bound="mfma", kernel="skg_gemm_kernel<MUL_RELU>", achieved=round(exact[2], 2),
+                                                 peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                                                 frac=round(exact[2] / PEAK_F32_MFMA_TFLOPS, 4),
+                                                 avg_launch_ms=round(exact[3], 4))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(12)
     if rank == 0:
