@@ -77,8 +77,8 @@ def cpu_baseline(n_images):
     from skghoi_amd import synth
     sd = synth.make_state_dict(117, C_FEAT, POOL, seed=0)
     o2v = synth.hico_object_to_verb()
-    cores = min(torch.get_num_threads(), 16)      # a 1-GPU box's CPU share
-    torch.set_num_threads(cores)
+    cores = torch.get_num_threads()               # set in main() to the process's CPU share
+
     times = []
     with torch.no_grad():
         for i in range(n_images + 1):
@@ -177,8 +177,14 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)          # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:                                   # one process per GPU on one host: share the cores instead of 8 full pools
-        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
+    # torch's intra-op pool: the cores this process can really use (cgroup quota, not the host's core count), shared
+    # between the ranks of the node; the host-bound training step wants few threads (its CPU ops are tiny)
+    from skghoi_amd import trainer as _trainer
+    from skghoi_amd.dist import host_cpu_share
+    if args.mode == "train":
+        _trainer.limit_host_threads(world)
+    else:
+        torch.set_num_threads(max(1, host_cpu_share() // world))
     if dist_on:
         import torch.distributed as dist
         backend = os.environ.get("SKG_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; gloo only for rehearsals

@@ -9,6 +9,34 @@ import torch
 import torch.distributed as dist
 
 
+def host_cpu_share():
+    """CPU cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (a container on a
+    256-core host with a 16-core quota reports 256 everywhere else, and torch then starts 128 intra-op threads that
+    fight over 16 cores: the host-bound training step ran 3-4x slower that way)."""
+    import math
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                    # cgroup v2: "<quota|max> <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:                                                         # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                n = min(n, max(1, math.ceil(quota / period)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def shard_range(n_items, rank, world):
     """Contiguous, balanced shard [lo, hi) of n_items for `rank` (the first n_items % world ranks get one extra)."""
     base, extra = divmod(n_items, world)

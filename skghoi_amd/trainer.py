@@ -15,6 +15,16 @@ import torch.distributed as dist
 from torch import nn
 
 
+def limit_host_threads(ranks_on_host: int = 1, cap: int = 4) -> int:
+    """Sizes torch's intra-op CPU pool for the training loop: this process's share of the usable cores (cgroup quota
+    aware, skghoi_amd.dist.host_cpu_share), at most `cap`.  The step is host-bound and its CPU ops are tiny
+    (randperm, small cats): on a 256-core host with a 16-core quota the default 128 threads made it 3-4x slower."""
+    from .dist import host_cpu_share
+    n = max(1, min(cap, host_cpu_share() // max(1, ranks_on_host)))
+    torch.set_num_threads(n)
+    return n
+
+
 def build_optimizer(net: nn.Module, lr: float = 1e-4, weight_decay: float = 1e-4, head_key: str = "interaction_head"):
     """main:109-127: parameters whose name contains `head_key` train at lr, the rest at lr * 0.1.  A bare
     InteractionHead (no wrapper, so no 'interaction_head' in its names) is treated as all-head."""

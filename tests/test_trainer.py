@@ -34,6 +34,18 @@ def test_optimizer_groups_and_schedule():
     assert len(bare.param_groups) == 1
 
 
+def test_host_cpu_share_and_thread_limit():
+    from skghoi_amd.dist import host_cpu_share
+    n = host_cpu_share()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    before = torch.get_num_threads()
+    try:
+        assert trainer.limit_host_threads(ranks_on_host=1, cap=2) == min(2, n) == torch.get_num_threads()
+        assert trainer.limit_host_threads(ranks_on_host=10 ** 6) == 1
+    finally:
+        torch.set_num_threads(before)
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
