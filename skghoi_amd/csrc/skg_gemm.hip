@@ -345,7 +345,7 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
         using I2 = std::integral_constant<int, 2>;
         using I3 = std::integral_constant<int, 3>;
         auto clampk = [&](int t) { return t < nk ? t : nk - 1; };
-        load_tile(I0{}, kt_begin);
+        load_tile(I0{}, clampk(kt_begin));                              // (an empty split-K slice has kt_begin >= nk)
         load_tile(I1{}, clampk(kt_begin + 1));
         load_tile(I2{}, clampk(kt_begin + 2));
         load_tile(I3{}, clampk(kt_begin + 3));
@@ -426,7 +426,8 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
             }
         };
         const int swr = (li >> 2) & 3;                                // (row >> 2) & 3 of the rows this lane READS
-        stage(kt_begin & 1, kt_begin);
+        // (a split-K slice can be empty -- more slices than k-tiles: stage a valid tile, the loop below does not run)
+        stage(kt_begin & 1, kt_begin < nk ? kt_begin : nk - 1);
         __syncthreads();                                              // drains vmcnt: the first tile has landed
         for (int kt = kt_begin; kt < nk; ++kt) {
             const int cur = kt & 1;

@@ -1,4 +1,6 @@
 """GPU tests of the individual HIP kernels through the C ABI against plain PyTorch fp32 on the same device."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -313,3 +315,55 @@ def test_linear_bf16_autograd_close_to_fp32():
     assert w.grad.dtype == torch.float32 and w.grad.shape == w.shape
     for a, r in ((x.grad, xr.grad), (w.grad, wr.grad), (b.grad, br.grad)):
         assert cos(a.flatten().double(), r.flatten(), dim=0) > 0.999
+
+
+def test_gemm_random_configurations(gemm_mode):
+    """120 seeded random problems: ragged M / N, K in steps of 4 (the fp16x2 loop needs K % 16 == 0, others take the exact
+    register-staged loop), every plain epilogue, optional row gather (with -1 rows), row scatter, split-K and column views."""
+    rng = np.random.RandomState(7)
+    for it in range(120):
+        M = int(rng.choice([1, 3, 31, 64, 65, 127, 128, 129, 200, 257, 511, 700]))
+        N = int(rng.choice([1, 7, 31, 32, 33, 64, 100, 128, 130, 255, 256, 300]))
+        K = int(rng.choice([4, 8, 16, 20, 32, 48, 64, 80, 96, 112, 128, 144, 256, 272]))
+        relu = bool(rng.randint(2)); use_bias = bool(rng.randint(2))
+        gather = rng.randint(4) == 0; scatter = rng.randint(4) == 0
+        split = int(rng.choice([1, 1, 2, 3])) if not scatter else 1
+        src_rows = M + 5 if gather else M
+        A = _rand(src_rows, K + 8, seed=1000 + it)[:, :K]                  # leading dimension K + 8
+        W = _rand(N, K, seed=2000 + it) / np.sqrt(K); b = _rand(N, seed=3000 + it) if use_bias else None
+        kw = {}
+        Aeff = A
+        if gather:
+            rows = torch.from_numpy(rng.randint(-1, src_rows, size=M).astype(np.int32)).cuda()
+            kw["a_rows"] = rows
+            Aeff = torch.where(rows[:, None] >= 0, A[rows.clamp(min=0).long()], torch.zeros(1, device="cuda"))
+        orow = None
+        if scatter:
+            orow = torch.from_numpy(rng.permutation(M).astype(np.int32)); orow[::5] = -1; orow = orow.cuda()
+            kw["out_rows"] = orow
+        if split > 1:
+            kw["split_k"] = split; kw["split_ws"] = torch.empty(split, M, N, device="cuda")
+        ldc = (N + 3) // 4 * 4 + 4
+        C = torch.full((M, ldc), -7.0, device="cuda")
+        tag = "%s it %d M %d N %d K %d relu %d bias %d gather %d scatter %d split %d" % (
+            gemm_mode, it, M, N, K, relu, use_bias, gather, scatter, split)
+        if os.environ.get("SKG_TEST_TRACE"):               # leaves the last configuration behind if the GPU faults
+            with open(os.environ["SKG_TEST_TRACE"], "w") as f:
+                f.write(tag + "\n")
+        gemm(A, W, b, C, M, N, K, _capi.EPI_BIAS_RELU if relu else _capi.EPI_BIAS, lda=K + 8, **kw)
+        torch.cuda.synchronize()
+        ref = Aeff.double() @ W.double().t()
+        if use_bias:
+            ref = ref + b.double()
+        if relu:
+            ref = torch.relu(ref)
+        ref = ref.float()
+        if orow is None:
+            assert (C[:, :N] - ref).abs().max().item() <= 3e-5, tag
+        else:
+            keep = orow >= 0
+            if bool(keep.any()):
+                assert (C[orow[keep].long(), :N] - ref[keep]).abs().max().item() <= 3e-5, tag
+            untouched = torch.ones(M, dtype=torch.bool, device="cuda"); untouched[orow[keep].long()] = False
+            assert torch.all(C[untouched] == -7.0), tag
+        assert torch.all(C[:, N:] == -7.0), tag
