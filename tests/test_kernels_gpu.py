@@ -367,3 +367,65 @@ def test_gemm_random_configurations(gemm_mode):
             untouched = torch.ones(M, dtype=torch.bool, device="cuda"); untouched[orow[keep].long()] = False
             assert torch.all(C[untouched] == -7.0), tag
         assert torch.all(C[:, N:] == -7.0), tag
+
+
+def test_gemm_random_fused_epilogues(gemm_mode):
+    """90 seeded random problems over the fused epilogues: gathered multiplier tables (one or two, with / without the raw
+    copy and a row scatter), the adjacency row-dot (with / without C), and the residual form; ragged M / N / K."""
+    rng = np.random.RandomState(11)
+    for it in range(90):
+        M = int(rng.choice([1, 5, 63, 64, 100, 128, 129, 300, 513]))
+        N = int(rng.choice([4, 12, 32, 36, 64, 100, 128, 132, 256, 260]))
+        K = int(rng.choice([4, 16, 24, 32, 48, 64, 100, 128, 160]))
+        kind = it % 3
+        A = _rand(M, K, seed=100 + it); W = _rand(N, K, seed=200 + it) / np.sqrt(K); b = _rand(N, seed=300 + it)
+        v = A.double() @ W.double().t() + b.double()
+        tag = "%s it %d kind %d M %d N %d K %d" % (gemm_mode, it, kind, M, N, K)
+        if os.environ.get("SKG_TEST_TRACE"):
+            with open(os.environ["SKG_TEST_TRACE"], "w") as f:
+                f.write(tag + "\n")
+        if kind == 0:                                                     # MUL_RELU
+            nP, nQ = int(rng.randint(1, 9)), int(rng.randint(1, 9))
+            P = _rand(nP, N, seed=400 + it); Q = _rand(nQ, N, seed=500 + it); mb = _rand(N, seed=600 + it)
+            pi = torch.from_numpy(rng.randint(0, nP, size=M).astype(np.int32)).cuda()
+            qi = torch.from_numpy(rng.randint(0, nQ, size=M).astype(np.int32)).cuda()
+            two = bool(rng.randint(2)); raw_on = bool(rng.randint(2)); scatter = bool(rng.randint(2))
+            C = torch.full((M, N), -7.0, device="cuda"); raw = torch.full((M, N), -7.0, device="cuda")
+            kw = dict(P=P, p_idx=pi, ldp=N)
+            mult = P[pi.long()].double()
+            if two:
+                kw.update(Q=Q, q_idx=qi, ldq=N, mbias=mb); mult = mult + Q[qi.long()].double() + mb.double()
+            if raw_on:
+                kw.update(C_raw=raw, ldc_raw=N)
+            orow = None
+            if scatter:
+                orow = torch.from_numpy(rng.permutation(M).astype(np.int32)); orow[::3] = -1; orow = orow.cuda()
+                kw["out_rows"] = orow
+            gemm(A, W, b, C, M, N, K, _capi.EPI_MUL_RELU, **kw)
+            torch.cuda.synchronize()
+            ref = torch.relu(v * mult).float()
+            if orow is None:
+                assert (C - ref).abs().max().item() <= 5e-5, tag
+            else:
+                keep = orow >= 0
+                if bool(keep.any()):
+                    assert (C[orow[keep].long()] - ref[keep]).abs().max().item() <= 5e-5, tag
+            if raw_on:
+                assert (raw - v.float()).abs().max().item() <= 3e-5, tag       # stored by row, not scattered
+        elif kind == 1:                                                   # RELU_DOT
+            dw = _rand(N, seed=700 + it)
+            part = torch.zeros(dot_partials(M, N, K, K, K), M, device="cuda")
+            with_c = bool(rng.randint(2))
+            C = torch.full((M, N), -7.0, device="cuda") if with_c else None
+            gemm(A, W, b, C, M, N, K, _capi.EPI_RELU_DOT, dot_w=dw, dot_partial=part)
+            torch.cuda.synchronize()
+            r = torch.relu(v)
+            assert (part.sum(0) - (r @ dw.double()).float()).abs().max().item() <= 2e-4, tag
+            if with_c:
+                assert (C - r.float()).abs().max().item() <= 3e-5, tag
+        else:                                                             # BIAS_RES_RELU
+            res = _rand(M, N, seed=800 + it)
+            C = torch.full((M, N), -7.0, device="cuda")
+            gemm(A, W, b, C, M, N, K, _capi.EPI_BIAS_RES_RELU, res=res, ldres=N)
+            torch.cuda.synchronize()
+            assert (C - (res.double() + torch.relu(v)).float()).abs().max().item() <= 3e-5, tag
