@@ -429,3 +429,30 @@ def test_gemm_random_fused_epilogues(gemm_mode):
             gemm(A, W, b, C, M, N, K, _capi.EPI_BIAS_RES_RELU, res=res, ldres=N)
             torch.cuda.synchronize()
             assert (C - (res.double() + torch.relu(v)).float()).abs().max().item() <= 3e-5, tag
+
+
+def test_gemm_group_random(gemm_mode):
+    """40 seeded random grouped launches of 1-4 descriptors with mixed shapes and epilogues (per-descriptor epilogue switch;
+    with weight twins everywhere the group takes the fp16x2 loop, one K % 16 != 0 member sends it to the exact one)."""
+    rng = np.random.RandomState(5)
+    for it in range(40):
+        specs, refs, outs = [], [], []
+        for j in range(int(rng.randint(1, 5))):
+            M = int(rng.choice([1, 40, 64, 129, 300])); N = int(rng.choice([8, 100, 128, 256, 300]))
+            K = int(rng.choice([16, 32, 64, 96, 100, 128]))
+            epi = int(rng.choice([_capi.EPI_BIAS, _capi.EPI_BIAS_RELU, _capi.EPI_BIAS_RES_RELU]))
+            A = _rand(M, K, seed=9000 + 10 * it + j); W = _rand(N, K, seed=9500 + 10 * it + j) / np.sqrt(K)
+            b = _rand(N, seed=9900 + 10 * it + j); res = _rand(M, N, seed=9950 + 10 * it + j)
+            C = torch.full((M, N), -7.0, device="cuda")
+            specs.append(((A, W, b, C, M, N, K, epi), dict(res=res, ldres=N) if epi == _capi.EPI_BIAS_RES_RELU else {}))
+            v = A.double() @ W.double().t() + b.double()
+            refs.append({_capi.EPI_BIAS: v, _capi.EPI_BIAS_RELU: torch.relu(v),
+                         _capi.EPI_BIAS_RES_RELU: res.double() + torch.relu(v)}[epi].float())
+            outs.append(C)
+        if os.environ.get("SKG_TEST_TRACE"):
+            with open(os.environ["SKG_TEST_TRACE"], "w") as f:
+                f.write("%s group it %d %s\n" % (gemm_mode, it, [a[4:8] for a, _ in specs]))
+        gemm_group(specs)
+        torch.cuda.synchronize()
+        for C, r in zip(outs, refs):
+            assert (C - r).abs().max().item() <= 3e-5, (gemm_mode, it)
