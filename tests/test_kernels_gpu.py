@@ -456,3 +456,37 @@ def test_gemm_group_random(gemm_mode):
         torch.cuda.synchronize()
         for C, r in zip(outs, refs):
             assert (C - r).abs().max().item() <= 3e-5, (gemm_mode, it)
+
+
+def test_gemm_bf16_random():
+    """40 seeded random bf16 problems through the C ABI: ragged M / N (N also not a multiple of 4: scalar epilogue), fp32 and
+    bf16 outputs, bias / ReLU on and off, split-K up to more slices than k-tiles."""
+    import ctypes as C
+    from skghoi_amd.engine import _stream as stream
+    rng = np.random.RandomState(3)
+    for it in range(40):
+        M = int(rng.choice([1, 64, 127, 128, 130, 400])); N = int(rng.choice([3, 64, 100, 128, 130, 257]))
+        K = int(rng.choice([64, 128, 192, 512])); relu = bool(rng.randint(2)); use_bias = bool(rng.randint(2))
+        out_bf16 = bool(rng.randint(2)); sk = int(rng.choice([1, 1, 2, 3, 5]))
+        A = _rand(M, K, seed=70 + it).bfloat16(); W = (_rand(N, K, seed=170 + it) / np.sqrt(K)).bfloat16()
+        b = _rand(N, seed=270 + it) if use_bias else None
+        ldc = (N + 3) // 4 * 4 if rng.randint(2) else N
+        out = torch.full((M, ldc), -7.0, device="cuda", dtype=torch.bfloat16 if out_bf16 else torch.float32)
+        ws = torch.empty(sk, M, N, device="cuda") if sk > 1 else None
+        d = _capi.GemmBf16Desc()
+        d.A = A.data_ptr(); d.lda = K; d.W = W.data_ptr(); d.ldw = K; d.bias = b.data_ptr() if use_bias else 0
+        d.C = out.data_ptr(); d.ldc = ldc; d.M, d.N, d.K = M, N, K
+        d.relu = int(relu); d.out_bf16 = int(out_bf16); d.split_k = sk; d.split_ws = ws.data_ptr() if sk > 1 else 0
+        if os.environ.get("SKG_TEST_TRACE"):
+            with open(os.environ["SKG_TEST_TRACE"], "w") as f:
+                f.write("bf16 it %d M %d N %d K %d sk %d ldc %d out_bf16 %d\n" % (it, M, N, K, sk, ldc, out_bf16))
+        _capi.check(_capi.lib().skg_gemm_bf16(C.byref(d), stream()), "skg_gemm_bf16")
+        torch.cuda.synchronize()
+        ref = A.double() @ W.double().t()
+        if use_bias:
+            ref = ref + b.double()
+        if relu:
+            ref = torch.relu(ref)
+        tol = 2e-2 if out_bf16 else 2e-5
+        assert (out[:, :N].double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), it
+        assert torch.all(out[:, N:].float() == -7.0), it
