@@ -44,7 +44,7 @@ def test_preprocess_nms_topk_bit_exact(seed):
         assert torch.equal(g["boxes"].cpu(), w["boxes"]) and torch.equal(g["scores"].cpu(), w["scores"])
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(6))
 def test_random_graphs_full_head_vs_oracle(seed, precision):
     """Random (n_h, n_o), random verb tables, overlapping boxes incl. zero-size ones: indices bit-exact, logits 1e-4."""
     rs = np.random.RandomState(200 + seed)
