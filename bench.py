@@ -13,6 +13,9 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline     : dominant kernel (the fp32-MFMA GEMM) algorithmic FLOP/s from HIP-event timings of every launch
   cpu_baseline : the CPU oracle (faithful restatement of the reference head, oracle/skg_oracle.py) timed on this
                  box's host cores on a bounded sample (rank 0, N=1 only)
+and, at N=1, extra legs of the same run: fp16x2 (the opt-in split-operand GEMM path, own roofline), b1_latency_ms /
+b4_latency_ms (the reference evaluates one image per forward), train (the batch-4 training step, fp32 and bf16).
+The headline value / dtype / roofline are the exact fp32 path (precision="fp32", the head's default).
 """
 import argparse
 import json
@@ -98,16 +101,14 @@ def cpu_baseline(n_images):
                        "median %.3f s/image" % (len(times), cores, float(np.median(times))))
 
 
-def train_mode(args, device, rank, world, dist_on):
-    """Secondary metric: images/s of the data-parallel training step (fp32; forward + backward on the HIP GEMMs,
-    AdamW, DDP gradient all-reduce over RCCL when world > 1).  Reference settings: batch 4 per GPU (main:158)."""
-    import torch.distributed as dist
+def run_train(B, precision, steps, warmup, device, rank, world, dist_on):
+    """The data-parallel training step (forward + backward on the HIP GEMMs, AdamW, DDP gradient all-reduce over RCCL
+    when world > 1) on B synthetic 20x20 images per GPU with ground truth appended.  Returns (elapsed seconds of `steps`
+    steps on this rank, last loss dict)."""
     from skghoi_amd import synth, trainer
-    B = args.batch if args.batch != 256 else 4
     head = build_head(device).train()
     head.distributed = dist_on
-    head.precision = args.precision or "fp32"
-    args.precision = head.precision
+    head.precision = precision
     dets, pooled, feats, shapes = make_inputs(B, rank, device)
     o2v = synth.hico_object_to_verb()
     cpu_dets = [dict(boxes=d["boxes"].cpu(), labels=d["labels"].cpu(), scores=d["scores"].cpu()) for d in dets]
@@ -124,19 +125,28 @@ def train_mode(args, device, rank, world, dist_on):
     net = trainer.wrap_ddp(head, device)
     opt = trainer.build_optimizer(net, lr=1e-4)
     torch.manual_seed(1234 + rank)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets)
     torch.cuda.synchronize()
     if dist_on:
-        dist.barrier()
+        torch.distributed.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets)
     torch.cuda.synchronize()
     if dist_on:
-        dist.barrier()
+        torch.distributed.barrier()
+    return time.perf_counter() - t0, losses
+
+
+def train_mode(args, device, rank, world, dist_on):
+    """Secondary metric: images/s of the training step.  Reference settings: batch 4 per GPU (main:158)."""
+    import torch.distributed as dist
     from skghoi_amd import dist as skd
-    elapsed = skd.max_over_ranks(time.perf_counter() - t0, device=device)
+    B = args.batch if args.batch != 256 else 4
+    args.precision = args.precision or "fp32"
+    elapsed, losses = run_train(B, args.precision, args.steps, args.warmup, device, rank, world, dist_on)
+    elapsed = skd.max_over_ranks(elapsed, device=device)
     if rank == 0:
         print(json.dumps(dict(metric="images/sec through the interaction-head TRAINING step (20x20 pairs)",
                               value=round(B * world * args.steps / elapsed, 2), unit="images/s", n_gpus=world,
@@ -151,6 +161,76 @@ def train_mode(args, device, rank, world, dist_on):
         dist.destroy_process_group()
 
 
+GEMM_NAMES = {0: "skg_gemm_kernel<BIAS>", 1: "skg_gemm_kernel<BIAS_RELU>", 2: "skg_gemm_kernel<MUL_RELU>",
+              3: "skg_gemm_kernel<RELU_DOT>", 4: "skg_gemm_kernel<BIAS_RES_RELU>", 5: "skg_gemm_group_kernel"}
+
+
+def timed_infer(step, barrier, steps, time_gemms):
+    """Times exactly `steps` forwards between barriers; HIP events on the launch stream around every launch of the
+    dominant kernel (MUL_RELU epilogue: the MBF fc_2 GEMMs) when time_gemms.  -> (seconds, [(e0, e1, M, N, K, epi)])."""
+    from skghoi_amd import engine
+    # an event pair costs a few microseconds of GPU time: ~150 pairs per step (every GEMM) would be 4 % of the step,
+    # the ~8 launches of the dominant kernel are not
+    engine.GEMM_TIMER = [] if time_gemms else None
+    engine.GEMM_TIMER_EPI = {2}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer, engine.GEMM_TIMER = (engine.GEMM_TIMER or []), None
+    engine.GEMM_TIMER_EPI = None
+    return elapsed, timer
+
+
+def gemm_roofline(timer, precision, traffic_table):
+    """Roofline record of the dominant kernel from per-launch HIP-event durations.  achieved = useful 2*M*N*K flops /
+    measured time; peak = fp32 MFMA dense peak for the exact path, fp16 dense MFMA peak / 3 passes for fp16x2."""
+    groups = {}
+    for e0, e1, M, N, K, epi in timer:
+        g = groups.setdefault(epi, [0.0, 0.0, 0])
+        g[0] += e0.elapsed_time(e1) * 1e-3; g[1] += 2.0 * M * N * K; g[2] += 1
+    if not groups:
+        return None, 0.0, 0
+    dom = max(groups, key=lambda k: groups[k][0])
+    t_dom, f_dom, n_dom = groups[dom]
+    split = precision == "fp16x2"
+    name = GEMM_NAMES[dom].replace(">", ", fp16x2>") if split and dom != 5 else GEMM_NAMES[dom]
+    peak = PEAK_F16_MFMA_TFLOPS / F16X2_PASSES if split else PEAK_F32_MFMA_TFLOPS
+    achieved = f_dom / t_dom / 1e12
+    traffic = traffic_table.get(name)
+    rec = dict(bound="mfma", kernel=name, achieved=round(achieved, 2), peak=round(peak, 1), unit="TFLOP/s",
+               frac=round(achieved / peak, 4), traffic=traffic,
+               traffic_source=(traffic_table.get("_source") if traffic else None),
+               peak_note=("useful (2MNK) flops; peak = fp16 dense MFMA %.0f TF / %d MFMA passes per useful flop"
+                          % (PEAK_F16_MFMA_TFLOPS, F16X2_PASSES)) if split else "fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32)",
+               launches=n_dom, avg_launch_ms=round(t_dom / max(n_dom, 1) * 1e3, 4))
+    return rec, t_dom, n_dom
+
+
+def small_batch_latency(head, dets, pooled, feats, shapes, B, iters=200, warmup=30):
+    """Mean wall time of one eval forward on B images (B = 1 is the reference's own evaluation mode, utils.py:166-167:
+    `assert len(output) == 1`), back to back, results left on the device."""
+    feat3 = feats["3"][:B]
+    f = OrderedDict((k, feat3) for k in "0123")
+    old_pool = head.box_roi_pool
+    head.box_roi_pool = ResidentPool(pooled[:B * (N_H + N_O)])
+    d, sh = dets[:B], shapes[:B]
+    try:
+        with torch.no_grad():
+            for _ in range(warmup):
+                head(f, d, sh)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                head(f, d, sh)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / iters * 1e3
+    finally:
+        head.box_roi_pool = old_pool
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,11 +243,12 @@ def main():
     ap.add_argument("--no-gemm-timer", action="store_true", help="skip the per-launch HIP-event GEMM timing")
     ap.add_argument("--gemm-table", action="store_true", help="per-shape GEMM timing table on stderr")
     ap.add_argument("--precision", choices=["fp16x2", "fp32", "bf16"], default=None,
-                    help="dense-layer path.  infer: fp16x2 (default; fp32-grade split operands on the fp16 MFMA) or "
-                         "fp32 (exact fp32 MFMA).  train: fp32 (default) or bf16")
-    ap.add_argument("--no-exact-leg", action="store_true", help="skip the extra timed steps on the exact fp32 path")
+                    help="dense-layer path of the HEADLINE leg.  infer: fp32 (default; exact fp32 MFMA, the reference's "
+                         "arithmetic) or fp16x2 (opt-in split operands on the fp16 MFMA).  train: fp32 (default) or bf16")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="headline only: skip the extra legs (fp16x2, small-batch latency, training step)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
-                    help="train: NegativeSampling+MarginLoss training step (fwd+bwd+AdamW), secondary metric")
+                    help="train: NegativeSampling+MarginLoss training step (fwd+bwd+AdamW) as the headline instead")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -200,7 +281,7 @@ def main():
     head = build_head(device)
     dets, pooled, feats, shapes = make_inputs(args.batch, rank, device)
     head.box_roi_pool = ResidentPool(pooled)
-    head.precision = args.precision or "fp16x2"
+    head.precision = args.precision or "fp32"
     if head.precision == "bf16":
         raise SystemExit("--precision bf16 is a training configuration (use --mode train)")
     if args.chunk:
@@ -218,23 +299,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    traffic_table = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")     # HBM bytes per launch from the rocprofv3 --pmc passes
+    if os.path.isfile(tpath):
+        try:
+            traffic_table = json.load(open(tpath))
+        except Exception:
+            traffic_table = {}
+
+    # ---- headline leg: W warm-up steps, then exactly K timed steps between barriers
     torch.manual_seed(1234 + rank)
     for _ in range(args.warmup):
         res = step()
     assert len(res) == args.batch and res[0]["boxes_h"].shape == (N_H * (N_H + N_O - 1), 4)
-
-    # HIP events around the launches of the dominant kernel only (MUL_RELU epilogue: the three MBF fc_2 GEMMs per
-    # chunk): an event pair costs a few microseconds of GPU time, ~150 pairs per step would be 4 % of the step
-    engine.GEMM_TIMER = None if args.no_gemm_timer else []
-    engine.GEMM_TIMER_EPI = {2}
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    timer, engine.GEMM_TIMER = (engine.GEMM_TIMER or []), None
-    engine.GEMM_TIMER_EPI = None
+    elapsed, timer = timed_infer(step, barrier, args.steps, not args.no_gemm_timer)
     timer_all = []
     if not args.no_gemm_timer:          # every GEMM launch of ONE extra, untimed step: the all-GEMM figures and the table
         engine.GEMM_TIMER = timer_all
@@ -242,38 +320,12 @@ def main():
         torch.cuda.synchronize()
         engine.GEMM_TIMER = None
 
-    # ---- secondary leg, same run: the exact fp32-MFMA path (precision="fp32") on the same inputs
-    exact = None
-    if head.precision != "fp32" and not args.no_exact_leg:
-        main_precision, head.precision = head.precision, "fp32"
-        k2 = max(2, min(args.steps, 5))
-        step(); step()
-        engine.GEMM_TIMER = None if args.no_gemm_timer else []
-        engine.GEMM_TIMER_EPI = {2}
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(k2):
-            step()
-        barrier()
-        el2 = time.perf_counter() - t1
-        timer2, engine.GEMM_TIMER = (engine.GEMM_TIMER or []), None
-        engine.GEMM_TIMER_EPI = None
-        head.precision = main_precision
-        t_d = sum(e0.elapsed_time(e1) * 1e-3 for e0, e1, *_ in timer2)
-        f_d = sum(2.0 * M * N * K for _, _, M, N, K, _ in timer2)
-        exact = (el2, k2, (f_d / t_d / 1e12) if t_d > 0 else None, (t_d / len(timer2) * 1e3) if timer2 else None)
-
     from skghoi_amd import dist as skd
     elapsed = skd.max_over_ranks(elapsed, device=device)
     total_images = sum(skd.gather_counts(args.batch * args.steps, device=device))
     value = total_images / elapsed
 
-    # ---- roofline of the dominant kernel: per-launch HIP-event durations, grouped by kernel instance (epilogue)
-    groups = {}
-    for e0, e1, M, N, K, epi in timer:
-        g = groups.setdefault(epi, [0.0, 0.0, 0])
-        g[0] += e0.elapsed_time(e1) * 1e-3; g[1] += 2.0 * M * N * K; g[2] += 1
-    t_all = sum(e0.elapsed_time(e1) * 1e-3 for e0, e1, *_ in timer_all)
+    t_all = sum(e0.elapsed_time(e1) * 1e-3 for e0, e1, *_ in timer_all) or 1e-9
     f_all = sum(2.0 * M * N * K for _, _, M, N, K, _ in timer_all)
     if args.gemm_table and rank == 0:
         tab = {}
@@ -283,42 +335,25 @@ def main():
         for (M, N, K, epi), (ms, n) in sorted(tab.items(), key=lambda kv: -kv[1][0]):
             print("M=%7d N=%5d K=%6d epi=%d  n=%3d  total %8.3f ms  avg %7.3f ms  %6.1f TFLOP/s" % (
                 M, N, K, epi, n, ms, ms / n, 2.0 * M * N * K * n / ms / 1e9), file=sys.stderr)
-    names = {0: "skg_gemm_kernel<BIAS>", 1: "skg_gemm_kernel<BIAS_RELU>", 2: "skg_gemm_kernel<MUL_RELU>",
-             3: "skg_gemm_kernel<RELU_DOT>", 4: "skg_gemm_kernel<BIAS_RES_RELU>", 5: "skg_gemm_group_kernel"}
-    if not groups:
-        groups = {2: [1e-9, 0.0, 0]}
-    dom = max(groups, key=lambda k: groups[k][0])
-    t_dom, f_dom, n_dom = groups[dom]
-    t_all = t_all or 1e-9
-    achieved = f_dom / t_dom / 1e12
-    split = head.precision == "fp16x2"
-    peak = PEAK_F16_MFMA_TFLOPS / F16X2_PASSES if split else PEAK_F32_MFMA_TFLOPS
-    if split:
-        names = {k: v.replace(">", ", fp16x2>") if k != 5 else v for k, v in names.items()}
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")     # HBM bytes per launch from the rocprofv3 --pmc passes
-    if os.path.isfile(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(names[dom])
-        except Exception:
-            traffic = None
-    roofline = dict(bound="mfma", kernel=names[dom], achieved=round(achieved, 2), peak=round(peak, 1),
-                    unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic,
-                    peak_note=("useful (2MNK) flops; peak = fp16 dense MFMA %.0f TF / %d MFMA passes per useful flop"
-                               % (PEAK_F16_MFMA_TFLOPS, F16X2_PASSES)) if split else "fp32 MFMA dense peak",
-                    launches=n_dom, avg_launch_ms=round(t_dom / max(n_dom, 1) * 1e3, 4),
-                    all_gemm_tflops=round(f_all / t_all / 1e12, 2),
-                    gemm_share_of_step=round(t_all / (elapsed / args.steps), 4),
-                    gflop_per_image=round(f_all / args.batch / 1e9, 3))
+    roofline, t_dom, n_dom = gemm_roofline(timer, head.precision, traffic_table)
+    if roofline is None:
+        roofline = dict(bound="mfma", kernel=GEMM_NAMES[2], achieved=None, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=None, traffic=None, note="per-launch timing disabled (--no-gemm-timer)")
+    else:
+        roofline.update(all_gemm_tflops=round(f_all / t_all / 1e12, 2),
+                        gemm_share_of_step=round(t_all / (elapsed / args.steps), 4),
+                        gflop_per_image=round(f_all / args.batch / 1e9, 3))
     # the north star also asks for the HBM-roofline view (it cannot bind -- ~7000 flop per compulsory byte)
     per_gpu = value / world
+    traffic = roofline.get("traffic")
     roofline["hbm"] = dict(peak_gbs=HBM_PEAK_GBS,
                            compulsory_frac=round(per_gpu * COMPULSORY_BYTES_PER_IMAGE / (HBM_PEAK_GBS * 1e9), 5),
                            dominant_kernel_frac=(round(traffic / (t_dom / max(n_dom, 1)) / (HBM_PEAK_GBS * 1e9), 4)
-                                                 if traffic else None),
+                                                 if traffic and n_dom else None),
                            note="compulsory = 2.47 MB per image (pooled features + TransH tables + outputs, SURVEY 8d); "
-                                "dominant kernel = measured HBM bytes per launch / launch time")
+                                "dominant kernel = HBM bytes per launch (traffic_source) / measured launch time")
 
+    split = head.precision == "fp16x2"
     out = OrderedDict(metric="images/sec through interaction head (20x20 pairs)", value=round(value, 2),
                       unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                       ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
@@ -330,16 +365,43 @@ def main():
                                   batch_per_gpu=args.batch, images_per_step=args.batch * world,
                                   parallelism="dp%d (independent image shards, no data-path collective)" % world),
                       roofline=roofline)
-    if exact is not None:
-        el2 = skd.max_over_ranks(exact[0], device=device)
-        out["exact_fp32"] = dict(value=round(args.batch * world * exact[1] / el2, 2), unit="images/s", steps=exact[1],
-                                 ms_per_step=round(el2 / exact[1] * 1e3, 3),
-                                 note="same run, same inputs, precision='fp32' (exact fp32 MFMA everywhere)")
-        if exact[2] is not None:
-            out["exact_fp32"]["roofline"] = dict(bound="mfma", kernel="skg_gemm_kernel<MUL_RELU>", achieved=round(exact[2], 2),
-                                                 peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                                                 frac=round(exact[2] / PEAK_F32_MFMA_TFLOPS, 4),
-                                                 avg_launch_ms=round(exact[3], 4))
+
+    # ---- extra legs, same run, one GPU only (the N-GPU runs of the scaling curve stay headline-only)
+    if world == 1 and not args.no_legs:
+        if head.precision == "fp32":
+            # (a) opt-in fp16x2 path on the same inputs, with its own roofline
+            head.precision = "fp16x2"
+            k2 = max(2, min(args.steps, 5))
+            for _ in range(2):
+                step()
+            el2, timer2 = timed_infer(step, barrier, k2, not args.no_gemm_timer)
+            head.precision = "fp32"
+            leg = dict(value=round(args.batch * k2 / el2, 2), unit="images/s", steps=k2,
+                       ms_per_step=round(el2 / k2 * 1e3, 3), dtype="f32 (fp16x2 split operands, fp32 accumulate)",
+                       note="opt-in precision='fp16x2': every GEMM operand carried as two fp16 numbers (22 significant "
+                            "bits), three fp16-MFMA passes, fp32 accumulation; narrower than the reference's fp32")
+            r2 = gemm_roofline(timer2, "fp16x2", traffic_table)[0]
+            if r2 is not None:
+                leg["roofline"] = r2
+            out["fp16x2"] = leg
+            step()                                  # back on the exact path (re-selects its kernels) before the next leg
+        # (b) small batches: the reference's own evaluation runs one image per forward (utils.py:166-167)
+        out["b1_latency_ms"] = round(small_batch_latency(head, dets, pooled, feats, shapes, 1), 4)
+        out["b4_latency_ms"] = round(small_batch_latency(head, dets, pooled, feats, shapes, min(4, args.batch)), 4)
+        out["small_batch"] = dict(precision=head.precision, b1_images_per_s=round(1e3 / out["b1_latency_ms"], 1),
+                                  b4_images_per_s=round(4e3 / out["b4_latency_ms"], 1),
+                                  note="mean wall time per eval forward, 200 back-to-back forwards after 30 warm-ups")
+        # (c) the training step at the reference's batch 4 per GPU (main:158): fwd + bwd + AdamW
+        _trainer.limit_host_threads(world)
+        train = {}
+        for prec in ("fp32", "bf16"):
+            el_t, losses = run_train(4, prec, 10, 4, device, rank, world, False)
+            train[prec] = dict(ms_per_step=round(el_t / 10 * 1e3, 3), images_per_s=round(40 / el_t, 2), batch=4,
+                               steps=10, losses={k: round(v, 6) for k, v in losses.items()})
+        train["note"] = ("NegativeSampling + MarginLoss + two focal terms, forward + backward + AdamW, 4 synthetic 20x20 "
+                         "images with ground truth appended; bf16 = bf16 GEMM operands, fp32 accumulation / master weights")
+        out["train"] = train
+        torch.set_num_threads(max(1, host_cpu_share() // world))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(12)
     if rank == 0:

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SKG_ABI_VERSION 3
+#define SKG_ABI_VERSION 4
 #define SKG_E_ARG   (-1)   /* null pointer / negative size / unsupported shape            */
 #define SKG_E_ALIGN (-2)   /* pointer or leading dimension not 16-byte aligned            */
 #define SKG_E_LIMIT (-3)   /* exceeds a compiled-in limit (boxes per image, verbs, ...)   */
@@ -59,7 +59,9 @@ typedef struct {
  *   nverbs[num_obj_classes] : number of target classes per object class (len(object_class_to_target_class[c]))
  *   prior_pow     : exponent applied to detection scores by compute_prior_scores (HEAD:742), used only for out_count
  *   out_index[B, max_human+max_object] : selected rows (index local to the image), humans first
- *   out_count[B,4] : {n_h, n, L, 0}; L = number of non-zero prior cells = size of the image's scored result (HEAD:315)
+ *   out_count[B,4] : {n_h, n, L, #candidates}; L = number of non-zero prior cells = size of the image's scored result
+ *                    (HEAD:315).  An image with more than SKG_MAX_DET_PER_IMAGE rows (or a negative row range) is not
+ *                    processed: its out_count is {-1, -1, -1, rows} and its out_index row is all -1.
  */
 int skg_preprocess_f32(const float* boxes, const float* scores, const int64_t* labels, const int32_t* det_off, int B,
                        int human_idx, float score_thresh, float nms_thresh, int max_human, int max_object,
@@ -259,6 +261,20 @@ int skg_transh_scores_f32(const float* ent, const float* rel, const float* nrm, 
 int skg_associate_f32(const float* boxes, const skg_image_meta* meta, int n_active, const int64_t* x_keep,
                       const int64_t* y_keep, const float* gt_h, const float* gt_o, const int64_t* gt_label,
                       const int32_t* gt_off, int K, float thresh, float* labels, int32_t* npos, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Order-independent 64-bit checksum of the live parameters (bit patterns weighted by position) over a table of
+ * chunks: chunk c covers `count` fp32 words at `ptr` (16-byte aligned) whose first word has global index `first`.
+ * The reference reads its nn.Linear / LayerNorm parameters afresh in every forward (HEAD:812-973, 410-411); the host
+ * engine keeps re-laid copies and uses this sum -- enqueued ahead of the preprocess kernel and read back with its
+ * counts -- to notice any in-place change, including writes that bypass autograd's version counters.  `out` (8-byte
+ * aligned, device) is zeroed on the stream and then accumulated with one atomic per wave.                          */
+typedef struct {
+    const void* ptr;
+    uint32_t    count;     /* fp32 words in this chunk */
+    uint32_t    first;     /* global word index of ptr[0] */
+} skg_param_chunk;
+int skg_param_checksum(const skg_param_chunk* chunks, int n_chunks, uint64_t* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ MAX_NODES = 160
 SPATIAL_LD = 48
 TRANSH_DIM = 50
 TRANSH_ENT = 80
-ABI_VERSION = 3
+ABI_VERSION = 4
 GEMM_GROUP_MAX = 4
 
 _vp = C.c_void_p
@@ -72,6 +72,7 @@ PROTOTYPES = {
                                       _f32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "skg_associate_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _f32, _vp, _vp, _vp]),
     "skg_transh_scores_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "skg_param_checksum": (C.c_int, [_vp, C.c_int, _vp, _vp]),
 }
 
 _LIB = None

@@ -244,12 +244,13 @@ class InteractionHead(Module):
     signature and result dictionaries.
 
     Extra keyword (not in the reference, defaults reproduce it):
-      precision: str = "fp16x2" -- dense layers of the inference forward:
-        "fp16x2" (default): operands split into two fp16 numbers each (22 significant bits), three fp16-MFMA passes
-          with fp32 accumulation -- fp32-grade results (~1e-6 relative to the exact path, far inside the 1e-4 logit
-          bar) at about twice the speed of the fp32 MFMA; tiles that leave the fp16 range or contain inf / nan are
+      precision: str = "fp32" -- dense layers of the inference forward:
+        "fp32" (default): the exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain) everywhere -- the
+          reference's own arithmetic.
+        "fp16x2" (opt-in): operands split into two fp16 numbers each (22 significant bits, narrower than fp32's 24),
+          three fp16-MFMA passes with fp32 accumulation -- ~1e-6 relative to the exact path on this head, far inside
+          the 1e-4 logit bar, at about twice the speed; tiles that leave the fp16 range or contain inf / nan are
           recomputed exactly (skghoi_amd/csrc/skg_gemm.hip).
-        "fp32": the exact fp32 MFMA (bit-for-bit an fmaf chain) everywhere.
         "bf16": TRAINING-mode dense layers with bf16 operands (fp32 accumulation, fp32 master weights / gradients /
           activations); inference as "fp16x2".  Training otherwise always uses the exact fp32 path.
       reference_quirks: bool = True -- reproduce (a) the node-offset bug on skipped images and (b) the
@@ -260,7 +261,7 @@ class InteractionHead(Module):
     def __init__(self, box_roi_pool: Module, box_pair_head: Module, box_pair_suppressor: Module,
                  box_pair_predictor: Module, human_idx: int, num_classes: int, box_nms_thresh: float = 0.5,
                  box_score_thresh: float = 0.2, max_human: int = 15, max_object: int = 15,
-                 distributed: bool = False, reference_quirks: bool = True, precision: str = "fp16x2") -> None:
+                 distributed: bool = False, reference_quirks: bool = True, precision: str = "fp32") -> None:
         super().__init__()
         self.box_roi_pool = box_roi_pool
         self.box_pair_head = box_pair_head
@@ -281,7 +282,9 @@ class InteractionHead(Module):
 
     def engine(self) -> HeadEngine:
         e = self._engine
-        if e is None or e.max_human != self.max_human or e.max_object != self.max_object \
+        if e is None or e.gh is not self.box_pair_head or e.predictor is not self.box_pair_predictor \
+                or e.suppressor is not self.box_pair_suppressor \
+                or e.max_human != self.max_human or e.max_object != self.max_object \
                 or e.box_nms_thresh != float(self.box_nms_thresh) or e.box_score_thresh != float(self.box_score_thresh):
             e = HeadEngine(self.box_pair_head, self.box_pair_predictor, self.box_pair_suppressor, self.human_idx,
                            self.num_classes, self.box_nms_thresh, self.box_score_thresh, self.max_human,
@@ -344,7 +347,7 @@ class InteractionHead(Module):
             with torch.no_grad():
                 return self._forward_train(features, detections, image_shapes, targets, with_losses=False)
         eng = self.engine()
-        pre = eng.preprocess(detections, targets, False, False)
+        pre = eng.preprocess(detections, targets, False, False, check_weights=True)
         box_coords = list(pre.boxes.split(pre.sizes))
         box_features = self.box_roi_pool(features, box_coords, image_shapes)
         g = eng.graph(features["3"], image_shapes, box_features, pre, training=False)
@@ -353,7 +356,7 @@ class InteractionHead(Module):
             raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")     # HEAD:408 on an empty batch
         dev = pre.device
         if lay.n_active:
-            logits = eng.classify(g["pair_features"])
+            logits = eng.classify(g["pair_features"], checked=True)
             r = eng.score(logits, pre, g, False)
             eng.last = dict(g, logits=logits)
         else:
@@ -370,8 +373,13 @@ class InteractionHead(Module):
         pre = eng.preprocess(detections, targets, self.training, self.training)
         box_coords = list(pre.boxes.split(pre.sizes))
         box_features = self.box_roi_pool(features, box_coords, image_shapes)
+        from skghoi_amd import dist as _skd
+        norm = []
+        # the three n_p normalisers (HEAD:162-172, 190-199, 219-228) leave as ONE 3-element all-reduce as soon as the
+        # labels exist, and come back as a device tensor when the loss scalars are formed: no barrier, no .item()
+        on_counts = (lambda c: norm.append(_skd.start_normalisers(c, self.distributed))) if with_losses else None
         (feats, bh, bo, oc, labels, prior, pos, neg, he, te, re, rn), lay, P = graph_train(
-            eng, self.box_pair_head, features["3"], image_shapes, box_features, pre, targets)
+            eng, self.box_pair_head, features["3"], image_shapes, box_features, pre, targets, on_counts=on_counts)
         if len(feats) == 0:
             raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
         pf = P["PF"] if P is not None else torch.cat(feats)       # skipped images contribute zero rows
@@ -383,10 +391,11 @@ class InteractionHead(Module):
         results = self._postprocess_packed(logits_p, logits_s, P, lay, pf.device)
         if not with_losses:
             return results
+        n_p = norm[0].get()
         results.append(dict(
-            hoi_loss=self.compute_interaction_classification_loss(results),
-            interactiveness_loss=self.compute_interactiveness_loss(results),
-            transH_loss=self.compute_transH_loss(pos, neg, he, re, rn, te, results)))
+            hoi_loss=self.compute_interaction_classification_loss(results, n_p=n_p[0]),
+            interactiveness_loss=self.compute_interactiveness_loss(results, n_p=n_p[1]),
+            transH_loss=self.compute_transH_loss(pos, neg, he, re, rn, te, results, n_p=n_p[2])))
         return results
 
     def _postprocess_packed(self, logits_p, logits_s, P, lay, dev):
@@ -421,9 +430,11 @@ class InteractionHead(Module):
             a += 1
         return results
 
-    def _n_p(self, n_p):
-        """HEAD:167-172: average the number of positives over the ranks (the barrier is dropped: all_reduce is
-        already a synchronising collective)."""
+    def _n_p(self, labels):
+        """HEAD:162-172 for a caller that invokes one loss method on its own: number of non-zero labels, averaged over
+        the ranks (the barrier is dropped: all_reduce is already a synchronising collective).  The forward pass does
+        not come through here -- it fuses the three normalisers into one collective (skghoi_amd/dist.py)."""
+        n_p = len(torch.nonzero(labels))
         if self.distributed:
             world_size = dist.get_world_size()
             t = torch.as_tensor([n_p], device="cuda", dtype=torch.float64)
@@ -431,28 +442,30 @@ class InteractionHead(Module):
             n_p = (t / world_size).item()
         return n_p
 
-    def compute_interaction_classification_loss(self, results: List[dict]) -> Tensor:
-        """HEAD:153-177."""
+    def compute_interaction_classification_loss(self, results: List[dict], n_p=None) -> Tensor:
+        """HEAD:153-177.  n_p: pre-reduced normaliser (0-d device tensor) from the forward's fused all-reduce."""
         from skghoi_amd.ops import binary_focal_loss
         labels = torch.cat([r["labels"] for r in results]); scores = torch.cat([r["scores"] for r in results])
-        n_p = self._n_p(len(torch.nonzero(labels)))
+        if n_p is None:
+            n_p = self._n_p(labels)
         return binary_focal_loss(scores, labels, reduction="sum", gamma=0.2) / n_p
 
-    def compute_interactiveness_loss(self, results: List[dict]) -> Tensor:
+    def compute_interactiveness_loss(self, results: List[dict], n_p=None) -> Tensor:
         """HEAD:180-205."""
         from skghoi_amd.ops import binary_focal_loss
         weights = torch.cat([r["weights"] for r in results]); labels = torch.cat([r["unary_labels"] for r in results])
-        n_p = self._n_p(len(torch.nonzero(labels)))
+        if n_p is None:
+            n_p = self._n_p(labels)
         return binary_focal_loss(weights, labels, reduction="sum", gamma=2.0) / n_p
 
     def compute_transH_loss(self, positive_scores, negative_scores, head, relation, relation_norm, tail,
-                            results: List[dict]) -> Tensor:
+                            results: List[dict], n_p=None) -> Tensor:
         """HEAD:207-235 with the semantics the code intends (the committed call passes six arguments to a
         one-argument NegativeSampling.forward and raises TypeError): NegativeSampling splits
         score = cat[pos, neg] in halves shaped [M, 1] (heads/NegativeSampling.py:30-40, 52-56) and applies
         MarginLoss(margin=1): mean(max(p - n, -margin)) + margin (heads/MarginLoss.py:28-36); regul_rate = 0."""
-        labels = torch.cat([r["unary_labels"] for r in results])
-        n_p = self._n_p(len(torch.nonzero(labels)))
+        if n_p is None:
+            n_p = self._n_p(torch.cat([r["unary_labels"] for r in results]))
         score = torch.cat([torch.cat(positive_scores), torch.cat(negative_scores)])
         half = len(score) // 2
         p = score[:half].view(-1, half).permute(1, 0); n = score[half:].view(-1, half).permute(1, 0)

@@ -35,6 +35,16 @@ __global__ __launch_bounds__(PRE_THREADS) void skg_preprocess_kernel(
     const int n0 = det_off[b + 1] - base;
     const int ld_out = max_human + max_object;
 
+    // More candidates than the LDS arrays hold (or a corrupt offset table): report it instead of writing past them.
+    // Uniform per workgroup and ahead of every barrier.  The host side turns count[0] == -1 into an error.
+    if (n0 < 0 || n0 > SKG_MAX_DET_PER_IMAGE) {
+        for (int t = tid; t < ld_out; t += PRE_THREADS) out_index[(int64_t)b * ld_out + t] = -1;
+        if (tid == 0) {
+            out_count[4 * b + 0] = -1; out_count[4 * b + 1] = -1; out_count[4 * b + 2] = -1; out_count[4 * b + 3] = n0;
+        }
+        return;
+    }
+
     int npow = 1;
     while (npow < n0) npow <<= 1;
 

@@ -3,7 +3,10 @@
 Images are independent units: inference shards the image list over ranks with no data-path collective.
 The only exchanges the reference's head performs are the three 1-element `n_p` all-reduces, each behind a barrier
 (heads/adamixer_transH_spatial_r50_head.py:167-172, 194-199, 223-228); they are fused here into ONE 3-element
-all-reduce without barriers.  Gradient all-reduce belongs to the trainer (DDP / RCCL) and is not part of this file.
+all-reduce without barriers, issued asynchronously right after label association (`start_normalisers`) and consumed as a
+device tensor when the loss scalars are formed -- no host synchronisation in between.  Gradient all-reduce belongs to the
+trainer (DDP / RCCL).  `gather_image_results` reassembles the per-rank result dicts of sharded inference / validation
+for a single-rank evaluator (the reference's `_synchronise_and_log_results`, utils.py:263-282).
 """
 import torch
 import torch.distributed as dist
@@ -73,3 +76,100 @@ def gather_counts(value, device=None, group=None):
     out = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(w)]
     dist.all_gather(out, torch.tensor([int(value)], dtype=torch.int64, device=device), group=group)
     return [int(o.item()) for o in out]
+
+
+class Normalisers:
+    """Handle of the in-flight fused `n_p` all-reduce.  `get()` -> float32 device tensor [3] = all_reduce_sum(counts) /
+    world_size (HEAD:167-172 per term), without a host synchronisation: waiting on the work object only orders the
+    collective's stream before the current one."""
+
+    def __init__(self, vals, work, world):
+        self.vals, self.work, self.world = vals, work, world
+        self._out = None
+
+    def get(self):
+        if self._out is None:
+            if self.work is not None:
+                self.work.wait()
+            self._out = (self.vals / self.world).to(torch.float32)
+        return self._out
+
+
+def start_normalisers(counts, distributed=True, group=None):
+    """counts: device (or CPU, for gloo) tensor of the three per-rank normaliser counts {#positive scored cells,
+    #positive pairs, #positive pairs}.  Starts ONE 3-element all-reduce (async) when a process group with more than
+    one rank is up and `distributed`; returns a Normalisers handle."""
+    vals = counts.to(torch.float64).reshape(3).clone()
+    work, world = None, 1
+    if distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        work = dist.all_reduce(vals, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return Normalisers(vals, work, world)
+
+
+def _all_gather_ragged(t, group=None):
+    """t: [n, ...] with a rank-dependent n -> list (one entry per rank) of the ranks' tensors."""
+    w = dist.get_world_size(group)
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    ns = [torch.zeros_like(n) for _ in range(w)]
+    dist.all_gather(ns, n, group=group)
+    ns = [int(v.item()) for v in ns]
+    m = max(ns + [1])
+    pad = t.new_zeros((m,) + tuple(t.shape[1:]))
+    pad[:t.shape[0]] = t
+    outs = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(outs, pad.contiguous(), group=group)
+    return [o[:k] for o, k in zip(outs, ns)]
+
+
+# the one result key whose ragged dimension is not the first (HEAD:317-322: prior is [2, L])
+_RAGGED_DIM = {"prior": 1}
+
+
+def gather_image_results(results, group=None):
+    """Sharded inference / validation: every rank holds the result dicts (HEAD:317-322) of ITS images; returns, on
+    every rank, the result dicts of ALL images in rank order (= global image order under `shard_range`).  Tensors stay
+    on the device they were on (device tensors travel over RCCL, CPU tensors over gloo).  Per key one padded
+    all_gather; the ragged per-image sizes travel in one more.  Single process: returns `results` unchanged."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return list(results)
+    w = dist.get_world_size(group)
+    keys = sorted(results[0].keys()) if results else []
+    # every rank must agree on the key set even when it holds no image: take it from the first rank that has one
+    keysets = [None] * w
+    dist.all_gather_object(keysets, keys, group=group)
+    keys = next((k for k in keysets if k), [])
+    if not keys:
+        return []
+    dev = results[0][keys[0]].device if results else None
+    if dev is None:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    lens = torch.zeros(len(results), len(keys), dtype=torch.int64, device=dev)
+    for i, r in enumerate(results):
+        for j, k in enumerate(keys):
+            lens[i, j] = r[k].shape[_RAGGED_DIM.get(k, 0)]
+    all_lens = _all_gather_ragged(lens, group)
+    protos = [None] * w                        # dtype / trailing shape of every key (a rank without images has none)
+    mine = {k: (str(results[0][k].dtype).replace("torch.", ""), tuple(results[0][k].movedim(_RAGGED_DIM.get(k, 0), 0).shape[1:]))
+            for k in keys} if results else None
+    dist.all_gather_object(protos, mine, group=group)
+    proto = next(p for p in protos if p)
+    gathered = {}
+    for k in keys:
+        d = _RAGGED_DIM.get(k, 0)
+        if results:
+            flat = torch.cat([r[k].movedim(d, 0) for r in results])
+        else:
+            flat = torch.zeros((0,) + proto[k][1], dtype=getattr(torch, proto[k][0]), device=dev)
+        gathered[k] = _all_gather_ragged(flat.contiguous(), group)
+    out = []
+    for r in range(w):
+        ln = all_lens[r].tolist()                    # [[length per key] per image of rank r]
+        base = len(out)
+        out.extend({} for _ in ln)
+        for j, k in enumerate(keys):
+            d = _RAGGED_DIM.get(k, 0)
+            parts = gathered[k][r].split([row[j] for row in ln]) if ln else []
+            for i, part in enumerate(parts):
+                out[base + i][k] = part.movedim(0, d) if d else part
+    return out

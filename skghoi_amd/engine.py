@@ -47,6 +47,64 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Bumped whenever ANY nn.Module registers a parameter or a sub-module (module.weight = nn.Parameter(...),
+# load_state_dict(assign=True), head.box_pair_predictor = nn.Linear(...)): the engine then re-enumerates its parameters
+# (by identity) before trusting its packed copies.  O(1) per forward while nothing is registered.
+_REG_EPOCH = [0]
+
+
+def _registration_hook(*_args):
+    _REG_EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_registration_hook)
+torch.nn.modules.module.register_module_module_registration_hook(_registration_hook)
+
+_CHUNK_DTYPE = np.dtype([("ptr", "u8"), ("count", "u4"), ("first", "u4")])      # skg_param_chunk
+
+
+class ParamWatch:
+    """Notices any change of the live parameters behind a PackedWeights: replaced Parameter objects (identity, checked
+    when the registration epoch moved), re-pointed storage (data_ptr walk) and changed VALUES -- by an on-device
+    checksum of the parameter bytes (skg_param_checksum), so that writes that bypass autograd's version counters
+    (`p.data.mul_(2)`) are seen too.  Parameters that are not contiguous fp32 on the engine's device fall back to
+    the version counters."""
+
+    CHUNK_WORDS = 1 << 14
+
+    def __init__(self, plist, device):
+        self.plist = plist
+        self.epoch = _REG_EPOCH[0]
+        self.ids = tuple(map(id, plist))
+        self.ptrs = tuple(map(torch.Tensor.data_ptr, plist))
+        self.versions = sum(p._version for p in plist)
+        self.device = device
+        self.table = None
+        self.sum = None
+        if all(p.device == device and p.dtype == torch.float32 and p.is_contiguous() and p.data_ptr() % 16 == 0
+               for p in plist):
+            rows = []
+            first = 0
+            for p in plist:
+                n, base = p.numel(), p.data_ptr()
+                for o in range(0, n, self.CHUNK_WORDS):
+                    rows.append((base + 4 * o, min(self.CHUNK_WORDS, n - o), (first + o) & 0xffffffff))
+                first += n
+            arr = np.array(rows, dtype=_CHUNK_DTYPE)
+            self.n_chunks = len(rows)
+            self.table = torch.from_numpy(arr.view(np.uint8).copy()).to(device)
+            self._out = torch.zeros(1, dtype=torch.int64, device=device)
+
+    def enqueue(self, out_ptr):
+        """Checksum of the live parameters onto the current stream; 8 bytes at device address out_ptr."""
+        _capi.check(_capi.lib().skg_param_checksum(self.table.data_ptr(), self.n_chunks, out_ptr, _stream()),
+                    "skg_param_checksum")
+
+    def checksum_sync(self):
+        self.enqueue(self._out.data_ptr())
+        return int(self._out.item())
+
+
 class PackedWeights:
     """Device copies of the head's parameters in the layouts the kernels want (stacked MBF branches, padded K)."""
 
@@ -148,6 +206,9 @@ class SplitWeights:
             twin = torch.empty(lib.skg_split_weights_bytes(N, K), dtype=torch.uint8, device=W.device)
             _capi.check(lib.skg_split_weights_f16x2(key[0], N, K, ldw, float(2.0 ** e), twin.data_ptr(), _stream()),
                         "skg_split_weights_f16x2")
+            # The twin is made on whichever stream first needs it, other streams (n_streams > 1) may read it later with
+            # no event in between: finish it now.  Once per weight; the amax read above has synchronised already.
+            torch.cuda.current_stream().synchronize()
             t = (twin, float(2.0 ** -e), W)                       # holding W keeps its address from being reused
             self.twins[key] = t
         return t[0], t[1]
@@ -248,9 +309,18 @@ class _NullCtx:
         return False
 
 
+class _DrawAborted(Exception):
+    pass
+
+
 class _TableDrawer:
-    """Draws the per-image TransH tables of every chunk, in order, on a helper thread (the global CPU RNG is
-    consumed exactly as the reference does, skghoi_amd/transh.py)."""
+    """Draws the per-image TransH tables of every chunk, in order (the global CPU RNG is consumed exactly as the
+    reference does, skghoi_amd/transh.py), into a ring of pinned staging buffers.
+
+    Chunk i uses slot i % len(slots).  A slot may be redrawn only after (a) the consumer has ENQUEUED the H2D copies
+    of the chunk that used it last -- `release(i)`, which also records the HIP event behind those copies -- and
+    (b) that event has completed.  Large batches draw on a helper thread that runs ahead of the consumer by at most
+    len(slots) chunks; a few images (<= INLINE_IMAGES) are drawn lazily inside get(), on the caller's thread."""
 
     INLINE_IMAGES = 8
 
@@ -260,22 +330,36 @@ class _TableDrawer:
         self.slots = slots
         self.out = [None] * len(sizes)
         self.err = None
+        self.abort = False
         self.ready = [threading.Event() for _ in sizes]
+        self.released = [threading.Event() for _ in sizes]
+        self.events = [None] * len(sizes)          # HIP event behind the H2D copies of chunk i (set by release)
+        self.drawn = 0                             # inline mode: chunks drawn so far
         if sum(sizes) <= self.INLINE_IMAGES:       # a few images: the draw (20 us each) is cheaper than starting a thread
             self.thread = None
-            self._run()
         else:
             self.thread = threading.Thread(target=self._run, daemon=True)
             self.thread.start()
 
+    def _draw(self, i):
+        ns = len(self.slots)
+        slot = self.slots[i % ns]
+        if i >= ns:                                # the chunk that used this staging buffer last, in this forward
+            self.released[i - ns].wait()
+            if self.abort:
+                raise _DrawAborted()
+            ev = self.events[i - ns]
+        else:                                      # ... or in an earlier forward
+            ev = slot["event"]
+        if ev is not None:
+            ev.synchronize()
+        slot["event"] = None
+        self.out[i] = transh.draw_batch(self.K, self.sizes[i], need_relations=self.need, out=slot["bufs"])
+
     def _run(self):
         try:
-            for i, n in enumerate(self.sizes):
-                slot = self.slots[i % len(self.slots)]
-                if slot["event"] is not None:          # the H2D copy that last read this staging buffer
-                    slot["event"].synchronize()
-                    slot["event"] = None
-                self.out[i] = transh.draw_batch(self.K, n, need_relations=self.need, out=slot["bufs"])
+            for i in range(len(self.sizes)):
+                self._draw(i)
                 self.ready[i].set()
         except BaseException as e:                 # surface the failure in the caller's thread
             self.err = e
@@ -283,15 +367,31 @@ class _TableDrawer:
                 ev.set()
 
     def get(self, i):
+        if self.thread is None:
+            while self.drawn <= i:                 # lazily and in order: the RNG stream is the reference's
+                self._draw(self.drawn)
+                self.drawn += 1
+            return self.out[i]
         self.ready[i].wait()
         if self.err is not None:
             raise self.err
         return self.out[i]
 
+    def release(self, i, event):
+        """The consumer has enqueued every H2D copy out of chunk i's staging buffers; `event` completes after them."""
+        self.events[i] = event
+        self.slots[i % len(self.slots)]["event"] = event
+        self.released[i].set()
+
     def join(self):
+        self.abort = True
+        for ev in self.released:                   # a consumer that failed midway must not leave the thread waiting
+            ev.set()
         if self.thread is not None:
             self.thread.join()
-        if self.err is not None:
+        # (inline mode draws on demand: chunks a failed consumer never asked for are not drawn, exactly as a reference
+        # forward that raised midway would have left the RNG)
+        if self.err is not None and not isinstance(self.err, _DrawAborted):
             raise self.err
 
 
@@ -317,29 +417,49 @@ class HeadEngine:
         self.faithful_skip_offset = faithful_skip_offset
         self.chunk_images = 128     # active images per graph chunk (RNG/GPU overlap + cache-sized intermediates)
         self.debug = False          # keep per-chunk intermediates (spatial46, h_node, node, adjacency) in graph()
-        self._plist = None
         self._slots = None
         self._streams = None
         self.n_streams = 1          # >1: alternate chunks over side streams (tail filling); see graph()
-        self.precision = "fp16x2"   # inference GEMMs on the fp16 matrix pipe from 2-way operand splits (fp32 grade); "fp32": exact
+        self.precision = "fp32"     # "fp32": exact fp32 MFMA; "fp16x2" (opt-in): fp16 matrix pipe from 2-way operand splits
         self._pw = None
         self._vt = None
         self.last = None          # intermediates of the last graph pass (parity tests read them)
 
     # ------------------------------------------------------------------------------------------ caches
-    def weights(self, device):
-        """Packed weights, re-packed when any parameter was modified in place, replaced or moved."""
-        if self._plist is None:
-            self._plist = list(self.gh.parameters()) + list(self.predictor.parameters()) + \
-                list(self.suppressor.parameters())
-        sig = (sum(p._version for p in self._plist), self._plist[0].data_ptr(), self._plist[-1].data_ptr())
-        if self._pw is None or self._pw.device != device or self._pw.sig != sig:
-            self._plist = list(self.gh.parameters()) + list(self.predictor.parameters()) + \
-                list(self.suppressor.parameters())
-            sig = (sum(p._version for p in self._plist), self._plist[0].data_ptr(), self._plist[-1].data_ptr())
-            self._pw = PackedWeights(self.gh, self.predictor, self.suppressor, device)
-            self._pw.sig = sig
-        return self._pw
+    def _enumerate(self):
+        return list(self.gh.parameters()) + list(self.predictor.parameters()) + list(self.suppressor.parameters())
+
+    def weights(self, device, wsum=None, walk=True):
+        """Packed weights, re-packed when any live parameter was modified in place (by any route), replaced or moved.
+
+        wsum: the parameter checksum this forward already brought back with the preprocess counts (None: computed
+        here, which costs a synchronisation).  walk=False skips the data_ptr walk (small-batch graph path)."""
+        pw = self._pw
+        if pw is not None and pw.device == device:
+            w = pw.watch
+            stale = False
+            if w.epoch != _REG_EPOCH[0]:                    # something was registered somewhere: compare identities
+                if tuple(map(id, self._enumerate())) != w.ids:
+                    stale = True
+                else:
+                    w.epoch = _REG_EPOCH[0]
+            if not stale and walk and tuple(map(torch.Tensor.data_ptr, w.plist)) != w.ptrs:
+                stale = True
+            if not stale:
+                if w.table is not None:
+                    stale = (w.checksum_sync() if wsum is None else wsum) != w.sum
+                else:
+                    stale = sum(p._version for p in w.plist) != w.versions
+            if not stale:
+                return pw
+        plist = self._enumerate()
+        pw = PackedWeights(self.gh, self.predictor, self.suppressor, device)
+        pw.watch = ParamWatch(plist, device)
+        if pw.watch.table is not None:
+            pw.watch.sum = pw.watch.checksum_sync()
+        self._pw = pw
+        self.plan_epoch = getattr(self, "plan_epoch", 0) + 1      # cached launch plans hold pointers into the old copies
+        return pw
 
     def _table_slots(self, cap, need_relations):
         """Persistent pinned staging buffers for the TransH tables (a ring of 4): allocating pinned memory per call
@@ -361,7 +481,7 @@ class HeadEngine:
         return self._vt
 
     # ------------------------------------------------------------------------------------------ preprocess
-    def preprocess(self, detections, targets, append_gt, training):
+    def preprocess(self, detections, targets, append_gt, training, check_weights=False):
         """HEAD:92-151 for the whole batch.  One D2H copy (per-image counts)."""
         lib = _capi.lib()
         dev = detections[0]["boxes"].device if detections else torch.device("cuda")
@@ -389,7 +509,12 @@ class HeadEngine:
         det_off = torch.from_numpy(det_off_h).to(dev, non_blocking=True)
         ld = self.max_human + self.max_object
         index = torch.empty(B, max(ld, 1), dtype=torch.int32, device=dev)
-        count = torch.empty(B, 4, dtype=torch.int32, device=dev)
+        countx = torch.empty(4 * B + 4, dtype=torch.int32, device=dev)     # counts [B,4] | parameter checksum (u64) | pad
+        count = countx[:4 * B].view(B, 4)
+        watch = None
+        if check_weights and self._pw is not None and self._pw.device == dev and self._pw.watch.table is not None:
+            watch = self._pw.watch
+            watch.enqueue(countx.data_ptr() + 16 * B)                      # rides on the one D2H copy below
         prior_pow = 1.0 if training else 2.8                                    # HEAD:742
         if boxes.numel() == 0:
             boxes = torch.zeros(1, 4, device=dev); scores = torch.zeros(1, device=dev)
@@ -399,8 +524,14 @@ class HeadEngine:
                                            self.max_human, self.max_object, vt.nverbs.data_ptr(), vt.num_obj,
                                            prior_pow, index.data_ptr(), count.data_ptr(), _stream()),
                     "skg_preprocess_f32")
-        cnt = count.cpu().numpy()                                               # the one synchronisation point
+        cntx = countx.cpu().numpy()                                             # the one synchronisation point
+        cnt = cntx[:4 * B].reshape(B, 4)
+        if B and cnt[:, 0].min() < 0:
+            bad = int(np.argmax(cnt[:, 0] < 0))
+            raise _capi.SkgError("image %d has %d detections; the preprocess kernel takes at most %d per image"
+                                 % (bad, int(cnt[bad, 3]), _capi.MAX_DET_PER_IMAGE))
         pre = Preprocessed()
+        pre.wsum = int(cntx[4 * B:4 * B + 2].view(np.int64)[0]) if watch is not None else None
         pre.device = dev
         pre.B = B
         pre.n_h = cnt[:, 0].astype(np.int64); pre.n = cnt[:, 1].astype(np.int64); pre.L = cnt[:, 2].astype(np.int64)
@@ -425,12 +556,13 @@ class HeadEngine:
         return pw.splits if self.precision in ("fp16x2", "bf16") else _NullCtx()
 
     def graph(self, feat3, image_shapes, pooled, pre, training=False, tables=None, want_scores=False):
-        pw = self.weights(pre.device)                 # one parameter-version check per call (408 tensors)
+        pw = self.weights(pre.device, wsum=getattr(pre, "wsum", None))
         with self._split_ctx(pw):
             return self._graph(feat3, image_shapes, pooled, pre, training, tables, want_scores, pw)
 
-    def classify(self, pair_features):
-        pw = self.weights(pair_features.device)
+    def classify(self, pair_features, checked=False):
+        """checked=True: the caller's graph() pass of this same forward has validated the packed weights already."""
+        pw = self._pw if (checked and self._pw is not None) else self.weights(pair_features.device)
         with self._split_ctx(pw):
             return self._classify(pair_features, pw)
 
@@ -531,7 +663,7 @@ class HeadEngine:
                     self._chunk_phase_b(ctxs.pop(ci), t, pw, pre, enc, PF, sc, keep)
                     if tables is None:                  # staging slot is free again once its H2D copies are done
                         ev = torch.cuda.Event(); ev.record()
-                        drawer.slots[ci % len(drawer.slots)]["event"] = ev
+                        drawer.release(ci, ev)
                 if ci + lookahead < len(bounds):
                     phase_a(ci + lookahead)
             if ns > 1:

@@ -58,8 +58,13 @@ def dense_prior(vt, pair_scores_h, pair_scores_o, pair_cls, K, power):
     return prior
 
 
-def graph_train(eng, gh, feat3, image_shapes, pooled, pre, targets):
-    """Returns (the reference's 12 training lists, layout, packed extras)."""
+def graph_train(eng, gh, feat3, image_shapes, pooled, pre, targets, on_counts=None):
+    """Returns (the reference's 12 training lists, layout, packed extras).
+
+    on_counts(counts): called as soon as the labels and priors of the batch are known -- before any of the dense
+    layers is enqueued -- with an int64 device tensor {#positive scored cells, #positive pairs, #positive pairs}: the
+    loss normalisers of HEAD:162-165, 190-192, 219-221.  The head starts its one fused all-reduce there, so that the
+    exchange overlaps the GEMMs."""
     lib = _capi.lib()
     dev = pre.device
     K = gh.num_cls
@@ -77,6 +82,8 @@ def graph_train(eng, gh, feat3, image_shapes, pooled, pre, targets):
     enc = linear(linear(x0, gh.box_head[1].weight, gh.box_head[1].bias, True),
                  gh.box_head[3].weight, gh.box_head[3].bias, True)
     packed = None
+    if not A and on_counts is not None:
+        on_counts(torch.zeros(3, dtype=torch.int64, device=dev))
     if A:
         buf, offs = layout.pack_int_arrays(lay)
         ibuf = torch.from_numpy(buf).to(dev)
@@ -122,6 +129,16 @@ def graph_train(eng, gh, feat3, image_shapes, pooled, pre, targets):
         labels_all = labels_all[:Mp]
         n_pos = npos_d.cpu().tolist()
         ppi = [int(v) for v in lay.pairs_per_image]
+        # ---- per-pair detection attributes and priors for the whole batch
+        pair_img = torch.repeat_interleave(torch.arange(A, device=dev), torch.tensor(ppi, device=dev))
+        box_off = torch.from_numpy(lay.meta["box_off"].astype(np.int64)).to(dev)
+        bx_h = box_off[pair_img] + x_keep; bx_o = box_off[pair_img] + y_keep
+        boxes_h_all = pre.boxes[bx_h]; boxes_o_all = pre.boxes[bx_o]; obj_all = pre.labels[bx_o]
+        prior_all = dense_prior(eng.verbs(dev), pre.scores[bx_h], pre.scores[bx_o], obj_all, K,
+                                1.0 if gh.training else 2.8)
+        if on_counts is not None:
+            on_counts(torch.stack([((prior_all[0] != 0) & (labels_all != 0)).sum(),
+                                   (labels_all.sum(dim=1) != 0).sum(), (labels_all.sum(dim=1) != 0).sum()]))
         # ---- host RNG in the reference's order (per image: six TransH draws, HEAD:574-580, then randperm(#negatives),
         # HEAD:938-939).  randperm(n) consumes n-1 32-bit draws: the stream is advanced with a cheap random_() of that
         # length and the permutation itself is computed from the saved generator state by worker threads with private
@@ -179,13 +196,6 @@ def graph_train(eng, gh, feat3, image_shapes, pooled, pre, targets):
         G1 = linear(gfeat, g_w1, g_b1)
         att2 = linear(F.relu(G1[gi_l[pg_l]] * linear(S, g_w2, g_b2)[pg_l]), g_w3, g_b3, True)
         PF = torch.cat([att1, att2], dim=1)
-        # ---- per-pair detection attributes and priors for the whole batch
-        pair_img = torch.repeat_interleave(torch.arange(A, device=dev), torch.tensor(ppi, device=dev))
-        box_off = torch.from_numpy(lay.meta["box_off"].astype(np.int64)).to(dev)
-        bx_h = box_off[pair_img] + x_keep; bx_o = box_off[pair_img] + y_keep
-        boxes_h_all = pre.boxes[bx_h]; boxes_o_all = pre.boxes[bx_o]; obj_all = pre.labels[bx_o]
-        prior_all = dense_prior(eng.verbs(dev), pre.scores[bx_h], pre.scores[bx_o], obj_all, K,
-                                1.0 if gh.training else 2.8)
         # ---- positives / sampled negatives (HEAD:936-963), all images at once
         pos_p, pos_k = torch.nonzero(labels_all).unbind(1)                       # row-major == per-image order
         zero_p, zero_k = torch.nonzero(labels_all == 0).unbind(1)

@@ -102,6 +102,20 @@ def build_case(name):
     elif name == "full15x2":
         imgs = _grid_images([(17, 18), (15, 12)], 256, 7, 49, 80, 1100)      # default top-15 truncation active
         c.update(C=256, p=7, weight_seed=0)
+    elif name == "full20x3":
+        # three full-width images walked in two chunks (chunk_images = 2): the BASELINE graph shape across a chunk
+        # boundary, output-only fixture
+        imgs = _grid_images([(20, 20), (20, 20), (20, 20)], 256, 7, 49, 80, 1200)
+        c.update(C=256, p=7, max_human=20, max_object=20, weight_seed=0, chunk_images=2)
+    elif name == "many8":
+        # eight one-image chunks: more chunks than the ring of TransH staging buffers (4), drawn inline
+        imgs = _grid_images([(2, 3), (1, 2), (3, 1), (2, 2), (1, 4), (4, 2), (2, 1), (3, 3)], 8, 2, 49, 80, 1300)
+        c.update(chunk_images=1)
+    elif name == "many12":
+        # six two-image chunks drawn by the helper thread (more than INLINE_IMAGES images), ring wrap-around
+        imgs = _grid_images([(2, 3), (1, 2), (3, 1), (2, 2), (1, 4), (4, 2), (2, 1), (3, 3), (1, 1), (2, 4), (3, 2),
+                             (1, 3)], 8, 2, 49, 80, 1400)
+        c.update(chunk_images=2)
     elif name == "eval_targets":
         # eval mode WITH targets (validation): labels are associated and the sampling RNG is consumed (HEAD:933-963)
         imgs = _grid_images([(3, 4), (2, 3)], 8, 2, 49, 80, 700)
@@ -123,7 +137,8 @@ def build_case(name):
 
 
 EVAL_CASES = ["tiny", "ragged3", "skips_eval", "nanbox", "vcoco", "nms", "iter1", "iter0", "full20", "full15x2",
-              "eval_targets"]
+              "eval_targets", "full20x3", "many8", "many12"]
+OUTPUT_ONLY = ["full20", "full15x2", "full20x3", "many8", "many12"]      # fixtures without the bulky intermediates
 TRAIN_CASES = ["train_tiny", "train_skips"]
 RAISING_CASES = ["skips_raise"]
 ALL_CASES = EVAL_CASES + TRAIN_CASES

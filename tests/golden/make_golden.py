@@ -114,7 +114,7 @@ def main(names):
     for name in names:
         case = cases.build_case(name)
         flat = run_reference(case)
-        if name.startswith("full"):
+        if name in cases.OUTPUT_ONLY:
             # output-only fixture: drop the bulky intermediates, keep what pins the result
             keep = ("logits_p", "logits_s", "n_results", "n_tables")
             flat = {k: v for k, v in flat.items()

@@ -191,3 +191,71 @@ def test_state_dict_matches_reference_module():
     b = [(k, tuple(v.shape)) for k, v in head.state_dict().items()]
     assert a == b and len(a) == 408
     head.load_state_dict(ref.state_dict())
+
+
+class _FakeEvent:
+    def __init__(self):
+        self.synced = False
+
+    def synchronize(self):
+        self.synced = True
+
+
+@pytest.mark.parametrize("sizes", [[1] * 6, [1, 2, 1, 1, 2, 1], [2] * 6, [3, 1, 4, 1, 5, 2, 6, 1]])
+def test_table_drawer_ring_wraps_without_overwriting(sizes):
+    """More chunks than staging slots (ring of 4): a slot is redrawn only after the consumer released the chunk that
+    used it last.  Inline mode (<= 8 images) and the helper thread both hand out, for every chunk, the tables a plain
+    sequential draw gives (chunks 0 and 1 used to come back holding the tables of chunks 4 and 5)."""
+    from skghoi_amd import engine
+    K = 5
+    torch.manual_seed(77)
+    want = [tuple(t.clone() for t in transh.draw_batch(K, n, need_relations=True)) for n in sizes]
+    state_after = torch.get_rng_state()
+    cap = max(sizes)
+    slots = [dict(cap=cap, bufs=(torch.empty(cap, _capi.TRANSH_ENT, _capi.TRANSH_DIM),
+                                 torch.empty(cap, K, _capi.TRANSH_DIM), torch.empty(cap, K, _capi.TRANSH_DIM)),
+                  event=None) for _ in range(4)]
+    torch.manual_seed(77)
+    drawer = engine._TableDrawer(K, sizes, True, slots)
+    assert (drawer.thread is None) == (sum(sizes) <= engine._TableDrawer.INLINE_IMAGES)
+    events = []
+    try:
+        for i in range(len(sizes)):
+            got = drawer.get(i)
+            for g, w in zip(got, want[i]):
+                assert torch.equal(g, w), "chunk %d" % i          # still intact when the consumer reads it
+            ev = _FakeEvent(); events.append(ev)
+            drawer.release(i, ev)
+    finally:
+        drawer.join()
+    assert torch.equal(torch.get_rng_state(), state_after)
+    assert all(e.synced for e in events[:len(sizes) - 4])        # every reused slot waited for its previous reader
+
+
+def test_table_drawer_consumer_failure_does_not_hang():
+    from skghoi_amd import engine
+    K = 5
+    sizes = [3] * 8
+    slots = [dict(cap=3, bufs=(torch.empty(3, _capi.TRANSH_ENT, _capi.TRANSH_DIM), None, None), event=None)
+             for _ in range(4)]
+    drawer = engine._TableDrawer(K, sizes, False, slots)
+    drawer.get(0)                      # the consumer "fails" here: it never releases anything
+    drawer.join()                      # must return (the helper thread is parked on chunk 4's slot)
+    assert not drawer.thread.is_alive()
+
+
+def test_registration_epoch_tracks_parameter_and_module_replacement():
+    from skghoi_amd import engine
+    lin = torch.nn.Linear(4, 4)
+    e0 = engine._REG_EPOCH[0]
+    lin.weight = torch.nn.Parameter(torch.zeros(4, 4))
+    e1 = engine._REG_EPOCH[0]
+    assert e1 > e0
+    seq = torch.nn.Sequential(lin)
+    seq[0] = torch.nn.Linear(4, 4)
+    assert engine._REG_EPOCH[0] > e1
+    e2 = engine._REG_EPOCH[0]
+    with torch.no_grad():
+        lin.weight.mul_(2.0)           # in-place writes do not register anything (the device checksum sees those)
+    lin.weight.data.mul_(2.0)
+    assert engine._REG_EPOCH[0] == e2

@@ -15,6 +15,16 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def _fake_result(i):
+    """A result dict shaped like HEAD:317-322 with image-dependent ragged sizes (image 3 is empty)."""
+    P, L = (0, 0) if i == 3 else (2 + i % 3, 5 + 2 * i)
+    g = torch.Generator().manual_seed(100 + i)
+    return dict(boxes_h=torch.rand(P, 4, generator=g), boxes_o=torch.rand(P, 4, generator=g),
+                index=torch.randint(0, max(P, 1), (L,), generator=g), prediction=torch.randint(0, 117, (L,), generator=g),
+                scores=torch.rand(L, generator=g), object=torch.randint(0, 80, (P,), generator=g),
+                prior=torch.rand(2, L, generator=g), weights=torch.rand(P, generator=g))
+
+
 def _worker(rank, world, port, n_items, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -27,7 +37,24 @@ def _worker(rank, world, port, n_items, q):
     for v in (10 + rank, 3 + rank, 3 + rank):
         x = torch.as_tensor([v]); dist.barrier(); dist.all_reduce(x); ref.append((x / world).item())
     counts = skd.gather_counts(hi - lo)
-    q.put((rank, lo, hi, t, (a, b, c), tuple(ref), counts))
+    # the product path: async 3-element all-reduce, consumed as a tensor (no .item())
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda t_, *a_, **k_: (calls.append(t_.numel()), orig(t_, *a_, **k_))[1]
+    try:
+        h = skd.start_normalisers(torch.tensor([10 + rank, 3 + rank, 3 + rank]))
+        fused_async = tuple(h.get().tolist())
+    finally:
+        dist.all_reduce = orig
+    assert calls == [3] and h.get().dtype == torch.float32
+    # sharded inference: rank r holds the result dicts of items [lo, hi); every rank gets all of them back, in order
+    mine = [_fake_result(i) for i in range(lo, hi)]
+    allres = skd.gather_image_results(mine)
+    ok = len(allres) == n_items
+    for i, r in enumerate(allres):
+        w = _fake_result(i)
+        ok = ok and set(r) == set(w) and all(torch.equal(r[k], w[k]) and r[k].dtype == w[k].dtype for k in w)
+    q.put((rank, lo, hi, t, (a, b, c), tuple(ref), counts, fused_async, ok))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -46,7 +73,8 @@ def test_two_rank_gloo(n_items):
         p.join(timeout=60)
         assert p.exitcode == 0
     covered = []
-    for rank, lo, hi, t, fused, ref, counts in res:
+    for rank, lo, hi, t, fused, ref, counts, fused_async, gathered_ok in res:
+        assert fused_async == pytest.approx(ref) and gathered_ok
         covered += list(range(lo, hi))
         assert t == 2.0                                    # max over ranks of (1.0, 2.0)
         assert fused == pytest.approx(ref) and fused == pytest.approx((10.5, 3.5, 3.5))
@@ -59,3 +87,7 @@ def test_single_process_fallbacks():
     assert skd.max_over_ranks(0.25) == 0.25
     assert skd.fused_normalisers(4, 2, 2) == (4.0, 2.0, 2.0)
     assert [skd.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    h = skd.start_normalisers(torch.tensor([4, 2, 2]))
+    assert h.work is None and h.get().tolist() == [4.0, 2.0, 2.0]
+    res = [_fake_result(0), _fake_result(1)]
+    assert skd.gather_image_results(res) == res

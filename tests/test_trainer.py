@@ -69,11 +69,18 @@ def _ddp_worker(rank, world, port, q):
     from collections import OrderedDict
     feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
     torch.manual_seed(7 + rank)
-    losses, results = trainer.train_step(ddp, opt, feats, gpu_run.to_cuda(case["detections"]), case["shapes"],
-                                         targets=gpu_run.to_cuda(case["targets"]))
+    small = []                      # python-level collectives of the step (DDP's gradient buckets go through the C++ reducer)
+    orig_ar, orig_bar = dist.all_reduce, dist.barrier
+    dist.all_reduce = lambda t_, *a_, **k_: (small.append(("all_reduce", t_.numel())), orig_ar(t_, *a_, **k_))[1]
+    dist.barrier = lambda *a_, **k_: (small.append(("barrier", 0)), orig_bar(*a_, **k_))[1]
+    try:
+        losses, results = trainer.train_step(ddp, opt, feats, gpu_run.to_cuda(case["detections"]), case["shapes"],
+                                             targets=gpu_run.to_cuda(case["targets"]))
+    finally:
+        dist.all_reduce, dist.barrier = orig_ar, orig_bar
     torch.cuda.synchronize()
     vec = torch.cat([p.detach().flatten()[:64].cpu() for p in head.parameters()])
-    q.put((rank, losses, vec.numpy(), len(results)))
+    q.put((rank, losses, vec.numpy(), len(results), small))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -91,8 +98,10 @@ def test_two_rank_ddp_train_step_on_one_gpu():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (r0, l0, v0, n0), (r1, l1, v1, n1) = res
+    (r0, l0, v0, n0, c0), (r1, l1, v1, n1, c1) = res
     assert n0 == 1 and n1 == 1
+    # HEAD:167-172,194-199,223-228 are three barrier + 1-element all-reduce pairs; here: ONE 3-element all-reduce
+    assert c0 == [("all_reduce", 3)] and c1 == [("all_reduce", 3)], (c0, c1)
     for l in (l0, l1):
         assert all(np.isfinite(v) for v in l.values()) and set(l) == {"hoi_loss", "interactiveness_loss", "transH_loss"}
     assert np.array_equal(v0, v1)            # gradients were averaged: both replicas took the same step
