@@ -136,7 +136,7 @@ typedef struct {
     float*       dot_partial;          /* [skg_gemm_dot_partials(desc), M]: one partial per column slab of a wave    */
     /* SKG_EPI_BIAS_RES_RELU */
     const float* res; int64_t ldres;   /* [M, N]                                                                    */
-    /* split-K (BIAS / BIAS_RELU only): K is cut in split_k slices computed by separate workgroups; raw partial sums
+    /* split-K (BIAS / BIAS_RELU / BIAS_RES_RELU): K is cut in split_k slices computed by separate workgroups; raw partial sums
      * go to split_ws [split_k, M, N] and a second kernel adds them in slice order and applies the epilogue.          */
     int32_t split_k;                   /* 0 or 1 = off                                                              */
     float   w_scale;                   /* with w_split: 1 / scale given to skg_split_weights_f16x2 (a power of two)  */
@@ -169,6 +169,11 @@ int skg_gemm_dot_partials(const skg_gemm_desc* desc_host);
  * BIAS_RES_RELU / MUL_RELU / RELU_DOT are selected per descriptor at run time. */
 #define SKG_GEMM_GROUP_MAX 4
 int skg_gemm_group_f32(const skg_gemm_desc* descs_host, int n, void* stream);
+/* Tile scale the grouped launch of these descriptors will use: 2 = 128 x 128 tiles, 1 = 64 x 64 tiles (every member fits
+ * the DMA-staged loop -- K % 16 == 0, no row gather, no weight twin -- and the group is small: a few images).  With 64 x 64
+ * tiles a member may carry split_k > 1 (epilogues BIAS / BIAS_RELU / BIAS_RES_RELU): one more launch then reduces all
+ * split members in slice order.  SKG_EPI_RELU_DOT members write 2 * ceil(N / (64 * scale)) dot_partial slabs.       */
+int skg_gemm_group_tile(const skg_gemm_desc* descs_host, int n);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * fc_head / fc_tail input rows (HEAD:884-885): out[r] = [ enc[enc_row[r], 0:1024] | ent[ent_img[r], ent_row[r], 0:50]
@@ -225,13 +230,15 @@ int skg_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const flo
  *   verb_off[num_obj+1], verb_list[]: CSR of object_class_to_target_class, verbs ascending per class
  * Per active image, cells are emitted in nonzero(prior[0]) order (pair-major, verb ascending) at meta.out_off.
  *   out_index/out_pred int64 [L], out_scores f32 [L], out_prior f32 [2, L_total] (row 0 = human, row 1 = object),
- *   out_weights f32 [sumP], out_object int64 [sumP], out_boxes_h/out_boxes_o f32 [sumP,4]                          */
+ *   out_weights f32 [sumP], out_object int64 [sumP], out_boxes_h/out_boxes_o f32 [sumP,4]
+ *   L_total_dev (optional): device int32 holding L_total (values < 1 count as 1); when given it overrides the L_total
+ *   argument, so that a launch captured into a hipGraph can be replayed for batches with other cell counts.        */
 int skg_postprocess_f32(const float* logits, int64_t ld_logits, int K, const float* boxes, const float* scores,
                         const int64_t* labels, const skg_image_meta* meta, int n_active, const int64_t* x_keep,
                         const int64_t* y_keep, const int32_t* verb_off, const int32_t* verb_list, int num_obj_classes,
-                        float prior_pow, int64_t L_total, int64_t* out_index, int64_t* out_pred, float* out_scores,
-                        float* out_prior, float* out_weights, int64_t* out_object, float* out_boxes_h,
-                        float* out_boxes_o, void* stream);
+                        float prior_pow, int64_t L_total, const int32_t* L_total_dev, int64_t* out_index,
+                        int64_t* out_pred, float* out_scores, float* out_prior, float* out_weights,
+                        int64_t* out_object, float* out_boxes_h, float* out_boxes_o, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * HOST function (no GPU work): the TransH tables of `n_images` consecutive processed images, drawn from PyTorch's CPU
@@ -263,12 +270,50 @@ int skg_associate_f32(const float* boxes, const skg_image_meta* meta, int n_acti
                       const int32_t* gt_off, int K, float thresh, float* labels, int32_t* npos, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * fp32 MFMA GEMM with free operand layouts -- the dense products of the TRAINING step (forward on branch-major MBF
+ * weights, and the backward of every nn.Linear / MultiBranchFusion layer: autograd of HEAD:469-474, 509-527, 635-701,
+ * 410-411) without operand transposes:
+ *     C(m, n) (+)= mask( relu( sum_k A(m, k) B(k, n) + bias[n] ) )
+ *   A(m, k) = A[m * a_sm + k * a_sk]                       exactly one of a_sm, a_sk is 1
+ *   B(k, n) = B[koff(k) + noff(n)],  koff(k) = b_kshift ? (k >> b_kshift) * b_kstride + (k & (2^b_kshift - 1)) * b_sk
+ *                                                       : k * b_sk        (noff likewise with b_nshift / b_nstride / b_sn)
+ *             exactly one of b_sk, b_sn is 1; the power-of-two blocking addresses the branch-major storage of the 16
+ *             MBF fc_3 weights ([16][1024][64]: blocks of 64 along the contraction in the forward, along n in dX)
+ *   C(m, n) = C[(n >> c_nshift) * c_nstride + m * ldc + (n & (2^c_nshift - 1))]   (c_nshift = 0: C[m * ldc + n])
+ *   forward        y  = x W^T + b   : A = x (a_sk = 1),    B(k, n) = W[n][k]   (b_sk = 1, b_sn = ld)
+ *   input grad     dx = dz W        : A = dz (a_sk = 1),   B(k, n) = W[k][n]   (b_sn = 1, b_sk = ld), mask = x's ReLU
+ *   weight grad    dW = dz^T x      : A(m, k) = dz[k][m]   (a_sm = 1, a_sk = ld), B(k, n) = x[k][n] (b_sn = 1);
+ *                  a_rowsum[m] = sum_k A(m, k) is the bias gradient, formed on the way by the workgroups of column tile 0
+ *   mask (optional) [M, >= N], ldmask: the result is zeroed where mask <= 0 (ReLU of the layer that produced the input)
+ *   accumulate: add to C / a_rowsum instead of overwriting (weights shared by two call sites)
+ *   split_k > 1: slices of K by separate workgroups into split_ws (skg_gemmx_ws_floats(desc) floats), reduced in slice
+ *   order by a second launch that applies the epilogue.
+ * Up to SKG_GEMMX_GROUP_MAX independent products per call share ONE launch (plus one reduce launch if any is split). */
+typedef struct {
+    const float* A; int64_t a_sm, a_sk;
+    const float* B; int64_t b_sn, b_sk;
+    int32_t b_kshift, b_nshift; int64_t b_kstride, b_nstride;
+    float*  C; int64_t ldc; int32_t c_nshift, accumulate; int64_t c_nstride;
+    int32_t M, N, K, relu;
+    const float* bias;
+    const float* mask; int64_t ldmask;
+    float*  a_rowsum;
+    int32_t split_k, reserved;
+    float*  split_ws;
+} skg_gemmx_desc;
+#define SKG_GEMMX_GROUP_MAX 8
+int64_t skg_gemmx_ws_floats(const skg_gemmx_desc* desc_host);
+int skg_gemmx_f32(const skg_gemmx_desc* descs_host, int n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Order-independent 64-bit checksum of the live parameters (bit patterns weighted by position) over a table of
  * chunks: chunk c covers `count` fp32 words at `ptr` (16-byte aligned) whose first word has global index `first`.
  * The reference reads its nn.Linear / LayerNorm parameters afresh in every forward (HEAD:812-973, 410-411); the host
  * engine keeps re-laid copies and uses this sum -- enqueued ahead of the preprocess kernel and read back with its
  * counts -- to notice any in-place change, including writes that bypass autograd's version counters.  `out` (8-byte
- * aligned, device) is zeroed on the stream and then accumulated with one atomic per wave.                          */
+ * aligned, device) receives SKG_CHECKSUM_PARTIALS partial sums; the checksum is their sum modulo 2^64 (formed by the
+ * host: no atomics, fixed order).                                                                                   */
+#define SKG_CHECKSUM_PARTIALS 1024
 typedef struct {
     const void* ptr;
     uint32_t    count;     /* fp32 words in this chunk */

@@ -14,6 +14,7 @@ TRANSH_DIM = 50
 TRANSH_ENT = 80
 ABI_VERSION = 4
 GEMM_GROUP_MAX = 4
+CHECKSUM_PARTIALS = 1024
 
 _vp = C.c_void_p
 _i32 = C.c_int32
@@ -28,6 +29,18 @@ class GemmDesc(C.Structure):
                 ("P", _vp), ("p_idx", _vp), ("ldp", _i64), ("Q", _vp), ("q_idx", _vp), ("ldq", _i64),
                 ("mbias", _vp), ("C_raw", _vp), ("ldc_raw", _i64), ("dot_w", _vp), ("dot_partial", _vp),
                 ("res", _vp), ("ldres", _i64), ("split_k", _i32), ("w_scale", _f32), ("split_ws", _vp), ("w_split", _vp)]
+
+
+class GemmXDesc(C.Structure):
+    """Mirror of skg_gemmx_desc."""
+    _fields_ = [("A", _vp), ("a_sm", _i64), ("a_sk", _i64), ("B", _vp), ("b_sn", _i64), ("b_sk", _i64),
+                ("b_kshift", _i32), ("b_nshift", _i32), ("b_kstride", _i64), ("b_nstride", _i64),
+                ("C", _vp), ("ldc", _i64), ("c_nshift", _i32), ("accumulate", _i32), ("c_nstride", _i64),
+                ("M", _i32), ("N", _i32), ("K", _i32), ("relu", _i32), ("bias", _vp), ("mask", _vp), ("ldmask", _i64),
+                ("a_rowsum", _vp), ("split_k", _i32), ("reserved", _i32), ("split_ws", _vp)]
+
+
+GEMMX_GROUP_MAX = 8
 
 
 class GemmBf16Desc(C.Structure):
@@ -59,6 +72,9 @@ PROTOTYPES = {
     "skg_split_weights_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "skg_split_weights_f16x2": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _f32, _vp, _vp]),
     "skg_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
+    "skg_gemm_group_tile": (C.c_int, [C.POINTER(GemmDesc), C.c_int]),
+    "skg_gemmx_ws_floats": (C.c_int64, [C.POINTER(GemmXDesc)]),
+    "skg_gemmx_f32": (C.c_int, [C.POINTER(GemmXDesc), C.c_int, _vp]),
     "skg_gemm_bf16": (C.c_int, [C.POINTER(GemmBf16Desc), _vp]),
     "skg_transpose_bf16": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _vp, _i64, _vp]),
     "skg_transpose_f32": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _vp, _i64, _vp]),
@@ -69,7 +85,7 @@ PROTOTYPES = {
                                           _vp, _i64, C.c_int, _vp, _vp, _i64, _vp, _vp]),
     "skg_layernorm_f32": (C.c_int, [_vp, _i64, _vp, _vp, C.c_int, C.c_int, _f32, _vp, _i64, _vp]),
     "skg_postprocess_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int,
-                                      _f32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                      _f32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "skg_associate_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _f32, _vp, _vp, _vp]),
     "skg_transh_scores_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     "skg_param_checksum": (C.c_int, [_vp, C.c_int, _vp, _vp]),

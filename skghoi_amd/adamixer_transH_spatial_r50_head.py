@@ -347,7 +347,20 @@ class InteractionHead(Module):
             with torch.no_grad():
                 return self._forward_train(features, detections, image_shapes, targets, with_losses=False)
         eng = self.engine()
+        if eng.small_batch_max and len(detections) <= eng.small_batch_max:
+            # a few images (the reference evaluates ONE per forward, utils.py:166-167): replay the captured launch plan
+            # of this batch shape instead of ~40 individually enqueued kernels (skghoi_amd/small.py)
+            from skghoi_amd.small import SmallBatchRunner
+            if eng._small is None:
+                eng._small = SmallBatchRunner(eng)
+            if eng._small.eligible(self, detections, targets):
+                return eng._small.forward(self, features, detections, image_shapes)
         pre = eng.preprocess(detections, targets, False, False, check_weights=True)
+        return self._forward_eager(pre, features, image_shapes)
+
+    def _forward_eager(self, pre, features, image_shapes):
+        """Eval forward from packed detections on: every kernel enqueued individually, chunked over the batch."""
+        eng = self.engine()
         box_coords = list(pre.boxes.split(pre.sizes))
         box_features = self.box_roi_pool(features, box_coords, image_shapes)
         g = eng.graph(features["3"], image_shapes, box_features, pre, training=False)

@@ -707,17 +707,43 @@ __global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_group_split_kernel(con
     skg_gemm_tile<-1, 2, 2>(g.d[k], blockIdx.x - g.start[k], smem);
 }
 
-__global__ __launch_bounds__(256) void skg_splitk_reduce_kernel(const skg_gemm_desc d) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// ... with 64 x 64 tiles on the DMA-staged loop: the node-row GEMMs of a FEW images (M = sum n_h / sum n of one to a
+// handful of graphs) and the grid-row GEMMs of a single image.  A 128 x 128 block walking all of K alone on its CU takes
+// ~1.4 us per k-tile whatever M is (88 us at K = 1024: measured, 42 % of the batch-1 forward); four times the blocks,
+// plus split-K for the one-tile-high problems, put the whole chip on them.
+__global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_group_small_kernel(const skg_gemm_group_args g) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * 32 * 36];
+    int k = 0;
+#pragma unroll
+    for (int t = 1; t < SKG_GEMM_GROUP_MAX; ++t)
+        if (t < g.n && (int)blockIdx.x >= g.start[t]) k = t;
+    skg_gemm_tile<-1, 1, 1>(g.d[k], blockIdx.x - g.start[k], smem);
+}
+
+// Split-K reduction: adds the slices in slice order (deterministic) and applies the plain epilogues.
+__device__ __forceinline__ void skg_splitk_reduce_one(const skg_gemm_desc& d, int64_t i) {
     const int64_t total = (int64_t)d.M * d.N;
     if (i >= total) return;
     const int row = (int)(i / d.N), col = (int)(i % d.N);
     float v = 0.f;
     for (int s = 0; s < d.split_k; ++s) v += d.split_ws[(int64_t)s * total + i];
     if (d.bias) v += d.bias[col];
-    if (d.epilogue == SKG_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+    if (d.epilogue == SKG_EPI_BIAS_RELU || d.epilogue == SKG_EPI_BIAS_RES_RELU) v = fmaxf(v, 0.f);
+    if (d.epilogue == SKG_EPI_BIAS_RES_RELU) v += d.res[(int64_t)row * d.ldres + col];
     const int orow = d.out_rows ? d.out_rows[row] : row;
     if (orow >= 0) d.C[(int64_t)orow * d.ldc + col] = v;
+}
+
+__global__ __launch_bounds__(256) void skg_splitk_reduce_kernel(const skg_gemm_desc d) {
+    skg_splitk_reduce_one(d, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void skg_splitk_reduce_group_kernel(const skg_gemm_group_args g) {
+    int k = 0;
+#pragma unroll
+    for (int t = 1; t < SKG_GEMM_GROUP_MAX; ++t)
+        if (t < g.n && (int)blockIdx.x >= g.start[t]) k = t;
+    skg_splitk_reduce_one(g.d[k], (int64_t)(blockIdx.x - g.start[k]) * 256 + threadIdx.x);
 }
 
 // One thread per (row, k quad) of the padded weight: writes 2 x 8 bytes in the plane format of the MODE 2 loop.
@@ -769,7 +795,8 @@ static int skg_gemm_tile_scale(const skg_gemm_desc* d) {
                       (int64_t)BM * d->lda * 4 < 0xffffffffLL && (int64_t)BN * d->ldw * 4 < 0xffffffffLL;
     const int64_t tiles128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * (d->split_k > 1 ? d->split_k : 1);
     if (d->w_split && (d->K % 16) == 0 && d->w_scale > 0.f) return 2;
-    return (glds && tiles128 < 384) ? 1 : 2;
+    // M <= 64: a 128-row tile would spend half of its MFMAs on padding rows whatever the grid size (box_head at one image)
+    return (glds && (tiles128 < 384 || d->M <= 64)) ? 1 : 2;
 }
 
 extern "C" int skg_gemm_dot_partials(const skg_gemm_desc* dh) {
@@ -779,8 +806,8 @@ extern "C" int skg_gemm_dot_partials(const skg_gemm_desc* dh) {
 }
 
 static int skg_gemm_validate(const skg_gemm_desc& d) {
-    if (d.split_k > 1 && (!d.split_ws || (d.epilogue != SKG_EPI_BIAS && d.epilogue != SKG_EPI_BIAS_RELU) ||
-                          d.split_k > 64))
+    if (d.split_k > 1 && (!d.split_ws || (d.epilogue != SKG_EPI_BIAS && d.epilogue != SKG_EPI_BIAS_RELU &&
+                                          d.epilogue != SKG_EPI_BIAS_RES_RELU) || d.split_k > 64))
         return SKG_E_ARG;
     if (d.M < 0 || d.N <= 0 || d.K <= 0 || !d.A || !d.W) return SKG_E_ARG;
     if ((d.K & 3) || (d.lda & 3) || (d.ldw & 3)) return SKG_E_ALIGN;
@@ -800,29 +827,64 @@ static int skg_gemm_validate(const skg_gemm_desc& d) {
     return 0;
 }
 
+// 64 x 64 tiles for a whole group?  Every member must be able to take the DMA-staged loop, none may carry a weight twin,
+// and together they must be small (the same bound as a single launch: fewer than 384 tiles of 128 x 128).
+static bool skg_gemm_group_small(const skg_gemm_desc* descs, int n) {
+    int64_t tiles128 = 0;
+    for (int i = 0; i < n; ++i) {
+        const skg_gemm_desc& d = descs[i];
+        if (d.M == 0) continue;
+        const bool glds = SKG_USE_GLDS && BK == 16 && (d.K % BK) == 0 && !d.a_rows &&
+                          (int64_t)BM * d.lda * 4 < 0xffffffffLL && (int64_t)BN * d.ldw * 4 < 0xffffffffLL;
+        if (!glds || (d.w_split && d.w_scale > 0.f)) return false;
+        tiles128 += (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128);
+    }
+    return tiles128 < 384;
+}
+
+extern "C" int skg_gemm_group_tile(const skg_gemm_desc* descs_host, int n) {
+    if (!descs_host || n < 1 || n > SKG_GEMM_GROUP_MAX) return SKG_E_ARG;
+    return skg_gemm_group_small(descs_host, n) ? 1 : 2;
+}
+
 extern "C" int skg_gemm_group_f32(const skg_gemm_desc* descs_host, int n, void* stream) {
     if (!descs_host || n < 1 || n > SKG_GEMM_GROUP_MAX) return SKG_E_ARG;
-    skg_gemm_group_args g;
-    g.n = 0;
-    int blocks = 0;
+    skg_gemm_group_args g, r;
+    g.n = r.n = 0;
+    int64_t blocks = 0, rblocks = 0;
     bool split = true;
     for (int i = 0; i < n; ++i) {
         const int rc = skg_gemm_validate(descs_host[i]);
         if (rc) return rc;
-        if (descs_host[i].split_k > 1) return SKG_E_ARG;
-        if (descs_host[i].M == 0) continue;
-        split = split && descs_host[i].w_split && (descs_host[i].K % 16) == 0 && descs_host[i].w_scale > 0.f;
-        const int64_t nb = skg_gemm_blocks(descs_host[i].M, descs_host[i].N, descs_host[i].K, 2);
+    }
+    const bool small = skg_gemm_group_small(descs_host, n);
+    for (int i = 0; i < n; ++i) {
+        const skg_gemm_desc& d = descs_host[i];
+        if (d.split_k > 1 && !small) return SKG_E_ARG;                     // split-K only with the 64 x 64 tiles
+        if (d.M == 0) continue;
+        split = split && d.w_split && (d.K % 16) == 0 && d.w_scale > 0.f;
+        const int64_t nb = skg_gemm_blocks(d.M, d.N, d.K, small ? 1 : 2) * (d.split_k > 1 ? d.split_k : 1);
         if (blocks + nb > 0x7fffffffLL) return SKG_E_LIMIT;
-        g.d[g.n] = descs_host[i];
-        g.start[g.n] = blocks;
-        blocks += (int)nb;
+        g.d[g.n] = d;
+        g.start[g.n] = (int)blocks;
+        blocks += nb;
         ++g.n;
+        if (d.split_k > 1) {
+            r.d[r.n] = d;
+            r.start[r.n] = (int)rblocks;
+            rblocks += ((int64_t)d.M * d.N + 255) / 256;
+            ++r.n;
+        }
     }
     if (g.n == 0) return 0;
-    for (int i = g.n; i <= SKG_GEMM_GROUP_MAX; ++i) g.start[i] = blocks;
-    if (split) hipLaunchKernelGGL(skg_gemm_group_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(skg_gemm_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+    for (int i = g.n; i <= SKG_GEMM_GROUP_MAX; ++i) g.start[i] = (int)blocks;
+    if (small) hipLaunchKernelGGL(skg_gemm_group_small_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    else if (split) hipLaunchKernelGGL(skg_gemm_group_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(skg_gemm_group_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    if (r.n) {
+        for (int i = r.n; i <= SKG_GEMM_GROUP_MAX; ++i) r.start[i] = (int)rblocks;
+        hipLaunchKernelGGL(skg_splitk_reduce_group_kernel, dim3((unsigned)rblocks), dim3(256), 0, (hipStream_t)stream, r);
+    }
     return skg_launch_status();
 }
 

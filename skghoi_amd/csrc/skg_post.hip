@@ -13,12 +13,16 @@ __global__ __launch_bounds__(256) void skg_postprocess_kernel(
     const float* __restrict__ scores, const int64_t* __restrict__ labels, const skg_image_meta* __restrict__ meta,
     const int64_t* __restrict__ x_keep,
     const int64_t* __restrict__ y_keep, const int32_t* __restrict__ verb_off, const int32_t* __restrict__ verb_list,
-    int num_obj_classes, float prior_pow, int64_t L_total, int64_t* __restrict__ out_index,
+    int num_obj_classes, float prior_pow, int64_t L_total_arg, const int32_t* __restrict__ L_total_dev,
+    int64_t* __restrict__ out_index,
     int64_t* __restrict__ out_pred, float* __restrict__ out_scores, float* __restrict__ out_prior,
     float* __restrict__ out_weights, int64_t* __restrict__ out_object, float* __restrict__ out_boxes_h,
     float* __restrict__ out_boxes_o) {
     __shared__ int swave[4];
     __shared__ int sbase;
+    // stride between the two rows of out_prior: from device memory when the launch is replayed from a captured graph
+    // (the number of scored cells changes from call to call, the launch arguments cannot)
+    const int64_t L_total = L_total_dev ? (int64_t)max(*L_total_dev, 1) : L_total_arg;
     const int a = blockIdx.x;
     const skg_image_meta mt = meta[a];
     const int P = mt.n_h * (mt.n - 1);
@@ -82,9 +86,9 @@ extern "C" int skg_postprocess_f32(const float* logits, int64_t ld_logits, int K
                                    const float* scores, const int64_t* labels, const skg_image_meta* meta,
                                    int n_active, const int64_t* x_keep, const int64_t* y_keep,
                                    const int32_t* verb_off, const int32_t* verb_list, int num_obj_classes,
-                                   float prior_pow, int64_t L_total, int64_t* out_index, int64_t* out_pred,
-                                   float* out_scores, float* out_prior, float* out_weights, int64_t* out_object,
-                                   float* out_boxes_h, float* out_boxes_o, void* stream) {
+                                   float prior_pow, int64_t L_total, const int32_t* L_total_dev, int64_t* out_index,
+                                   int64_t* out_pred, float* out_scores, float* out_prior, float* out_weights,
+                                   int64_t* out_object, float* out_boxes_h, float* out_boxes_o, void* stream) {
     if (n_active < 0 || K <= 0 || ld_logits <= K || L_total < 0 || num_obj_classes <= 0) return SKG_E_ARG;
     if (n_active == 0) return 0;
     if (!logits || !boxes || !scores || !labels || !meta || !x_keep || !y_keep || !verb_off || !verb_list ||
@@ -94,7 +98,7 @@ extern "C" int skg_postprocess_f32(const float* logits, int64_t ld_logits, int K
     if (!skg_aligned16(boxes) || !skg_aligned16(out_boxes_h) || !skg_aligned16(out_boxes_o)) return SKG_E_ALIGN;
     hipLaunchKernelGGL(skg_postprocess_kernel, dim3(n_active), dim3(256), 0, (hipStream_t)stream, logits, ld_logits, K,
                        boxes, scores, labels, meta, x_keep, y_keep, verb_off, verb_list, num_obj_classes, prior_pow,
-                       L_total, out_index, out_pred, out_scores, out_prior, out_weights, out_object, out_boxes_h,
+                       L_total, L_total_dev, out_index, out_pred, out_scores, out_prior, out_weights, out_object, out_boxes_h,
                        out_boxes_o);
     return skg_launch_status();
 }

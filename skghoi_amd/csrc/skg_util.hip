@@ -12,26 +12,34 @@
 #define CK_THREADS 256
 
 __device__ __forceinline__ unsigned long long skg_ck_mix(uint32_t bits, uint32_t gidx) {
-    // position-dependent so that permuted or shifted contents change the sum; odd multiplier keeps it a bijection per slot
+    // position-dependent so that permuted or shifted contents change the sum; the odd 32-bit multiplier is a bijection per
+    // slot (one v_mul_lo_u32 + one v_mul_hi_u32)
     return (unsigned long long)(bits + 0x9E3779B9u * (gidx + 1u)) * (unsigned long long)(2u * gidx + 1u);
 }
 
+// Grid-stride over the chunk table: a fixed, small grid (SKG_CHECKSUM_PARTIALS blocks) so that the result is a short
+// array of per-block partial sums the host adds up -- no atomics (thousands of same-address atomics serialise in L2: the
+// first version of this kernel spent 100 us on them), no memset, and the order of the additions is fixed.
 __global__ __launch_bounds__(CK_THREADS) void skg_param_checksum_kernel(const skg_param_chunk* __restrict__ chunks,
+                                                                       int n_chunks,
                                                                        unsigned long long* __restrict__ out) {
-    const skg_param_chunk c = chunks[blockIdx.x];
-    const uint32_t* __restrict__ p = reinterpret_cast<const uint32_t*>(c.ptr);
-    const uint32_t n = c.count, g0 = c.first;
+    __shared__ unsigned long long sred[CK_THREADS / 64];
     unsigned long long acc = 0;
-    const uint32_t n4 = n >> 2;
-    const uint4* __restrict__ p4 = reinterpret_cast<const uint4*>(p);
-    for (uint32_t i = threadIdx.x; i < n4; i += CK_THREADS) {
-        const uint4 v = p4[i];
-        const uint32_t g = g0 + 4u * i;
-        acc += skg_ck_mix(v.x, g) + skg_ck_mix(v.y, g + 1u) + skg_ck_mix(v.z, g + 2u) + skg_ck_mix(v.w, g + 3u);
+    for (int ci = blockIdx.x; ci < n_chunks; ci += gridDim.x) {
+        const skg_param_chunk c = chunks[ci];
+        const uint32_t* __restrict__ p = reinterpret_cast<const uint32_t*>(c.ptr);
+        const uint32_t n = c.count, g0 = c.first;
+        const uint32_t n4 = n >> 2;
+        const uint4* __restrict__ p4 = reinterpret_cast<const uint4*>(p);
+#pragma unroll 4
+        for (uint32_t i = threadIdx.x; i < n4; i += CK_THREADS) {
+            const uint4 v = p4[i];
+            const uint32_t g = g0 + 4u * i;
+            acc += skg_ck_mix(v.x, g) + skg_ck_mix(v.y, g + 1u) + skg_ck_mix(v.z, g + 2u) + skg_ck_mix(v.w, g + 3u);
+        }
+        for (uint32_t i = 4u * n4 + threadIdx.x; i < n; i += CK_THREADS) acc += skg_ck_mix(p[i], g0 + i);
     }
-    for (uint32_t i = 4u * n4 + threadIdx.x; i < n; i += CK_THREADS) acc += skg_ck_mix(p[i], g0 + i);
     uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
-    // wave reduction of a 64-bit sum through two 32-bit lanes' worth of shuffles
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)hi, off, 64) << 32) |
@@ -39,16 +47,15 @@ __global__ __launch_bounds__(CK_THREADS) void skg_param_checksum_kernel(const sk
         acc += o;
         lo = (uint32_t)acc; hi = (uint32_t)(acc >> 32);
     }
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 
 extern "C" int skg_param_checksum(const skg_param_chunk* chunks, int n_chunks, uint64_t* out, void* stream) {
     if (n_chunks < 0 || !out || (n_chunks > 0 && !chunks)) return SKG_E_ARG;
     if ((((uintptr_t)out) & 7u) != 0) return SKG_E_ALIGN;
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(uint64_t), (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
-    if (n_chunks == 0) return 0;
-    hipLaunchKernelGGL(skg_param_checksum_kernel, dim3(n_chunks), dim3(CK_THREADS), 0, (hipStream_t)stream, chunks,
-                       reinterpret_cast<unsigned long long*>(out));
+    hipLaunchKernelGGL(skg_param_checksum_kernel, dim3(SKG_CHECKSUM_PARTIALS), dim3(CK_THREADS), 0, (hipStream_t)stream,
+                       chunks, n_chunks, reinterpret_cast<unsigned long long*>(out));
     return skg_launch_status();
 }

@@ -70,7 +70,7 @@ class ParamWatch:
     (`p.data.mul_(2)`) are seen too.  Parameters that are not contiguous fp32 on the engine's device fall back to
     the version counters."""
 
-    CHUNK_WORDS = 1 << 14
+    CHUNK_WORDS = 1 << 13
 
     def __init__(self, plist, device):
         self.plist = plist
@@ -93,16 +93,22 @@ class ParamWatch:
             arr = np.array(rows, dtype=_CHUNK_DTYPE)
             self.n_chunks = len(rows)
             self.table = torch.from_numpy(arr.view(np.uint8).copy()).to(device)
-            self._out = torch.zeros(1, dtype=torch.int64, device=device)
+            self._out = torch.zeros(_capi.CHECKSUM_PARTIALS, dtype=torch.int64, device=device)
 
     def enqueue(self, out_ptr):
-        """Checksum of the live parameters onto the current stream; 8 bytes at device address out_ptr."""
+        """Checksum of the live parameters onto the current stream: CHECKSUM_PARTIALS int64 partial sums at device
+        address out_ptr (their sum modulo 2^64 is the checksum, see fold())."""
         _capi.check(_capi.lib().skg_param_checksum(self.table.data_ptr(), self.n_chunks, out_ptr, _stream()),
                     "skg_param_checksum")
 
+    @staticmethod
+    def fold(partials):
+        """numpy int64 / uint64 partial sums -> the checksum (Python int, modulo 2^64)."""
+        return int(partials.view(np.uint64).sum(dtype=np.uint64))
+
     def checksum_sync(self):
         self.enqueue(self._out.data_ptr())
-        return int(self._out.item())
+        return self.fold(self._out.cpu().numpy())
 
 
 class PackedWeights:
@@ -253,6 +259,10 @@ def pick_split_k(M, N, K, target_blocks=1024):
     """Split-K factor for a plain layer whose M x N tile grid would leave most of the 256 CUs idle while each
     workgroup walks a long K (box_head: K = 12544).  Slices keep >= 16 k-tiles (256 k) each."""
     blocks = ((M + 127) // 128) * ((N + 127) // 128)
+    if M <= 64:
+        # one tile high: the launcher takes 64 x 64 tiles (skg_gemm_tile_scale); slices of >= 4 k-tiles
+        blocks = (N + 63) // 64
+        return int(max(1, min(-(-512 // blocks), K // 64, 32))) if K >= 512 else 1
     if blocks >= target_blocks or K < 2048:
         return 1
     return int(max(1, min(-(-target_blocks // blocks), K // 256, 64)))
@@ -283,19 +293,39 @@ def gemm(A, W, bias, C_out, M, N, K, epilogue, **kw):
         GEMM_TIMER.append((e0, e1, M, N, K, epilogue))
 
 
+SMALL_GROUP_BLOCKS = 512         # workgroups a small (64 x 64 tile) grouped launch aims for; split-K supplies them
+
+
 def gemm_group(specs):
-    """Independent small GEMMs in one launch: specs = [(args, kwargs), ...] as for gemm()."""
+    """Independent small GEMMs in one launch: specs = [(args, kwargs), ...] as for gemm().
+
+    When the launcher takes 64 x 64 tiles for the group (a few images, skg_gemm_group_tile) the members whose grid is
+    still tiny -- node-row GEMMs: M = a few dozen rows, N = K = 1024 is 16 workgroups walking 64 k-tiles each -- get
+    split-K slices (>= 4 k-tiles each) and a second launch reduces them in slice order."""
     n = len(specs)
     arr = (_capi.GemmDesc * n)()
     flops = 0.0
     for i, (a, kw) in enumerate(specs):
         gemm_desc(*a, d=arr[i], **kw)
         flops += 2.0 * a[4] * a[5] * a[6]
+    lib = _capi.lib()
+    if lib.skg_gemm_group_tile(arr, n) == 1:
+        tiles = [((d.M + 63) // 64) * ((d.N + 63) // 64) if d.M else 0 for d in arr]
+        total = sum(tiles)
+        keep = []
+        for d, t in zip(arr, tiles):
+            if t == 0 or d.split_k > 1 or d.epilogue not in (_capi.EPI_BIAS, _capi.EPI_BIAS_RELU, _capi.EPI_BIAS_RES_RELU):
+                continue
+            sk = min(-(-SMALL_GROUP_BLOCKS // max(total, 1)), d.K // 64, 64)
+            if sk > 1:
+                ws = torch.empty(sk * d.M * d.N, device=specs[0][0][0].device, dtype=torch.float32)
+                keep.append(ws)
+                d.split_k = sk; d.split_ws = ws.data_ptr()
     timed = GEMM_TIMER is not None and (GEMM_TIMER_EPI is None or 5 in GEMM_TIMER_EPI)
     if timed:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    _capi.check(_capi.lib().skg_gemm_group_f32(arr, n, _stream()), "skg_gemm_group_f32[%d]" % n)
+    _capi.check(lib.skg_gemm_group_f32(arr, n, _stream()), "skg_gemm_group_f32[%d]" % n)
     if timed:
         e1.record()
         GEMM_TIMER.append((e0, e1, int(flops // 2), 1, 1, 5))       # epilogue id 5 = grouped launch
@@ -423,6 +453,10 @@ class HeadEngine:
         self.precision = "fp32"     # "fp32": exact fp32 MFMA; "fp16x2" (opt-in): fp16 matrix pipe from 2-way operand splits
         self._pw = None
         self._vt = None
+        self._det_off_cache = {}
+        self.plan_epoch = 0
+        self.small_batch_max = 8    # eval batches of up to this many images replay a captured hipGraph (skghoi_amd/small.py); 0: off
+        self._small = None
         self.last = None          # intermediates of the last graph pass (parity tests read them)
 
     # ------------------------------------------------------------------------------------------ caches
@@ -458,7 +492,7 @@ class HeadEngine:
         if pw.watch.table is not None:
             pw.watch.sum = pw.watch.checksum_sync()
         self._pw = pw
-        self.plan_epoch = getattr(self, "plan_epoch", 0) + 1      # cached launch plans hold pointers into the old copies
+        self.plan_epoch += 1                          # cached launch plans hold pointers into the old copies
         return pw
 
     def _table_slots(self, cap, need_relations):
@@ -481,8 +515,23 @@ class HeadEngine:
         return self._vt
 
     # ------------------------------------------------------------------------------------------ preprocess
-    def preprocess(self, detections, targets, append_gt, training, check_weights=False):
-        """HEAD:92-151 for the whole batch.  One D2H copy (per-image counts)."""
+    def _det_offsets(self, sizes, dev):
+        """int32 prefix of the per-image detection counts on the device, cached by the count tuple (one H2D copy per
+        distinct tuple instead of one per forward)."""
+        key = (tuple(sizes), dev)
+        t = self._det_off_cache.get(key)
+        if t is None:
+            if len(self._det_off_cache) >= 4096:
+                self._det_off_cache.clear()
+            h = np.zeros(len(sizes) + 1, np.int32); h[1:] = np.cumsum(sizes)
+            t = torch.from_numpy(h).to(dev)
+            self._det_off_cache[key] = t
+        return t
+
+    def pre_launch(self, detections, targets, append_gt, training, check_weights=False):
+        """First half of preprocess: score filter + class-wise NMS + top-k on the device and the ONE host
+        synchronisation of a forward (per-image counts, plus the parameter checksum riding on the same copy).
+        Returns a Preprocessed holding the raw inputs, the selection and the counts; pre_pack() gathers."""
         lib = _capi.lib()
         dev = detections[0]["boxes"].device if detections else torch.device("cuda")
         if dev.type != "cuda":
@@ -502,15 +551,23 @@ class HeadEngine:
             sizes.append(int(boxes.shape[0]))
         if max(sizes, default=0) > _capi.MAX_DET_PER_IMAGE:
             raise _capi.SkgError("more than %d detections in one image" % _capi.MAX_DET_PER_IMAGE)
-        boxes = torch.cat(bl).float().contiguous() if B else torch.zeros(0, 4, device=dev)
-        scores = torch.cat(sl).float().contiguous() if B else torch.zeros(0, device=dev)
-        labels = torch.cat(ll).long().contiguous() if B else torch.zeros(0, dtype=torch.int64, device=dev)
-        det_off_h = np.zeros(B + 1, np.int32); det_off_h[1:] = np.cumsum(sizes)
-        det_off = torch.from_numpy(det_off_h).to(dev, non_blocking=True)
+        if B == 1:                                   # the reference's evaluation mode: nothing to concatenate
+            boxes, scores, labels = bl[0], sl[0], ll[0]
+            if boxes.dtype != torch.float32 or not boxes.is_contiguous():
+                boxes = boxes.float().contiguous()
+            if scores.dtype != torch.float32 or not scores.is_contiguous():
+                scores = scores.float().contiguous()
+            if labels.dtype != torch.int64 or not labels.is_contiguous():
+                labels = labels.long().contiguous()
+        else:
+            boxes = torch.cat(bl).float().contiguous() if B else torch.zeros(0, 4, device=dev)
+            scores = torch.cat(sl).float().contiguous() if B else torch.zeros(0, device=dev)
+            labels = torch.cat(ll).long().contiguous() if B else torch.zeros(0, dtype=torch.int64, device=dev)
+        det_off = self._det_offsets(sizes, dev)
         ld = self.max_human + self.max_object
         index = torch.empty(B, max(ld, 1), dtype=torch.int32, device=dev)
-        countx = torch.empty(4 * B + 4, dtype=torch.int32, device=dev)     # counts [B,4] | parameter checksum (u64) | pad
-        count = countx[:4 * B].view(B, 4)
+        # counts [B,4] | parameter checksum partials (u64 x CHECKSUM_PARTIALS): one buffer, one D2H copy
+        countx = torch.empty(4 * B + 2 * _capi.CHECKSUM_PARTIALS, dtype=torch.int32, device=dev)
         watch = None
         if check_weights and self._pw is not None and self._pw.device == dev and self._pw.watch.table is not None:
             watch = self._pw.watch
@@ -522,7 +579,7 @@ class HeadEngine:
         _capi.check(lib.skg_preprocess_f32(boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(), det_off.data_ptr(),
                                            B, self.human_idx, self.box_score_thresh, self.box_nms_thresh,
                                            self.max_human, self.max_object, vt.nverbs.data_ptr(), vt.num_obj,
-                                           prior_pow, index.data_ptr(), count.data_ptr(), _stream()),
+                                           prior_pow, index.data_ptr(), countx.data_ptr(), _stream()),
                     "skg_preprocess_f32")
         cntx = countx.cpu().numpy()                                             # the one synchronisation point
         cnt = cntx[:4 * B].reshape(B, 4)
@@ -531,25 +588,39 @@ class HeadEngine:
             raise _capi.SkgError("image %d has %d detections; the preprocess kernel takes at most %d per image"
                                  % (bad, int(cnt[bad, 3]), _capi.MAX_DET_PER_IMAGE))
         pre = Preprocessed()
-        pre.wsum = int(cntx[4 * B:4 * B + 2].view(np.int64)[0]) if watch is not None else None
+        pre.wsum = ParamWatch.fold(cntx[4 * B:].view(np.int64)) if watch is not None else None
         pre.device = dev
         pre.B = B
         pre.n_h = cnt[:, 0].astype(np.int64); pre.n = cnt[:, 1].astype(np.int64); pre.L = cnt[:, 2].astype(np.int64)
-        sel_off_h = np.zeros(B + 1, np.int32); sel_off_h[1:] = np.cumsum(pre.n)
-        total = int(sel_off_h[-1])
-        pre.boxes = torch.empty(max(total, 1), 4, device=dev)[:total]
-        pre.scores = torch.empty(max(total, 1), device=dev)[:total]
-        pre.labels = torch.empty(max(total, 1), dtype=torch.int64, device=dev)[:total]
-        pre.index = index
-        sel_off = torch.from_numpy(sel_off_h).to(dev, non_blocking=True)
-        if total:
-            _capi.check(lib.skg_pack_detections_f32(boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(),
-                                                    det_off.data_ptr(), index.data_ptr(), index.stride(0),
-                                                    sel_off.data_ptr(), B, pre.boxes.data_ptr(),
-                                                    pre.scores.data_ptr(), pre.labels.data_ptr(), _stream()),
-                        "skg_pack_detections_f32")
         pre.sizes = [int(v) for v in pre.n]
+        pre.index = index
+        pre.raw = (boxes, scores, labels, det_off)
         return pre
+
+    def pre_pack(self, pre, out=None, sel_off=None):
+        """Second half: gathers the selected detections, humans first (HEAD:144-149), into packed arrays -- fresh
+        ones, or `out` = (boxes [sumN,4], scores [sumN], labels [sumN] int64) with `sel_off` the device prefix of n."""
+        dev = pre.device
+        total = int(sum(pre.sizes))
+        if out is None:
+            pre.boxes = torch.empty(max(total, 1), 4, device=dev)[:total]
+            pre.scores = torch.empty(max(total, 1), device=dev)[:total]
+            pre.labels = torch.empty(max(total, 1), dtype=torch.int64, device=dev)[:total]
+        else:
+            pre.boxes, pre.scores, pre.labels = out
+        if sel_off is None:
+            sel_off = self._det_offsets(pre.sizes, dev)
+        boxes, scores, labels, det_off = pre.raw
+        if total:
+            _capi.check(_capi.lib().skg_pack_detections_f32(
+                boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(), det_off.data_ptr(), pre.index.data_ptr(),
+                pre.index.stride(0), sel_off.data_ptr(), pre.B, pre.boxes.data_ptr(), pre.scores.data_ptr(),
+                pre.labels.data_ptr(), _stream()), "skg_pack_detections_f32")
+        return pre
+
+    def preprocess(self, detections, targets, append_gt, training, check_weights=False):
+        """HEAD:92-151 for the whole batch.  One D2H copy (per-image counts)."""
+        return self.pre_pack(self.pre_launch(detections, targets, append_gt, training, check_weights))
 
     # ------------------------------------------------------------------------------------------ graph head
     def _split_ctx(self, pw):
@@ -683,9 +754,10 @@ class HeadEngine:
                 out[k] = torch.cat(v)
         return out
 
-    def _chunk_phase_a(self, ch, pw, pre, G1, x_keep, y_keep, PF):
+    def _chunk_phase_a(self, ch, pw, pre, G1, x_keep, y_keep, PF, ibuf=None, offs=None, meta=None):
         """Pairs, spatial encoding, spatial head and the global read-out branch of one chunk: everything that does not
-        depend on the TransH tables."""
+        depend on the TransH tables.  ibuf / offs / meta: index arrays already on the device (captured-graph path:
+        they are part of the launch plan, `meta` is its per-call record array)."""
         lib = _capi.lib()
         dev = pre.device
         st = _stream()
@@ -693,14 +765,16 @@ class HeadEngine:
         i32 = dict(device=dev, dtype=torch.int32)
         A = ch.n_active
         Mh, Mn, Mg, Mp = ch.sum_h, ch.sum_n, ch.sum_g, ch.sum_p
-        buf, offs = layout.pack_int_arrays(ch)
-        ibuf = torch.from_numpy(buf).to(dev, non_blocking=True)
+        if ibuf is None:
+            buf, offs = layout.pack_int_arrays(ch)
+            ibuf = torch.from_numpy(buf).to(dev, non_blocking=True)
 
         def isl(name):
             o, l = offs[name]
             return ibuf[o:o + l]
 
-        meta = isl("meta")
+        if meta is None:
+            meta = isl("meta")
         xk = x_keep[ch.P0:]; yk = y_keep[ch.P0:]               # global arrays, written at the chunk's pair offset
         # ---- pairs + spatial encoding (no dependence on the TransH tables: enqueued before they are drawn)
         grid_h = torch.empty(Mg, **i32); grid_o = torch.empty(Mg, **i32); grid_pair = torch.empty(Mg, **i32)
@@ -746,9 +820,7 @@ class HeadEngine:
         if gh.num_iter > 0:
             # ---- fc_head / fc_tail on unique rows (HEAD:884-885)
             X = torch.empty(Mh + Mn, 1088, **f32)
-            rows = torch.cat([isl("hum_enc_row"), isl("node_enc_row")])
-            eimg = torch.cat([isl("hum_img"), isl("node_img")])
-            erow = torch.cat([isl("hum_ent_row"), isl("node_ent_row")])
+            rows, eimg, erow = isl("enc_row_hn"), isl("img_hn"), isl("ent_row_hn")
             _capi.check(lib.skg_concat_entity_f32(enc.data_ptr(), 1024, rows.data_ptr(), ent_d.data_ptr(),
                                                   eimg.data_ptr(), erow.data_ptr(), Mh + Mn, X.data_ptr(), 1088, st),
                         "skg_concat_entity_f32")
@@ -838,14 +910,18 @@ class HeadEngine:
         logits = torch.empty(max(Mp, 1), ld, device=dev, dtype=torch.float32)
         if pw.fused_cls:
             if Mp:
-                gemm(pair_features, pw.cls_w, pw.cls_b, logits, Mp, self.K + 1, 2048, _capi.EPI_BIAS)
+                sk = pick_split_k(Mp, self.K + 1, 2048)          # a few images: 2 column tiles x K = 2048 would idle the chip
+                ws = torch.empty(sk, Mp, self.K + 1, device=dev, dtype=torch.float32) if sk > 1 else None
+                gemm(pair_features, pw.cls_w, pw.cls_b, logits, Mp, self.K + 1, 2048, _capi.EPI_BIAS, split_k=sk,
+                     split_ws=ws)
         else:                       # injected modules that are not plain Linear layers are honoured as given
             logits[:Mp, :self.K] = self.predictor(pair_features)
             logits[:Mp, self.K:self.K + 1] = self.suppressor(pair_features)
         return logits[:Mp]
 
-    def score(self, logits, pre, g, training):
-        """compute_prior_scores + postprocess (HEAD:721-767, 237-337) -> packed result tensors."""
+    def score(self, logits, pre, g, training, out=None, L_dev=None):
+        """compute_prior_scores + postprocess (HEAD:721-767, 237-337) -> packed result tensors.  out: pre-allocated
+        result arrays; L_dev: device int32 with the total number of scored cells (captured-graph path)."""
         lib = _capi.lib()
         lay = g["layout"]
         dev = pre.device
@@ -853,16 +929,17 @@ class HeadEngine:
         Mp, Lt = lay.sum_p, lay.sum_l
         i64 = dict(device=dev, dtype=torch.int64)
         f32 = dict(device=dev, dtype=torch.float32)
-        r = dict(index=torch.empty(max(Lt, 1), **i64), prediction=torch.empty(max(Lt, 1), **i64),
-                 scores=torch.empty(max(Lt, 1), **f32), prior=torch.empty(2, max(Lt, 1), **f32),
-                 weights=torch.empty(max(Mp, 1), **f32), object=torch.empty(max(Mp, 1), **i64),
-                 boxes_h=torch.empty(max(Mp, 1), 4, **f32), boxes_o=torch.empty(max(Mp, 1), 4, **f32))
+        r = out if out is not None else dict(
+            index=torch.empty(max(Lt, 1), **i64), prediction=torch.empty(max(Lt, 1), **i64),
+            scores=torch.empty(max(Lt, 1), **f32), prior=torch.empty(2, max(Lt, 1), **f32),
+            weights=torch.empty(max(Mp, 1), **f32), object=torch.empty(max(Mp, 1), **i64),
+            boxes_h=torch.empty(max(Mp, 1), 4, **f32), boxes_o=torch.empty(max(Mp, 1), 4, **f32))
         if lay.n_active and Mp:
             _capi.check(lib.skg_postprocess_f32(
                 logits.data_ptr(), logits.stride(0), self.K, pre.boxes.data_ptr(), pre.scores.data_ptr(),
                 pre.labels.data_ptr(), g["meta"].data_ptr(), lay.n_active, g["x_keep"].data_ptr(),
                 g["y_keep"].data_ptr(), vt.off.data_ptr(), vt.flat.data_ptr(), vt.num_obj,
-                1.0 if training else 2.8, max(Lt, 1), r["index"].data_ptr(), r["prediction"].data_ptr(),
+                1.0 if training else 2.8, max(Lt, 1), _ptr(L_dev), r["index"].data_ptr(), r["prediction"].data_ptr(),
                 r["scores"].data_ptr(), r["prior"].data_ptr(), r["weights"].data_ptr(), r["object"].data_ptr(),
                 r["boxes_h"].data_ptr(), r["boxes_o"].data_ptr(), _stream()), "skg_postprocess_f32")
         return r

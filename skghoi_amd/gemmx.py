@@ -1,0 +1,124 @@
+"""Python face of skg_gemmx_f32 (include/skghoi.h): the free-layout fp32 MFMA GEMM of the training step.
+
+    C(m, n) (+)= mask(relu(sum_k A(m, k) B(k, n) + bias[n]))
+
+Operands are described by `Op` records (pointer + strides + optional power-of-two blocking), built from torch tensors by
+the helpers below; `launch([...])` enqueues up to GEMMX_GROUP_MAX independent products in one launch (dX and dW of a
+layer, the node-row GEMMs of a graph) and picks split-K factors for long contractions with small outputs.
+Replaces the autograd of every nn.Linear / MultiBranchFusion on the path (heads/adamixer_transH_spatial_r50_head.py:
+469-474, 509-527, 635-701) without the operand transposes a k-contiguous-only kernel needs.
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi
+from .engine import _stream
+
+TARGET_BLOCKS = 512
+
+
+class Op:
+    """One product.  Set fields directly or through the constructors below."""
+    __slots__ = ("A", "a_sm", "a_sk", "B", "b_sn", "b_sk", "b_kshift", "b_kstride", "b_nshift", "b_nstride", "C", "ldc",
+                 "c_nshift", "c_nstride", "M", "N", "K", "bias", "relu", "mask", "ldmask", "accumulate", "a_rowsum",
+                 "split_k", "keep")
+
+    def __init__(self, **kw):
+        self.b_kshift = self.b_nshift = self.c_nshift = 0
+        self.b_kstride = self.b_nstride = self.c_nstride = 0
+        self.bias = self.mask = self.a_rowsum = None
+        self.ldmask = 0
+        self.relu = self.accumulate = False
+        self.split_k = 0                       # 0: chosen by launch()
+        self.keep = []
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def forward(x, W, out, bias=None, relu=False, M=None, K=None, w_blocks=None):
+    """out[M, N] = act(x[M, K] W[N, K]^T + bias).  w_blocks = (log2 block, block stride): W stored branch-major,
+    [K / block][N][block] (the 16 fc_3 weights of an MBF, block 64)."""
+    M = x.shape[0] if M is None else M
+    K = x.shape[1] if K is None else K
+    N = out.shape[1]
+    op = Op(A=x.data_ptr(), a_sm=x.stride(0), a_sk=1, B=W.data_ptr(), b_sk=1, C=out.data_ptr(), ldc=out.stride(0), M=M, N=N,
+            K=K, bias=bias, relu=relu)
+    if w_blocks is None:
+        op.b_sn = W.stride(0)
+    else:
+        op.b_kshift, op.b_kstride = w_blocks
+        op.b_sn = 1 << op.b_kshift
+    op.keep = [x, W, out, bias]
+    return op
+
+
+def input_grad(dz, W, dx, mask=None, accumulate=False, M=None, N_in=None, w_blocks=None):
+    """dx[M, K_in] (+)= (dz[M, N_out] W[N_out, K_in]) * (mask > 0).  w_blocks as in forward()."""
+    M = dz.shape[0] if M is None else M
+    n_out = dz.shape[1]
+    k_in = dx.shape[1] if N_in is None else N_in
+    op = Op(A=dz.data_ptr(), a_sm=dz.stride(0), a_sk=1, B=W.data_ptr(), b_sn=1, C=dx.data_ptr(), ldc=dx.stride(0), M=M,
+            N=k_in, K=n_out, mask=mask, ldmask=(mask.stride(0) if mask is not None else 0), accumulate=accumulate)
+    if w_blocks is None:
+        op.b_sk = W.stride(0)                  # B(k = out index, n = in index) = W[k][n]
+    else:
+        op.b_nshift, op.b_nstride = w_blocks   # W[(n >> s)][k][n & mask]: blocked along the in index
+        op.b_sk = 1 << op.b_nshift
+    op.keep = [dz, W, dx, mask]
+    return op
+
+
+def weight_grad(dz, x, dW, db=None, accumulate=False, rows=None, n_out=None, k_in=None, w_blocks=None):
+    """dW[N_out, K_in] (+)= dz[rows, N_out]^T x[rows, K_in];  db[N_out] (+)= column sums of dz.  w_blocks: dW stored
+    branch-major like the weight."""
+    rows = dz.shape[0] if rows is None else rows
+    n_out = dz.shape[1] if n_out is None else n_out
+    k_in = x.shape[1] if k_in is None else k_in
+    op = Op(A=dz.data_ptr(), a_sm=1, a_sk=dz.stride(0), B=x.data_ptr(), b_sn=1, b_sk=x.stride(0), C=dW.data_ptr(), M=n_out,
+            N=k_in, K=rows, a_rowsum=db, accumulate=accumulate)
+    if w_blocks is None:
+        op.ldc = dW.stride(0)
+    else:
+        op.c_nshift, op.c_nstride = w_blocks
+        op.ldc = 1 << op.c_nshift
+    op.keep = [dz, x, dW, db]
+    return op
+
+
+def pick_split(op, blocks_so_far=0, target=TARGET_BLOCKS):
+    tiles = ((op.M + 127) // 128) * ((op.N + 127) // 128)
+    kt = (op.K + 15) // 16
+    if tiles == 0 or tiles >= target // 2 or kt < 8:
+        return 1
+    return int(max(1, min(-(-target // tiles), kt // 4, 64)))
+
+
+def launch(ops):
+    """Enqueues the products (one launch, plus one reduce launch when any of them is split along K)."""
+    lib = _capi.lib()
+    ops = [o for o in ops if o.M > 0 and o.N > 0]
+    for i0 in range(0, len(ops), _capi.GEMMX_GROUP_MAX):
+        chunk = ops[i0:i0 + _capi.GEMMX_GROUP_MAX]
+        arr = (_capi.GemmXDesc * len(chunk))()
+        keep = []
+        for d, o in zip(arr, chunk):
+            d.A, d.a_sm, d.a_sk = o.A, o.a_sm, o.a_sk
+            d.B, d.b_sn, d.b_sk = o.B, o.b_sn, o.b_sk
+            d.b_kshift, d.b_nshift, d.b_kstride, d.b_nstride = o.b_kshift, o.b_nshift, o.b_kstride, o.b_nstride
+            d.C, d.ldc, d.c_nshift, d.c_nstride = o.C, o.ldc, o.c_nshift, o.c_nstride
+            d.accumulate = int(bool(o.accumulate))
+            d.M, d.N, d.K, d.relu = o.M, o.N, o.K, int(bool(o.relu))
+            d.bias = _p(o.bias); d.mask = _p(o.mask); d.ldmask = o.ldmask; d.a_rowsum = _p(o.a_rowsum)
+            sk = o.split_k or pick_split(o)
+            d.split_k = sk if sk > 1 else 0
+            if sk > 1:
+                dev = o.keep[0].device if o.keep else torch.device("cuda")
+                ws = torch.empty(sk * (o.M * o.N + o.M), device=dev, dtype=torch.float32)
+                keep.append(ws)
+                d.split_ws = ws.data_ptr()
+        _capi.check(lib.skg_gemmx_f32(arr, len(chunk), _stream()), "skg_gemmx_f32[%d]" % len(chunk))

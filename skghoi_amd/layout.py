@@ -115,9 +115,14 @@ def chunk(lay, a0, a1):
 
 def pack_int_arrays(lay):
     """One contiguous int32 host buffer (single H2D copy) + the slices of each array inside it."""
+    # `*_hn` = [human rows | node rows]: the row tables of the fc_head | fc_tail input gather (HEAD:884-885), laid out
+    # back to back so that one slice serves the kernel (no device-side concatenation)
     parts = [("meta", lay.meta.view(np.int32).reshape(-1)), ("node_img", lay.node_img), ("hum_img", lay.hum_img),
              ("node_enc_row", lay.node_enc_row), ("hum_enc_row", lay.hum_enc_row),
-             ("node_ent_row", lay.node_ent_row), ("hum_ent_row", lay.hum_ent_row)]
+             ("node_ent_row", lay.node_ent_row), ("hum_ent_row", lay.hum_ent_row),
+             ("enc_row_hn", np.concatenate([lay.hum_enc_row, lay.node_enc_row])),
+             ("img_hn", np.concatenate([lay.hum_img, lay.node_img])),
+             ("ent_row_hn", np.concatenate([lay.hum_ent_row, lay.node_ent_row]))]
     offs = {}
     cur = 0
     for k, v in parts:

@@ -1,0 +1,250 @@
+"""Small-batch inference: the eval forward replayed from a captured hipGraph.
+
+The reference evaluates ONE image per forward (utils.py:166-167 asserts it).  At that size the head is launch-bound:
+~40 kernels of a few microseconds each, every one paying Python + ctypes + allocator time on the host.  Here the part of
+the forward whose launch sequence depends only on the batch's SHAPE -- (humans, nodes) per image -- is captured once
+per shape into a hipGraph (torch.cuda.CUDAGraph) and replayed:
+
+    per call (eager, ~6 launches):  preprocess/NMS  -> [the one D2H of the counts] -> plan lookup by shape
+                                    -> one H2D of the per-call records (image meta, cell count, TransH entity tables,
+                                       drawn straight into the pinned staging buffer with the reference's RNG stream)
+                                    -> pack detections into the plan's static buffers -> box_roi_pool (caller's module)
+                                    -> global average pool + box_head layer 1 (they read caller-owned tensors)
+    graph replay (~25 kernels):     box_head layer 2, pairs + spatial encoding, spatial head, the MBF GEMMs, softmax
+                                    aggregation, LayerNorms, read-out, classifier, prior + scoring + compaction
+    per call:                       one copy of the result arena out of the plan's static output buffer
+
+Everything inside the graph is the same kernel sequence the eager path enqueues for a single chunk (HeadEngine.
+_chunk_phase_a / _chunk_phase_b / _classify / score), so results are bit-identical to it.  What varies between calls of
+the same shape never enters a launch argument: image sizes and result offsets travel in the device-side meta records,
+the number of scored cells in a device word (skg_postprocess_f32's L_total_dev).
+
+Reference path replaced: heads/adamixer_transH_spatial_r50_head.py:341-429 (InteractionHead.forward, eval mode).
+"""
+import copy
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _capi, layout, transh
+from .engine import Preprocessed, gemm, gemm_group, pick_split_k, _stream
+
+META_WORDS = layout.META_DTYPE.itemsize // 4
+
+
+class _Plan:
+    pass
+
+
+class SmallBatchRunner:
+    """Owns the captured plans of one HeadEngine (LRU by shape key)."""
+
+    def __init__(self, engine, max_plans=128):
+        self.eng = engine
+        self.max_plans = max_plans
+        self.plans = OrderedDict()
+        self.pool = None                   # graph memory pool shared by the plans (one forward at a time per engine)
+        self.hits = self.misses = 0
+        self.epoch = engine.plan_epoch
+
+    # ------------------------------------------------------------------------------------------------ plan
+    def _build_plan(self, key, pre, lay, pw, feat3, pooled):
+        eng = self.eng
+        dev = pre.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        p = _Plan()
+        p.key = key
+        p.pw = pw
+        p.lay = lay
+        A = lay.n_active
+        NA = lay.sum_all
+        K = eng.K
+        p.ch = layout.chunk(lay, 0, A)
+        buf, p.offs = layout.pack_int_arrays(p.ch)
+        p.ibuf = torch.from_numpy(buf).to(dev)
+        # per-call records: [meta A x 12 words | L_total, pad x3 | ent A x 80 x 50 floats], one pinned block, one H2D
+        n_meta = A * META_WORDS
+        words = n_meta + 4 + A * _capi.TRANSH_ENT * _capi.TRANSH_DIM
+        p.dyn_host = torch.empty(words, dtype=torch.int32, pin_memory=True)
+        p.dyn_dev = torch.empty(words, dtype=torch.int32, device=dev)
+        p.meta_host = p.dyn_host[:n_meta].numpy().view(layout.META_DTYPE)
+        p.lt_host = p.dyn_host[n_meta:n_meta + 4].numpy()
+        p.ent_host = p.dyn_host[n_meta + 4:].view(torch.float32).view(A, _capi.TRANSH_ENT, _capi.TRANSH_DIM)
+        p.meta_dev = p.dyn_dev[:n_meta]
+        p.lt_dev = p.dyn_dev[n_meta:n_meta + 4]
+        p.ent_dev = p.dyn_dev[n_meta + 4:].view(torch.float32).view(A, _capi.TRANSH_ENT, _capi.TRANSH_DIM)
+        p.h2d_done = None
+        # static inputs of the graph
+        p.boxes = torch.zeros(max(NA, 1), 4, **f32)[:NA]
+        p.scores = torch.zeros(max(NA, 1), **f32)[:NA]
+        p.labels = torch.zeros(max(NA, 1), dtype=torch.int64, device=dev)[:NA]
+        p.sel_off = eng._det_offsets(pre.sizes, dev)
+        p.gfeat = torch.zeros(feat3.shape[0], feat3.shape[1], **f32)
+        p.enc1 = torch.zeros(max(NA, 1), 1024, **f32)
+        kp = pw.bh1_w.shape[1]
+        p.x0_pad = torch.zeros(NA, kp, **f32) if pooled[0].numel() != kp else None
+        p.sk = pick_split_k(NA, 1024, kp)
+        p.ws = torch.empty(p.sk, NA, 1024, **f32) if p.sk > 1 else None
+        p.pre = Preprocessed()
+        p.pre.device = dev; p.pre.B = pre.B
+        p.pre.boxes, p.pre.scores, p.pre.labels = p.boxes, p.scores, p.labels
+        # static outputs: one byte arena [index | prediction | object | scores | prior (2 rows) | weights | boxes_h | boxes_o]
+        Mp = lay.sum_p
+        Lmax = (max(Mp * K, 1) + 3) // 4 * 4        # region sizes in multiples of 4 words: every array stays 16-byte aligned
+        Mq = (max(Mp, 1) + 3) // 4 * 4
+        p.Mp, p.Lmax, p.Mq = Mp, Lmax, Mq
+        n_i64 = 2 * Lmax + Mq
+        n_f32 = 3 * Lmax + Mq + 8 * Mq
+        p.arena = torch.zeros(8 * n_i64 + 4 * n_f32, dtype=torch.uint8, device=dev)
+        p.n_i64 = n_i64
+        i64 = p.arena[:8 * n_i64].view(torch.int64)
+        f = p.arena[8 * n_i64:].view(torch.float32)
+        p.r = dict(index=i64[:Lmax], prediction=i64[Lmax:2 * Lmax], object=i64[2 * Lmax:],
+                   scores=f[:Lmax], prior=f[Lmax:3 * Lmax], weights=f[3 * Lmax:3 * Lmax + Mq],
+                   boxes_h=f[3 * Lmax + Mq:3 * Lmax + 5 * Mq].view(Mq, 4), boxes_o=f[3 * Lmax + 5 * Mq:].view(Mq, 4))
+        p.graph = None
+        p.out = None
+        return p
+
+    def _body(self, p):
+        """The shape-dependent part of the forward (HEAD:812-982, 408-411, 237-337) for a single chunk."""
+        eng, pw, lay = self.eng, p.pw, p.lay
+        dev = p.pre.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        NA, Mp = lay.sum_all, lay.sum_p
+        with eng._split_ctx(pw):
+            enc = torch.empty(max(NA, 1), 1024, **f32)
+            Bf, Cf = p.gfeat.shape
+            G1 = torch.empty(Bf, 1024, **f32)
+            # box_head layer 2 (HEAD:812) and attention_head_g's fc_1 on the global features (HEAD:971): independent
+            gemm_group([((p.enc1, pw.bh3_w, pw.bh3_b, enc, NA, 1024, 1024, _capi.EPI_BIAS_RELU), {}),
+                        ((p.gfeat, pw.att_g["w1"], pw.att_g["b1"], G1, Bf, 1024, Cf, _capi.EPI_BIAS), {})])
+            x_keep = torch.empty(max(Mp, 1), device=dev, dtype=torch.int64); y_keep = torch.empty_like(x_keep)
+            PF = torch.empty(max(Mp, 1), 2048, **f32)
+            cx = eng._chunk_phase_a(p.ch, pw, p.pre, G1, x_keep, y_keep, PF, ibuf=p.ibuf, offs=p.offs, meta=p.meta_dev)
+            eng._chunk_phase_b(cx, (p.ent_dev, None, None), pw, p.pre, enc, PF, None, None)
+            logits = eng._classify(PF[:Mp], pw)
+            g = dict(layout=lay, meta=p.meta_dev, x_keep=x_keep[:Mp], y_keep=y_keep[:Mp])
+            eng.score(logits, p.pre, g, False, out=p.r, L_dev=p.lt_dev)
+        return dict(logits=logits, pair_features=PF[:Mp], x_keep=x_keep[:Mp], y_keep=y_keep[:Mp], enc=enc)
+
+    def _capture(self, p):
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        p.out = self._body(p)                      # eager once: first-use work (weight twins, lazy module init) happens here
+        torch.cuda.current_stream().synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
+            p.out = self._body(p)
+        p.graph = g
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def eligible(self, head, detections, targets):
+        eng = self.eng
+        return (not head.training and targets is None and 0 < len(detections) <= eng.small_batch_max
+                and not eng.debug)
+
+    def forward(self, head, features, detections, image_shapes):
+        """Returns the list of result dicts, or None when this batch has to take the eager path."""
+        eng = self.eng
+        pre = eng.pre_launch(detections, None, False, False, check_weights=True)
+        dev = pre.device
+        pw = eng.weights(dev, wsum=pre.wsum, walk=False)
+        if not pw.fused_cls:
+            return self._fallback(head, pre, features, image_shapes)
+        if self.epoch != eng.plan_epoch:           # the packed weights were rebuilt: every plan points into the old copies
+            self.plans.clear()
+            self.epoch = eng.plan_epoch
+        feat3 = features["3"]
+        key = (tuple(pre.n_h.tolist()), tuple(pre.n.tolist()), tuple(feat3.shape[:2]), eng.precision,
+               eng.gh.num_iter, eng.faithful_skip_offset, eng.plan_epoch, dev.index)
+        p = self.plans.get(key)
+        if p is None:
+            lay = layout.build(pre.n_h, pre.n, pre.L, image_shapes, eng.human_idx,
+                               faithful_skip_offset=eng.faithful_skip_offset)
+            if lay.n_active == 0 or lay.n_visit == 0 or lay.sum_p == 0:
+                return self._fallback(head, pre, features, image_shapes)
+        else:
+            lay = p.lay
+        # ---- static inputs of this call
+        new = p is None
+        if new:
+            self.misses += 1
+            eng.pre_pack(pre)
+            box_coords = list(pre.boxes.split(pre.sizes))
+            pooled = head.box_roi_pool(features, box_coords, image_shapes)
+            if pooled.shape[0] != lay.sum_all:
+                raise _capi.SkgError("box_roi_pool returned %d rows for %d boxes" % (pooled.shape[0], lay.sum_all))
+            if pooled[0].numel() != pw.bh1_k:
+                raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)" % (
+                    pooled.shape[0], pooled[0].numel(), pw.bh1_k, 1024))
+            p = self._build_plan(key, pre, lay, pw, feat3, pooled)
+            p.boxes.copy_(pre.boxes); p.scores.copy_(pre.scores); p.labels.copy_(pre.labels)
+            while len(self.plans) >= self.max_plans:
+                self.plans.popitem(last=False)
+            self.plans[key] = p
+        else:
+            self.hits += 1
+            self.plans.move_to_end(key)
+            eng.pre_pack(pre, out=(p.boxes, p.scores, p.labels), sel_off=p.sel_off)
+            pooled = head.box_roi_pool(features, list(p.boxes.split(pre.sizes)), image_shapes)
+            if pooled.shape[0] != lay.sum_all:
+                raise _capi.SkgError("box_roi_pool returned %d rows for %d boxes" % (pooled.shape[0], lay.sum_all))
+        # per-call records: meta (image sizes, result offsets), cell count, TransH entity tables
+        if p.h2d_done is not None:
+            p.h2d_done.synchronize()               # the staging block's previous copy (normally long finished)
+        act = lay.active
+        L = pre.L[act]
+        m = p.meta_host
+        m[:] = lay.meta
+        m["out_off"] = np.cumsum(L) - L
+        m["img_h"] = [float(image_shapes[int(b)][0]) for b in act]
+        m["img_w"] = [float(image_shapes[int(b)][1]) for b in act]
+        Lt = int(L.sum())
+        p.lt_host[0] = Lt
+        transh.draw_batch(eng.K, lay.n_active, need_relations=False, out=(p.ent_host, None, None))
+        p.dyn_dev.copy_(p.dyn_host, non_blocking=True)
+        if p.h2d_done is None:
+            p.h2d_done = torch.cuda.Event()
+        p.h2d_done.record()
+        # the two launches that read caller-owned tensors: global average pool (HEAD:811), box_head layer 1 (HEAD:812)
+        lib = _capi.lib()
+        f3 = feat3 if (feat3.dtype == torch.float32 and feat3.is_contiguous()) else feat3.float().contiguous()
+        _capi.check(lib.skg_global_avgpool_f32(f3.data_ptr(), f3.shape[0], f3.shape[1], f3.shape[2] * f3.shape[3],
+                                               p.gfeat.data_ptr(), _stream()), "skg_global_avgpool_f32")
+        x0 = pooled.reshape(pooled.shape[0], -1)
+        if x0.dtype != torch.float32:
+            x0 = x0.float()
+        if p.x0_pad is not None:
+            p.x0_pad[:, :x0.shape[1]] = x0
+            x0 = p.x0_pad
+        elif not x0.is_contiguous():
+            x0 = x0.contiguous()
+        with eng._split_ctx(pw):
+            gemm(x0, pw.bh1_w, pw.bh1_b, p.enc1, lay.sum_all, 1024, x0.shape[1], _capi.EPI_BIAS_RELU, split_k=p.sk,
+                 split_ws=p.ws)
+        if p.graph is None:
+            self._capture(p)
+        p.graph.replay()
+        out = p.arena.clone()                      # the plan's output buffer is overwritten by the next replay
+        # ---- per-call views of the copied arena
+        Mp, Lmax, Mq = p.Mp, p.Lmax, p.Mq
+        i64 = out[:8 * p.n_i64].view(torch.int64)
+        f = out[8 * p.n_i64:].view(torch.float32)
+        r = dict(index=i64[:Lt], prediction=i64[Lmax:Lmax + Lt], object=i64[2 * Lmax:2 * Lmax + Mp],
+                 scores=f[:Lt], prior=f[Lmax:Lmax + 2 * max(Lt, 1)].view(2, max(Lt, 1))[:, :Lt],
+                 weights=f[3 * Lmax:3 * Lmax + Mp], boxes_h=f[3 * Lmax + Mq:3 * Lmax + Mq + 4 * Mp].view(Mp, 4),
+                 boxes_o=f[3 * Lmax + 5 * Mq:3 * Lmax + 5 * Mq + 4 * Mp].view(Mp, 4))
+        call_lay = copy.copy(lay)
+        cells = np.zeros(lay.n_active, np.int64); cells[:] = L
+        call_lay.cells_per_image = cells
+        call_lay.sum_l = Lt
+        eng.last = dict(p.out, layout=call_lay, plan=p)
+        return head._results(call_lay, r, dev)
+
+    def _fallback(self, head, pre, features, image_shapes):
+        """Batches without a single kept pair, or with injected non-Linear classifiers: the eager path, continuing from
+        the preprocess that has already run."""
+        self.eng.pre_pack(pre)
+        return head._forward_eager(pre, features, image_shapes)

@@ -1,0 +1,142 @@
+"""The captured-graph small-batch path (skghoi_amd/small.py) against the eager path of the same head: the graph holds the
+same kernel sequence, so every result tensor must be BIT-identical -- on the capturing call, on replays, and on replays
+with other contents of the same shape (other boxes / scores / classes / image sizes / TransH tables).  The eager path
+itself is pinned to the reference's goldens in test_parity_gpu.py."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import gpu_run
+import helpers
+from skghoi_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SMALL_CASES = [c for c in cases.EVAL_CASES if c not in ("eval_targets", "many12")]
+
+
+def _run(head, case, seed, small, det=None, shapes=None, feat3=None):
+    eng = head.engine()
+    eng.debug = False
+    eng.small_batch_max = 8 if small else 0
+    det = gpu_run.to_cuda(case["detections"]) if det is None else det
+    feat3 = case["feat3"].cuda() if feat3 is None else feat3
+    feats = OrderedDict((k, feat3) for k in "0123")
+    with torch.no_grad():
+        torch.manual_seed(seed)
+        res = head(feats, det, case["shapes"] if shapes is None else shapes)
+        after = torch.empty(3).uniform_()
+    K = case["cfg"]["K"]
+    last = eng.last
+    logits = last["logits"][:, :K + 1].clone() if "logits" in last else None
+    return res, logits, after
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for ra, rb in zip(a, b):
+        assert set(ra) == set(rb)
+        for k in ra:
+            assert ra[k].shape == rb[k].shape and ra[k].dtype == rb[k].dtype, k
+            assert torch.equal(ra[k], rb[k]), k
+
+
+@pytest.mark.parametrize("name", SMALL_CASES)
+def test_graph_path_is_bit_identical_to_eager(name, precision):
+    case = cases.build_case(name)
+    head = gpu_run.build_head(case).eval()
+    want, wl, wa = _run(head, case, 11, small=False)
+    got, gl, ga = _run(head, case, 11, small=True)          # capturing call
+    _same(got, want)
+    assert torch.equal(ga, wa)                               # the host RNG was consumed identically
+    if wl is not None:
+        assert torch.equal(gl, wl)
+    runner = head.engine()._small
+    for seed in (12, 13):                                    # replays, other TransH tables
+        want, wl, _ = _run(head, case, seed, small=False)
+        got, gl, _ = _run(head, case, seed, small=True)
+        _same(got, want)
+        if wl is not None:
+            assert torch.equal(gl, wl)
+    lay_active = head.engine().last["layout"].n_active
+    if lay_active:
+        assert runner.misses == 1 and runner.hits == 2, (runner.misses, runner.hits)
+    # and the result still matches the reference's golden (same comparison as the eager parity test, result level)
+    g = helpers.load_golden(name)
+    res, _, _ = _run(head, case, case["rng_seed"], small=True)
+    assert len(res) == int(g["n_results"])
+    for b, r in enumerate(res):
+        for k in ("index", "prediction", "object"):
+            if "res%d.%s" % (b, k) in g:
+                assert np.array_equal(r[k].cpu().numpy(), g["res%d.%s" % (b, k)]), (b, k)
+        if name != "nanbox" and "res%d.scores" % b in g and g["res%d.scores" % b].size:
+            assert np.abs(r["scores"].cpu().numpy() - g["res%d.scores" % b]).max() <= 1e-5
+
+
+def test_replay_with_other_contents_of_the_same_shape(precision):
+    """One plan, many images: detections with other boxes, scores and object classes (another number of scored cells),
+    another image size and other feature maps replay the plan captured for the first image."""
+    case = cases.build_case("full20")
+    head = gpu_run.build_head(case).eval()
+
+    class Pool(torch.nn.Module):
+        pooled = None
+
+        def forward(self, features, boxes, image_shapes):
+            return self.pooled
+
+    head.box_roi_pool = Pool()
+    runner = None
+    cells = set()
+    for i, hw in enumerate([(800, 1200), (640, 960), (800, 1200), (480, 640)]):
+        im = synth.make_image(3000 + i, n_h=20, n_o=20)
+        scale = torch.tensor([hw[1] / 1200.0, hw[0] / 800.0] * 2)
+        det = [dict(boxes=(im["boxes"] * scale).cuda(), labels=im["labels"].cuda(), scores=im["scores"].cuda())]
+        Pool.pooled = im["pooled"].cuda()
+        feat3 = im["feat3"].cuda()
+        want, wl, _ = _run(head, case, 50 + i, small=False, det=det, shapes=[hw], feat3=feat3)
+        got, gl, _ = _run(head, case, 50 + i, small=True, det=det, shapes=[hw], feat3=feat3)
+        _same(got, want)
+        assert torch.equal(gl, wl)
+        assert got[0]["prior"].is_contiguous() and got[0]["prior"].shape[0] == 2
+        cells.add(int(got[0]["index"].numel()))
+        runner = head.engine()._small
+    assert runner.misses == 1 and runner.hits == 3
+    assert len(cells) > 1                                   # the number of scored cells really changed between replays
+
+
+def test_small_path_reference_quirks_and_errors():
+    case = cases.build_case("skips_raise")                  # eval, batch 2, skipped image after one with pairs: HEAD:327
+    head = gpu_run.build_head(case).eval()
+    with pytest.raises(IndexError):
+        _run(head, case, 3, small=True)
+    head2 = gpu_run.build_head(case, reference_quirks=False).eval()
+    want, _, _ = _run(head2, case, 3, small=False)
+    got, _, _ = _run(head2, case, 3, small=True)
+    _same(got, want)
+    assert len(got) == 2 and got[1]["index"].numel() == 0
+    # a batch without any pair takes the eager route from inside the small path
+    only = dict(cases.build_case("skips_eval"))
+    only["detections"] = only["detections"][:1]; only["feat3"] = only["feat3"][:1]; only["shapes"] = only["shapes"][:1]
+    head3 = gpu_run.build_head(only, reference_quirks=False).eval()
+    got, _, _ = _run(head3, only, 3, small=True)
+    assert len(got) == 1 and got[0]["boxes_h"].shape == (0, 4)
+
+
+def test_plans_are_dropped_when_weights_change():
+    case = cases.build_case("tiny")
+    head = gpu_run.build_head(case).eval()
+    a, la, _ = _run(head, case, 5, small=True)
+    runner = head.engine()._small
+    assert len(runner.plans) == 1
+    head.box_pair_predictor.weight.data.mul_(2.0)
+    b, lb, _ = _run(head, case, 5, small=True)
+    assert runner.misses == 2 and len(runner.plans) == 1     # re-captured against the re-packed weights
+    K = case["cfg"]["K"]
+    bias = head.box_pair_predictor.bias.detach()
+    assert torch.allclose(lb[:, :K] - bias, 2.0 * (la[:, :K] - bias), rtol=1e-4, atol=1e-5)
+    want, lw, _ = _run(head, case, 5, small=False)
+    _same(b, want)
