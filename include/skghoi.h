@@ -232,12 +232,14 @@ int skg_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const flo
  *   out_index/out_pred int64 [L], out_scores f32 [L], out_prior f32 [2, L_total] (row 0 = human, row 1 = object),
  *   out_weights f32 [sumP], out_object int64 [sumP], out_boxes_h/out_boxes_o f32 [sumP,4]
  *   L_total_dev (optional): device int32 holding L_total (values < 1 count as 1); when given it overrides the L_total
- *   argument, so that a launch captured into a hipGraph can be replayed for batches with other cell counts.        */
+ *   argument, so that a launch captured into a hipGraph can be replayed for batches with other cell counts.
+ *   max_pairs_per_image: the largest n_h * (n - 1) of the batch (sizes the grid: one workgroup per 256 kept pairs of an
+ *   image; <= 0: the compiled-in bound).                                                                           */
 int skg_postprocess_f32(const float* logits, int64_t ld_logits, int K, const float* boxes, const float* scores,
                         const int64_t* labels, const skg_image_meta* meta, int n_active, const int64_t* x_keep,
                         const int64_t* y_keep, const int32_t* verb_off, const int32_t* verb_list, int num_obj_classes,
-                        float prior_pow, int64_t L_total, const int32_t* L_total_dev, int64_t* out_index,
-                        int64_t* out_pred, float* out_scores, float* out_prior, float* out_weights,
+                        float prior_pow, int64_t L_total, const int32_t* L_total_dev, int max_pairs_per_image,
+                        int64_t* out_index, int64_t* out_pred, float* out_scores, float* out_prior, float* out_weights,
                         int64_t* out_object, float* out_boxes_h, float* out_boxes_o, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -304,6 +306,60 @@ typedef struct {
 #define SKG_GEMMX_GROUP_MAX 8
 int64_t skg_gemmx_ws_floats(const skg_gemmx_desc* desc_host);
 int skg_gemmx_f32(const skg_gemmx_desc* descs_host, int n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Non-GEMM stages of the fused TRAINING step (skg_train.hip): the forward pieces that keep what the backward needs and
+ * the hand-written backward of the graph stages the reference leaves to autograd (HEAD:884-925, 966-973; losses
+ * HEAD:153-205 with ops.py:159-211).  All feature rows are 1024 wide; every neighbourhood reduction runs per
+ * destination row in index order (no atomics).                                                                      */
+/* skg_graph_aggregate_f32 that also returns the softmax weights alpha / beta [sumG] (per human / per node senders).  */
+int skg_graph_aggregate_train_f32(const float* dot_partial, int n_partial, int64_t partial_ld, float adj_bias,
+                                  const skg_image_meta* meta, int n_active, const int32_t* hum_img,
+                                  const int32_t* node_img, int sum_h, int sum_n, const float* T_os, const float* T_so,
+                                  int64_t ldt, int cols, float* U, float* V, int64_t ldu, float* adj_out,
+                                  float* alpha_out, float* beta_out, void* stream);
+/* out[r] = X[r, :] . w  (adjacency Linear(1024 -> 1) without its bias, HEAD:897).                                   */
+int skg_rowdot_f32(const float* X, int64_t ld, const float* w, int rows, int cols, float* out, void* stream);
+/* xsum = a + b (node + message, HEAD:912-914, 923-925), y = LayerNorm(xsum) * gamma + beta, stats[r] = {mean, rstd}.  */
+int skg_add_layernorm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gamma,
+                          const float* beta, int rows, float eps, float* xsum, float* y, float* stats, void* stream);
+/* LayerNorm backward from the saved xsum / stats: dx [rows, 1024], dgamma / dbeta [1024] (sums over the rows).         */
+int skg_layernorm_bwd_f32(const float* dy, int64_t lddy, const float* x, const float* stats, const float* gamma,
+                          int rows, float* dx, float* dgamma, float* dbeta, void* stream);
+/* Backward of t = relu(m * f), m = P[p_idx] + Q[q_idx] + mbias, f = F[f_idx] (MBF fc_1 * fc_2, HEAD:469-474): g = dt
+ * (zero where t <= 0) is overwritten with dm = g * f;  dF[f_idx] = (or +=, accumulate) g * m.                          */
+int skg_mul_bwd_f32(float* g, int64_t ldg, const float* F, const int32_t* f_idx, int64_t ldf, const float* P,
+                    const int32_t* p_idx, int64_t ldp, const float* Q, const int32_t* q_idx, int64_t ldq,
+                    const float* mbias, int rows, float* dF, int64_t lddf, int accumulate, void* stream);
+/* Row sums per human / node / image (gradients of the gathered fc_1 tables).  mode 0: src = grid rows; mode 1: src =
+ * kept pairs; mode 2: src = kept pairs, outH[a] = sum over the pairs of image a.  outH [sumH|n_active, 1024],
+ * outN [sumN, 1024]; either may be NULL.                                                                              */
+int skg_segment_sum_f32(const float* src, int64_t ld, const skg_image_meta* meta, int n_active, const int32_t* hum_img,
+                        const int32_t* node_img, int sum_h, int sum_n, int mode, float* outH, float* outN,
+                        int accumulate, void* stream);
+/* Backward of the softmax-weighted aggregation (HEAD:907-922): from dU [sumH, 1024], dV [sumN, 1024] and the saved
+ * Tos / Tso / alpha / beta:  dTos = alpha dU[h] (where Tos > 0), dTso = beta dV[o] (where Tso > 0), and the adjacency
+ * gradient in two halves dadj_h + dadj_n [sumG] (softmax over a human's resp. a node's senders); da / db [sumG] scratch. */
+int skg_aggregate_bwd_f32(const float* dU, const float* dV, const float* Tos, const float* Tso, const float* alpha,
+                          const float* beta, const int32_t* grid_h, const int32_t* grid_o, int sum_g,
+                          const skg_image_meta* meta, const int32_t* hum_img, const int32_t* node_img, int sum_h,
+                          int sum_n, float* dTos, float* dTso, float* da, float* db, float* dadj_h, float* dadj_n,
+                          void* stream);
+/* dadj = dadj_h + dadj_n;  dWt[r, c] = dadj[r] * w[c] where Wt[r, c] > 0   (adjacency = relu(.) . w, HEAD:896-897).   */
+int skg_adjacency_bwd_f32(const float* dadj_h, const float* dadj_n, const float* w, const float* Wt, int rows,
+                          float* dadj, float* dWt, void* stream);
+/* Backward of skg_concat_entity_f32: d_enc[e] = dX[hum_of[e]] + dX[sum_h + node_of[e]] (first 1024 columns; an index of
+ * -1 = no reader), zeroed where enc[e] <= 0 (box_head's second ReLU, HEAD:639).                                       */
+int skg_entity_rows_bwd_f32(const float* dX, int64_t ldx, const int32_t* hum_of, const int32_t* node_of, int sum_h,
+                            int n_enc, const float* enc, float* d_enc, void* stream);
+/* Both focal losses (HEAD:153-205, ops.py:159-211) forward + d/dlogits in one pass over what skg_postprocess_f32
+ * emitted (training: prior_pow 1).  labels [sumP, K] from skg_associate_f32.  Outputs: cell_labels [L] (labels at the
+ * scored cells), unary [sumP] (min(sum_v labels, 1)), partial [n_active, 2] = per-image sums of the two losses,
+ * dlogits [sumP, ldl] (ZERO-FILLED by the caller): columns < K d(cell loss sum)/dlogit, column K d(pair loss sum).    */
+int skg_hoi_loss_f32(const float* logits, int64_t ldl, int K, const skg_image_meta* meta, int n_active,
+                     int64_t cells_total, const int64_t* index, const int64_t* pred, const float* scores,
+                     const float* labels, float* cell_labels, float* unary, float* partial, float* dlogits,
+                     void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Order-independent 64-bit checksum of the live parameters (bit patterns weighted by position) over a table of

@@ -85,10 +85,24 @@ PROTOTYPES = {
                                           _vp, _i64, C.c_int, _vp, _vp, _i64, _vp, _vp]),
     "skg_layernorm_f32": (C.c_int, [_vp, _i64, _vp, _vp, C.c_int, C.c_int, _f32, _vp, _i64, _vp]),
     "skg_postprocess_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int,
-                                      _f32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                      _f32, _i64, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "skg_associate_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _f32, _vp, _vp, _vp]),
     "skg_transh_scores_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     "skg_param_checksum": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "skg_graph_aggregate_train_f32": (C.c_int, [_vp, C.c_int, _i64, _f32, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp,
+                                                _vp, _i64, C.c_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "skg_rowdot_f32": (C.c_int, [_vp, _i64, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "skg_add_layernorm_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, C.c_int, _f32, _vp, _vp, _vp, _vp]),
+    "skg_layernorm_bwd_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "skg_mul_bwd_f32": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, C.c_int, _vp, _i64,
+                                  C.c_int, _vp]),
+    "skg_segment_sum_f32": (C.c_int, [_vp, _i64, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int,
+                                      _vp]),
+    "skg_aggregate_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int,
+                                        _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "skg_adjacency_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
+    "skg_entity_rows_bwd_f32": (C.c_int, [_vp, _i64, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "skg_hoi_loss_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _LIB = None

@@ -725,8 +725,18 @@ __device__ __forceinline__ void skg_splitk_reduce_one(const skg_gemm_desc& d, in
     const int64_t total = (int64_t)d.M * d.N;
     if (i >= total) return;
     const int row = (int)(i / d.N), col = (int)(i % d.N);
-    float v = 0.f;
-    for (int s = 0; s < d.split_k; ++s) v += d.split_ws[(int64_t)s * total + i];
+    // four independent chains keep four loads in flight (one chain walks the slices at one HBM round trip each); the
+    // order of the additions is fixed, so the result is deterministic
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int s = 0;
+    for (; s + 3 < d.split_k; s += 4) {
+        v0 += d.split_ws[(int64_t)s * total + i];
+        v1 += d.split_ws[(int64_t)(s + 1) * total + i];
+        v2 += d.split_ws[(int64_t)(s + 2) * total + i];
+        v3 += d.split_ws[(int64_t)(s + 3) * total + i];
+    }
+    for (; s < d.split_k; ++s) v0 += d.split_ws[(int64_t)s * total + i];
+    float v = (v0 + v1) + (v2 + v3);
     if (d.bias) v += d.bias[col];
     if (d.epilogue == SKG_EPI_BIAS_RELU || d.epilogue == SKG_EPI_BIAS_RES_RELU) v = fmaxf(v, 0.f);
     if (d.epilogue == SKG_EPI_BIAS_RES_RELU) v += d.res[(int64_t)row * d.ldres + col];

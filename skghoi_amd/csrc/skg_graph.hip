@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void skg_graph_aggregate_kernel(
     const float* __restrict__ dot_partial, int n_partial, int64_t partial_ld, float adj_bias,
     const skg_image_meta* __restrict__ meta, const int32_t* __restrict__ hum_img, const int32_t* __restrict__ node_img,
     int sum_h, const float* __restrict__ T_os, const float* __restrict__ T_so, int64_t ldt, int cols,
-    float* __restrict__ U, float* __restrict__ V, int64_t ldu, float* __restrict__ adj_out) {
+    float* __restrict__ U, float* __restrict__ V, int64_t ldu, float* __restrict__ adj_out,
+    float* __restrict__ alpha_out, float* __restrict__ beta_out) {
     __shared__ float sw[SKG_MAX_NODES];
     __shared__ float sred[4];
     const int tid = threadIdx.x;
@@ -54,6 +55,10 @@ __global__ __launch_bounds__(256) void skg_graph_aggregate_kernel(
     }
     se = skg_block_sum256(se, sred);                           // barriers inside also publish sw[]
     const float inv = 1.f / se;
+    // training: the softmax weights themselves (alpha over a human's senders, beta over a node's), kept for the backward
+    float* wout = to_human ? alpha_out : beta_out;
+    if (wout)
+        for (int t = tid; t < cnt; t += 256) wout[row0 + t * rstep] = sw[t] * inv;
 
     const float* T = to_human ? T_os : T_so;
     float* out = (to_human ? U : V) + (int64_t)dst * ldu;
@@ -82,7 +87,27 @@ extern "C" int skg_graph_aggregate_f32(const float* dot_partial, int n_partial, 
         return SKG_E_ALIGN;
     hipLaunchKernelGGL(skg_graph_aggregate_kernel, dim3(sum_h + sum_n), dim3(256), 0, (hipStream_t)stream, dot_partial,
                        n_partial, partial_ld, adj_bias, meta, hum_img, node_img, sum_h, T_os, T_so, ldt, cols, U, V,
-                       ldu, adj_out);
+                       ldu, adj_out, (float*)nullptr, (float*)nullptr);
+    return skg_launch_status();
+}
+
+// The same aggregation for the training step: also returns the softmax weights alpha[sumG] (over the senders of every
+// human) and beta[sumG] (over the senders of every node), which the backward (skg_aggregate_bwd_f32) needs.
+extern "C" int skg_graph_aggregate_train_f32(const float* dot_partial, int n_partial, int64_t partial_ld, float adj_bias,
+                                             const skg_image_meta* meta, int n_active, const int32_t* hum_img,
+                                             const int32_t* node_img, int sum_h, int sum_n, const float* T_os,
+                                             const float* T_so, int64_t ldt, int cols, float* U, float* V, int64_t ldu,
+                                             float* adj_out, float* alpha_out, float* beta_out, void* stream) {
+    if (n_active < 0 || sum_h < 0 || sum_n < 0 || n_partial <= 0 || cols <= 0 || (cols & 3)) return SKG_E_ARG;
+    if (sum_h + sum_n == 0) return 0;
+    if (!dot_partial || !meta || !hum_img || !node_img || !T_os || !T_so || !U || !V || !alpha_out || !beta_out)
+        return SKG_E_ARG;
+    if ((ldt & 3) || (ldu & 3) || !skg_aligned16(T_os) || !skg_aligned16(T_so) || !skg_aligned16(U) ||
+        !skg_aligned16(V))
+        return SKG_E_ALIGN;
+    hipLaunchKernelGGL(skg_graph_aggregate_kernel, dim3(sum_h + sum_n), dim3(256), 0, (hipStream_t)stream, dot_partial,
+                       n_partial, partial_ld, adj_bias, meta, hum_img, node_img, sum_h, T_os, T_so, ldt, cols, U, V,
+                       ldu, adj_out, alpha_out, beta_out);
     return skg_launch_status();
 }
 

@@ -2,13 +2,15 @@
 //
 // Reference: heads/adamixer_transH_spatial_r50_head.py:847-868 (meshgrid / nonzero(x != y), NaN scrub) and
 // ops.py:85-157 (compute_spatial_ratio_encodings; feature order ops.py:134-152, eps 1e-10).
-// One wavefront owns one image: its boxes are staged in LDS, every lane walks grid rows r = lane, lane+64, ...
+// One workgroup (4 wavefronts) owns one image: its boxes are staged in LDS, every lane walks grid rows r = t, t+256, ...
+// (one wavefront per image until round 2: at a single image that is one wave on the whole chip walking 800 rows)
 // The reference builds a G x G IoU matrix to take its diagonal (ops.py:119); only the diagonal is computed here.
 // Compiled with -ffp-contract=off: each feature is the same sequence of IEEE fp32 operations as the CPU code
 // (the log is the only non-correctly-rounded function).
 #include "skg_common.h"
 
-__global__ __launch_bounds__(64) void skg_pairs_spatial_kernel(
+#define PS_THREADS 256
+__global__ __launch_bounds__(PS_THREADS) void skg_pairs_spatial_kernel(
     const float* __restrict__ boxes, const skg_image_meta* __restrict__ meta, int32_t* __restrict__ grid_h,
     int32_t* __restrict__ grid_o, int32_t* __restrict__ grid_pair, int32_t* __restrict__ grid_img,
     int32_t* __restrict__ pair_grid, int64_t* __restrict__ x_keep, int64_t* __restrict__ y_keep,
@@ -18,7 +20,7 @@ __global__ __launch_bounds__(64) void skg_pairs_spatial_kernel(
     const skg_image_meta mt = meta[a];
     const int lane = threadIdx.x;
     const int n = mt.n, n_h = mt.n_h;
-    for (int t = lane; t < n; t += 64)
+    for (int t = lane; t < n; t += PS_THREADS)
         sbox[t] = *reinterpret_cast<const float4*>(boxes + 4 * (int64_t)(mt.box_off + t));
     __syncthreads();
 
@@ -26,7 +28,7 @@ __global__ __launch_bounds__(64) void skg_pairs_spatial_kernel(
     const float eps = 1e-10f;
     const int G = n_h * n;
     bool any_nan = false;
-    for (int r = lane; r < G; r += 64) {
+    for (int r = lane; r < G; r += PS_THREADS) {
         const int i = r / n, j = r - i * n;
         const int gr = mt.grid_off + r;
         grid_h[gr] = mt.hum_off + i;
@@ -85,8 +87,8 @@ __global__ __launch_bounds__(64) void skg_pairs_spatial_kernel(
         for (int k = 0; k < SKG_SPATIAL_LD / 4; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
     }
     // torch.nan_to_num over the whole image tensor if it holds any NaN (HEAD:866-868): NaN -> 0, +-inf -> +-FLT_MAX
-    if (scrub_nan && __any(any_nan)) {
-        for (int r = lane; r < G; r += 64) {
+    if (__syncthreads_or(scrub_nan && any_nan)) {
+        for (int r = lane; r < G; r += PS_THREADS) {
             float* row = spatial + (int64_t)(mt.grid_off + r) * SKG_SPATIAL_LD;     // rows this lane wrote itself
             for (int k = 0; k < 46; ++k) {
                 const float v = row[k];
@@ -108,7 +110,7 @@ extern "C" int skg_pairs_spatial_f32(const float* boxes, const skg_image_meta* m
         !pair_h || !pair_o || !spatial)
         return SKG_E_ARG;
     if (!skg_aligned16(boxes) || !skg_aligned16(spatial)) return SKG_E_ALIGN;
-    hipLaunchKernelGGL(skg_pairs_spatial_kernel, dim3(n_active), dim3(64), 0, (hipStream_t)stream, boxes, meta, grid_h,
+    hipLaunchKernelGGL(skg_pairs_spatial_kernel, dim3(n_active), dim3(PS_THREADS), 0, (hipStream_t)stream, boxes, meta, grid_h,
                        grid_o, grid_pair, grid_img, pair_grid, x_keep, y_keep, pair_h, pair_o, spatial, scrub_nan);
     return skg_launch_status();
 }

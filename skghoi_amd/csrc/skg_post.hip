@@ -8,6 +8,23 @@
 
 __device__ __forceinline__ float skg_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
+// Number of scored cells of kept pair `pl` of image `mt` (HEAD:747-760): the verbs valid for the object's class, if
+// the human's prior score is non-zero.
+__device__ __forceinline__ int skg_pair_cells(const skg_image_meta& mt, int pl, const int64_t* __restrict__ x_keep,
+                                              const int64_t* __restrict__ y_keep, const float* __restrict__ scores,
+                                              const int64_t* __restrict__ labels, const int32_t* __restrict__ verb_off,
+                                              int num_obj_classes, float prior_pow) {
+    const int64_t gp = (int64_t)mt.pair_off + pl;
+    const int bh = mt.box_off + (int)x_keep[gp];
+    const int bo = mt.box_off + (int)y_keep[gp];
+    const int64_t lab = labels[bo];
+    const int nv = (lab >= 0 && lab < num_obj_classes) ? verb_off[(int)lab + 1] - verb_off[(int)lab] : 0;
+    return (powf(scores[bh], prior_pow) != 0.f) ? nv : 0;
+}
+
+// Grid: (active image, chunk of 256 kept pairs).  A workgroup first counts the cells of the image's earlier pairs (a few
+// loads per pair) to find where its own chunk starts in the packed result -- one workgroup per image walking all chunks
+// in turn took 40 us at a single 20 x 20 image -- then scans its chunk and emits.
 __global__ __launch_bounds__(256) void skg_postprocess_kernel(
     const float* __restrict__ logits, int64_t ld_logits, int K, const float* __restrict__ boxes,
     const float* __restrict__ scores, const int64_t* __restrict__ labels, const skg_image_meta* __restrict__ meta,
@@ -19,66 +36,70 @@ __global__ __launch_bounds__(256) void skg_postprocess_kernel(
     float* __restrict__ out_weights, int64_t* __restrict__ out_object, float* __restrict__ out_boxes_h,
     float* __restrict__ out_boxes_o) {
     __shared__ int swave[4];
-    __shared__ int sbase;
+    __shared__ int spre[4];
     // stride between the two rows of out_prior: from device memory when the launch is replayed from a captured graph
     // (the number of scored cells changes from call to call, the launch arguments cannot)
     const int64_t L_total = L_total_dev ? (int64_t)max(*L_total_dev, 1) : L_total_arg;
     const int a = blockIdx.x;
     const skg_image_meta mt = meta[a];
     const int P = mt.n_h * (mt.n - 1);
+    const int p0 = blockIdx.y * 256;
+    if (p0 >= P) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) sbase = 0;
-    __syncthreads();
-    for (int p0 = 0; p0 < P; p0 += 256) {
-        const int pl = p0 + tid;
-        int cnt = 0, cls = 0;
-        float ph = 0.f, po = 0.f, wgt = 0.f;
-        int64_t gp = 0;
-        if (pl < P) {
-            gp = (int64_t)mt.pair_off + pl;
-            const int bh = mt.box_off + (int)x_keep[gp];
-            const int bo = mt.box_off + (int)y_keep[gp];
-            ph = powf(scores[bh], prior_pow);
-            po = powf(scores[bo], prior_pow);
-            const int64_t lab = labels[bo];
-            cls = (int)lab;
-            const int nv = (lab >= 0 && lab < num_obj_classes) ? verb_off[cls + 1] - verb_off[cls] : 0;
-            cnt = (ph != 0.f) ? nv : 0;
-            wgt = skg_sigmoid(logits[gp * ld_logits + K]);
-            out_weights[gp] = wgt;
-            out_object[gp] = lab;
-            *reinterpret_cast<float4*>(out_boxes_h + 4 * gp) = *reinterpret_cast<const float4*>(boxes + 4 * (int64_t)bh);
-            *reinterpret_cast<float4*>(out_boxes_o + 4 * gp) = *reinterpret_cast<const float4*>(boxes + 4 * (int64_t)bo);
-        }
-        // exclusive scan of cnt over the 256 pairs of this chunk
-        int inc = cnt;
+    // ---- cells of the pairs in front of this chunk
+    int before = 0;
+    for (int q = tid; q < p0; q += 256)
+        before += skg_pair_cells(mt, q, x_keep, y_keep, scores, labels, verb_off, num_obj_classes, prior_pow);
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += t;
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+    if (lane == 0) spre[wv] = before;
+    __syncthreads();
+    const int sbase = spre[0] + spre[1] + spre[2] + spre[3];
+    // ---- this chunk
+    const int pl = p0 + tid;
+    int cnt = 0, cls = 0;
+    float ph = 0.f, po = 0.f, wgt = 0.f;
+    int64_t gp = 0;
+    if (pl < P) {
+        gp = (int64_t)mt.pair_off + pl;
+        const int bh = mt.box_off + (int)x_keep[gp];
+        const int bo = mt.box_off + (int)y_keep[gp];
+        ph = powf(scores[bh], prior_pow);
+        po = powf(scores[bo], prior_pow);
+        const int64_t lab = labels[bo];
+        cls = (int)lab;
+        const int nv = (lab >= 0 && lab < num_obj_classes) ? verb_off[cls + 1] - verb_off[cls] : 0;
+        cnt = (ph != 0.f) ? nv : 0;
+        wgt = skg_sigmoid(logits[gp * ld_logits + K]);
+        out_weights[gp] = wgt;
+        out_object[gp] = lab;
+        *reinterpret_cast<float4*>(out_boxes_h + 4 * gp) = *reinterpret_cast<const float4*>(boxes + 4 * (int64_t)bh);
+        *reinterpret_cast<float4*>(out_boxes_o + 4 * gp) = *reinterpret_cast<const float4*>(boxes + 4 * (int64_t)bo);
+    }
+    // exclusive scan of cnt over the 256 pairs of this chunk
+    int inc = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) swave[wv] = inc;
+    __syncthreads();
+    int wbase = 0;
+    for (int k = 0; k < wv; ++k) wbase += swave[k];
+    const int64_t o0 = (int64_t)mt.out_off + sbase + wbase + (inc - cnt);
+    if (cnt > 0) {
+        const int v0 = verb_off[cls];
+        for (int t = 0; t < cnt; ++t) {
+            const int v = verb_list[v0 + t];
+            const int64_t o = o0 + t;
+            out_index[o] = pl;
+            out_pred[o] = v;
+            out_prior[o] = ph;
+            out_prior[L_total + o] = po;
+            const float s = skg_sigmoid(logits[gp * ld_logits + v]);
+            out_scores[o] = s * (ph * po) * wgt;
         }
-        if (lane == 63) swave[wv] = inc;
-        __syncthreads();
-        int wbase = 0;
-        for (int k = 0; k < wv; ++k) wbase += swave[k];
-        const int chunk_total = swave[0] + swave[1] + swave[2] + swave[3];
-        const int64_t o0 = (int64_t)mt.out_off + sbase + wbase + (inc - cnt);
-        if (cnt > 0) {
-            const int v0 = verb_off[cls];
-            for (int t = 0; t < cnt; ++t) {
-                const int v = verb_list[v0 + t];
-                const int64_t o = o0 + t;
-                out_index[o] = pl;
-                out_pred[o] = v;
-                out_prior[o] = ph;
-                out_prior[L_total + o] = po;
-                const float s = skg_sigmoid(logits[gp * ld_logits + v]);
-                out_scores[o] = s * (ph * po) * wgt;
-            }
-        }
-        __syncthreads();
-        if (tid == 0) sbase += chunk_total;
-        __syncthreads();
     }
 }
 
@@ -86,7 +107,8 @@ extern "C" int skg_postprocess_f32(const float* logits, int64_t ld_logits, int K
                                    const float* scores, const int64_t* labels, const skg_image_meta* meta,
                                    int n_active, const int64_t* x_keep, const int64_t* y_keep,
                                    const int32_t* verb_off, const int32_t* verb_list, int num_obj_classes,
-                                   float prior_pow, int64_t L_total, const int32_t* L_total_dev, int64_t* out_index,
+                                   float prior_pow, int64_t L_total, const int32_t* L_total_dev,
+                                   int max_pairs_per_image, int64_t* out_index,
                                    int64_t* out_pred, float* out_scores, float* out_prior, float* out_weights,
                                    int64_t* out_object, float* out_boxes_h, float* out_boxes_o, void* stream) {
     if (n_active < 0 || K <= 0 || ld_logits <= K || L_total < 0 || num_obj_classes <= 0) return SKG_E_ARG;
@@ -96,7 +118,9 @@ extern "C" int skg_postprocess_f32(const float* logits, int64_t ld_logits, int K
         !out_boxes_o)
         return SKG_E_ARG;
     if (!skg_aligned16(boxes) || !skg_aligned16(out_boxes_h) || !skg_aligned16(out_boxes_o)) return SKG_E_ALIGN;
-    hipLaunchKernelGGL(skg_postprocess_kernel, dim3(n_active), dim3(256), 0, (hipStream_t)stream, logits, ld_logits, K,
+    // pair chunks per image: SKG_MAX_NODES bounds n_h * (n - 1); chunks past an image's pairs return at once
+    const int max_pairs = max_pairs_per_image > 0 ? max_pairs_per_image : (SKG_MAX_NODES / 2) * (SKG_MAX_NODES - 1);
+    hipLaunchKernelGGL(skg_postprocess_kernel, dim3(n_active, (max_pairs + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, ld_logits, K,
                        boxes, scores, labels, meta, x_keep, y_keep, verb_off, verb_list, num_obj_classes, prior_pow,
                        L_total, L_total_dev, out_index, out_pred, out_scores, out_prior, out_weights, out_object, out_boxes_h,
                        out_boxes_o);

@@ -106,55 +106,102 @@ __global__ __launch_bounds__(PRE_THREADS) void skg_preprocess_kernel(
     }
     __syncthreads();
 
-    // ---- greedy NMS over the sorted candidates; selection of the first max_human humans / max_object others
+    // ---- greedy NMS over the sorted candidates; selection of the first max_human humans / max_object others.
+    // Up to 256 candidates (the usual case: a detector hands over ~100 boxes per image) ONE wavefront runs the greedy
+    // loop on its own: every lane keeps up to four candidates' boxes and suppression bits in registers, the kept box is
+    // an LDS broadcast read, "is candidate i suppressed" a lane read -- no barrier per candidate (the four-wave loop
+    // below pays one per candidate: 40 candidates took 12 us).  Same comparisons in the same order either way.
+    __shared__ int scnt[2];
     int nh = 0, no = 0;
-    for (int i = 0; i < nact; ++i) {
-        if (nh >= max_human && no >= max_object) break;          // uniform
-        const bool sup = ssup[i] != 0;                           // uniform (LDS broadcast)
-        if (!sup) {
-            const bool hum = shum[i] != 0;
-            if (hum) { if (nh < max_human) { if (tid == 0) ssel[nh] = i; ++nh; } }
-            else     { if (no < max_object) { if (tid == 0) ssel[max_human + no] = i; ++no; } }
-            const float4 bi = sbox[i];
-            const float ai = sarea[i];
-            for (int j = i + 1 + tid; j < nact; j += PRE_THREADS) {
-                if (ssup[j]) continue;
-                const float4 bj = sbox[j];
-                const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
-                const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
-                const float w = fmaxf(xx2 - xx1, 0.f), h = fmaxf(yy2 - yy1, 0.f);
-                const float inter = w * h;
-                const float ovr = inter / (ai + sarea[j] - inter);
-                if (ovr > nms_thresh) ssup[j] = 1;
+    if (nact <= 256) {
+        if (tid < 64) {
+            float4 mb[4]; float ma[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = tid + 64 * u;
+                mb[u] = j < nact ? sbox[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                ma[u] = j < nact ? sarea[j] : 0.f;
             }
+            int supmask = 0;
+            for (int i = 0; i < nact; ++i) {
+                if (nh >= max_human && no >= max_object) break;                  // uniform
+                const bool sup = (__shfl(supmask, i & 63, 64) >> (i >> 6)) & 1;  // uniform
+                if (sup) continue;
+                const bool hum = shum[i] != 0;
+                if (hum) { if (nh < max_human) { if (tid == 0) ssel[nh] = i; ++nh; } }
+                else     { if (no < max_object) { if (tid == 0) ssel[max_human + no] = i; ++no; } }
+                const float4 bi = sbox[i];
+                const float ai = sarea[i];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = tid + 64 * u;
+                    if (j <= i || j >= nact || ((supmask >> u) & 1)) continue;
+                    const float4 bj = mb[u];
+                    const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+                    const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+                    const float w = fmaxf(xx2 - xx1, 0.f), h = fmaxf(yy2 - yy1, 0.f);
+                    const float inter = w * h;
+                    const float ovr = inter / (ai + ma[u] - inter);
+                    if (ovr > nms_thresh) supmask |= 1 << u;
+                }
+            }
+            if (tid == 0) { scnt[0] = nh; scnt[1] = no; }
+        }
+        __syncthreads();
+        nh = scnt[0]; no = scnt[1];
+    } else {
+        for (int i = 0; i < nact; ++i) {
+            if (nh >= max_human && no >= max_object) break;          // uniform
+            const bool sup = ssup[i] != 0;                           // uniform (LDS broadcast)
+            if (!sup) {
+                const bool hum = shum[i] != 0;
+                if (hum) { if (nh < max_human) { if (tid == 0) ssel[nh] = i; ++nh; } }
+                else     { if (no < max_object) { if (tid == 0) ssel[max_human + no] = i; ++no; } }
+                const float4 bi = sbox[i];
+                const float ai = sarea[i];
+                for (int j = i + 1 + tid; j < nact; j += PRE_THREADS) {
+                    if (ssup[j]) continue;
+                    const float4 bj = sbox[j];
+                    const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+                    const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+                    const float w = fmaxf(xx2 - xx1, 0.f), h = fmaxf(yy2 - yy1, 0.f);
+                    const float inter = w * h;
+                    const float ovr = inter / (ai + sarea[j] - inter);
+                    if (ovr > nms_thresh) ssup[j] = 1;
+                }
+            }
+            __syncthreads();
         }
         __syncthreads();
     }
-    __syncthreads();
 
-    // ---- outputs: indices (humans first), counts, and L = number of non-zero prior cells (HEAD:315, 721-767)
+    // ---- outputs: indices (humans first), counts, and L = number of non-zero prior cells (HEAD:315, 721-767):
+    //      every human whose prior score is non-zero pairs with every other node, each pair carrying the verbs of the
+    //      partner's class:  L = #(humans with s^p != 0) * (sum of verbs over all nodes - verbs of the human class).
     const int n = nh + no;
+    if (tid < 2) scnt[tid] = 0;
+    __syncthreads();
+    int lv = 0, lz = 0;
     for (int t = tid; t < ld_out; t += PRE_THREADS) {
         int v = -1;
-        if (t < nh) v = (int)(skey[ssel[t]] & 0xffffffffu);
-        else if (t < n) v = (int)(skey[ssel[max_human + (t - nh)]] & 0xffffffffu);
+        if (t < n) {
+            const int s = (t < nh) ? ssel[t] : ssel[max_human + (t - nh)];
+            v = (int)(skey[s] & 0xffffffffu);
+            const int64_t lab = labels[base + v];
+            lv += (lab >= 0 && lab < num_obj_classes) ? nverbs[lab] : 0;
+            if (t < nh && powf(scores[base + v], prior_pow) != 0.f) ++lz;
+        }
         out_index[(int64_t)b * ld_out + t] = v;
     }
+    if (lv) atomicAdd(&scnt[0], lv);
+    if (lz) atomicAdd(&scnt[1], lz);
+    __syncthreads();
     if (tid == 0) {
         int L = 0;
         if (nh > 0 && n > 1) {
-            int vtot = 0;
-            for (int t = 0; t < n; ++t) {
-                const int s = (t < nh) ? ssel[t] : ssel[max_human + (t - nh)];
-                const int64_t lab = labels[base + (int)(skey[s] & 0xffffffffu)];
-                vtot += (lab >= 0 && lab < num_obj_classes) ? nverbs[lab] : 0;
-            }
             const int64_t hl = human_idx;
             const int vh = (hl >= 0 && hl < num_obj_classes) ? nverbs[hl] : 0;
-            for (int t = 0; t < nh; ++t) {
-                const float s = scores[base + (int)(skey[ssel[t]] & 0xffffffffu)];
-                if (powf(s, prior_pow) != 0.f) L += vtot - vh;
-            }
+            L = scnt[1] * (scnt[0] - vh);
         }
         out_count[4 * b + 0] = nh;
         out_count[4 * b + 1] = n;

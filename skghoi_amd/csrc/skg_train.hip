@@ -1,0 +1,451 @@
+// skg_train.hip -- the non-GEMM kernels of the fused TRAINING step of the interaction head (forward pieces that must keep
+// what the backward needs, and the hand-written backward of every element-wise / graph stage).
+//
+// Reference (all heads/adamixer_transH_spatial_r50_head.py unless noted): message passing and normalisation HEAD:892-925,
+// read-out HEAD:966-973, fc_head / fc_tail inputs HEAD:884-885, focal losses HEAD:153-205 with ops.py:159-211.  The
+// reference leaves the backward to autograd: ~1000 small element-wise kernels per step.  Here each stage is one kernel
+// forward and one or two backward; reductions over graph neighbourhoods are done per destination row (no atomics, fixed
+// order, deterministic), exactly like the forward aggregation in skg_graph.hip.  All row widths are the head's 1024.
+#include "skg_common.h"
+
+#define TR_COLS 1024
+
+// ------------------------------------------------------------------------------------------------ row dot
+// out[r] = sum_c X[r, c] * w[c]   (the adjacency Linear(1024 -> 1) without its bias, HEAD:897).  One wavefront per row.
+__global__ __launch_bounds__(256) void skg_rowdot_kernel(const float* __restrict__ X, int64_t ld,
+                                                         const float* __restrict__ w, int rows, int cols,
+                                                         float* __restrict__ out) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* x = X + (int64_t)r * ld;
+    float s = 0.f;
+    for (int c = lane * 4; c < cols; c += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(x + c);
+        const float4 b = *reinterpret_cast<const float4*>(w + c);
+        s += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+    }
+    s = skg_wave_sum(s);
+    if (lane == 0) out[r] = s;
+}
+
+extern "C" int skg_rowdot_f32(const float* X, int64_t ld, const float* w, int rows, int cols, float* out, void* stream) {
+    if (rows < 0 || cols <= 0 || (cols & 3)) return SKG_E_ARG;
+    if (rows == 0) return 0;
+    if (!X || !w || !out) return SKG_E_ARG;
+    if ((ld & 3) || !skg_aligned16(X) || !skg_aligned16(w)) return SKG_E_ALIGN;
+    hipLaunchKernelGGL(skg_rowdot_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, X, ld, w, rows, cols, out);
+    return skg_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ add + LayerNorm
+// x = a + b (node + message, HEAD:912-914 / 923-925), y = LayerNorm(x); keeps x and (mean, rstd) for the backward.
+__global__ __launch_bounds__(256) void skg_add_layernorm_kernel(const float* __restrict__ a, int64_t lda,
+                                                                const float* __restrict__ b, int64_t ldb,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps,
+                                                                float* __restrict__ xsum, float* __restrict__ y,
+                                                                float* __restrict__ stats) {
+    __shared__ float sred[4];
+    const int r = blockIdx.x;
+    const int c = threadIdx.x * 4;
+    const float4 va = *reinterpret_cast<const float4*>(a + (int64_t)r * lda + c);
+    const float4 vb = *reinterpret_cast<const float4*>(b + (int64_t)r * ldb + c);
+    const float4 v = make_float4(va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w);
+    const float mean = skg_block_sum256((v.x + v.y) + (v.z + v.w), sred) / (float)TR_COLS;
+    const float4 d = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+    const float var = skg_block_sum256((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w), sred) / (float)TR_COLS;
+    const float rstd = 1.f / sqrtf(var + eps);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 bb = *reinterpret_cast<const float4*>(beta + c);
+    *reinterpret_cast<float4*>(xsum + (int64_t)r * TR_COLS + c) = v;
+    *reinterpret_cast<float4*>(y + (int64_t)r * TR_COLS + c) =
+        make_float4(d.x * rstd * g.x + bb.x, d.y * rstd * g.y + bb.y, d.z * rstd * g.z + bb.z, d.w * rstd * g.w + bb.w);
+    if (threadIdx.x == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+}
+
+extern "C" int skg_add_layernorm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gamma,
+                                     const float* beta, int rows, float eps, float* xsum, float* y, float* stats,
+                                     void* stream) {
+    if (rows < 0) return SKG_E_ARG;
+    if (rows == 0) return 0;
+    if (!a || !b || !gamma || !beta || !xsum || !y || !stats) return SKG_E_ARG;
+    if ((lda & 3) || (ldb & 3) || !skg_aligned16(a) || !skg_aligned16(b) || !skg_aligned16(gamma) ||
+        !skg_aligned16(beta) || !skg_aligned16(xsum) || !skg_aligned16(y))
+        return SKG_E_ALIGN;
+    hipLaunchKernelGGL(skg_add_layernorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, gamma,
+                       beta, eps, xsum, y, stats);
+    return skg_launch_status();
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mean) * rstd.
+__global__ __launch_bounds__(256) void skg_layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                                const float* __restrict__ x,
+                                                                const float* __restrict__ stats,
+                                                                const float* __restrict__ gamma,
+                                                                float* __restrict__ dx) {
+    __shared__ float sred[4];
+    const int r = blockIdx.x;
+    const int c = threadIdx.x * 4;
+    const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+    const float4 vx = *reinterpret_cast<const float4*>(x + (int64_t)r * TR_COLS + c);
+    const float4 vd = *reinterpret_cast<const float4*>(dy + (int64_t)r * lddy + c);
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 xh = make_float4((vx.x - mean) * rstd, (vx.y - mean) * rstd, (vx.z - mean) * rstd, (vx.w - mean) * rstd);
+    const float4 g = make_float4(vd.x * gm.x, vd.y * gm.y, vd.z * gm.z, vd.w * gm.w);
+    const float c1 = skg_block_sum256((g.x + g.y) + (g.z + g.w), sred) / (float)TR_COLS;
+    const float c2 = skg_block_sum256((g.x * xh.x + g.y * xh.y) + (g.z * xh.z + g.w * xh.w), sred) / (float)TR_COLS;
+    *reinterpret_cast<float4*>(dx + (int64_t)r * TR_COLS + c) =
+        make_float4(rstd * (g.x - c1 - xh.x * c2), rstd * (g.y - c1 - xh.y * c2), rstd * (g.z - c1 - xh.z * c2),
+                    rstd * (g.w - c1 - xh.w * c2));
+}
+
+// dgamma[c] = sum_r dy[r, c] * xhat[r, c],  dbeta[c] = sum_r dy[r, c]: one thread per column, rows in order.
+__global__ __launch_bounds__(256) void skg_layernorm_param_grad_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                                       const float* __restrict__ x,
+                                                                       const float* __restrict__ stats, int rows,
+                                                                       float* __restrict__ dgamma,
+                                                                       float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    float sg = 0.f, sb = 0.f;
+    for (int r = 0; r < rows; ++r) {
+        const float d = dy[(int64_t)r * lddy + c];
+        sg += d * ((x[(int64_t)r * TR_COLS + c] - stats[2 * r]) * stats[2 * r + 1]);
+        sb += d;
+    }
+    dgamma[c] = sg;
+    dbeta[c] = sb;
+}
+
+extern "C" int skg_layernorm_bwd_f32(const float* dy, int64_t lddy, const float* x, const float* stats,
+                                     const float* gamma, int rows, float* dx, float* dgamma, float* dbeta, void* stream) {
+    if (rows < 0) return SKG_E_ARG;
+    if (!dy || !x || !stats || !gamma || !dx || !dgamma || !dbeta) return SKG_E_ARG;
+    if ((lddy & 3) || !skg_aligned16(dy) || !skg_aligned16(x) || !skg_aligned16(gamma) || !skg_aligned16(dx))
+        return SKG_E_ALIGN;
+    if (rows)
+        hipLaunchKernelGGL(skg_layernorm_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, stats,
+                           gamma, dx);
+    hipLaunchKernelGGL(skg_layernorm_param_grad_kernel, dim3(TR_COLS / 256), dim3(256), 0, (hipStream_t)stream, dy, lddy,
+                       x, stats, rows, dgamma, dbeta);
+    return skg_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ fc_1 * fc_2 backward
+// Forward (MBF / MessageMBF, HEAD:469-474, 509-527):  t = relu(m * f),  m = P[pi] + Q[qi] + mbias,  f = F[fi].
+// Given g = dt (already zeroed where t <= 0):   dF[fi] (+)= g * m,   dm = g * f  (written over g, in place).
+__global__ __launch_bounds__(256) void skg_mul_bwd_kernel(float* __restrict__ g, int64_t ldg,
+                                                          const float* __restrict__ F, const int32_t* __restrict__ f_idx,
+                                                          int64_t ldf, const float* __restrict__ P,
+                                                          const int32_t* __restrict__ p_idx, int64_t ldp,
+                                                          const float* __restrict__ Q, const int32_t* __restrict__ q_idx,
+                                                          int64_t ldq, const float* __restrict__ mbias,
+                                                          float* __restrict__ dF, int64_t lddf, int accumulate) {
+    const int r = blockIdx.x;
+    const int c = threadIdx.x * 4;
+    const int fi = f_idx ? f_idx[r] : r;
+    float4 m = *reinterpret_cast<const float4*>(P + (int64_t)(p_idx ? p_idx[r] : r) * ldp + c);
+    if (Q) {
+        const float4 t = *reinterpret_cast<const float4*>(Q + (int64_t)(q_idx ? q_idx[r] : r) * ldq + c);
+        m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
+    }
+    if (mbias) {
+        const float4 t = *reinterpret_cast<const float4*>(mbias + c);
+        m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
+    }
+    float4* gp = reinterpret_cast<float4*>(g + (int64_t)r * ldg + c);
+    const float4 gv = *gp;
+    const float4 fv = *reinterpret_cast<const float4*>(F + (int64_t)fi * ldf + c);
+    float4* dp = reinterpret_cast<float4*>(dF + (int64_t)fi * lddf + c);
+    float4 o = make_float4(gv.x * m.x, gv.y * m.y, gv.z * m.z, gv.w * m.w);
+    if (accumulate) { const float4 t = *dp; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+    *dp = o;
+    *gp = make_float4(gv.x * fv.x, gv.y * fv.y, gv.z * fv.z, gv.w * fv.w);
+}
+
+extern "C" int skg_mul_bwd_f32(float* g, int64_t ldg, const float* F, const int32_t* f_idx, int64_t ldf, const float* P,
+                               const int32_t* p_idx, int64_t ldp, const float* Q, const int32_t* q_idx, int64_t ldq,
+                               const float* mbias, int rows, float* dF, int64_t lddf, int accumulate, void* stream) {
+    if (rows < 0) return SKG_E_ARG;
+    if (rows == 0) return 0;
+    if (!g || !F || !P || !dF) return SKG_E_ARG;
+    if ((ldg & 3) || (ldf & 3) || (ldp & 3) || (lddf & 3) || (Q && (ldq & 3))) return SKG_E_ALIGN;
+    if (!skg_aligned16(g) || !skg_aligned16(F) || !skg_aligned16(P) || !skg_aligned16(dF) || (Q && !skg_aligned16(Q)) ||
+        (mbias && !skg_aligned16(mbias)))
+        return SKG_E_ALIGN;
+    hipLaunchKernelGGL(skg_mul_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, g, ldg, F, f_idx, ldf, P, p_idx,
+                       ldp, Q, q_idx, ldq, mbias, dF, lddf, accumulate);
+    return skg_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ neighbourhood sums
+// Sums of the rows of `src` that belong to one human / one node / one image: the gradients of the gathered fc_1 tables.
+//   mode 0  src = grid rows (r = grid_off + i * n + j):   outH[(a, i)] = sum_j src[r],   outN[(a, j)] = sum_i src[r]
+//   mode 1  src = kept pairs (p = pair_off + i * (n - 1) + jj):  outH[(a, i)] = sum_jj src[p];
+//                                                          outN[(a, j)] = sum_{i != j} src[pair of (i, j)]
+//   mode 2  src = kept pairs:  outH[a] = sum of all pairs of image a            (outN unused)
+// One workgroup per destination row, rows added in index order.
+__global__ __launch_bounds__(256) void skg_segment_sum_kernel(const float* __restrict__ src, int64_t ld,
+                                                              const skg_image_meta* __restrict__ meta,
+                                                              const int32_t* __restrict__ hum_img,
+                                                              const int32_t* __restrict__ node_img, int n_dst_h, int mode,
+                                                              float* __restrict__ outH, float* __restrict__ outN,
+                                                              int accumulate) {
+    const bool to_h = (int)blockIdx.x < n_dst_h;
+    const int dst = to_h ? blockIdx.x : blockIdx.x - n_dst_h;
+    float* out = to_h ? outH : outN;
+    if (!out) return;
+    const int a = mode == 2 ? dst : (to_h ? hum_img[dst] : node_img[dst]);
+    const skg_image_meta mt = meta[a];
+    const int c = threadIdx.x * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add = [&](int64_t row) {
+        const float4 v = *reinterpret_cast<const float4*>(src + row * ld + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    };
+    if (mode == 0) {
+        if (to_h) { const int i = dst - mt.hum_off; for (int j = 0; j < mt.n; ++j) add((int64_t)mt.grid_off + (int64_t)i * mt.n + j); }
+        else { const int j = dst - mt.node_off; for (int i = 0; i < mt.n_h; ++i) add((int64_t)mt.grid_off + (int64_t)i * mt.n + j); }
+    } else if (mode == 1) {
+        if (to_h) { const int i = dst - mt.hum_off; for (int jj = 0; jj < mt.n - 1; ++jj) add((int64_t)mt.pair_off + (int64_t)i * (mt.n - 1) + jj); }
+        else {
+            const int j = dst - mt.node_off;
+            for (int i = 0; i < mt.n_h; ++i) if (i != j) add((int64_t)mt.pair_off + (int64_t)i * (mt.n - 1) + (j < i ? j : j - 1));
+        }
+    } else {
+        const int P = mt.n_h * (mt.n - 1);
+        for (int p = 0; p < P; ++p) add((int64_t)mt.pair_off + p);
+    }
+    float4* o = reinterpret_cast<float4*>(out + (int64_t)dst * TR_COLS + c);
+    if (accumulate) { const float4 t = *o; acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
+    *o = acc;
+}
+
+extern "C" int skg_segment_sum_f32(const float* src, int64_t ld, const skg_image_meta* meta, int n_active,
+                                   const int32_t* hum_img, const int32_t* node_img, int sum_h, int sum_n, int mode,
+                                   float* outH, float* outN, int accumulate, void* stream) {
+    if (n_active < 0 || sum_h < 0 || sum_n < 0 || mode < 0 || mode > 2) return SKG_E_ARG;
+    const int nh = mode == 2 ? n_active : sum_h, nn = mode == 2 ? 0 : sum_n;
+    if (nh + nn == 0) return 0;
+    if (!src || !meta || (mode != 2 && (!hum_img || !node_img)) || (!outH && !outN)) return SKG_E_ARG;
+    if ((ld & 3) || !skg_aligned16(src) || !skg_aligned16(outH) || !skg_aligned16(outN)) return SKG_E_ALIGN;
+    hipLaunchKernelGGL(skg_segment_sum_kernel, dim3(nh + nn), dim3(256), 0, (hipStream_t)stream, src, ld, meta, hum_img,
+                       node_img, nh, mode, outH, outN, accumulate);
+    return skg_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ aggregation backward
+// Forward (skg_graph_aggregate): U[h] = sum_j alpha[(i,j)] Tos[(i,j)],  V[o] = sum_i beta[(i,j)] Tso[(i,j)].
+// Stage 1, one wavefront per grid row r = (i, j):
+//   dTos[r] = alpha[r] * dU[h] where Tos[r] > 0 else 0       (Tos = relu(...): the mask of the fc_1 * fc_2 stage)
+//   dTso[r] = beta[r]  * dV[o] where Tso[r] > 0 else 0
+//   da[r]   = dU[h] . Tos[r],   db[r] = dV[o] . Tso[r]       (gradients of the softmax weights)
+__global__ __launch_bounds__(256) void skg_aggregate_bwd_rows_kernel(
+    const float* __restrict__ dU, const float* __restrict__ dV, const float* __restrict__ Tos,
+    const float* __restrict__ Tso, const float* __restrict__ alpha, const float* __restrict__ beta,
+    const int32_t* __restrict__ grid_h, const int32_t* __restrict__ grid_o, int rows, float* __restrict__ dTos,
+    float* __restrict__ dTso, float* __restrict__ da, float* __restrict__ db) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float al = alpha[r], be = beta[r];
+    const float* u = dU + (int64_t)grid_h[r] * TR_COLS;
+    const float* v = dV + (int64_t)grid_o[r] * TR_COLS;
+    const float* ts = Tos + (int64_t)r * TR_COLS;
+    const float* tv = Tso + (int64_t)r * TR_COLS;
+    float sa = 0.f, sb = 0.f;
+    for (int c = lane * 4; c < TR_COLS; c += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(u + c), t = *reinterpret_cast<const float4*>(ts + c);
+        const float4 b = *reinterpret_cast<const float4*>(v + c), s = *reinterpret_cast<const float4*>(tv + c);
+        sa += (a.x * t.x + a.y * t.y) + (a.z * t.z + a.w * t.w);
+        sb += (b.x * s.x + b.y * s.y) + (b.z * s.z + b.w * s.w);
+        *reinterpret_cast<float4*>(dTos + (int64_t)r * TR_COLS + c) =
+            make_float4(t.x > 0.f ? al * a.x : 0.f, t.y > 0.f ? al * a.y : 0.f, t.z > 0.f ? al * a.z : 0.f, t.w > 0.f ? al * a.w : 0.f);
+        *reinterpret_cast<float4*>(dTso + (int64_t)r * TR_COLS + c) =
+            make_float4(s.x > 0.f ? be * b.x : 0.f, s.y > 0.f ? be * b.y : 0.f, s.z > 0.f ? be * b.z : 0.f, s.w > 0.f ? be * b.w : 0.f);
+    }
+    sa = skg_wave_sum(sa); sb = skg_wave_sum(sb);
+    if (lane == 0) { da[r] = sa; db[r] = sb; }
+}
+
+// Stage 2, softmax backward per destination (one workgroup each, like the forward): for human (a, i) over its n senders
+//   dadj_h[r] = alpha[r] * (da[r] - sum_j alpha[(i,j)] da[(i,j)]),  for node (a, j) over its n_h senders likewise with
+// beta / db into dadj_n.  The adjacency logit feeds both softmaxes: its gradient is dadj_h + dadj_n.
+__global__ __launch_bounds__(64) void skg_aggregate_bwd_softmax_kernel(
+    const skg_image_meta* __restrict__ meta, const int32_t* __restrict__ hum_img, const int32_t* __restrict__ node_img,
+    int sum_h, const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ da,
+    const float* __restrict__ db, float* __restrict__ dadj_h, float* __restrict__ dadj_n) {
+    const bool to_h = (int)blockIdx.x < sum_h;
+    const int dst = to_h ? blockIdx.x : blockIdx.x - sum_h;
+    const skg_image_meta mt = meta[to_h ? hum_img[dst] : node_img[dst]];
+    const int local = to_h ? dst - mt.hum_off : dst - mt.node_off;
+    const int cnt = to_h ? mt.n : mt.n_h;
+    const int64_t row0 = to_h ? (int64_t)mt.grid_off + (int64_t)local * mt.n : (int64_t)mt.grid_off + local;
+    const int64_t step = to_h ? 1 : mt.n;
+    const float* w = to_h ? alpha : beta;
+    const float* d = to_h ? da : db;
+    float* out = to_h ? dadj_h : dadj_n;
+    float s = 0.f;
+    for (int t = threadIdx.x; t < cnt; t += 64) s += w[row0 + t * step] * d[row0 + t * step];
+    s = skg_wave_sum(s);
+    for (int t = threadIdx.x; t < cnt; t += 64) {
+        const int64_t r = row0 + t * step;
+        out[r] = w[r] * (d[r] - s);
+    }
+}
+
+extern "C" int skg_aggregate_bwd_f32(const float* dU, const float* dV, const float* Tos, const float* Tso,
+                                     const float* alpha, const float* beta, const int32_t* grid_h, const int32_t* grid_o,
+                                     int sum_g, const skg_image_meta* meta, const int32_t* hum_img,
+                                     const int32_t* node_img, int sum_h, int sum_n, float* dTos, float* dTso,
+                                     float* da, float* db, float* dadj_h, float* dadj_n, void* stream) {
+    if (sum_g < 0 || sum_h < 0 || sum_n < 0) return SKG_E_ARG;
+    if (sum_g == 0) return 0;
+    if (!dU || !dV || !Tos || !Tso || !alpha || !beta || !grid_h || !grid_o || !meta || !hum_img || !node_img || !dTos ||
+        !dTso || !da || !db || !dadj_h || !dadj_n)
+        return SKG_E_ARG;
+    if (!skg_aligned16(dU) || !skg_aligned16(dV) || !skg_aligned16(Tos) || !skg_aligned16(Tso) || !skg_aligned16(dTos) ||
+        !skg_aligned16(dTso))
+        return SKG_E_ALIGN;
+    hipLaunchKernelGGL(skg_aggregate_bwd_rows_kernel, dim3((sum_g + 3) / 4), dim3(256), 0, (hipStream_t)stream, dU, dV, Tos,
+                       Tso, alpha, beta, grid_h, grid_o, sum_g, dTos, dTso, da, db);
+    hipLaunchKernelGGL(skg_aggregate_bwd_softmax_kernel, dim3(sum_h + sum_n), dim3(64), 0, (hipStream_t)stream, meta, hum_img,
+                       node_img, sum_h, alpha, beta, da, db, dadj_h, dadj_n);
+    return skg_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ adjacency backward
+// adj[r] = Wt[r] . w + b with Wt = relu(...) (HEAD:896-897):  dadj[r] = dadj_h[r] + dadj_n[r],
+// dWt[r, c] = dadj[r] * w[c] where Wt[r, c] > 0.  (dw and db come from the GEMM  dadj^T Wt  on the matrix core.)
+__global__ __launch_bounds__(256) void skg_adjacency_bwd_kernel(const float* __restrict__ dadj_h,
+                                                                const float* __restrict__ dadj_n,
+                                                                const float* __restrict__ w,
+                                                                const float* __restrict__ Wt, float* __restrict__ dadj,
+                                                                float* __restrict__ dWt) {
+    const int r = blockIdx.x;
+    const int c = threadIdx.x * 4;
+    const float d = dadj_h[r] + dadj_n[r];
+    if (threadIdx.x == 0) dadj[r] = d;
+    const float4 wv = *reinterpret_cast<const float4*>(w + c);
+    const float4 t = *reinterpret_cast<const float4*>(Wt + (int64_t)r * TR_COLS + c);
+    *reinterpret_cast<float4*>(dWt + (int64_t)r * TR_COLS + c) =
+        make_float4(t.x > 0.f ? d * wv.x : 0.f, t.y > 0.f ? d * wv.y : 0.f, t.z > 0.f ? d * wv.z : 0.f, t.w > 0.f ? d * wv.w : 0.f);
+}
+
+extern "C" int skg_adjacency_bwd_f32(const float* dadj_h, const float* dadj_n, const float* w, const float* Wt, int rows,
+                                     float* dadj, float* dWt, void* stream) {
+    if (rows < 0) return SKG_E_ARG;
+    if (rows == 0) return 0;
+    if (!dadj_h || !dadj_n || !w || !Wt || !dadj || !dWt) return SKG_E_ARG;
+    if (!skg_aligned16(w) || !skg_aligned16(Wt) || !skg_aligned16(dWt)) return SKG_E_ALIGN;
+    hipLaunchKernelGGL(skg_adjacency_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dadj_h, dadj_n, w, Wt, dadj,
+                       dWt);
+    return skg_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ fc_head / fc_tail inputs
+// Backward of skg_concat_entity: d_enc[e] = (dX[hum_of[e]] + dX[sum_h + node_of[e]])[:1024], zeroed where enc[e] <= 0 (the
+// ReLU of box_head's second layer, HEAD:639).  hum_of / node_of: the human / node row that reads encoding row e, or -1.
+__global__ __launch_bounds__(256) void skg_entity_rows_bwd_kernel(const float* __restrict__ dX, int64_t ldx,
+                                                                  const int32_t* __restrict__ hum_of,
+                                                                  const int32_t* __restrict__ node_of, int sum_h,
+                                                                  const float* __restrict__ enc,
+                                                                  float* __restrict__ d_enc) {
+    const int e = blockIdx.x;
+    const int c = threadIdx.x * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int h = hum_of[e], o = node_of[e];
+    if (h >= 0) { const float4 v = *reinterpret_cast<const float4*>(dX + (int64_t)h * ldx + c); acc = v; }
+    if (o >= 0) {
+        const float4 v = *reinterpret_cast<const float4*>(dX + (int64_t)(sum_h + o) * ldx + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const float4 m = *reinterpret_cast<const float4*>(enc + (int64_t)e * TR_COLS + c);
+    *reinterpret_cast<float4*>(d_enc + (int64_t)e * TR_COLS + c) =
+        make_float4(m.x > 0.f ? acc.x : 0.f, m.y > 0.f ? acc.y : 0.f, m.z > 0.f ? acc.z : 0.f, m.w > 0.f ? acc.w : 0.f);
+}
+
+extern "C" int skg_entity_rows_bwd_f32(const float* dX, int64_t ldx, const int32_t* hum_of, const int32_t* node_of,
+                                       int sum_h, int n_enc, const float* enc, float* d_enc, void* stream) {
+    if (n_enc < 0 || sum_h < 0) return SKG_E_ARG;
+    if (n_enc == 0) return 0;
+    if (!dX || !hum_of || !node_of || !enc || !d_enc) return SKG_E_ARG;
+    if ((ldx & 3) || !skg_aligned16(dX) || !skg_aligned16(enc) || !skg_aligned16(d_enc)) return SKG_E_ALIGN;
+    hipLaunchKernelGGL(skg_entity_rows_bwd_kernel, dim3(n_enc), dim3(256), 0, (hipStream_t)stream, dX, ldx, hum_of, node_of,
+                       sum_h, enc, d_enc);
+    return skg_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ focal losses
+// compute_interaction_classification_loss + compute_interactiveness_loss (HEAD:153-205) with binary_focal_loss
+// (ops.py:159-211: |1 - y - alpha| * (|y - x| + eps)^gamma * BCE(x, y), alpha 0.5, eps 1e-6; gamma 0.2 on the scored
+// cells, 2.0 on the pair weights), forward AND the gradient w.r.t. the logits in one pass over what postprocess emitted:
+//   cell c of image a: pair p = pair_off + index[c], verb v = pred[c]; x = scores[c] = sigmoid(lp) * ph * po * w.detach()
+//   pair p: w = sigmoid(ls), y = unary[p] = min(sum_v labels[p, v], 1)
+// BCE and its derivative as torch defines them (log clamped at -100; (x - y) / max(x (1 - x), 1e-12)).
+// One workgroup per image; partial[a] = {sum of cell losses, sum of pair losses} (the caller adds and divides by n_p).
+// dlogits [sumP, ldl] must be zero-filled; columns < K receive d(sum cell loss)/dlp, column K d(sum pair loss)/dls.
+__device__ __forceinline__ float skg_focal(float x, float y, float gamma, float& dldx) {
+    const float alpha = 0.5f, eps = 1e-6f;
+    const float c = fabsf(1.f - y - alpha);
+    const float u = fabsf(y - x) + eps;
+    const float lx = fmaxf(logf(x), -100.f), l1x = fmaxf(logf(1.f - x), -100.f);
+    const float bce = -(y * lx + (1.f - y) * l1x);
+    const float pw = powf(u, gamma);
+    const float sgn = (x > y) ? 1.f : ((x < y) ? -1.f : 0.f);
+    const float dbce = (x - y) / fmaxf((1.f - x) * x, 1e-12f);
+    dldx = c * (gamma * powf(u, gamma - 1.f) * sgn * bce + pw * dbce);
+    return c * pw * bce;
+}
+
+__global__ __launch_bounds__(256) void skg_hoi_loss_kernel(
+    const float* __restrict__ logits, int64_t ldl, int K, const skg_image_meta* __restrict__ meta, int n_active,
+    int64_t cells_total, const int64_t* __restrict__ index, const int64_t* __restrict__ pred,
+    const float* __restrict__ scores, const float* __restrict__ labels, float* __restrict__ cell_labels,
+    float* __restrict__ unary, float* __restrict__ partial, float* __restrict__ dlogits) {
+    __shared__ float sred[4];
+    const int a = blockIdx.x;
+    const skg_image_meta mt = meta[a];
+    const int64_t c0 = mt.out_off;
+    const int64_t c1 = (a + 1 < n_active) ? (int64_t)meta[a + 1].out_off : cells_total;
+    const int P = mt.n_h * (mt.n - 1);
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t c = c0 + threadIdx.x; c < c1; c += 256) {
+        const int64_t p = (int64_t)mt.pair_off + index[c];
+        const int v = (int)pred[c];
+        const float y = labels[p * K + v];
+        const float x = scores[c];
+        cell_labels[c] = y;
+        float dldx;
+        s1 += skg_focal(x, y, 0.2f, dldx);
+        const float sg = 1.f / (1.f + expf(-logits[p * ldl + v]));
+        dlogits[p * ldl + v] = dldx * x * (1.f - sg);
+    }
+    for (int pl = threadIdx.x; pl < P; pl += 256) {
+        const int64_t p = (int64_t)mt.pair_off + pl;
+        float ys = 0.f;
+        for (int v = 0; v < K; ++v) ys += labels[p * K + v];
+        const float y = fminf(ys, 1.f);
+        unary[p] = y;
+        const float w = 1.f / (1.f + expf(-logits[p * ldl + K]));
+        float dldw;
+        s2 += skg_focal(w, y, 2.0f, dldw);
+        dlogits[p * ldl + K] = dldw * w * (1.f - w);
+    }
+    s1 = skg_block_sum256(s1, sred);
+    s2 = skg_block_sum256(s2, sred);
+    if (threadIdx.x == 0) { partial[2 * a] = s1; partial[2 * a + 1] = s2; }
+}
+
+extern "C" int skg_hoi_loss_f32(const float* logits, int64_t ldl, int K, const skg_image_meta* meta, int n_active,
+                                int64_t cells_total, const int64_t* index, const int64_t* pred, const float* scores,
+                                const float* labels, float* cell_labels, float* unary, float* partial, float* dlogits,
+                                void* stream) {
+    if (n_active < 0 || K <= 0 || ldl <= K || cells_total < 0) return SKG_E_ARG;
+    if (n_active == 0) return 0;
+    if (!logits || !meta || !index || !pred || !scores || !labels || !cell_labels || !unary || !partial || !dlogits)
+        return SKG_E_ARG;
+    hipLaunchKernelGGL(skg_hoi_loss_kernel, dim3(n_active), dim3(256), 0, (hipStream_t)stream, logits, ldl, K, meta, n_active,
+                       cells_total, index, pred, scores, labels, cell_labels, unary, partial, dlogits);
+    return skg_launch_status();
+}

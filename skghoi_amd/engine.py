@@ -262,7 +262,7 @@ def pick_split_k(M, N, K, target_blocks=1024):
     if M <= 64:
         # one tile high: the launcher takes 64 x 64 tiles (skg_gemm_tile_scale); slices of >= 4 k-tiles
         blocks = (N + 63) // 64
-        return int(max(1, min(-(-512 // blocks), K // 64, 32))) if K >= 512 else 1
+        return int(max(1, min(-(-1024 // blocks), K // 64, 64))) if K >= 512 else 1
     if blocks >= target_blocks or K < 2048:
         return 1
     return int(max(1, min(-(-target_blocks // blocks), K // 256, 64)))
@@ -293,7 +293,10 @@ def gemm(A, W, bias, C_out, M, N, K, epilogue, **kw):
         GEMM_TIMER.append((e0, e1, M, N, K, epilogue))
 
 
-SMALL_GROUP_BLOCKS = 512         # workgroups a small (64 x 64 tile) grouped launch aims for; split-K supplies them
+# Workgroups a small (64 x 64 tile) grouped launch aims for; split-K supplies them.  These GEMMs stream 4 MB of weights
+# each through a one-tile-deep prefetch: what hides the HBM latency is the number of workgroups in flight, so the slices
+# are short (>= 2 k-tiles) and many.
+SMALL_GROUP_BLOCKS = 1024
 
 
 def gemm_group(specs):
@@ -316,7 +319,7 @@ def gemm_group(specs):
         for d, t in zip(arr, tiles):
             if t == 0 or d.split_k > 1 or d.epilogue not in (_capi.EPI_BIAS, _capi.EPI_BIAS_RELU, _capi.EPI_BIAS_RES_RELU):
                 continue
-            sk = min(-(-SMALL_GROUP_BLOCKS // max(total, 1)), d.K // 64, 64)
+            sk = min(-(-SMALL_GROUP_BLOCKS // max(total, 1)), d.K // 32, 64)
             if sk > 1:
                 ws = torch.empty(sk * d.M * d.N, device=specs[0][0][0].device, dtype=torch.float32)
                 keep.append(ws)
@@ -670,17 +673,19 @@ class HeadEngine:
         NA = lay.sum_all
         enc1 = torch.empty(max(NA, 1), 1024, **f32)
         enc = torch.empty(max(NA, 1), 1024, **f32)
+        G1 = torch.empty(Bf, 1024, **f32)                       # attention_head_g fc_1(global) per image (HEAD:971)
         if NA:
             sk = pick_split_k(NA, 1024, x0.shape[1])
             ws = torch.empty(sk, NA, 1024, **f32) if sk > 1 else None
             gemm(x0, pw.bh1_w, pw.bh1_b, enc1, NA, 1024, x0.shape[1], _capi.EPI_BIAS_RELU, split_k=sk, split_ws=ws)
-            gemm(enc1, pw.bh3_w, pw.bh3_b, enc, NA, 1024, 1024, _capi.EPI_BIAS_RELU)
+        # box_head layer 2 and fc_1(global features) are independent: one launch (the same call the captured small-batch
+        # plan makes, skghoi_amd/small.py -- the two paths stay bit-identical)
+        gemm_group([((enc1, pw.bh3_w, pw.bh3_b, enc, NA, 1024, 1024, _capi.EPI_BIAS_RELU), {}),
+                    ((gfeat, pw.att_g["w1"], pw.att_g["b1"], G1, Bf, 1024, Cf, _capi.EPI_BIAS), {})])
         out["enc"] = enc[:NA]
         out["gfeat"] = gfeat
         if A == 0:
             return out
-        G1 = torch.empty(Bf, 1024, **f32)                       # attention_head_g fc_1(global) per image (HEAD:971)
-        gemm(gfeat, pw.att_g["w1"], pw.att_g["b1"], G1, Bf, 1024, Cf, _capi.EPI_BIAS)
         Mp = lay.sum_p
         meta_g = torch.from_numpy(lay.meta.view(np.int32).reshape(-1).copy()).to(dev, non_blocking=True)
         x_keep = torch.empty(max(Mp, 1), device=dev, dtype=torch.int64); y_keep = torch.empty_like(x_keep)
@@ -792,18 +797,29 @@ class HeadEngine:
         gemm(s1, pw.sp2_w, pw.sp2_b, s2, Mg, 256, 128, _capi.EPI_BIAS_RELU)
         gemm(s2, pw.sp4_w, pw.sp4_b, S, Mg, 1024, 256, _capi.EPI_BIAS_RELU)
         del s1, s2
-        # ---- global read-out branch: attention_head_g needs only S and the image's global feature (HEAD:971-972)
-        Tg = torch.empty(max(Mp, 1), 1024, **f32)
+        cx = dict(ch=ch, isl=isl, meta=meta, grid_h=grid_h, grid_o=grid_o, grid_img=grid_img, grid_pair=grid_pair,
+                  pair_grid=pair_grid, pair_h=pair_h, pair_o=pair_o, sp48=sp48, S=S, ibuf=ibuf)
+        if G1 is not None:
+            self._chunk_phase_a2(cx, pw, pre, G1, PF)
+        return cx
+
+    def _chunk_phase_a2(self, cx, pw, pre, G1, PF):
+        """Global read-out branch of one chunk: attention_head_g needs only S and the image's global feature
+        (HEAD:971-972).  (Split off phase A so that a captured plan can run it beside the message-passing chain.)"""
+        ch = cx["ch"]
+        Mg, Mp = ch.sum_g, ch.sum_p
+        Tg = torch.empty(max(Mp, 1), 1024, device=pre.device, dtype=torch.float32)
         if Mp:
-            gemm(S, pw.att_g["w2"], pw.att_g["b2"], Tg, Mg, 1024, 1024, _capi.EPI_MUL_RELU, P=G1, p_idx=grid_img,
-                 ldp=1024, out_rows=grid_pair)
+            gemm(cx["S"], pw.att_g["w2"], pw.att_g["b2"], Tg, Mg, 1024, 1024, _capi.EPI_MUL_RELU, P=G1,
+                 p_idx=cx["grid_img"], ldp=1024, out_rows=cx["grid_pair"])
             gemm(Tg, pw.att_g["w3"], pw.att_g["b3"], PF, Mp, 1024, 1024, _capi.EPI_BIAS_RELU, ldc=2048,
                  C_off=ch.P0 * 2048 + 1024)
-        return dict(ch=ch, isl=isl, meta=meta, grid_h=grid_h, grid_o=grid_o, grid_img=grid_img, grid_pair=grid_pair,
-                    pair_grid=pair_grid, pair_h=pair_h, pair_o=pair_o, sp48=sp48, S=S, Tg=Tg, ibuf=ibuf)
+        cx["Tg"] = Tg
 
-    def _chunk_phase_b(self, cx, tabs, pw, pre, enc, PF, sc, keep):
-        """Message passing and pair read-out of one chunk (needs the chunk's TransH entity tables)."""
+    def _chunk_phase_b(self, cx, tabs, pw, pre, enc, PF, sc, keep, need_S=None, need_Tg=None):
+        """Message passing and pair read-out of one chunk (needs the chunk's TransH entity tables).  need_S / need_Tg:
+        callables invoked right before the first use of the spatial features S resp. of the global branch's buffer
+        (a captured plan produces them on a side stream and joins there)."""
         lib = _capi.lib()
         gh = self.gh
         dev = pre.device
@@ -811,7 +827,7 @@ class HeadEngine:
         f32 = dict(device=dev, dtype=torch.float32)
         ch, isl, meta = cx["ch"], cx["isl"], cx["meta"]
         grid_h, grid_o, pair_grid, pair_h, pair_o = cx["grid_h"], cx["grid_o"], cx["pair_grid"], cx["pair_h"], cx["pair_o"]
-        sp48, S, Tg = cx["sp48"], cx["S"], cx["Tg"]
+        sp48, S = cx["sp48"], cx["S"]
         A = ch.n_active
         Mh, Mn, Mg, Mp = ch.sum_h, ch.sum_n, ch.sum_g, ch.sum_p
         ent, rel, nrm = tabs
@@ -844,6 +860,8 @@ class HeadEngine:
                     dict(P=C1o, p_idx=grid_o, ldp=1024)),
                    ((S, pw.so["w2"], pw.so["b2"], Tso, Mg, 1024, 1024, _capi.EPI_MUL_RELU),
                     dict(P=C1h, p_idx=grid_h, ldp=1024))]
+            if need_S is not None:
+                need_S()
             if Mg < self.GROUP_FC2_BELOW:       # small grids: one launch fills the CUs better than three (+17 % at 4 images)
                 gemm_group(fc2)
             else:
@@ -874,6 +892,8 @@ class HeadEngine:
                                               EPS_LN, node.data_ptr(), 1024, st), "skg_layernorm_f32")
         else:
             # num_iter == 0: the raw box_head encodings reach the read-out (HEAD:843-845)
+            if need_S is not None:
+                need_S()
             gemm(S, pw.att["w2"], pw.att["b2"], F2, Mg, 1024, 1024, _capi.EPI_BIAS)
             h_node = enc.index_select(0, isl("hum_enc_row").long())
             node = enc.index_select(0, isl("node_enc_row").long())
@@ -883,7 +903,9 @@ class HeadEngine:
             B1h = torch.empty(Mh, 1024, **f32); B1o = torch.empty(Mn, 1024, **f32)
             gemm_group([((h_node, pw.att["w1"], None, B1h, Mh, 1024, 1024, _capi.EPI_BIAS), dict(ldw=2048)),
                         ((node, pw.att["w1"], None, B1o, Mn, 1024, 1024, _capi.EPI_BIAS), dict(ldw=2048, W_off=1024))])
-            Tp = Tg                                              # the global branch has consumed this buffer
+            if need_Tg is not None:
+                need_Tg()
+            Tp = cx["Tg"]                                        # the global branch has consumed this buffer
             _capi.check(lib.skg_rows_mul_relu_f32(B1h.data_ptr(), pair_h.data_ptr(), 1024, B1o.data_ptr(),
                                                   pair_o.data_ptr(), 1024, pw.att["b1"].data_ptr(), F2.data_ptr(),
                                                   pair_grid.data_ptr(), 1024, Mp, 1024, Tp.data_ptr(), 1024, st),
@@ -939,7 +961,8 @@ class HeadEngine:
                 logits.data_ptr(), logits.stride(0), self.K, pre.boxes.data_ptr(), pre.scores.data_ptr(),
                 pre.labels.data_ptr(), g["meta"].data_ptr(), lay.n_active, g["x_keep"].data_ptr(),
                 g["y_keep"].data_ptr(), vt.off.data_ptr(), vt.flat.data_ptr(), vt.num_obj,
-                1.0 if training else 2.8, max(Lt, 1), _ptr(L_dev), r["index"].data_ptr(), r["prediction"].data_ptr(),
+                1.0 if training else 2.8, max(Lt, 1), _ptr(L_dev), int(lay.pairs_per_image.max()),
+                r["index"].data_ptr(), r["prediction"].data_ptr(),
                 r["scores"].data_ptr(), r["prior"].data_ptr(), r["weights"].data_ptr(), r["object"].data_ptr(),
                 r["boxes_h"].data_ptr(), r["boxes_o"].data_ptr(), _stream()), "skg_postprocess_f32")
         return r

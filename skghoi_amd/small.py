@@ -46,6 +46,7 @@ class SmallBatchRunner:
         self.plans = OrderedDict()
         self.pool = None                   # graph memory pool shared by the plans (one forward at a time per engine)
         self.hits = self.misses = 0
+        self.side = None                   # second stream of the plan bodies (second branch of the captured graphs)
         self.epoch = engine.plan_epoch
 
     # ------------------------------------------------------------------------------------------------ plan
@@ -108,26 +109,48 @@ class SmallBatchRunner:
         return p
 
     def _body(self, p):
-        """The shape-dependent part of the forward (HEAD:812-982, 408-411, 237-337) for a single chunk."""
+        """The shape-dependent part of the forward (HEAD:812-982, 408-411, 237-337) for a single chunk.
+
+        Two branches run side by side (two streams while capturing = two branches of the hipGraph): at one image every
+        kernel fills a fraction of the chip, and the spatial chain (pairs -> spatial head -> global read-out branch) shares
+        nothing with the box_head -> fc_head/fc_tail -> fc_1 chain until the fc_2 GEMMs."""
         eng, pw, lay = self.eng, p.pw, p.lay
         dev = p.pre.device
         f32 = dict(device=dev, dtype=torch.float32)
         NA, Mp = lay.sum_all, lay.sum_p
+        main = torch.cuda.current_stream()
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=dev)
+        side = self.side
         with eng._split_ctx(pw):
             enc = torch.empty(max(NA, 1), 1024, **f32)
             Bf, Cf = p.gfeat.shape
             G1 = torch.empty(Bf, 1024, **f32)
+            x_keep = torch.empty(max(Mp, 1), device=dev, dtype=torch.int64); y_keep = torch.empty_like(x_keep)
+            PF = torch.empty(max(Mp, 1), 2048, **f32)
+            fork = torch.cuda.Event(); fork.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(fork)
+                cx = eng._chunk_phase_a(p.ch, pw, p.pre, None, x_keep, y_keep, PF, ibuf=p.ibuf, offs=p.offs,
+                                        meta=p.meta_dev)
+                s_ready = torch.cuda.Event(); s_ready.record(side)
             # box_head layer 2 (HEAD:812) and attention_head_g's fc_1 on the global features (HEAD:971): independent
             gemm_group([((p.enc1, pw.bh3_w, pw.bh3_b, enc, NA, 1024, 1024, _capi.EPI_BIAS_RELU), {}),
                         ((p.gfeat, pw.att_g["w1"], pw.att_g["b1"], G1, Bf, 1024, Cf, _capi.EPI_BIAS), {})])
-            x_keep = torch.empty(max(Mp, 1), device=dev, dtype=torch.int64); y_keep = torch.empty_like(x_keep)
-            PF = torch.empty(max(Mp, 1), 2048, **f32)
-            cx = eng._chunk_phase_a(p.ch, pw, p.pre, G1, x_keep, y_keep, PF, ibuf=p.ibuf, offs=p.offs, meta=p.meta_dev)
-            eng._chunk_phase_b(cx, (p.ent_dev, None, None), pw, p.pre, enc, PF, None, None)
+            g1_ready = torch.cuda.Event(); g1_ready.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(g1_ready)
+                eng._chunk_phase_a2(cx, pw, p.pre, G1, PF)
+                g_done = torch.cuda.Event(); g_done.record(side)
+            eng._chunk_phase_b(cx, (p.ent_dev, None, None), pw, p.pre, enc, PF, None, None,
+                               need_S=lambda: main.wait_event(s_ready), need_Tg=lambda: main.wait_event(g_done))
+            main.wait_event(g_done)
             logits = eng._classify(PF[:Mp], pw)
             g = dict(layout=lay, meta=p.meta_dev, x_keep=x_keep[:Mp], y_keep=y_keep[:Mp])
             eng.score(logits, p.pre, g, False, out=p.r, L_dev=p.lt_dev)
-        return dict(logits=logits, pair_features=PF[:Mp], x_keep=x_keep[:Mp], y_keep=y_keep[:Mp], enc=enc)
+        # everything both branches touched stays referenced until the plan dies: a block handed back to the allocator
+        # inside the capture could be given to the other branch while this one still uses it
+        return dict(logits=logits, pair_features=PF[:Mp], x_keep=x_keep[:Mp], y_keep=y_keep[:Mp], enc=enc, _cx=cx, _G1=G1)
 
     def _capture(self, p):
         if self.pool is None:
@@ -191,6 +214,23 @@ class SmallBatchRunner:
             pooled = head.box_roi_pool(features, list(p.boxes.split(pre.sizes)), image_shapes)
             if pooled.shape[0] != lay.sum_all:
                 raise _capi.SkgError("box_roi_pool returned %d rows for %d boxes" % (pooled.shape[0], lay.sum_all))
+        # the two launches that read caller-owned tensors go first: global average pool (HEAD:811), box_head layer 1
+        # (HEAD:812, 51 MB of weights) -- the GPU works on them while the host fills in the per-call records below
+        lib = _capi.lib()
+        f3 = feat3 if (feat3.dtype == torch.float32 and feat3.is_contiguous()) else feat3.float().contiguous()
+        _capi.check(lib.skg_global_avgpool_f32(f3.data_ptr(), f3.shape[0], f3.shape[1], f3.shape[2] * f3.shape[3],
+                                               p.gfeat.data_ptr(), _stream()), "skg_global_avgpool_f32")
+        x0 = pooled.reshape(pooled.shape[0], -1)
+        if x0.dtype != torch.float32:
+            x0 = x0.float()
+        if p.x0_pad is not None:
+            p.x0_pad[:, :x0.shape[1]] = x0
+            x0 = p.x0_pad
+        elif not x0.is_contiguous():
+            x0 = x0.contiguous()
+        with eng._split_ctx(pw):
+            gemm(x0, pw.bh1_w, pw.bh1_b, p.enc1, lay.sum_all, 1024, x0.shape[1], _capi.EPI_BIAS_RELU, split_k=p.sk,
+                 split_ws=p.ws)
         # per-call records: meta (image sizes, result offsets), cell count, TransH entity tables
         if p.h2d_done is not None:
             p.h2d_done.synchronize()               # the staging block's previous copy (normally long finished)
@@ -208,22 +248,6 @@ class SmallBatchRunner:
         if p.h2d_done is None:
             p.h2d_done = torch.cuda.Event()
         p.h2d_done.record()
-        # the two launches that read caller-owned tensors: global average pool (HEAD:811), box_head layer 1 (HEAD:812)
-        lib = _capi.lib()
-        f3 = feat3 if (feat3.dtype == torch.float32 and feat3.is_contiguous()) else feat3.float().contiguous()
-        _capi.check(lib.skg_global_avgpool_f32(f3.data_ptr(), f3.shape[0], f3.shape[1], f3.shape[2] * f3.shape[3],
-                                               p.gfeat.data_ptr(), _stream()), "skg_global_avgpool_f32")
-        x0 = pooled.reshape(pooled.shape[0], -1)
-        if x0.dtype != torch.float32:
-            x0 = x0.float()
-        if p.x0_pad is not None:
-            p.x0_pad[:, :x0.shape[1]] = x0
-            x0 = p.x0_pad
-        elif not x0.is_contiguous():
-            x0 = x0.contiguous()
-        with eng._split_ctx(pw):
-            gemm(x0, pw.bh1_w, pw.bh1_b, p.enc1, lay.sum_all, 1024, x0.shape[1], _capi.EPI_BIAS_RELU, split_k=p.sk,
-                 split_ws=p.ws)
         if p.graph is None:
             self._capture(p)
         p.graph.replay()
