@@ -174,6 +174,9 @@ int skg_gemm_group_f32(const skg_gemm_desc* descs_host, int n, void* stream);
  * tiles a member may carry split_k > 1 (epilogues BIAS / BIAS_RELU / BIAS_RES_RELU): one more launch then reduces all
  * split members in slice order.  SKG_EPI_RELU_DOT members write 2 * ceil(N / (64 * scale)) dot_partial slabs.       */
 int skg_gemm_group_tile(const skg_gemm_desc* descs_host, int n);
+/* Developer switch: which 64 x 64 main loop the small launches take (3 = 64-k steps, register staged: the default;
+ * 1 = 16-k steps, DMA staged).  Returns the previous setting; other values only query.                              */
+int skg_gemm_small_mode(int mode);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * fc_head / fc_tail input rows (HEAD:884-885): out[r] = [ enc[enc_row[r], 0:1024] | ent[ent_img[r], ent_row[r], 0:50]
@@ -286,8 +289,10 @@ int skg_associate_f32(const float* boxes, const skg_image_meta* meta, int n_acti
  *   input grad     dx = dz W        : A = dz (a_sk = 1),   B(k, n) = W[k][n]   (b_sn = 1, b_sk = ld), mask = x's ReLU
  *   weight grad    dW = dz^T x      : A(m, k) = dz[k][m]   (a_sm = 1, a_sk = ld), B(k, n) = x[k][n] (b_sn = 1);
  *                  a_rowsum[m] = sum_k A(m, k) is the bias gradient, formed on the way by the workgroups of column tile 0
- *   mask (optional) [M, >= N], ldmask: the result is zeroed where mask <= 0 (ReLU of the layer that produced the input)
- *   accumulate: add to C / a_rowsum instead of overwriting (weights shared by two call sites)
+ *   accumulate: add to C / a_rowsum instead of overwriting (weights shared by two call sites; gradients with several
+ *   consumers)
+ *   mask (optional) [M, >= N], ldmask: C is zeroed where mask <= 0 -- the ReLU of the layer that produced the tensor C is
+ *   the gradient of; applied AFTER the accumulation (the sum of all contributions is what the ReLU cuts)
  *   split_k > 1: slices of K by separate workgroups into split_ws (skg_gemmx_ws_floats(desc) floats), reduced in slice
  *   order by a second launch that applies the epilogue.
  * Up to SKG_GEMMX_GROUP_MAX independent products per call share ONE launch (plus one reduce launch if any is split). */
@@ -323,17 +328,20 @@ int skg_rowdot_f32(const float* X, int64_t ld, const float* w, int rows, int col
 /* xsum = a + b (node + message, HEAD:912-914, 923-925), y = LayerNorm(xsum) * gamma + beta, stats[r] = {mean, rstd}.  */
 int skg_add_layernorm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gamma,
                           const float* beta, int rows, float eps, float* xsum, float* y, float* stats, void* stream);
-/* LayerNorm backward from the saved xsum / stats: dx [rows, 1024], dgamma / dbeta [1024] (sums over the rows).         */
+/* LayerNorm backward from the saved xsum / stats: dx [rows, 1024], dgamma / dbeta [1024] (sums over the rows).
+ * relu_src / dx_masked (optional, [rows, 1024]): dx_masked = dx where relu_src > 0 else 0 -- xsum = node + relu(message):
+ * dx itself continues along the residual, dx_masked is the gradient in front of the message's ReLU.                    */
 int skg_layernorm_bwd_f32(const float* dy, int64_t lddy, const float* x, const float* stats, const float* gamma,
-                          int rows, float* dx, float* dgamma, float* dbeta, void* stream);
+                          int rows, float* dx, const float* relu_src, float* dx_masked, float* dgamma, float* dbeta,
+                          void* stream);
 /* Backward of t = relu(m * f), m = P[p_idx] + Q[q_idx] + mbias, f = F[f_idx] (MBF fc_1 * fc_2, HEAD:469-474): g = dt
  * (zero where t <= 0) is overwritten with dm = g * f;  dF[f_idx] = (or +=, accumulate) g * m.                          */
 int skg_mul_bwd_f32(float* g, int64_t ldg, const float* F, const int32_t* f_idx, int64_t ldf, const float* P,
                     const int32_t* p_idx, int64_t ldp, const float* Q, const int32_t* q_idx, int64_t ldq,
                     const float* mbias, int rows, float* dF, int64_t lddf, int accumulate, void* stream);
 /* Row sums per human / node / image (gradients of the gathered fc_1 tables).  mode 0: src = grid rows; mode 1: src =
- * kept pairs; mode 2: src = kept pairs, outH[a] = sum over the pairs of image a.  outH [sumH|n_active, 1024],
- * outN [sumN, 1024]; either may be NULL.                                                                              */
+ * kept pairs; mode 2: src = kept pairs, outH[meta[a].image] = sum over the pairs of active image a (rows of images
+ * without pairs are not written).  outH [sumH | batch, 1024], outN [sumN, 1024]; either may be NULL.                   */
 int skg_segment_sum_f32(const float* src, int64_t ld, const skg_image_meta* meta, int n_active, const int32_t* hum_img,
                         const int32_t* node_img, int sum_h, int sum_n, int mode, float* outH, float* outN,
                         int accumulate, void* stream);
@@ -354,7 +362,8 @@ int skg_entity_rows_bwd_f32(const float* dX, int64_t ldx, const int32_t* hum_of,
                             int n_enc, const float* enc, float* d_enc, void* stream);
 /* Both focal losses (HEAD:153-205, ops.py:159-211) forward + d/dlogits in one pass over what skg_postprocess_f32
  * emitted (training: prior_pow 1).  labels [sumP, K] from skg_associate_f32.  Outputs: cell_labels [L] (labels at the
- * scored cells), unary [sumP] (min(sum_v labels, 1)), partial [n_active, 2] = per-image sums of the two losses,
+ * scored cells), unary [sumP] (min(sum_v labels, 1)), partial [n_active, 4] = per image {sum of the cell losses, sum of the
+ * pair losses, number of positive cells, number of positive pairs} (the counts are the normalisers n_p of HEAD:162-165),
  * dlogits [sumP, ldl] (ZERO-FILLED by the caller): columns < K d(cell loss sum)/dlogit, column K d(pair loss sum).    */
 int skg_hoi_loss_f32(const float* logits, int64_t ldl, int K, const skg_image_meta* meta, int n_active,
                      int64_t cells_total, const int64_t* index, const int64_t* pred, const float* scores,

@@ -73,6 +73,7 @@ PROTOTYPES = {
     "skg_split_weights_f16x2": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _f32, _vp, _vp]),
     "skg_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
     "skg_gemm_group_tile": (C.c_int, [C.POINTER(GemmDesc), C.c_int]),
+    "skg_gemm_small_mode": (C.c_int, [C.c_int]),
     "skg_gemmx_ws_floats": (C.c_int64, [C.POINTER(GemmXDesc)]),
     "skg_gemmx_f32": (C.c_int, [C.POINTER(GemmXDesc), C.c_int, _vp]),
     "skg_gemm_bf16": (C.c_int, [C.POINTER(GemmBf16Desc), _vp]),
@@ -93,7 +94,7 @@ PROTOTYPES = {
                                                 _vp, _i64, C.c_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "skg_rowdot_f32": (C.c_int, [_vp, _i64, _vp, C.c_int, C.c_int, _vp, _vp]),
     "skg_add_layernorm_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, C.c_int, _f32, _vp, _vp, _vp, _vp]),
-    "skg_layernorm_bwd_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "skg_layernorm_bwd_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "skg_mul_bwd_f32": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, C.c_int, _vp, _i64,
                                   C.c_int, _vp]),
     "skg_segment_sum_f32": (C.c_int, [_vp, _i64, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int,
@@ -127,6 +128,8 @@ def lib():
         fn.argtypes = args
     if l.skg_abi_version() != ABI_VERSION:
         raise SkgError("libskghoi_hip.so ABI %d != binding ABI %d" % (l.skg_abi_version(), ABI_VERSION))
+    if os.environ.get("SKG_SMALL_MODE"):                 # developer switch: 64 x 64 main loop of the small launches
+        l.skg_gemm_small_mode(int(os.environ["SKG_SMALL_MODE"]))
     _LIB = l
     return l
 

@@ -278,6 +278,7 @@ class InteractionHead(Module):
         if precision not in ("fp32", "bf16", "fp16x2"):
             raise ValueError("precision must be 'fp32', 'fp16x2' or 'bf16'")
         self.precision = precision
+        self.fused_training = True      # False: training through autograd over per-layer Functions (skghoi_amd/train_graph.py)
         self._engine = None
 
     def engine(self) -> HeadEngine:
@@ -386,6 +387,13 @@ class InteractionHead(Module):
         pre = eng.preprocess(detections, targets, self.training, self.training)
         box_coords = list(pre.boxes.split(pre.sizes))
         box_features = self.box_roi_pool(features, box_coords, image_shapes)
+        if with_losses and self.training and self.fused_training:
+            # the training step proper: one autograd.Function around the hand-written forward / backward kernels
+            from skghoi_amd import train_fused
+            if train_fused.supported(self):
+                out = train_fused.train_forward(self, eng, features, image_shapes, box_features, pre, targets)
+                if out is not None:
+                    return out
         from skghoi_amd import dist as _skd
         norm = []
         # the three n_p normalisers (HEAD:162-172, 190-199, 219-228) leave as ONE 3-element all-reduce as soon as the
@@ -497,9 +505,12 @@ class InteractionHead(Module):
             d["unary_labels"] = torch.zeros(0, device=dev)
         return d
 
-    def _results(self, lay, r, dev):
+    def _results(self, lay, r, dev, train_extras=None):
+        """Per-image result dicts (HEAD:317-322) as views of the packed arrays.  train_extras = (labels at the scored
+        cells [L], unary labels [sumP]): training-mode results carry `labels` / `unary_labels` (HEAD:323-327)."""
         n_skipped = int(lay.skipped[:lay.n_visit].sum())
-        quirk = self.reference_quirks and n_skipped > 0
+        # (training appends a label entry for every image, HEAD:838 / 934: nothing is truncated there)
+        quirk = self.reference_quirks and n_skipped > 0 and train_extras is None
         # HEAD:298-310: in eval only skipped images append to the label list; postprocess then zips over it
         n_out = min(lay.n_visit, n_skipped) if quirk else lay.n_visit
         if quirk:
@@ -514,12 +525,17 @@ class InteractionHead(Module):
             ob = r["object"][:Mp].split(ppi); wt = r["weights"][:Mp].split(ppi)
             ix = r["index"][:Lt].split(cpi); pr = r["prediction"][:Lt].split(cpi); sc = r["scores"][:Lt].split(cpi)
             pri = r["prior"][:, :Lt].split(cpi, dim=1)
+            if train_extras is not None:
+                lb = train_extras[0][:Lt].split(cpi); un = train_extras[1][:Mp].split(ppi)
         a = 0
         for b in range(n_out):
             if lay.skipped[b]:
-                results.append(self._empty_result(dev, with_labels=quirk))
+                results.append(self._empty_result(dev, with_labels=quirk or train_extras is not None))
                 continue
-            results.append(dict(boxes_h=bh[a], boxes_o=bo[a], index=ix[a], prediction=pr[a], scores=sc[a],
-                                object=ob[a], prior=pri[a], weights=wt[a]))
+            d = dict(boxes_h=bh[a], boxes_o=bo[a], index=ix[a], prediction=pr[a], scores=sc[a],
+                     object=ob[a], prior=pri[a], weights=wt[a])
+            if train_extras is not None:
+                d["labels"] = lb[a]; d["unary_labels"] = un[a]
+            results.append(d)
             a += 1
         return results

@@ -53,6 +53,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define A_TILE (BM * LDS_LD)
 #define B_TILE (BN * LDS_LD)
 
+// Grids of up to this many tiles skip the XCD-group map: it rounds the grid up to whole groups (up to 4x the workgroups,
+// the surplus returning at once), and for a launch this small the workgroup dispatch rate (~100 per microsecond chip-wide,
+// measured) is what the launch costs, not L2 reuse.
+#define SKG_DIRECT_MAP_TILES 1024
 // g = N-tiles per group (W slice <= 2 MiB), NG = number of groups rounded up to a power of two.
 __host__ __device__ __forceinline__ void skg_gemm_map(int nbn, int K, int T, int& g, int& NG) {
     g = (8192 / T) / (K > 0 ? K : 1);                    // tiles of 64*T columns whose W slice fits in ~2 MiB
@@ -67,7 +71,7 @@ __host__ __device__ __forceinline__ int64_t skg_gemm_blocks(int M, int N, int K,
     const int64_t nbm = (M + 64 * T - 1) / (64 * T), nbn = (N + 64 * T - 1) / (64 * T);
     int g, NG;
     skg_gemm_map((int)nbn, K, T, g, NG);
-    if (NG >= 8) return nbm * nbn;
+    if (NG >= 8 || nbm * nbn <= SKG_DIRECT_MAP_TILES) return nbm * nbn;
     const int XG = 8 / NG;
     return 8LL * g * ((nbm + XG - 1) / XG);
 }
@@ -86,7 +90,8 @@ __device__ __forceinline__ const char* skg_uniform_ptr(const char* p) {
 // MODE = main loop: 0 register-staged fp32 MFMA, 1 DMA-staged fp32 MFMA, 2 fp16x2-split operands on the fp16 MFMA.
 template <int EPI_T, int MODE, int T>
 __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_id, float* smem) {
-    static_assert(MODE == 1 || T == 2, "only the DMA-staged fp32 loop has a 64 x 64 variant");
+    static_assert(MODE == 1 || MODE == 3 || T == 2, "only the DMA-staged and the latency loop have a 64 x 64 variant");
+    static_assert(MODE != 3 || T == 1, "the latency loop is a 64 x 64 tile");
     constexpr bool GLDS = MODE == 1;
     const int Kmap = d.K;
     constexpr int TBM = 64 * T, TBN = 64 * T;
@@ -120,7 +125,7 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
     {
         int g, NG;
         skg_gemm_map(nbn, Kmap, T, g, NG);
-        if (NG >= 8) {
+        if (NG >= 8 || (int64_t)nbm * nbn <= SKG_DIRECT_MAP_TILES) {
             bn = block_id % nbn;
             bm = block_id / nbn;
         } else {
@@ -232,6 +237,85 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
     };
     if constexpr (MODE == 0) {
         loop_exact();
+    } else if constexpr (MODE == 3) {
+        // ---- latency loop for a FEW images (64 x 64 tile, 64 k per step, exact fp32 MFMA).  At one to a handful of
+        // graphs a launch has a few hundred workgroups at most: every workgroup walks its K range alone, and what a
+        // step costs is one memory round trip (~1 us) whatever it computes.  The 16-k steps of the throughput loops make
+        // K = 1024 sixty-four such round trips (34 us per GEMM of one image's grid, measured); here a step carries 64 k:
+        // sixteen round trips, each hidden behind 32 MFMAs per wave (0.85 us) -- the loads of step t+1 are in flight in
+        // registers while step t computes.  One LDS buffer, rows padded to 68 dwords (conflict-free ds_read_b128),
+        // two barriers per step; gathers, K % 4 and split-K as in the register-staged loop.
+        constexpr int BK3 = 64, LD3 = BK3 + 4;
+        float* a_s3 = smem;
+        float* b_s3 = smem + 64 * LD3;
+        const int lr = tid >> 4;                     // 16 rows per pass, 4 passes
+        const int lc = (tid & 15) * 4;               // k quad inside the 64-k step
+        const float* pa[4];
+        const float* pw[4];
+        bool va[4], vw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = m0 + lr + 16 * i;
+            int src = -1;
+            if (r < d.M) src = d.a_rows ? d.a_rows[r] : r;
+            va[i] = src >= 0;
+            pa[i] = d.A + (int64_t)(va[i] ? src : 0) * d.lda;
+            const int c = n0 + lr + 16 * i;
+            vw[i] = c < d.N;
+            pw[i] = d.W + (int64_t)(vw[i] ? c : 0) * d.ldw;
+        }
+        int s_begin = 0, s_end = (d.K + BK3 - 1) / BK3;
+        if (d.split_k > 1) {
+            const int per = (s_end + d.split_k - 1) / d.split_k;
+            s_begin = split_slice * per;
+            s_end = s_begin + per < s_end ? s_begin + per : s_end;
+        }
+        float4 ra[4], rw[4];
+        auto gload3 = [&](int st) {
+            const int k = st * BK3 + lc;
+            const int kk = (k < d.K) ? k : 0;        // clamped, masked when written to LDS (K % 4 == 0: whole quads)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = *reinterpret_cast<const float4*>(pa[i] + kk);
+                rw[i] = *reinterpret_cast<const float4*>(pw[i] + kk);
+            }
+        };
+        auto lstore3 = [&](int st) {
+            const bool kin = st * BK3 + lc < d.K;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ma = kin && va[i], mw = kin && vw[i];
+                const float4 x = ra[i], w = rw[i];
+                *reinterpret_cast<float4*>(a_s3 + (lr + 16 * i) * LD3 + lc) =
+                    make_float4(ma ? x.x : 0.f, ma ? x.y : 0.f, ma ? x.z : 0.f, ma ? x.w : 0.f);
+                *reinterpret_cast<float4*>(b_s3 + (lr + 16 * i) * LD3 + lc) =
+                    make_float4(mw ? w.x : 0.f, mw ? w.y : 0.f, mw ? w.z : 0.f, mw ? w.w : 0.f);
+            }
+        };
+        if (s_begin < s_end) {
+            gload3(s_begin);
+            lstore3(s_begin);
+        }
+        __syncthreads();
+        for (int st = s_begin; st < s_end; ++st) {
+            if (st + 1 < s_end) gload3(st + 1);
+            const float* ap = a_s3 + (wr * 32 + li) * LD3 + 4 * lh;
+            const float* bp = b_s3 + (wc * 32 + li) * LD3 + 4 * lh;
+#pragma unroll
+            for (int ks = 0; ks < BK3 / 8; ++ks) {
+                const float4 a4 = *reinterpret_cast<const float4*>(ap + ks * 8);
+                const float4 b4 = *reinterpret_cast<const float4*>(bp + ks * 8);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[0][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[0][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[0][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[0][0], 0, 0, 0);
+            }
+            __syncthreads();                          // every wave is done reading this step's tile
+            if (st + 1 < s_end) {
+                lstore3(st + 1);
+                __syncthreads();
+            }
+        }
     } else if constexpr (MODE == 2) {
         // ---- fp32-grade result from the fp16 matrix pipe (3 MFMA passes instead of the 8 of the fp32 MFMA per 16 k).
         // Every operand value x is carried as h + m with h = fp16(x), m = fp16(x - h): 22 significant bits, i.e.
@@ -674,9 +758,10 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
     }
 }
 
+#define SKG_SMEM3 (2 * 64 * 68)              // latency loop: one 64 x 64(+4) tile per operand (34 KB)
 template <int EPI, int MODE, int T>
 __global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_kernel(const skg_gemm_desc d) {
-    __shared__ __attribute__((aligned(16))) float smem[T == 2 ? 2 * (A_TILE + B_TILE) : 4 * 32 * 36];
+    __shared__ __attribute__((aligned(16))) float smem[MODE == 3 ? SKG_SMEM3 : (T == 2 ? 2 * (A_TILE + B_TILE) : 4 * 32 * 36)];
     skg_gemm_tile<EPI, MODE, T>(d, blockIdx.x, smem);
 }
 
@@ -718,6 +803,15 @@ __global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_group_small_kernel(con
     for (int t = 1; t < SKG_GEMM_GROUP_MAX; ++t)
         if (t < g.n && (int)blockIdx.x >= g.start[t]) k = t;
     skg_gemm_tile<-1, 1, 1>(g.d[k], blockIdx.x - g.start[k], smem);
+}
+
+__global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_group_latency_kernel(const skg_gemm_group_args g) {
+    __shared__ __attribute__((aligned(16))) float smem[SKG_SMEM3];
+    int k = 0;
+#pragma unroll
+    for (int t = 1; t < SKG_GEMM_GROUP_MAX; ++t)
+        if (t < g.n && (int)blockIdx.x >= g.start[t]) k = t;
+    skg_gemm_tile<-1, 3, 1>(g.d[k], blockIdx.x - g.start[k], smem);
 }
 
 // Split-K reduction: adds the slices in slice order (deterministic) and applies the plain epilogues.
@@ -797,6 +891,16 @@ extern "C" int skg_split_weights_f16x2(const float* W, int N, int K, int64_t ldw
     hipLaunchKernelGGL(skg_split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        W, N, K, ldw, scale, reinterpret_cast<char*>(out));
     return skg_launch_status();
+}
+
+// Which 64 x 64 loop the small launches take: 3 = latency loop (64 k per step, register staged), 1 = DMA-staged 16-k
+// steps.  A developer switch for A/B measurements (tools/small_batch_loop.py); both give bit-identical results only
+// with themselves (the summation order over k differs).
+static int g_small_mode = 3;
+extern "C" int skg_gemm_small_mode(int mode) {
+    const int old = g_small_mode;
+    if (mode == 1 || mode == 3) g_small_mode = mode;
+    return old;
 }
 
 // 64 x 64 tiles when the 128 x 128 grid would leave most CUs idle (small M: low-batch inference); needs the DMA path.
@@ -888,7 +992,8 @@ extern "C" int skg_gemm_group_f32(const skg_gemm_desc* descs_host, int n, void* 
     }
     if (g.n == 0) return 0;
     for (int i = g.n; i <= SKG_GEMM_GROUP_MAX; ++i) g.start[i] = (int)blocks;
-    if (small) hipLaunchKernelGGL(skg_gemm_group_small_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    if (small && g_small_mode == 3) hipLaunchKernelGGL(skg_gemm_group_latency_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    else if (small) hipLaunchKernelGGL(skg_gemm_group_small_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     else if (split) hipLaunchKernelGGL(skg_gemm_group_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(skg_gemm_group_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     if (r.n) {
@@ -914,6 +1019,7 @@ extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
     hipStream_t s = (hipStream_t)stream;
 #define SKG_LAUNCH(E)                                                                              \
     if (split) hipLaunchKernelGGL((skg_gemm_kernel<E, 2, 2>), grid, block, 0, s, d);               \
+    else if (glds && T == 1 && g_small_mode == 3) hipLaunchKernelGGL((skg_gemm_kernel<E, 3, 1>), grid, block, 0, s, d); \
     else if (glds && T == 1) hipLaunchKernelGGL((skg_gemm_kernel<E, 1, 1>), grid, block, 0, s, d); \
     else if (glds) hipLaunchKernelGGL((skg_gemm_kernel<E, 1, 2>), grid, block, 0, s, d);           \
     else hipLaunchKernelGGL((skg_gemm_kernel<E, 0, 2>), grid, block, 0, s, d);

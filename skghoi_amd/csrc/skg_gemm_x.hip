@@ -210,23 +210,26 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
                 const bool two = col + 1 < d.N;
                 if (d.bias) { v0 += d.bias[col]; if (two) v1 += d.bias[col + 1]; }
                 if (d.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                // accumulate first, mask last: a gradient that reaches a ReLU output from several consumers is summed
+                // and THEN cut by the ReLU (the mask belongs to the tensor C describes, not to this one contribution)
+                bool k0 = true, k1 = true;
                 if (d.mask) {
                     const float* mp = d.mask + (int64_t)row * d.ldmask + col;
-                    if (!(mp[0] > 0.f)) v0 = 0.f;
-                    if (two && !(mp[1] > 0.f)) v1 = 0.f;
+                    k0 = mp[0] > 0.f;
+                    k1 = two && mp[1] > 0.f;
                 }
                 float* p = d.C + xoff(col, d.c_nshift, d.c_nstride, 1) + (int64_t)row * d.ldc;
                 if (two && vecC) {
                     float2* p2 = reinterpret_cast<float2*>(p);
                     if (d.accumulate) { const float2 o = *p2; v0 += o.x; v1 += o.y; }
-                    *p2 = make_float2(v0, v1);
+                    *p2 = make_float2(k0 ? v0 : 0.f, k1 ? v1 : 0.f);
                 } else {
                     if (d.accumulate) v0 += p[0];
-                    p[0] = v0;
+                    p[0] = k0 ? v0 : 0.f;
                     if (two) {
                         float* q = d.C + xoff(col + 1, d.c_nshift, d.c_nstride, 1) + (int64_t)row * d.ldc;
                         if (d.accumulate) v1 += q[0];
-                        q[0] = v1;
+                        q[0] = k1 ? v1 : 0.f;
                     }
                 }
             }
@@ -257,9 +260,10 @@ __global__ __launch_bounds__(256) void skg_gemmx_reduce_kernel(const skg_gemmx_g
     const int row = (int)(i / d.N), col = (int)(i % d.N);
     if (d.bias) v += d.bias[col];
     if (d.relu) v = fmaxf(v, 0.f);
-    if (d.mask && !(d.mask[(int64_t)row * d.ldmask + col] > 0.f)) v = 0.f;
     float* p = d.C + xoff(col, d.c_nshift, d.c_nstride, 1) + (int64_t)row * d.ldc;
-    *p = d.accumulate ? *p + v : v;
+    if (d.accumulate) v += *p;
+    if (d.mask && !(d.mask[(int64_t)row * d.ldmask + col] > 0.f)) v = 0.f;      // accumulate first, mask last
+    *p = v;
 }
 
 static int skg_gemmx_validate(const skg_gemmx_desc& d) {

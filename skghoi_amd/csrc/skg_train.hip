@@ -83,7 +83,9 @@ __global__ __launch_bounds__(256) void skg_layernorm_bwd_kernel(const float* __r
                                                                 const float* __restrict__ x,
                                                                 const float* __restrict__ stats,
                                                                 const float* __restrict__ gamma,
-                                                                float* __restrict__ dx) {
+                                                                float* __restrict__ dx,
+                                                                const float* __restrict__ relu_src,
+                                                                float* __restrict__ dx_masked) {
     __shared__ float sred[4];
     const int r = blockIdx.x;
     const int c = threadIdx.x * 4;
@@ -95,9 +97,14 @@ __global__ __launch_bounds__(256) void skg_layernorm_bwd_kernel(const float* __r
     const float4 g = make_float4(vd.x * gm.x, vd.y * gm.y, vd.z * gm.z, vd.w * gm.w);
     const float c1 = skg_block_sum256((g.x + g.y) + (g.z + g.w), sred) / (float)TR_COLS;
     const float c2 = skg_block_sum256((g.x * xh.x + g.y * xh.y) + (g.z * xh.z + g.w * xh.w), sred) / (float)TR_COLS;
-    *reinterpret_cast<float4*>(dx + (int64_t)r * TR_COLS + c) =
-        make_float4(rstd * (g.x - c1 - xh.x * c2), rstd * (g.y - c1 - xh.y * c2), rstd * (g.z - c1 - xh.z * c2),
-                    rstd * (g.w - c1 - xh.w * c2));
+    const float4 o = make_float4(rstd * (g.x - c1 - xh.x * c2), rstd * (g.y - c1 - xh.y * c2),
+                                 rstd * (g.z - c1 - xh.z * c2), rstd * (g.w - c1 - xh.w * c2));
+    *reinterpret_cast<float4*>(dx + (int64_t)r * TR_COLS + c) = o;
+    if (dx_masked) {
+        const float4 m = *reinterpret_cast<const float4*>(relu_src + (int64_t)r * TR_COLS + c);
+        *reinterpret_cast<float4*>(dx_masked + (int64_t)r * TR_COLS + c) =
+            make_float4(m.x > 0.f ? o.x : 0.f, m.y > 0.f ? o.y : 0.f, m.z > 0.f ? o.z : 0.f, m.w > 0.f ? o.w : 0.f);
+    }
 }
 
 // dgamma[c] = sum_r dy[r, c] * xhat[r, c],  dbeta[c] = sum_r dy[r, c]: one thread per column, rows in order.
@@ -118,14 +125,16 @@ __global__ __launch_bounds__(256) void skg_layernorm_param_grad_kernel(const flo
 }
 
 extern "C" int skg_layernorm_bwd_f32(const float* dy, int64_t lddy, const float* x, const float* stats,
-                                     const float* gamma, int rows, float* dx, float* dgamma, float* dbeta, void* stream) {
+                                     const float* gamma, int rows, float* dx, const float* relu_src, float* dx_masked,
+                                     float* dgamma, float* dbeta, void* stream) {
     if (rows < 0) return SKG_E_ARG;
-    if (!dy || !x || !stats || !gamma || !dx || !dgamma || !dbeta) return SKG_E_ARG;
-    if ((lddy & 3) || !skg_aligned16(dy) || !skg_aligned16(x) || !skg_aligned16(gamma) || !skg_aligned16(dx))
+    if (!dy || !x || !stats || !gamma || !dx || !dgamma || !dbeta || (dx_masked && !relu_src)) return SKG_E_ARG;
+    if ((lddy & 3) || !skg_aligned16(dy) || !skg_aligned16(x) || !skg_aligned16(gamma) || !skg_aligned16(dx) ||
+        !skg_aligned16(relu_src) || !skg_aligned16(dx_masked))
         return SKG_E_ALIGN;
     if (rows)
         hipLaunchKernelGGL(skg_layernorm_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, stats,
-                           gamma, dx);
+                           gamma, dx, relu_src, dx_masked);
     hipLaunchKernelGGL(skg_layernorm_param_grad_kernel, dim3(TR_COLS / 256), dim3(256), 0, (hipStream_t)stream, dy, lddy,
                        x, stats, rows, dgamma, dbeta);
     return skg_launch_status();
@@ -183,7 +192,7 @@ extern "C" int skg_mul_bwd_f32(float* g, int64_t ldg, const float* F, const int3
 //   mode 0  src = grid rows (r = grid_off + i * n + j):   outH[(a, i)] = sum_j src[r],   outN[(a, j)] = sum_i src[r]
 //   mode 1  src = kept pairs (p = pair_off + i * (n - 1) + jj):  outH[(a, i)] = sum_jj src[p];
 //                                                          outN[(a, j)] = sum_{i != j} src[pair of (i, j)]
-//   mode 2  src = kept pairs:  outH[a] = sum of all pairs of image a            (outN unused)
+//   mode 2  src = kept pairs:  outH[meta[a].image] = sum of all pairs of active image a   (outN unused)
 // One workgroup per destination row, rows added in index order.
 __global__ __launch_bounds__(256) void skg_segment_sum_kernel(const float* __restrict__ src, int64_t ld,
                                                               const skg_image_meta* __restrict__ meta,
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(256) void skg_segment_sum_kernel(const float* __res
         const int P = mt.n_h * (mt.n - 1);
         for (int p = 0; p < P; ++p) add((int64_t)mt.pair_off + p);
     }
-    float4* o = reinterpret_cast<float4*>(out + (int64_t)dst * TR_COLS + c);
+    float4* o = reinterpret_cast<float4*>(out + (int64_t)(mode == 2 ? mt.image : dst) * TR_COLS + c);
     if (accumulate) { const float4 t = *o; acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
     *o = acc;
 }
@@ -383,7 +392,8 @@ extern "C" int skg_entity_rows_bwd_f32(const float* dX, int64_t ldx, const int32
 //   cell c of image a: pair p = pair_off + index[c], verb v = pred[c]; x = scores[c] = sigmoid(lp) * ph * po * w.detach()
 //   pair p: w = sigmoid(ls), y = unary[p] = min(sum_v labels[p, v], 1)
 // BCE and its derivative as torch defines them (log clamped at -100; (x - y) / max(x (1 - x), 1e-12)).
-// One workgroup per image; partial[a] = {sum of cell losses, sum of pair losses} (the caller adds and divides by n_p).
+// One workgroup per image; partial[a] = {sum of cell losses, sum of pair losses, #positive cells, #positive pairs}: the
+// caller adds them up; the two counts are the loss normalisers n_p (HEAD:162-165, 190-192).
 // dlogits [sumP, ldl] must be zero-filled; columns < K receive d(sum cell loss)/dlp, column K d(sum pair loss)/dls.
 __device__ __forceinline__ float skg_focal(float x, float y, float gamma, float& dldx) {
     const float alpha = 0.5f, eps = 1e-6f;
@@ -409,13 +419,14 @@ __global__ __launch_bounds__(256) void skg_hoi_loss_kernel(
     const int64_t c0 = mt.out_off;
     const int64_t c1 = (a + 1 < n_active) ? (int64_t)meta[a + 1].out_off : cells_total;
     const int P = mt.n_h * (mt.n - 1);
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, n1 = 0.f, n2 = 0.f;
     for (int64_t c = c0 + threadIdx.x; c < c1; c += 256) {
         const int64_t p = (int64_t)mt.pair_off + index[c];
         const int v = (int)pred[c];
         const float y = labels[p * K + v];
         const float x = scores[c];
         cell_labels[c] = y;
+        if (y != 0.f) n1 += 1.f;
         float dldx;
         s1 += skg_focal(x, y, 0.2f, dldx);
         const float sg = 1.f / (1.f + expf(-logits[p * ldl + v]));
@@ -427,6 +438,7 @@ __global__ __launch_bounds__(256) void skg_hoi_loss_kernel(
         for (int v = 0; v < K; ++v) ys += labels[p * K + v];
         const float y = fminf(ys, 1.f);
         unary[p] = y;
+        if (y != 0.f) n2 += 1.f;
         const float w = 1.f / (1.f + expf(-logits[p * ldl + K]));
         float dldw;
         s2 += skg_focal(w, y, 2.0f, dldw);
@@ -434,7 +446,9 @@ __global__ __launch_bounds__(256) void skg_hoi_loss_kernel(
     }
     s1 = skg_block_sum256(s1, sred);
     s2 = skg_block_sum256(s2, sred);
-    if (threadIdx.x == 0) { partial[2 * a] = s1; partial[2 * a + 1] = s2; }
+    n1 = skg_block_sum256(n1, sred);
+    n2 = skg_block_sum256(n2, sred);
+    if (threadIdx.x == 0) { partial[4 * a] = s1; partial[4 * a + 1] = s2; partial[4 * a + 2] = n1; partial[4 * a + 3] = n2; }
 }
 
 extern "C" int skg_hoi_loss_f32(const float* logits, int64_t ldl, int K, const skg_image_meta* meta, int n_active,

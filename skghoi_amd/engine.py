@@ -31,6 +31,7 @@ GEMM_TIMER_EPI = None      # ... restricted to these epilogue ids (None: every l
 
 import os as _os
 _PIN_TABLES = _os.environ.get("SKG_PIN_TABLES", "1") == "1"     # developer switch
+_NO_SPIN = _os.environ.get("SKG_NO_SPIN", "0") == "1"           # developer switch: blocking count read at every batch size
 
 
 def _ptr(t):
@@ -262,7 +263,7 @@ def pick_split_k(M, N, K, target_blocks=1024):
     if M <= 64:
         # one tile high: the launcher takes 64 x 64 tiles (skg_gemm_tile_scale); slices of >= 4 k-tiles
         blocks = (N + 63) // 64
-        return int(max(1, min(-(-1024 // blocks), K // 64, 64))) if K >= 512 else 1
+        return int(max(1, min(-(-512 // blocks), K // 64, 64))) if K >= 512 else 1
     if blocks >= target_blocks or K < 2048:
         return 1
     return int(max(1, min(-(-target_blocks // blocks), K // 256, 64)))
@@ -293,10 +294,10 @@ def gemm(A, W, bias, C_out, M, N, K, epilogue, **kw):
         GEMM_TIMER.append((e0, e1, M, N, K, epilogue))
 
 
-# Workgroups a small (64 x 64 tile) grouped launch aims for; split-K supplies them.  These GEMMs stream 4 MB of weights
-# each through a one-tile-deep prefetch: what hides the HBM latency is the number of workgroups in flight, so the slices
-# are short (>= 2 k-tiles) and many.
-SMALL_GROUP_BLOCKS = 1024
+# Workgroups a small (64 x 64 tile) grouped launch aims for; split-K supplies them.  Two costs pull against each other at a
+# few images (measured on MI355X): every workgroup costs ~10 ns of dispatch, and every k-tile a workgroup walks costs ~1 us
+# (one HBM / L2 round trip behind a one-tile-deep prefetch).  ~512 workgroups of >= 4 k-tiles sit near the minimum.
+SMALL_GROUP_BLOCKS = 512
 
 
 def gemm_group(specs):
@@ -319,7 +320,7 @@ def gemm_group(specs):
         for d, t in zip(arr, tiles):
             if t == 0 or d.split_k > 1 or d.epilogue not in (_capi.EPI_BIAS, _capi.EPI_BIAS_RELU, _capi.EPI_BIAS_RES_RELU):
                 continue
-            sk = min(-(-SMALL_GROUP_BLOCKS // max(total, 1)), d.K // 32, 64)
+            sk = min(-(-SMALL_GROUP_BLOCKS // max(total, 1)), d.K // 64, 64)
             if sk > 1:
                 ws = torch.empty(sk * d.M * d.N, device=specs[0][0][0].device, dtype=torch.float32)
                 keep.append(ws)
@@ -457,6 +458,9 @@ class HeadEngine:
         self._pw = None
         self._vt = None
         self._det_off_cache = {}
+        self._cnt_host = None
+        self._cnt_event = None
+        self._cnt_host_dev = None
         self.plan_epoch = 0
         self.small_batch_max = 8    # eval batches of up to this many images replay a captured hipGraph (skghoi_amd/small.py); 0: off
         self._small = None
@@ -531,6 +535,25 @@ class HeadEngine:
             self._det_off_cache[key] = t
         return t
 
+    def _read_counts(self, countx):
+        """The forward's one device -> host read.  Small batches poll a HIP event behind an asynchronous copy into pinned
+        memory: a blocking copy parks the thread and the wake-up costs tens of microseconds, which at one image per
+        forward is a tenth of the whole latency.  Returns a numpy int32 array (a private copy)."""
+        n = countx.numel()
+        if n > 4 * 16 + 2 * _capi.CHECKSUM_PARTIALS or _NO_SPIN:   # larger batches: the plain blocking copy
+            return countx.cpu().numpy()
+        if self._cnt_host is None or self._cnt_host.numel() < n or self._cnt_host_dev != countx.device:
+            self._cnt_host = torch.empty(max(n, 4 * 16 + 2 * _capi.CHECKSUM_PARTIALS), dtype=torch.int32, pin_memory=True)
+            self._cnt_event = torch.cuda.Event()
+            self._cnt_host_dev = countx.device
+        host = self._cnt_host[:n]
+        host.copy_(countx, non_blocking=True)
+        ev = self._cnt_event
+        ev.record()
+        while not ev.query():
+            pass
+        return host.numpy().copy()
+
     def pre_launch(self, detections, targets, append_gt, training, check_weights=False):
         """First half of preprocess: score filter + class-wise NMS + top-k on the device and the ONE host
         synchronisation of a forward (per-image counts, plus the parameter checksum riding on the same copy).
@@ -584,7 +607,7 @@ class HeadEngine:
                                            self.max_human, self.max_object, vt.nverbs.data_ptr(), vt.num_obj,
                                            prior_pow, index.data_ptr(), countx.data_ptr(), _stream()),
                     "skg_preprocess_f32")
-        cntx = countx.cpu().numpy()                                             # the one synchronisation point
+        cntx = self._read_counts(countx)                                        # the one synchronisation point
         cnt = cntx[:4 * B].reshape(B, 4)
         if B and cnt[:, 0].min() < 0:
             bad = int(np.argmax(cnt[:, 0] < 0))

@@ -40,12 +40,12 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
-def forward(x, W, out, bias=None, relu=False, M=None, K=None, w_blocks=None):
+def forward(x, W, out, bias=None, relu=False, M=None, K=None, N=None, w_blocks=None):
     """out[M, N] = act(x[M, K] W[N, K]^T + bias).  w_blocks = (log2 block, block stride): W stored branch-major,
     [K / block][N][block] (the 16 fc_3 weights of an MBF, block 64)."""
     M = x.shape[0] if M is None else M
     K = x.shape[1] if K is None else K
-    N = out.shape[1]
+    N = out.shape[1] if N is None else N
     op = Op(A=x.data_ptr(), a_sm=x.stride(0), a_sk=1, B=W.data_ptr(), b_sk=1, C=out.data_ptr(), ldc=out.stride(0), M=M, N=N,
             K=K, bias=bias, relu=relu)
     if w_blocks is None:
@@ -57,10 +57,11 @@ def forward(x, W, out, bias=None, relu=False, M=None, K=None, w_blocks=None):
     return op
 
 
-def input_grad(dz, W, dx, mask=None, accumulate=False, M=None, N_in=None, w_blocks=None):
-    """dx[M, K_in] (+)= (dz[M, N_out] W[N_out, K_in]) * (mask > 0).  w_blocks as in forward()."""
+def input_grad(dz, W, dx, mask=None, accumulate=False, M=None, N_in=None, K_out=None, w_blocks=None):
+    """dx[M, N_in] (+)= dz[M, K_out] W[K_out, N_in], zeroed where mask <= 0 (after the accumulation).  w_blocks as in
+    forward()."""
     M = dz.shape[0] if M is None else M
-    n_out = dz.shape[1]
+    n_out = dz.shape[1] if K_out is None else K_out
     k_in = dx.shape[1] if N_in is None else N_in
     op = Op(A=dz.data_ptr(), a_sm=dz.stride(0), a_sk=1, B=W.data_ptr(), b_sn=1, C=dx.data_ptr(), ldc=dx.stride(0), M=M,
             N=k_in, K=n_out, mask=mask, ldmask=(mask.stride(0) if mask is not None else 0), accumulate=accumulate)

@@ -22,13 +22,14 @@ the number of scored cells in a device word (skg_postprocess_f32's L_total_dev).
 Reference path replaced: heads/adamixer_transH_spatial_r50_head.py:341-429 (InteractionHead.forward, eval mode).
 """
 import copy
+import ctypes as C
 from collections import OrderedDict
 
 import numpy as np
 import torch
 
 from . import _capi, layout, transh
-from .engine import Preprocessed, gemm, gemm_group, pick_split_k, _stream
+from .engine import Preprocessed, gemm_desc, gemm_group, pick_split_k, _stream
 
 META_WORDS = layout.META_DTYPE.itemsize // 4
 
@@ -70,6 +71,9 @@ class SmallBatchRunner:
         p.dyn_host = torch.empty(words, dtype=torch.int32, pin_memory=True)
         p.dyn_dev = torch.empty(words, dtype=torch.int32, device=dev)
         p.meta_host = p.dyn_host[:n_meta].numpy().view(layout.META_DTYPE)
+        p.meta_host[:] = lay.meta                        # everything but out_off / img_h / img_w is fixed by the shape
+        p.meta_i32 = p.dyn_host[:n_meta].numpy().reshape(A, META_WORDS)
+        p.meta_f32 = p.meta_i32.view(np.float32)
         p.lt_host = p.dyn_host[n_meta:n_meta + 4].numpy()
         p.ent_host = p.dyn_host[n_meta + 4:].view(torch.float32).view(A, _capi.TRANSH_ENT, _capi.TRANSH_DIM)
         p.meta_dev = p.dyn_dev[:n_meta]
@@ -87,6 +91,7 @@ class SmallBatchRunner:
         p.x0_pad = torch.zeros(NA, kp, **f32) if pooled[0].numel() != kp else None
         p.sk = pick_split_k(NA, 1024, kp)
         p.ws = torch.empty(p.sk, NA, 1024, **f32) if p.sk > 1 else None
+        p.bh1_desc = None                                # filled on first use (needs the weight-twin context)
         p.pre = Preprocessed()
         p.pre.device = dev; p.pre.B = pre.B
         p.pre.boxes, p.pre.scores, p.pre.labels = p.boxes, p.scores, p.labels
@@ -158,8 +163,18 @@ class SmallBatchRunner:
         p.out = self._body(p)                      # eager once: first-use work (weight twins, lazy module init) happens here
         torch.cuda.current_stream().synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
-            p.out = self._body(p)
+        # No cyclic garbage collection while the stream captures: a collection that happens to run inside the capture
+        # frees whatever dead cycles hold -- pinned staging buffers, HIP events, other plans' graphs -- and those frees are
+        # not allowed on a capturing thread (the process aborts).  torch.cuda.graph collects once before it starts.
+        import gc
+        gc_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
+                p.out = self._body(p)
+        finally:
+            if gc_on:
+                gc.enable()
         p.graph = g
 
     # ------------------------------------------------------------------------------------------------ forward
@@ -228,20 +243,27 @@ class SmallBatchRunner:
             x0 = p.x0_pad
         elif not x0.is_contiguous():
             x0 = x0.contiguous()
-        with eng._split_ctx(pw):
-            gemm(x0, pw.bh1_w, pw.bh1_b, p.enc1, lay.sum_all, 1024, x0.shape[1], _capi.EPI_BIAS_RELU, split_k=p.sk,
-                 split_ws=p.ws)
+        if p.bh1_desc is None:
+            with eng._split_ctx(pw):
+                p.bh1_desc = gemm_desc(x0, pw.bh1_w, pw.bh1_b, p.enc1, lay.sum_all, 1024, x0.shape[1],
+                                       _capi.EPI_BIAS_RELU, split_k=p.sk, split_ws=p.ws)
+        p.bh1_desc.A = x0.data_ptr()               # the one field that changes from call to call
+        _capi.check(lib.skg_gemm_f32(C.byref(p.bh1_desc), _stream()), "skg_gemm_f32[box_head 1]")
         # per-call records: meta (image sizes, result offsets), cell count, TransH entity tables
         if p.h2d_done is not None:
             p.h2d_done.synchronize()               # the staging block's previous copy (normally long finished)
         act = lay.active
         L = pre.L[act]
-        m = p.meta_host
-        m[:] = lay.meta
-        m["out_off"] = np.cumsum(L) - L
-        m["img_h"] = [float(image_shapes[int(b)][0]) for b in act]
-        m["img_w"] = [float(image_shapes[int(b)][1]) for b in act]
-        Lt = int(L.sum())
+        if lay.n_active == 1:
+            b0 = int(act[0])
+            p.meta_i32[0, 9] = 0
+            p.meta_f32[0, 10] = float(image_shapes[b0][0]); p.meta_f32[0, 11] = float(image_shapes[b0][1])
+            Lt = int(L[0])
+        else:
+            p.meta_i32[:, 9] = np.cumsum(L) - L
+            p.meta_f32[:, 10] = [float(image_shapes[int(b)][0]) for b in act]
+            p.meta_f32[:, 11] = [float(image_shapes[int(b)][1]) for b in act]
+            Lt = int(L.sum())
         p.lt_host[0] = Lt
         transh.draw_batch(eng.K, lay.n_active, need_relations=False, out=(p.ent_host, None, None))
         p.dyn_dev.copy_(p.dyn_host, non_blocking=True)

@@ -1,0 +1,626 @@
+"""The fused TRAINING step of the interaction head: forward and hand-written backward on the HIP kernels.
+
+Reference: InteractionHead.forward in training mode (heads/adamixer_transH_spatial_r50_head.py:380-429) over
+GraphHead.forward (HEAD:769-993) and the losses (HEAD:153-235, ops.py:159-211), with autograd doing the backward.  The
+first MI355X version kept autograd and only replaced nn.Linear (skghoi_amd/train_graph.py + autograd.py): ~1000 kernel
+launches per step (gathers, products, masks, transposes, segment softmax, LayerNorm, the losses), host-bound at 13 ms for
+four images.  Here the differentiable part of the step is ONE autograd.Function:
+
+    forward   ~35 launches: every dense layer on skg_gemmx_f32 / skg_gemm_f32 (MBF fc_1 * fc_2 fused in the fc_2
+              epilogue; the 16 branch weights of every MBF are gathered once per step into stacked copies, fc_3
+              branch-major), message aggregation, add + LayerNorm, read-out, classifier
+    backward  ~55 launches: dX and dW (+ bias gradient as row sums) of a layer in ONE grouped launch with the ReLU mask
+              of the layer below in its epilogue -- no transposes, no mask kernels; the graph stages by the kernels of
+              skg_train.hip (per-destination reductions, deterministic)
+    losses    one kernel: both focal terms forward + d/dlogits (skg_hoi_loss_f32)
+
+The same algebra as the inference engine (message passing once, fc_head / fc_tail / fc_1 on unique
+node rows, aggregation before the linear fc_3), so gradients equal the reference's up to fp32 summation order.
+Parameter gradients are returned to autograd as views of one gradient arena laid out like the stacked copies (16
+branches = 16 contiguous slices), so `loss.backward()`, DDP and the optimizer see the reference's 408 parameters.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi, gemmx, layout
+from .engine import _ptr, _stream, gemm, gemm_desc
+
+MBF_NAMES = ("attention_head", "obj_to_sub", "sub_to_obj", "attention_head_g")      # order of the stacked fc_2 block
+ATT, OS, SO, GL = range(4)
+EPS_LN = 1e-5
+
+
+def _check(rc, what):
+    _capi.check(rc, what)
+
+
+class Stacked:
+    """Stacked copies of the MBF / classifier parameters (refreshed from the live parameters once per step by one
+    multi-tensor copy) and the matching views of a gradient arena.
+
+    Segments (fp32, one flat buffer):  per MBF m: W1[m] [1024, in_m] (16 x [64, in_m] row blocks), b1[m] [1024],
+    W3[m] [16][1024][64] (branch-major: branch b is the contiguous fc_3[b].weight), b3[m] [16][1024];
+    W2 [4 x 1024, 1024] and b2 [4 x 1024] of all four MBFs back to back (one GEMM for their input gradient);
+    classifier [K + 1, 2048] = predictor rows then the suppressor row, bias [K + 1]."""
+
+    def __init__(self, head, device):
+        gh = head.box_pair_head
+        self.device = device
+        self.K = head.num_classes
+        mbfs = [getattr(gh, n) for n in MBF_NAMES]
+        self.in_dim = [m.fc_1[0].weight.shape[1] for m in mbfs]
+        seg = {}
+        off = 0
+
+        def add(name, *shape):
+            nonlocal off
+            n = int(np.prod(shape))
+            seg[name] = (off, shape)
+            off += (n + 3) // 4 * 4
+        for i in range(4):
+            add("W1_%d" % i, 1024, self.in_dim[i]); add("b1_%d" % i, 1024)
+            add("W3_%d" % i, 16, 1024, 64)
+        add("b3", 4, 16, 1024)
+        add("W2", 4096, 1024); add("b2", 4096)
+        add("clsW", self.K + 1, 2048); add("clsb", self.K + 1)
+        self.seg, self.total = seg, off
+        self.buf = torch.empty(off, device=device, dtype=torch.float32)
+        # (live parameter, segment, selector inside the segment's view) in a fixed order
+        self.entries = []
+        for i, m in enumerate(mbfs):
+            for b in range(16):
+                self.entries.append((m.fc_1[b].weight, "W1_%d" % i, (slice(64 * b, 64 * b + 64),)))
+                self.entries.append((m.fc_1[b].bias, "b1_%d" % i, (slice(64 * b, 64 * b + 64),)))
+                self.entries.append((m.fc_2[b].weight, "W2", (slice(1024 * i + 64 * b, 1024 * i + 64 * b + 64),)))
+                self.entries.append((m.fc_2[b].bias, "b2", (slice(1024 * i + 64 * b, 1024 * i + 64 * b + 64),)))
+                self.entries.append((m.fc_3[b].weight, "W3_%d" % i, (b,)))
+                self.entries.append((m.fc_3[b].bias, "b3", (i, b)))
+        K = self.K
+        self.entries.append((head.box_pair_predictor.weight, "clsW", (slice(0, K),)))
+        self.entries.append((head.box_pair_suppressor.weight, "clsW", (slice(K, K + 1),)))
+        self.entries.append((head.box_pair_predictor.bias, "clsb", (slice(0, K),)))
+        self.entries.append((head.box_pair_suppressor.bias, "clsb", (slice(K, K + 1),)))
+        self.src = [e[0] for e in self.entries]
+        self.dst = [self.view(self.buf, e[1])[e[2]] for e in self.entries]
+        self.ids = {id(p): k for k, p in enumerate(self.src)}
+
+    def view(self, flat, name):
+        off, shape = self.seg[name]
+        return flat[off:off + int(np.prod(shape))].view(*shape)
+
+    def refresh(self):
+        with torch.no_grad():
+            torch._foreach_copy_(self.dst, [p.detach() for p in self.src])
+        self.b3sum = self.view(self.buf, "b3").sum(dim=1)                 # [4, 1024]: fc_3 biases summed over branches
+
+    def grad_views(self, garena):
+        """Views of a gradient arena (same layout) for the stacked parameters, in `entries` order."""
+        return [self.view(garena, e[1])[e[2]] for e in self.entries]
+
+
+def _lin(x, W, out, bias=None, relu=False, **kw):
+    return gemmx.forward(x, W, out, bias=bias, relu=relu, **kw)
+
+
+class HeadTrainFn(torch.autograd.Function):
+    """(pooled box features, global features, 408 parameters) -> classifier logits [sumP, ld] of the kept pairs."""
+
+    @staticmethod
+    def forward(ctx, job, x0, gfeat, *params):
+        S = job.forward(x0, gfeat)
+        ctx.job = job
+        return S["logits"]
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        job = ctx.job
+        dx0, dgfeat, pgrads = job.backward(dlogits, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return (None, dx0, dgfeat) + tuple(pgrads)
+
+
+class HoiLossFn(torch.autograd.Function):
+    """logits -> (sum of the focal losses over the scored cells, over the pairs); backward scales the gradient the loss
+    kernel produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, job, logits):
+        sums = job.loss_forward(logits)
+        ctx.job = job
+        return sums[0], sums[1]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        job = ctx.job
+        d = job.dlogits
+        K = job.K
+        # columns < K belong to the cell loss, column K to the pair loss (the pair weight is detached in the scores)
+        d[:, :K].mul_(g1)
+        d[:, K:K + 1].mul_(g2)
+        return None, d
+
+
+class TrainJob:
+    """One training forward / backward of the dense part of the head on a packed batch."""
+
+    def __init__(self, head, eng, stacked, lay, pre, ibuf, offs, ent, image_meta_dev):
+        self.head, self.eng, self.st = head, eng, stacked
+        self.gh = head.box_pair_head
+        self.lay, self.pre = lay, pre
+        self.ibuf, self.offs = ibuf, offs
+        self.ent = ent
+        self.meta = image_meta_dev
+        self.K = head.num_classes
+        self.dev = pre.device
+        self.S = {}
+
+    def isl(self, name):
+        o, l = self.offs[name]
+        return self.ibuf[o:o + l]
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, x0, gfeat):
+        lib = _capi.lib()
+        st, gh, lay, dev = self.st, self.gh, self.lay, self.dev
+        f32 = dict(device=dev, dtype=torch.float32)
+        i32 = dict(device=dev, dtype=torch.int32)
+        stream = _stream()
+        S = self.S
+        NA, Mg, Mp, Mh, Mn, A = lay.sum_all, lay.sum_g, lay.sum_p, lay.sum_h, lay.sum_n, lay.n_active
+        K = self.K
+        st.refresh()
+        W2, b2 = st.view(st.buf, "W2"), st.view(st.buf, "b2")
+        W1 = [st.view(st.buf, "W1_%d" % i) for i in range(4)]
+        b1 = [st.view(st.buf, "b1_%d" % i) for i in range(4)]
+        W3 = [st.view(st.buf, "W3_%d" % i) for i in range(4)]
+        b3 = st.b3sum
+        blk = (6, 1024 * 64)
+        x0 = x0.detach().float().reshape(x0.shape[0], -1).contiguous()
+        gfeat = gfeat.detach().float().contiguous()
+        S["x0"], S["gfeat"] = x0, gfeat
+        Bf = gfeat.shape[0]
+        bh1, bh3 = gh.box_head[1], gh.box_head[3]
+        # ---- box_head (HEAD:812) and fc_1 of the global branch (HEAD:971)
+        E1 = torch.empty(NA, 1024, **f32); enc = torch.empty(NA, 1024, **f32); G1 = torch.empty(Bf, 1024, **f32)
+        gemmx.launch([_lin(x0, bh1.weight, E1, bh1.bias, True)])
+        gemmx.launch([_lin(E1, bh3.weight, enc, bh3.bias, True), _lin(gfeat, W1[GL], G1, b1[GL])])
+        S.update(E1=E1, enc=enc, G1=G1)
+        # ---- spatial head (HEAD:888) on the 46-d encodings the step driver produced with the pair enumeration
+        grid_h, grid_o, grid_pair, grid_img, pair_grid, pair_h, pair_o, sp48 = (
+            S[k] for k in ("grid_h", "grid_o", "grid_pair", "grid_img", "pair_grid", "pair_h", "pair_o", "sp48"))
+        sp = gh.spatial_head
+        s1 = torch.empty(Mg, 128, **f32); s2 = torch.empty(Mg, 256, **f32); Sp = torch.empty(Mg, 1024, **f32)
+        gemmx.launch([_lin(sp48, sp[0].weight, s1, sp[0].bias, True, K=46)])
+        gemmx.launch([_lin(s1, sp[2].weight, s2, sp[2].bias, True)])
+        gemmx.launch([_lin(s2, sp[4].weight, Sp, sp[4].bias, True)])
+        S.update(s1=s1, s2=s2, Sp=Sp)
+        # ---- fc_head / fc_tail on unique node rows (HEAD:884-885)
+        Xhn = torch.empty(Mh + Mn, 1088, **f32)
+        _check(lib.skg_concat_entity_f32(enc.data_ptr(), 1024, self.isl("enc_row_hn").data_ptr(), self.ent.data_ptr(),
+                                         self.isl("img_hn").data_ptr(), self.isl("ent_row_hn").data_ptr(), Mh + Mn,
+                                         Xhn.data_ptr(), 1088, stream), "skg_concat_entity_f32")
+        GH = torch.empty(Mh, 1024, **f32); GO = torch.empty(Mn, 1024, **f32)
+        fh, ft = gh.fc_head[0], gh.fc_tail[0]
+        gemmx.launch([_lin(Xhn[:Mh], fh.weight, GH, fh.bias, True, K=1074), _lin(Xhn[Mh:], ft.weight, GO, ft.bias, True, K=1074)])
+        S.update(Xhn=Xhn, GH=GH, GO=GO)
+        # ---- fc_1 projections on node rows (HEAD:894-896 separable over [human | object]; HEAD:514, 524)
+        A1h = torch.empty(Mh, 1024, **f32); A1o = torch.empty(Mn, 1024, **f32)
+        C1o = torch.empty(Mn, 1024, **f32); C1h = torch.empty(Mh, 1024, **f32)
+        Wa1 = W1[ATT]
+        gemmx.launch([_lin(GH, Wa1, A1h, K=1024), _lin(GO, Wa1[:, 1024:], A1o, K=1024),
+                      _lin(GO, W1[OS], C1o, b1[OS]), _lin(GH, W1[SO], C1h, b1[SO])])
+        S.update(A1h=A1h, A1o=A1o, C1o=C1o, C1h=C1h)
+        # ---- fc_2 on the grid rows with the fc_1 * fc_2 -> ReLU product in the epilogue; the raw fc_2 output is kept
+        F = torch.empty(Mg, 4096, **f32)                     # [F2 | F_os | F_so | F_g], leading dimension 4096
+        T = torch.empty(Mg, 1024, **f32); Tos = torch.empty(Mg, 1024, **f32); Tso = torch.empty(Mg, 1024, **f32)
+        Tg = torch.empty(max(Mp, 1), 1024, **f32)
+
+        def fc2(i, out, **kw):
+            gemm(Sp, W2, b2[1024 * i:1024 * i + 1024], out, Mg, 1024, 1024, _capi.EPI_MUL_RELU, W_off=1024 * 1024 * i,
+                 C_raw=F[:, 1024 * i:], ldc_raw=4096, **kw)
+        fc2(ATT, T, P=A1h, p_idx=grid_h, ldp=1024, Q=A1o, q_idx=grid_o, ldq=1024, mbias=b1[ATT])
+        fc2(OS, Tos, P=C1o, p_idx=grid_o, ldp=1024)
+        fc2(SO, Tso, P=C1h, p_idx=grid_h, ldp=1024)
+        fc2(GL, Tg, P=G1, p_idx=grid_img, ldp=1024, out_rows=grid_pair)
+        S.update(F=F, T=T, Tos=Tos, Tso=Tso, Tg=Tg)
+        # ---- attention fc_3 + ReLU, adjacency logits (HEAD:896-897)
+        Wt = torch.empty(Mg, 1024, **f32)
+        gemmx.launch([_lin(T, W3[ATT], Wt, b3[ATT], True, w_blocks=blk)])
+        adj_raw = torch.empty(Mg, **f32)
+        wadj = gh.adjacency.weight.detach().reshape(-1)
+        _check(lib.skg_rowdot_f32(Wt.data_ptr(), 1024, wadj.data_ptr(), Mg, 1024, adj_raw.data_ptr(), stream),
+               "skg_rowdot_f32")
+        # ---- softmax-weighted aggregation before the linear fc_3 (HEAD:907-922)
+        U = torch.empty(Mh, 1024, **f32); V = torch.empty(Mn, 1024, **f32)
+        adj = torch.empty(Mg, **f32); alpha = torch.empty(Mg, **f32); beta = torch.empty(Mg, **f32)
+        # (the adjacency bias shifts every logit of a softmax alike: it cancels in alpha / beta, and its gradient -- the sum of
+        #  a softmax gradient -- is zero up to rounding, which is what the GEMM row sum below returns)
+        _check(lib.skg_graph_aggregate_train_f32(adj_raw.data_ptr(), 1, Mg, 0.0, self.meta.data_ptr(), A,
+                                                 self.isl("hum_img").data_ptr(), self.isl("node_img").data_ptr(), Mh, Mn,
+                                                 Tos.data_ptr(), Tso.data_ptr(), 1024, 1024, U.data_ptr(), V.data_ptr(),
+                                                 1024, adj.data_ptr(), alpha.data_ptr(), beta.data_ptr(), stream),
+               "skg_graph_aggregate_train_f32")
+        S.update(Wt=Wt, U=U, V=V, alpha=alpha, beta=beta, adj=adj)
+        # ---- message fc_3 + ReLU, residual, LayerNorm (HEAD:909-914, 916-925)
+        M1 = torch.empty(Mh, 1024, **f32); M2 = torch.empty(Mn, 1024, **f32)
+        gemmx.launch([_lin(U, W3[OS], M1, b3[OS], True, w_blocks=blk), _lin(V, W3[SO], M2, b3[SO], True, w_blocks=blk)])
+        Hp = torch.empty(Mh, 1024, **f32); h_node = torch.empty(Mh, 1024, **f32); st_h = torch.empty(Mh, 2, **f32)
+        Op = torch.empty(Mn, 1024, **f32); node = torch.empty(Mn, 1024, **f32); st_o = torch.empty(Mn, 2, **f32)
+        nh, no = gh.norm_h, gh.norm_o
+        _check(lib.skg_add_layernorm_f32(GH.data_ptr(), 1024, M1.data_ptr(), 1024, nh.weight.data_ptr(), nh.bias.data_ptr(),
+                                         Mh, EPS_LN, Hp.data_ptr(), h_node.data_ptr(), st_h.data_ptr(), stream),
+               "skg_add_layernorm_f32")
+        _check(lib.skg_add_layernorm_f32(GO.data_ptr(), 1024, M2.data_ptr(), 1024, no.weight.data_ptr(), no.bias.data_ptr(),
+                                         Mn, EPS_LN, Op.data_ptr(), node.data_ptr(), st_o.data_ptr(), stream),
+               "skg_add_layernorm_f32")
+        S.update(M1=M1, M2=M2, Hp=Hp, Op=Op, h_node=h_node, node=node, st_h=st_h, st_o=st_o)
+        # ---- read-out on the kept pairs (HEAD:966-973)
+        B1h = torch.empty(Mh, 1024, **f32); B1o = torch.empty(Mn, 1024, **f32)
+        gemmx.launch([_lin(h_node, Wa1, B1h, K=1024), _lin(node, Wa1[:, 1024:], B1o, K=1024)])
+        Tp = torch.empty(max(Mp, 1), 1024, **f32)
+        _check(lib.skg_rows_mul_relu_f32(B1h.data_ptr(), pair_h.data_ptr(), 1024, B1o.data_ptr(), pair_o.data_ptr(), 1024,
+                                         b1[ATT].data_ptr(), F.data_ptr(), pair_grid.data_ptr(), 4096, Mp, 1024,
+                                         Tp.data_ptr(), 1024, stream), "skg_rows_mul_relu_f32")
+        PF = torch.empty(max(Mp, 1), 2048, **f32)
+        gemmx.launch([_lin(Tp, W3[ATT], PF, b3[ATT], True, M=Mp, N=1024, w_blocks=blk),
+                      _lin(Tg, W3[GL], PF[:, 1024:], b3[GL], True, M=Mp, N=1024, w_blocks=blk)])
+        # ---- classifier: predictor | suppressor as one product (HEAD:410-411)
+        ld = (K + 1 + 3) // 4 * 4
+        logits = torch.zeros(max(Mp, 1), ld, **f32)
+        gemmx.launch([_lin(PF, st.view(st.buf, "clsW"), logits, st.view(st.buf, "clsb"), M=Mp, N=K + 1)])
+        S.update(B1h=B1h, B1o=B1o, Tp=Tp, PF=PF, logits=logits[:Mp])
+        return S
+
+    # ------------------------------------------------------------------------------------------------ losses
+    def loss_forward(self, logits):
+        """Both focal terms summed (HEAD:162-165, 190-192 before the division by n_p) + d/dlogits, from the packed result
+        arrays `self.result` (skg_postprocess_f32 on these logits) and the label matrix `self.labels`."""
+        lib = _capi.lib()
+        lay, dev, K = self.lay, self.dev, self.K
+        r = self.result
+        Mp, Lt = lay.sum_p, lay.sum_l
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.dlogits = torch.zeros_like(logits)
+        self.cell_labels = torch.empty(max(Lt, 1), **f32)
+        self.unary = torch.empty(max(Mp, 1), **f32)
+        partial = torch.empty(lay.n_active, 4, **f32)
+        _check(lib.skg_hoi_loss_f32(logits.data_ptr(), logits.stride(0), K, self.meta.data_ptr(), lay.n_active, Lt,
+                                    r["index"].data_ptr(), r["prediction"].data_ptr(), r["scores"].data_ptr(),
+                                    self.labels.data_ptr(), self.cell_labels.data_ptr(), self.unary.data_ptr(),
+                                    partial.data_ptr(), self.dlogits.data_ptr(), _stream()), "skg_hoi_loss_f32")
+        self.partial_sums = partial.sum(dim=0)            # {cell loss, pair loss, #positive cells, #positive pairs}
+        return self.partial_sums
+
+    # ------------------------------------------------------------------------------------------------ backward
+    def backward(self, dlogits, need_dx0, need_dgfeat):
+        lib = _capi.lib()
+        st, gh, lay, dev, S = self.st, self.gh, self.lay, self.dev, self.S
+        f32 = dict(device=dev, dtype=torch.float32)
+        stream = _stream()
+        NA, Mg, Mp, Mh, Mn, A = lay.sum_all, lay.sum_g, lay.sum_p, lay.sum_h, lay.sum_n, lay.n_active
+        K = self.K
+        blk = (6, 1024 * 64)
+        IG, WG = gemmx.input_grad, gemmx.weight_grad
+        ga = torch.empty(st.total, **f32)                       # gradient arena of the stacked parameters
+        gv = lambda name: st.view(ga, name)
+        W2 = st.view(st.buf, "W2")
+        W1 = [st.view(st.buf, "W1_%d" % i) for i in range(4)]
+        b1 = [st.view(st.buf, "b1_%d" % i) for i in range(4)]
+        W3 = [st.view(st.buf, "W3_%d" % i) for i in range(4)]
+        dW1 = [gv("W1_%d" % i) for i in range(4)]
+        db1 = [gv("b1_%d" % i) for i in range(4)]
+        dW3 = [gv("W3_%d" % i) for i in range(4)]
+        db3 = torch.empty(4, 1024, **f32)                        # one bias gradient per MBF, replicated over its branches
+        dlogits = dlogits.contiguous()
+        ld = dlogits.stride(0)
+        PF, Tp, Tg = S["PF"], S["Tp"], S["Tg"]
+        # ---- classifier
+        dPF = torch.empty(max(Mp, 1), 2048, **f32)
+        gemmx.launch([IG(dlogits, st.view(st.buf, "clsW"), dPF, mask=PF, M=Mp, N_in=2048, K_out=K + 1),
+                      WG(dlogits, PF, gv("clsW"), db=gv("clsb"), rows=Mp, n_out=K + 1, k_in=2048)])
+        # ---- read-out fc_3 (both branches): dT = dPF W3 cut by the product's ReLU; dW3 = dPF^T T
+        dTp = torch.empty(max(Mp, 1), 1024, **f32); dTg = torch.empty(max(Mp, 1), 1024, **f32)
+        gemmx.launch([IG(dPF, W3[ATT], dTp, mask=Tp, M=Mp, N_in=1024, K_out=1024, w_blocks=blk),
+                      IG(dPF[:, 1024:], W3[GL], dTg, mask=Tg, M=Mp, N_in=1024, K_out=1024, w_blocks=blk),
+                      WG(dPF, Tp, dW3[ATT], db=db3[ATT], rows=Mp, n_out=1024, k_in=1024, w_blocks=blk),
+                      WG(dPF[:, 1024:], Tg, dW3[GL], db=db3[GL], rows=Mp, n_out=1024, k_in=1024, w_blocks=blk)])
+        # ---- read-out fc_1 * fc_2 products: dF at the pairs' grid rows, dm in place
+        F = S["F"]
+        dF = torch.zeros(Mg, 4096, **f32)                        # [dF2 | dF_os | dF_so | dF_g]; self-pair rows stay zero
+        pair_grid, pair_h, pair_o, grid_h, grid_o, grid_img = (S[k] for k in ("pair_grid", "pair_h", "pair_o", "grid_h",
+                                                                              "grid_o", "grid_img"))
+        _check(lib.skg_mul_bwd_f32(dTp.data_ptr(), 1024, F.data_ptr(), pair_grid.data_ptr(), 4096, S["B1h"].data_ptr(),
+                                   pair_h.data_ptr(), 1024, S["B1o"].data_ptr(), pair_o.data_ptr(), 1024,
+                                   b1[ATT].data_ptr(), Mp, dF.data_ptr(), 4096, 0, stream), "skg_mul_bwd_f32")
+        pair_img = self.pair_img
+        _check(lib.skg_mul_bwd_f32(dTg.data_ptr(), 1024, F.data_ptr() + 4 * 3072, pair_grid.data_ptr(), 4096,
+                                   S["G1"].data_ptr(), pair_img.data_ptr(), 1024, None, None, 0, None, Mp,
+                                   dF.data_ptr() + 4 * 3072, 4096, 0, stream), "skg_mul_bwd_f32")
+        dB1h = torch.empty(Mh, 1024, **f32); dB1o = torch.empty(Mn, 1024, **f32)
+        hum_img, node_img = self.isl("hum_img"), self.isl("node_img")
+        _check(lib.skg_segment_sum_f32(dTp.data_ptr(), 1024, self.meta.data_ptr(), A, hum_img.data_ptr(),
+                                       node_img.data_ptr(), Mh, Mn, 1, dB1h.data_ptr(), dB1o.data_ptr(), 0, stream),
+               "skg_segment_sum_f32")
+        dG1 = torch.zeros(S["G1"].shape[0], 1024, **f32)
+        _check(lib.skg_segment_sum_f32(dTg.data_ptr(), 1024, self.meta.data_ptr(), A, None, None, 0, 0, 2,
+                                       dG1.data_ptr(), None, 0, stream), "skg_segment_sum_f32")
+        # ---- read-out fc_1 on the normalised nodes: dh_node, dnode; dW1[att] from both halves
+        dh_node = torch.empty(Mh, 1024, **f32); dnode = torch.empty(Mn, 1024, **f32)
+        Wa1, dWa1 = W1[ATT], dW1[ATT]
+        gemmx.launch([IG(dB1h, Wa1, dh_node, N_in=1024), IG(dB1o, Wa1[:, 1024:], dnode, N_in=1024),
+                      WG(dB1h, S["h_node"], dWa1, k_in=1024), WG(dB1o, S["node"], dWa1[:, 1024:], k_in=1024)])
+        # ---- LayerNorm + residual: dHp continues to the node, dHp cut by the message's ReLU goes to fc_3
+        nh, no = gh.norm_h, gh.norm_o
+        dHp = torch.empty(Mh, 1024, **f32); dHm = torch.empty(Mh, 1024, **f32)
+        dOp = torch.empty(Mn, 1024, **f32); dOm = torch.empty(Mn, 1024, **f32)
+        g_nh = torch.empty(2, 1024, **f32); g_no = torch.empty(2, 1024, **f32)
+        _check(lib.skg_layernorm_bwd_f32(dh_node.data_ptr(), 1024, S["Hp"].data_ptr(), S["st_h"].data_ptr(),
+                                         nh.weight.data_ptr(), Mh, dHp.data_ptr(), S["M1"].data_ptr(), dHm.data_ptr(),
+                                         g_nh[0].data_ptr(), g_nh[1].data_ptr(), stream), "skg_layernorm_bwd_f32")
+        _check(lib.skg_layernorm_bwd_f32(dnode.data_ptr(), 1024, S["Op"].data_ptr(), S["st_o"].data_ptr(),
+                                         no.weight.data_ptr(), Mn, dOp.data_ptr(), S["M2"].data_ptr(), dOm.data_ptr(),
+                                         g_no[0].data_ptr(), g_no[1].data_ptr(), stream), "skg_layernorm_bwd_f32")
+        # ---- message fc_3
+        dU = torch.empty(Mh, 1024, **f32); dV = torch.empty(Mn, 1024, **f32)
+        gemmx.launch([IG(dHm, W3[OS], dU, N_in=1024, w_blocks=blk), IG(dOm, W3[SO], dV, N_in=1024, w_blocks=blk),
+                      WG(dHm, S["U"], dW3[OS], db=db3[OS], w_blocks=blk), WG(dOm, S["V"], dW3[SO], db=db3[SO], w_blocks=blk)])
+        # ---- aggregation + softmax
+        dTos = torch.empty(Mg, 1024, **f32); dTso = torch.empty(Mg, 1024, **f32)
+        da = torch.empty(4, Mg, **f32)                            # da | db | dadj_h | dadj_n
+        _check(lib.skg_aggregate_bwd_f32(dU.data_ptr(), dV.data_ptr(), S["Tos"].data_ptr(), S["Tso"].data_ptr(),
+                                         S["alpha"].data_ptr(), S["beta"].data_ptr(), grid_h.data_ptr(), grid_o.data_ptr(),
+                                         Mg, self.meta.data_ptr(), hum_img.data_ptr(), node_img.data_ptr(), Mh, Mn,
+                                         dTos.data_ptr(), dTso.data_ptr(), da[0].data_ptr(), da[1].data_ptr(),
+                                         da[2].data_ptr(), da[3].data_ptr(), stream), "skg_aggregate_bwd_f32")
+        # ---- adjacency Linear(1024 -> 1) over relu(fc_3(T))
+        dadj = torch.empty(Mg, 1, **f32); dWt = torch.empty(Mg, 1024, **f32)
+        wadj = gh.adjacency.weight.detach().reshape(-1)
+        _check(lib.skg_adjacency_bwd_f32(da[2].data_ptr(), da[3].data_ptr(), wadj.data_ptr(), S["Wt"].data_ptr(), Mg,
+                                         dadj.data_ptr(), dWt.data_ptr(), stream), "skg_adjacency_bwd_f32")
+        g_adj_w = torch.empty(1, 1024, **f32); g_adj_b = torch.empty(1, **f32)
+        dT = torch.empty(Mg, 1024, **f32)
+        T = S["T"]
+        gemmx.launch([IG(dWt, W3[ATT], dT, mask=T, N_in=1024, w_blocks=blk),
+                      WG(dWt, T, dW3[ATT], db=db3[ATT], accumulate=True, w_blocks=blk),
+                      WG(dadj, S["Wt"], g_adj_w, db=g_adj_b)])
+        # ---- in-loop fc_1 * fc_2 products
+        _check(lib.skg_mul_bwd_f32(dT.data_ptr(), 1024, F.data_ptr(), None, 4096, S["A1h"].data_ptr(), grid_h.data_ptr(),
+                                   1024, S["A1o"].data_ptr(), grid_o.data_ptr(), 1024, b1[ATT].data_ptr(), Mg,
+                                   dF.data_ptr(), 4096, 1, stream), "skg_mul_bwd_f32")
+        _check(lib.skg_mul_bwd_f32(dTos.data_ptr(), 1024, F.data_ptr() + 4 * 1024, None, 4096, S["C1o"].data_ptr(),
+                                   grid_o.data_ptr(), 1024, None, None, 0, None, Mg, dF.data_ptr() + 4 * 1024, 4096, 0,
+                                   stream), "skg_mul_bwd_f32")
+        _check(lib.skg_mul_bwd_f32(dTso.data_ptr(), 1024, F.data_ptr() + 4 * 2048, None, 4096, S["C1h"].data_ptr(),
+                                   grid_h.data_ptr(), 1024, None, None, 0, None, Mg, dF.data_ptr() + 4 * 2048, 4096, 0,
+                                   stream), "skg_mul_bwd_f32")
+        dA1h = torch.empty(Mh, 1024, **f32); dA1o = torch.empty(Mn, 1024, **f32)
+        dC1o = torch.empty(Mn, 1024, **f32); dC1h = torch.empty(Mh, 1024, **f32)
+        seg = lambda src, oh, on: _check(lib.skg_segment_sum_f32(
+            src.data_ptr(), 1024, self.meta.data_ptr(), A, hum_img.data_ptr(), node_img.data_ptr(), Mh, Mn, 0,
+            _ptr(oh), _ptr(on), 0, stream), "skg_segment_sum_f32")
+        seg(dT, dA1h, dA1o); seg(dTos, None, dC1o); seg(dTso, dC1h, None)
+        # the multiplier bias of attention_head's fc_1 is added once per row: its gradient is the sum over all rows
+        g_ab1 = dA1h.sum(dim=0) + dB1h.sum(dim=0)
+        db1[ATT].copy_(g_ab1)
+        # ---- fc_2 of all four MBFs: ONE product for the input gradient (K = 4096), one for the weights
+        Sp = S["Sp"]
+        dS = torch.empty(Mg, 1024, **f32)
+        gemmx.launch([IG(dF, W2, dS, mask=Sp, N_in=1024), WG(dF, Sp, gv("W2"), db=gv("b2"))])
+        # ---- fc_1 projections on node rows: gradients of the nodes accumulate on top of the residual path
+        GH, GO = S["GH"], S["GO"]
+        gemmx.launch([IG(dA1h, Wa1, dHp, accumulate=True, N_in=1024), IG(dA1o, Wa1[:, 1024:], dOp, accumulate=True, N_in=1024),
+                      WG(dA1h, GH, dWa1, accumulate=True, k_in=1024), WG(dA1o, GO, dWa1[:, 1024:], accumulate=True, k_in=1024)])
+        gemmx.launch([IG(dC1h, W1[SO], dHp, mask=GH, accumulate=True), IG(dC1o, W1[OS], dOp, mask=GO, accumulate=True),
+                      WG(dC1h, GH, dW1[SO], db=db1[SO]), WG(dC1o, GO, dW1[OS], db=db1[OS])])
+        # ---- fc_head / fc_tail
+        Xhn = S["Xhn"]
+        fh, ft = gh.fc_head[0], gh.fc_tail[0]
+        dXhn = torch.empty(Mh + Mn, 1088, **f32)
+        g_fh_w = torch.empty_like(fh.weight); g_fh_b = torch.empty_like(fh.bias)
+        g_ft_w = torch.empty_like(ft.weight); g_ft_b = torch.empty_like(ft.bias)
+        gemmx.launch([IG(dHp, fh.weight, dXhn[:Mh], N_in=1074), IG(dOp, ft.weight, dXhn[Mh:], N_in=1074),
+                      WG(dHp, Xhn[:Mh], g_fh_w, db=g_fh_b, k_in=1074), WG(dOp, Xhn[Mh:], g_ft_w, db=g_ft_b, k_in=1074)])
+        d_enc = torch.empty(NA, 1024, **f32)
+        _check(lib.skg_entity_rows_bwd_f32(dXhn.data_ptr(), 1088, self.hum_of.data_ptr(), self.node_of.data_ptr(), Mh, NA,
+                                           S["enc"].data_ptr(), d_enc.data_ptr(), stream), "skg_entity_rows_bwd_f32")
+        # ---- box_head
+        bh1, bh3 = gh.box_head[1], gh.box_head[3]
+        E1, x0 = S["E1"], S["x0"]
+        dE1 = torch.empty(NA, 1024, **f32)
+        g_bh3_w = torch.empty_like(bh3.weight); g_bh3_b = torch.empty_like(bh3.bias)
+        g_bh1_w = torch.empty_like(bh1.weight); g_bh1_b = torch.empty_like(bh1.bias)
+        gemmx.launch([IG(d_enc, bh3.weight, dE1, mask=E1), WG(d_enc, E1, g_bh3_w, db=g_bh3_b)])
+        ops = [WG(dE1, x0, g_bh1_w, db=g_bh1_b)]
+        dx0 = None
+        if need_dx0:
+            dx0 = torch.empty_like(x0)
+            ops.append(IG(dE1, bh1.weight, dx0))
+        gemmx.launch(ops)
+        # ---- spatial head
+        sp = gh.spatial_head
+        s1, s2, sp48 = S["s1"], S["s2"], S["sp48"]
+        ds2 = torch.empty(Mg, 256, **f32); ds1 = torch.empty(Mg, 128, **f32)
+        g_sp = [(torch.empty_like(sp[i].weight), torch.empty_like(sp[i].bias)) for i in (0, 2, 4)]
+        gemmx.launch([IG(dS, sp[4].weight, ds2, mask=s2), WG(dS, s2, g_sp[2][0], db=g_sp[2][1])])
+        gemmx.launch([IG(ds2, sp[2].weight, ds1, mask=s1), WG(ds2, s1, g_sp[1][0], db=g_sp[1][1])])
+        # ---- global branch fc_1 (HEAD:971) and the first spatial layer
+        gfeat = S["gfeat"]
+        ops = [WG(ds1, sp48, g_sp[0][0], db=g_sp[0][1], k_in=46), WG(dG1, gfeat, dW1[GL], db=db1[GL])]
+        dgfeat = None
+        if need_dgfeat:
+            dgfeat = torch.empty_like(gfeat)
+            ops.append(IG(dG1, W1[GL], dgfeat))
+        gemmx.launch(ops)
+        # ---- the fc_3 bias of branch b is added once per row whatever b: every branch gets the MBF's bias gradient
+        gv("b3").copy_(db3.unsqueeze(1).expand(4, 16, 1024))
+        # ---- hand the gradients back in the order of the Function's parameter inputs
+        direct = {id(bh1.weight): g_bh1_w, id(bh1.bias): g_bh1_b, id(bh3.weight): g_bh3_w, id(bh3.bias): g_bh3_b,
+                  id(gh.adjacency.weight): g_adj_w, id(gh.adjacency.bias): g_adj_b,
+                  id(nh.weight): g_nh[0], id(nh.bias): g_nh[1], id(no.weight): g_no[0], id(no.bias): g_no[1],
+                  id(sp[0].weight): g_sp[0][0], id(sp[0].bias): g_sp[0][1], id(sp[2].weight): g_sp[1][0],
+                  id(sp[2].bias): g_sp[1][1], id(sp[4].weight): g_sp[2][0], id(sp[4].bias): g_sp[2][1],
+                  id(fh.weight): g_fh_w, id(fh.bias): g_fh_b, id(ft.weight): g_ft_w, id(ft.bias): g_ft_b}
+        sviews = st.grad_views(ga)
+        out = []
+        for p in self.params:
+            k = st.ids.get(id(p))
+            out.append(sviews[k] if k is not None else direct.get(id(p)))
+        self.S = None                                            # the saved activations die with the step
+        return dx0, dgfeat, out
+
+
+# ---------------------------------------------------------------------------------------------------- step driver
+def _perm(state, n, m):
+    g = torch.Generator(); g.set_state(state)
+    return torch.randperm(n, generator=g)[:m]
+
+
+def supported(head):
+    """The fused step covers the reference's configuration: fp32, message passing on (num_iter >= 1), plain Linear
+    predictor / suppressor.  Anything else takes the autograd path (skghoi_amd/train_graph.py)."""
+    gh = head.box_pair_head
+    return (head.precision == "fp32" and gh.num_iter > 0 and isinstance(head.box_pair_predictor, torch.nn.Linear)
+            and isinstance(head.box_pair_suppressor, torch.nn.Linear)
+            and head.box_pair_predictor.in_features == 2048 and head.box_pair_suppressor.in_features == 2048
+            and head.box_pair_suppressor.out_features == 1 and head.box_pair_predictor.out_features == head.num_classes
+            and head.box_pair_predictor.bias is not None and head.box_pair_suppressor.bias is not None)
+
+
+def train_forward(head, eng, features, image_shapes, box_features, pre, targets):
+    """InteractionHead.forward in training mode (HEAD:380-429) on the fused step.  Returns the reference's result list
+    with the loss dict appended, or None when the batch has no image with pairs (the caller takes the generic path)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import dist as skd, transh
+    lib = _capi.lib()
+    gh = head.box_pair_head
+    dev = pre.device
+    K = head.num_classes
+    stream = _stream()
+    lay = layout.build(pre.n_h, pre.n, pre.L, image_shapes, gh.human_idx, faithful_skip_offset=eng.faithful_skip_offset)
+    A = lay.n_active
+    if A == 0 or lay.sum_p == 0:
+        return None
+    if box_features.shape[0] != lay.sum_all:
+        raise _capi.SkgError("box_roi_pool returned %d rows for %d boxes" % (box_features.shape[0], lay.sum_all))
+    st = getattr(head, "_stacked", None)
+    if st is None or st.device != dev or any(a is not b for a, b in zip(st.src[-4:], (
+            head.box_pair_predictor.weight, head.box_pair_suppressor.weight, head.box_pair_predictor.bias,
+            head.box_pair_suppressor.bias))) or st.epoch != _reg_epoch():
+        st = Stacked(head, dev)
+        st.epoch = _reg_epoch()
+        head._stacked = st
+    Mg, Mp, Mh, Mn, NA = lay.sum_g, lay.sum_p, lay.sum_h, lay.sum_n, lay.sum_all
+    f32 = dict(device=dev, dtype=torch.float32)
+    i32 = dict(device=dev, dtype=torch.int32)
+    # ---- every index array of the step in one upload
+    buf, offs = layout.pack_int_arrays(lay)
+    hum_of = np.full(max(NA, 1), -1, np.int32); node_of = np.full(max(NA, 1), -1, np.int32)
+    hum_of[lay.hum_enc_row] = np.arange(Mh, dtype=np.int32)
+    node_of[lay.node_enc_row] = np.arange(Mn, dtype=np.int32)
+    pair_img = np.repeat(lay.meta["image"].astype(np.int32), lay.pairs_per_image)
+    act_imgs = [int(b) for b in lay.active]
+    gt_cnt = [int(targets[b]["boxes_h"].shape[0]) for b in act_imgs]
+    gt_off_h = np.zeros(A + 1, np.int32); gt_off_h[1:] = np.cumsum(gt_cnt)
+    extra = [("hum_of", hum_of), ("node_of", node_of), ("pair_img", pair_img), ("gt_off", gt_off_h)]
+    cur = len(buf)
+    parts = [buf]
+    for name, arr in extra:
+        pad = (-cur) % 4
+        if pad:
+            parts.append(np.zeros(pad, np.int32)); cur += pad
+        offs[name] = (cur, len(arr))
+        parts.append(arr.astype(np.int32)); cur += len(arr)
+    ibuf = torch.from_numpy(np.concatenate(parts)).to(dev, non_blocking=True)
+    isl = lambda name: ibuf[offs[name][0]:offs[name][0] + offs[name][1]]
+    meta = isl("meta")
+    # ---- pairs + spatial encoding, GT association (HEAD:847-868, 703-719): ahead of the dense part because the
+    # number of positives per image sizes the host RNG draws below
+    grid_h = torch.empty(Mg, **i32); grid_o = torch.empty(Mg, **i32); grid_pair = torch.empty(Mg, **i32)
+    grid_img = torch.empty(Mg, **i32); pair_grid = torch.empty(max(Mp, 1), **i32)
+    pair_h = torch.empty(max(Mp, 1), **i32); pair_o = torch.empty(max(Mp, 1), **i32)
+    x_keep = torch.empty(max(Mp, 1), device=dev, dtype=torch.int64); y_keep = torch.empty_like(x_keep)
+    sp48 = torch.empty(Mg, _capi.SPATIAL_LD, **f32)
+    _check(lib.skg_pairs_spatial_f32(pre.boxes.data_ptr(), meta.data_ptr(), A, grid_h.data_ptr(), grid_o.data_ptr(),
+                                     grid_pair.data_ptr(), grid_img.data_ptr(), pair_grid.data_ptr(), x_keep.data_ptr(),
+                                     y_keep.data_ptr(), pair_h.data_ptr(), pair_o.data_ptr(), sp48.data_ptr(), 1, stream),
+           "skg_pairs_spatial_f32")
+    if gt_off_h[-1]:
+        gt_h = torch.cat([targets[b]["boxes_h"].reshape(-1, 4) for b in act_imgs]).float().contiguous()
+        gt_o = torch.cat([targets[b]["boxes_o"].reshape(-1, 4) for b in act_imgs]).float().contiguous()
+        gt_l = torch.cat([targets[b]["labels"].reshape(-1) for b in act_imgs]).long().contiguous()
+    else:
+        gt_h = torch.zeros(1, 4, device=dev); gt_o = torch.zeros(1, 4, device=dev)
+        gt_l = torch.zeros(1, dtype=torch.int64, device=dev)
+    labels_all = torch.zeros(max(Mp, 1), K, **f32)
+    npos_d = torch.empty(A, **i32)
+    _check(lib.skg_associate_f32(pre.boxes.data_ptr(), meta.data_ptr(), A, x_keep.data_ptr(), y_keep.data_ptr(),
+                                 gt_h.data_ptr(), gt_o.data_ptr(), gt_l.data_ptr(), isl("gt_off").data_ptr(), K,
+                                 float(gh.fg_iou_thresh), labels_all.data_ptr(), npos_d.data_ptr(), stream),
+           "skg_associate_f32")
+    # ---- the dense part does not depend on the sampling below: enqueue it first, then pay the one host sync of the step
+    params = list(head.box_pair_head.parameters()) + list(head.box_pair_suppressor.parameters()) + \
+        list(head.box_pair_predictor.parameters())
+    job = TrainJob(head, eng, st, lay, pre, ibuf, offs, None, meta)
+    job.params = params
+    job.S.update(grid_h=grid_h, grid_o=grid_o, grid_pair=grid_pair, grid_img=grid_img, pair_grid=pair_grid,
+                 pair_h=pair_h, pair_o=pair_o, x_keep=x_keep[:Mp], y_keep=y_keep[:Mp], sp48=sp48)
+    job.pair_img, job.hum_of, job.node_of = isl("pair_img"), isl("hum_of"), isl("node_of")
+    job.labels = labels_all
+    # host RNG in the reference's order: per image six TransH draws (HEAD:574-580), then randperm(#negatives) (HEAD:939).
+    # The entity tables feed fc_head / fc_tail, so they are needed before the dense part; the permutations only after it.
+    n_pos = npos_d.cpu().tolist()                                   # the step's host synchronisation
+    ppi = [int(v) for v in lay.pairs_per_image]
+    tabs, perms = [], []
+    pool = ThreadPoolExecutor(max_workers=min(8, A))
+    for a in range(A):
+        tabs.append(transh.draw_tables(K, need_relations=True))
+        n_neg = ppi[a] * K - n_pos[a]
+        state = torch.get_rng_state()
+        if n_neg > 1:
+            torch.empty(n_neg - 1, dtype=torch.int32).random_()
+        perms.append(pool.submit(_perm, state, n_neg, n_pos[a]))
+    pool.shutdown(wait=False)
+    ent = torch.stack([t[0] for t in tabs]).to(dev, non_blocking=True)
+    rel = torch.stack([t[1] for t in tabs]).to(dev, non_blocking=True)
+    nrm = torch.stack([t[2] for t in tabs]).to(dev, non_blocking=True)
+    job.ent = ent
+    gfeat = torch.nn.functional.adaptive_avg_pool2d(features["3"].float(), 1).flatten(start_dim=1)    # HEAD:811
+    logits = HeadTrainFn.apply(job, box_features, gfeat, *params)
+    # ---- scoring + result packing (HEAD:721-767, 237-337), on the detached logits
+    g = dict(layout=lay, meta=meta, x_keep=x_keep[:Mp], y_keep=y_keep[:Mp])
+    r = eng.score(logits.detach(), pre, g, True)
+    job.result = r
+    sums = HoiLossFn.apply(job, logits)
+    # ---- normalisers: ONE fused all-reduce of the three n_p (HEAD:167-172, 194-199, 223-228), consumed as a tensor
+    part = job.partial_sums
+    norm = skd.start_normalisers(torch.stack([part[2], part[3], part[3]]), head.distributed).get()
+    hoi_loss = sums[0] / norm[0]
+    int_loss = sums[1] / norm[1]
+    # ---- TransH term (HEAD:207-235, intended semantics): positives and as many sampled negatives per image
+    scores_all = torch.empty(max(Mp, 1), K, **f32)
+    _check(lib.skg_transh_scores_f32(ent.data_ptr(), rel.data_ptr(), nrm.data_ptr(), K, gh.human_idx, meta.data_ptr(), A,
+                                     scores_all.data_ptr(), stream), "skg_transh_scores_f32")
+    labels_v = labels_all[:Mp]
+    pos_p, pos_k = torch.nonzero(labels_v).unbind(1)
+    zero_p, zero_k = torch.nonzero(labels_v == 0).unbind(1)
+    neg_cnt = [ppi[a] * K - n_pos[a] for a in range(A)]
+    neg_base = np.concatenate([[0], np.cumsum(neg_cnt)])
+    sel = torch.cat([perms[a].result() + int(neg_base[a]) for a in range(A)]).to(dev)
+    neg_p, neg_k = zero_p[sel], zero_k[sel]
+    score = torch.cat([scores_all[pos_p, pos_k], scores_all[neg_p, neg_k]])
+    half = len(score) // 2
+    p_ = score[:half].view(-1, half).permute(1, 0); n_ = score[half:].view(-1, half).permute(1, 0)
+    transh_loss = (torch.max(p_ - n_, torch.tensor([-1.0], device=dev)).mean() + 1.0) / norm[2]
+    if eng.debug:                                                   # parity tests read these
+        head._last_train = dict(pair_features=job.S["PF"][:Mp], pos_scores=scores_all[pos_p, pos_k].split(n_pos),
+                                neg_scores=scores_all[neg_p, neg_k].split(n_pos), job=job)
+    # ---- per-image result dicts (views of the packed arrays)
+    results = head._results(lay, r, dev, train_extras=(job.cell_labels, job.unary))
+    results.append(dict(hoi_loss=hoi_loss, interactiveness_loss=int_loss, transH_loss=transh_loss))
+    return results
+
+
+def _reg_epoch():
+    from .engine import _REG_EPOCH
+    return _REG_EPOCH[0]

@@ -103,7 +103,10 @@ def run_head(case, head=None, reference_quirks=True):
 def _run_train(case, head, det, tg, feats, backward=False):
     """Training-mode forward (and optionally backward of the summed losses).  Captures graph_train's lists."""
     import skghoi_amd.train_graph as tgm
+    from skghoi_amd import train_fused
     K = case["cfg"]["K"]
+    if getattr(head, "fused_training", False) and train_fused.supported(head):
+        return _run_train_fused(case, head, det, tg, feats, backward)
     cap = {}
     orig = tgm.graph_train
 
@@ -142,8 +145,40 @@ def _run_train(case, head, det, tg, feats, backward=False):
     return (flat, grads) if backward else flat
 
 
-def run_train_with_grads(case):
+def _run_train_fused(case, head, det, tg, feats, backward):
+    """Training forward on the fused step (skghoi_amd/train_fused.py): result dicts, losses, pair features and the
+    TransH pos / neg scores; gradients of all parameters when `backward`."""
+    out = {}
+    for b, d in enumerate(head.preprocess(det, tg)):
+        out["pre%d.boxes" % b] = d["boxes"]; out["pre%d.labels" % b] = d["labels"]; out["pre%d.scores" % b] = d["scores"]
+    head.engine().debug = True
+    torch.manual_seed(case["rng_seed"])
+    results = head(feats, det, case["shapes"], tg)
+    losses = results[-1]
+    for b, r in enumerate(results[:-1]):
+        for k, v in r.items():
+            out["res%d.%s" % (b, k)] = v
+    out["n_results"] = torch.tensor(len(results) - 1)
+    for k, v in losses.items():
+        out[k] = v
+    last = getattr(head, "_last_train", None)
+    if last is not None:
+        out["pair_features"] = last["pair_features"].clone()
+        for i in range(len(last["pos_scores"])):
+            out["timg%d.pos_scores" % i] = last["pos_scores"][i]; out["timg%d.neg_scores" % i] = last["neg_scores"][i]
+        out["n_tables"] = torch.tensor(len(last["pos_scores"]))
+    grads = None
+    if backward:
+        head.zero_grad()
+        sum(losses.values()).backward()
+        grads = {k: p.grad.detach().cpu().numpy() for k, p in head.named_parameters() if p.grad is not None}
+    flat = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()}
+    return (flat, grads) if backward else flat
+
+
+def run_train_with_grads(case, fused=True):
     head = build_head(case)
+    head.fused_training = fused
     det = to_cuda(case["detections"]); tg = to_cuda(case["targets"])
     feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
     return _run_train(case, head, det, tg, feats, backward=True)

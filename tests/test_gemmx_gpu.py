@@ -61,7 +61,7 @@ def test_input_grad_with_relu_mask_and_accumulate(M, N_out, K_in, split):
     op = gemmx.input_grad(dz, W, dx, mask=y_prev, accumulate=True)
     op.split_k = split
     gemmx.launch([op])
-    want = before.double() + (dz.double() @ W.double()) * (y_prev > 0)
+    want = (before.double() + dz.double() @ W.double()) * (y_prev > 0)      # accumulate first, mask last (see header)
     _close(dx, want, "input grad")
 
 

@@ -153,12 +153,16 @@ def test_fp16x2_tracks_exact_path_at_other_magnitudes(gain):
         assert np.array_equal(out["fp32"]["res0." + k], out["fp16x2"]["res0." + k])
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "autograd"])
 @pytest.mark.parametrize("name", cases.TRAIN_CASES)
-def test_training_forward_matches_reference_golden(name):
+def test_training_forward_matches_reference_golden(name, fused):
     """Rows 15-17 of SURVEY 8(a): GT association, TransH pos/neg sampling (host RNG: tables + randperm), the three
-    loss terms (TransH term per the intended semantics).  Golden = the reference's own pieces."""
+    loss terms (TransH term per the intended semantics).  Golden = the reference's own pieces.  Both
+    training paths: the fused step (default) and autograd over per-layer Functions."""
     case = cases.build_case(name)
-    got = gpu_run.run_head(case)
+    head = gpu_run.build_head(case)
+    head.fused_training = fused
+    got = gpu_run.run_head(case, head=head)
     want = helpers.load_golden(name)
     helpers.compare_flat(got, want, atol=LOGIT_TOL, rtol=1e-4, only_common=True,
                          skip=(".spatial46", ".rel_table", ".norm_table", ".adjacency", ".h_node", ".node", ".ent"))
@@ -169,10 +173,13 @@ def test_training_forward_matches_reference_golden(name):
             assert np.array_equal(got["res%d.%s" % (b, k)], want["res%d.%s" % (b, k)]), (b, k)
 
 
-def test_training_gradients_match_oracle_autograd():
-    """Backward through the HIP GEMMs (dX, dW via skg_gemm_f32 + skg_transpose_f32) vs CPU autograd of the oracle."""
-    case = cases.build_case("train_tiny")
-    flat, grads = gpu_run.run_train_with_grads(case)
+@pytest.mark.parametrize("fused,name", [(True, "train_tiny"), (True, "train_skips"), (False, "train_tiny")],
+                         ids=["fused-tiny", "fused-skips", "autograd-tiny"])
+def test_training_gradients_match_oracle_autograd(fused, name):
+    """Gradients of all 408 parameters vs CPU autograd of the oracle: the hand-written backward of the fused step
+    (skghoi_amd/train_fused.py: skg_gemmx_f32 + skg_train.hip) and the autograd path over the per-layer Functions."""
+    case = cases.build_case(name)
+    flat, grads = gpu_run.run_train_with_grads(case, fused=fused)
     want, losses = helpers.oracle_train_grads(case)
     for k in ("hoi_loss", "interactiveness_loss", "transH_loss"):
         assert abs(float(flat[k]) - losses[k]) <= 1e-5 * max(1.0, abs(losses[k]))
@@ -181,9 +188,11 @@ def test_training_gradients_match_oracle_autograd():
     for k, w in want.items():
         g = grads[k]
         scale = max(np.abs(w).max(), 1e-6)
-        err = np.abs(g - w).max() / scale
+        # (+1e-9 absolute: the adjacency bias shifts all logits of a softmax alike -- its exact gradient is zero and both
+        #  sides return rounding noise of the order 1e-10)
+        err = max(np.abs(g - w).max() - 1e-9, 0.0) / scale
         worst = max(worst, err)
-        assert err <= 2e-3, "%s: rel err %.3e (|grad| max %.3e)" % (k, err, scale)
+        assert err <= 1e-4, "%s: rel err %.3e (|grad| max %.3e)" % (k, err, scale)
     print("max relative gradient error %.3e over %d tensors" % (worst, len(want)))
 
 
