@@ -256,6 +256,14 @@ int skg_postprocess_f32(const float* logits, int64_t ld_logits, int K, const flo
 int skg_transh_draw_f32(void* torch_cpu_rng_state, int64_t state_bytes, int n_images, int K, int need_relations,
                         int fused_affine, float* ent, float* rel, float* nrm);
 
+/* HOST function: the host RNG of a TRAINING forward in the reference's order, for `n_images` processed images: per image
+ * the six TransH table fills (HEAD:574-580; ent, rel, nrm all kept) followed by torch.randperm(n_neg[a]) (HEAD:938-939:
+ * the sampled negatives), of which the first n_take[a] entries are written to perm_out (concatenated over the images).
+ * The generator state ends where the reference's calls leave it (randperm draws n - 1 words).                          */
+int skg_transh_draw_train_f32(void* torch_cpu_rng_state, int64_t state_bytes, int n_images, int K, int fused_affine,
+                              const int64_t* n_neg, const int64_t* n_take, float* ent, float* rel, float* nrm,
+                              int64_t* perm_out);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * TransH hyperplane scores (heads/TransH/TransH.py:56-106) for every (kept pair, relation):
  *   w = norm(nrm[k]); h = ent[human_idx] - (ent[human_idx].w) w; t = ent[y] - (ent[y].w) w
@@ -362,13 +370,24 @@ int skg_entity_rows_bwd_f32(const float* dX, int64_t ldx, const int32_t* hum_of,
                             int n_enc, const float* enc, float* d_enc, void* stream);
 /* Both focal losses (HEAD:153-205, ops.py:159-211) forward + d/dlogits in one pass over what skg_postprocess_f32
  * emitted (training: prior_pow 1).  labels [sumP, K] from skg_associate_f32.  Outputs: cell_labels [L] (labels at the
- * scored cells), unary [sumP] (min(sum_v labels, 1)), partial [n_active, 4] = per image {sum of the cell losses, sum of the
- * pair losses, number of positive cells, number of positive pairs} (the counts are the normalisers n_p of HEAD:162-165),
+ * scored cells), unary [sumP] (min(sum_v labels, 1)), partial [n_active, SKG_LOSS_CHUNKS, 4] = per image and workgroup
+ * {sum of the cell losses, sum of the pair losses, number of positive cells, number of positive pairs} (to be added up;
+ * the counts are the normalisers n_p of HEAD:162-165),
  * dlogits [sumP, ldl] (ZERO-FILLED by the caller): columns < K d(cell loss sum)/dlogit, column K d(pair loss sum).    */
+#define SKG_LOSS_CHUNKS 16
 int skg_hoi_loss_f32(const float* logits, int64_t ldl, int K, const skg_image_meta* meta, int n_active,
                      int64_t cells_total, const int64_t* index, const int64_t* pred, const float* scores,
                      const float* labels, float* cell_labels, float* unary, float* partial, float* dlogits,
                      void* stream);
+
+/* TransH positive / negative sampling of the training step (HEAD:936-963) and the margin term (HEAD:207-235 as intended;
+ * heads/MarginLoss.py:28-36): labels, scores [sumP, K]; pos_off [n_active + 1] = prefix of the positives per image (host
+ * knows them from skg_associate_f32's npos); perm [sum m] = per image the first m entries of randperm(#zero cells)
+ * (skg_transh_draw_train_f32).  pos_scores[i] = score of the i-th positive cell (row-major), neg_scores[i] = score of the
+ * zero cell of rank perm[i]; partial[a] = sum_i max(pos_i - neg_i, -margin).  One workgroup per image.               */
+int skg_transh_sample_f32(const float* labels, const float* scores, int K, const skg_image_meta* meta, int n_active,
+                          const int32_t* pos_off, const int64_t* perm, float margin, float* pos_scores,
+                          float* neg_scores, float* partial, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Order-independent 64-bit checksum of the live parameters (bit patterns weighted by position) over a table of

@@ -15,6 +15,7 @@ TRANSH_ENT = 80
 ABI_VERSION = 4
 GEMM_GROUP_MAX = 4
 CHECKSUM_PARTIALS = 1024
+LOSS_CHUNKS = 16
 
 _vp = C.c_void_p
 _i32 = C.c_int32
@@ -68,6 +69,7 @@ PROTOTYPES = {
     "skg_global_avgpool_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "skg_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "skg_transh_draw_f32": (C.c_int, [_vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "skg_transh_draw_train_f32": (C.c_int, [_vp, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "skg_gemm_dot_partials": (C.c_int, [C.POINTER(GemmDesc)]),
     "skg_split_weights_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "skg_split_weights_f16x2": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _f32, _vp, _vp]),
@@ -103,6 +105,7 @@ PROTOTYPES = {
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "skg_adjacency_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "skg_entity_rows_bwd_f32": (C.c_int, [_vp, _i64, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "skg_transh_sample_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _f32, _vp, _vp, _vp, _vp]),
     "skg_hoi_loss_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -108,20 +108,27 @@ __global__ __launch_bounds__(256) void skg_layernorm_bwd_kernel(const float* __r
 }
 
 // dgamma[c] = sum_r dy[r, c] * xhat[r, c],  dbeta[c] = sum_r dy[r, c]: one thread per column, rows in order.
+// 64 columns x 4 row groups per workgroup (16 workgroups): rows r = g, g + 4, ... per group, groups added in order.
 __global__ __launch_bounds__(256) void skg_layernorm_param_grad_kernel(const float* __restrict__ dy, int64_t lddy,
                                                                        const float* __restrict__ x,
                                                                        const float* __restrict__ stats, int rows,
                                                                        float* __restrict__ dgamma,
                                                                        float* __restrict__ dbeta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float sg_s[4][64], sb_s[4][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float sg = 0.f, sb = 0.f;
-    for (int r = 0; r < rows; ++r) {
+    for (int r = g; r < rows; r += 4) {
         const float d = dy[(int64_t)r * lddy + c];
         sg += d * ((x[(int64_t)r * TR_COLS + c] - stats[2 * r]) * stats[2 * r + 1]);
         sb += d;
     }
-    dgamma[c] = sg;
-    dbeta[c] = sb;
+    sg_s[g][cl] = sg; sb_s[g][cl] = sb;
+    __syncthreads();
+    if (g == 0) {
+        dgamma[c] = (sg_s[0][cl] + sg_s[1][cl]) + (sg_s[2][cl] + sg_s[3][cl]);
+        dbeta[c] = (sb_s[0][cl] + sb_s[1][cl]) + (sb_s[2][cl] + sb_s[3][cl]);
+    }
 }
 
 extern "C" int skg_layernorm_bwd_f32(const float* dy, int64_t lddy, const float* x, const float* stats,
@@ -135,7 +142,7 @@ extern "C" int skg_layernorm_bwd_f32(const float* dy, int64_t lddy, const float*
     if (rows)
         hipLaunchKernelGGL(skg_layernorm_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, stats,
                            gamma, dx, relu_src, dx_masked);
-    hipLaunchKernelGGL(skg_layernorm_param_grad_kernel, dim3(TR_COLS / 256), dim3(256), 0, (hipStream_t)stream, dy, lddy,
+    hipLaunchKernelGGL(skg_layernorm_param_grad_kernel, dim3(TR_COLS / 64), dim3(256), 0, (hipStream_t)stream, dy, lddy,
                        x, stats, rows, dgamma, dbeta);
     return skg_launch_status();
 }
@@ -222,8 +229,25 @@ __global__ __launch_bounds__(256) void skg_segment_sum_kernel(const float* __res
             for (int i = 0; i < mt.n_h; ++i) if (i != j) add((int64_t)mt.pair_off + (int64_t)i * (mt.n - 1) + (j < i ? j : j - 1));
         }
     } else {
+        // all kept pairs of the image: hundreds of rows through one workgroup -- four independent chains keep four loads in
+        // flight per lane (a single chain walks 780 rows of a 20 x 20 image at one L2 round trip each: 190 us, measured)
         const int P = mt.n_h * (mt.n - 1);
-        for (int p = 0; p < P; ++p) add((int64_t)mt.pair_off + p);
+        float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1, a3 = a1;
+        const float* base = src + (int64_t)mt.pair_off * ld + c;
+        int p = 0;
+        for (; p + 3 < P; p += 4) {
+            const float4 v0 = *reinterpret_cast<const float4*>(base + (int64_t)p * ld);
+            const float4 v1 = *reinterpret_cast<const float4*>(base + (int64_t)(p + 1) * ld);
+            const float4 v2 = *reinterpret_cast<const float4*>(base + (int64_t)(p + 2) * ld);
+            const float4 v3 = *reinterpret_cast<const float4*>(base + (int64_t)(p + 3) * ld);
+            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+            a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+            a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+        }
+        for (; p < P; ++p) add((int64_t)mt.pair_off + p);
+        acc.x = (acc.x + a1.x) + (a2.x + a3.x); acc.y = (acc.y + a1.y) + (a2.y + a3.y);
+        acc.z = (acc.z + a1.z) + (a2.z + a3.z); acc.w = (acc.w + a1.w) + (a2.w + a3.w);
     }
     float4* o = reinterpret_cast<float4*>(out + (int64_t)(mode == 2 ? mt.image : dst) * TR_COLS + c);
     if (accumulate) { const float4 t = *o; acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
@@ -392,8 +416,9 @@ extern "C" int skg_entity_rows_bwd_f32(const float* dX, int64_t ldx, const int32
 //   cell c of image a: pair p = pair_off + index[c], verb v = pred[c]; x = scores[c] = sigmoid(lp) * ph * po * w.detach()
 //   pair p: w = sigmoid(ls), y = unary[p] = min(sum_v labels[p, v], 1)
 // BCE and its derivative as torch defines them (log clamped at -100; (x - y) / max(x (1 - x), 1e-12)).
-// One workgroup per image; partial[a] = {sum of cell losses, sum of pair losses, #positive cells, #positive pairs}: the
-// caller adds them up; the two counts are the loss normalisers n_p (HEAD:162-165, 190-192).
+// SKG_LOSS_CHUNKS workgroups per image (strided over its cells and pairs); partial[a][chunk] = {sum of cell losses, sum
+// of pair losses, #positive cells, #positive pairs}: the caller adds them up; the two counts are the loss normalisers
+// n_p (HEAD:162-165, 190-192).
 // dlogits [sumP, ldl] must be zero-filled; columns < K receive d(sum cell loss)/dlp, column K d(sum pair loss)/dls.
 __device__ __forceinline__ float skg_focal(float x, float y, float gamma, float& dldx) {
     const float alpha = 0.5f, eps = 1e-6f;
@@ -419,8 +444,9 @@ __global__ __launch_bounds__(256) void skg_hoi_loss_kernel(
     const int64_t c0 = mt.out_off;
     const int64_t c1 = (a + 1 < n_active) ? (int64_t)meta[a + 1].out_off : cells_total;
     const int P = mt.n_h * (mt.n - 1);
+    const int stride = 256 * gridDim.y, first = blockIdx.y * 256 + threadIdx.x;
     float s1 = 0.f, s2 = 0.f, n1 = 0.f, n2 = 0.f;
-    for (int64_t c = c0 + threadIdx.x; c < c1; c += 256) {
+    for (int64_t c = c0 + first; c < c1; c += stride) {
         const int64_t p = (int64_t)mt.pair_off + index[c];
         const int v = (int)pred[c];
         const float y = labels[p * K + v];
@@ -432,7 +458,7 @@ __global__ __launch_bounds__(256) void skg_hoi_loss_kernel(
         const float sg = 1.f / (1.f + expf(-logits[p * ldl + v]));
         dlogits[p * ldl + v] = dldx * x * (1.f - sg);
     }
-    for (int pl = threadIdx.x; pl < P; pl += 256) {
+    for (int pl = first; pl < P; pl += stride) {
         const int64_t p = (int64_t)mt.pair_off + pl;
         float ys = 0.f;
         for (int v = 0; v < K; ++v) ys += labels[p * K + v];
@@ -448,7 +474,10 @@ __global__ __launch_bounds__(256) void skg_hoi_loss_kernel(
     s2 = skg_block_sum256(s2, sred);
     n1 = skg_block_sum256(n1, sred);
     n2 = skg_block_sum256(n2, sred);
-    if (threadIdx.x == 0) { partial[4 * a] = s1; partial[4 * a + 1] = s2; partial[4 * a + 2] = n1; partial[4 * a + 3] = n2; }
+    if (threadIdx.x == 0) {
+        float* o = partial + 4 * ((int64_t)a * gridDim.y + blockIdx.y);
+        o[0] = s1; o[1] = s2; o[2] = n1; o[3] = n2;
+    }
 }
 
 extern "C" int skg_hoi_loss_f32(const float* logits, int64_t ldl, int K, const skg_image_meta* meta, int n_active,
@@ -459,7 +488,81 @@ extern "C" int skg_hoi_loss_f32(const float* logits, int64_t ldl, int K, const s
     if (n_active == 0) return 0;
     if (!logits || !meta || !index || !pred || !scores || !labels || !cell_labels || !unary || !partial || !dlogits)
         return SKG_E_ARG;
-    hipLaunchKernelGGL(skg_hoi_loss_kernel, dim3(n_active), dim3(256), 0, (hipStream_t)stream, logits, ldl, K, meta, n_active,
+    hipLaunchKernelGGL(skg_hoi_loss_kernel, dim3(n_active, SKG_LOSS_CHUNKS), dim3(256), 0, (hipStream_t)stream, logits, ldl, K, meta, n_active,
                        cells_total, index, pred, scores, labels, cell_labels, unary, partial, dlogits);
+    return skg_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ TransH pos / neg sampling
+// HEAD:936-963 + the intended MarginLoss (HEAD:207-235; heads/NegativeSampling.py:52-56, heads/MarginLoss.py:28-36):
+// per image the TransH scores of the positive cells (labels != 0, row-major over (pair, verb)) and of as many sampled
+// negatives -- the cells of rank perm[i] among the image's ZERO cells (nonzero(labels == 0)[randperm(#zeros)[:m]]).  The
+// reference materialises both index lists with nonzero(); here one workgroup per image counts, scans and selects:
+//   phase 1: every thread counts the positives of its contiguous span of cells, exclusive scan over the 256 spans
+//   phase 2: positives are emitted in order; the cell of zero-rank r is found by a binary search over the span prefixes
+//            and a walk inside one span
+// Outputs pos_scores / neg_scores [sum m] (image a at pos_off[a]) and partial[a] = sum_i max(pos_i - neg_i, -margin).
+__global__ __launch_bounds__(256) void skg_transh_sample_kernel(const float* __restrict__ labels,
+                                                                const float* __restrict__ scores, int K,
+                                                                const skg_image_meta* __restrict__ meta,
+                                                                const int32_t* __restrict__ pos_off,
+                                                                const int64_t* __restrict__ perm, float margin,
+                                                                float* __restrict__ pos_scores,
+                                                                float* __restrict__ neg_scores,
+                                                                float* __restrict__ partial) {
+    __shared__ int pbase[257];
+    __shared__ float sred[4];
+    const int a = blockIdx.x, tid = threadIdx.x;
+    const skg_image_meta mt = meta[a];
+    const int64_t cells = (int64_t)mt.n_h * (mt.n - 1) * K;
+    const float* lab = labels + (int64_t)mt.pair_off * K;
+    const float* sc = scores + (int64_t)mt.pair_off * K;
+    const int64_t span = (cells + 255) / 256;
+    const int64_t c0 = min((int64_t)tid * span, cells), c1 = min(c0 + span, cells);
+    int cnt = 0;
+    for (int64_t c = c0; c < c1; ++c) cnt += lab[c] != 0.f;
+    pbase[tid + 1] = cnt;
+    if (tid == 0) pbase[0] = 0;
+    __syncthreads();
+    if (tid == 0)
+        for (int t = 1; t <= 256; ++t) pbase[t] += pbase[t - 1];          // 256 additions: not worth a parallel scan
+    __syncthreads();
+    const int o0 = pos_off[a], m = pos_off[a + 1] - o0;
+    int k = pbase[tid];
+    for (int64_t c = c0; c < c1; ++c)
+        if (lab[c] != 0.f) { if (k < m) pos_scores[o0 + k] = sc[c]; ++k; }
+    for (int i = tid; i < m; i += 256) {
+        const int64_t r = perm[o0 + i];
+        // zero cells in front of span t: min(t * span, cells) - pbase[t]; largest t whose count is <= r
+        int lo = 0, hi = 255;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            const int64_t z = min((int64_t)mid * span, cells) - pbase[mid];
+            if (z <= r) lo = mid; else hi = mid - 1;
+        }
+        int64_t c = min((int64_t)lo * span, cells);
+        int64_t left = r - (c - pbase[lo]);
+        const int64_t ce = min(c + span, cells);
+        float v = 0.f;
+        for (; c < ce; ++c)
+            if (lab[c] == 0.f) { if (left == 0) { v = sc[c]; break; } --left; }
+        neg_scores[o0 + i] = v;
+    }
+    __threadfence_block();
+    __syncthreads();
+    float s = 0.f;
+    for (int i = tid; i < m; i += 256) s += fmaxf(pos_scores[o0 + i] - neg_scores[o0 + i], -margin);
+    s = skg_block_sum256(s, sred);
+    if (tid == 0) partial[a] = s;
+}
+
+extern "C" int skg_transh_sample_f32(const float* labels, const float* scores, int K, const skg_image_meta* meta,
+                                     int n_active, const int32_t* pos_off, const int64_t* perm, float margin,
+                                     float* pos_scores, float* neg_scores, float* partial, void* stream) {
+    if (n_active < 0 || K <= 0) return SKG_E_ARG;
+    if (n_active == 0) return 0;
+    if (!labels || !scores || !meta || !pos_off || !perm || !pos_scores || !neg_scores || !partial) return SKG_E_ARG;
+    hipLaunchKernelGGL(skg_transh_sample_kernel, dim3(n_active), dim3(256), 0, (hipStream_t)stream, labels, scores, K, meta,
+                       pos_off, perm, margin, pos_scores, neg_scores, partial);
     return skg_launch_status();
 }

@@ -83,6 +83,8 @@ class Stacked:
         self.entries.append((head.box_pair_predictor.bias, "clsb", (slice(0, K),)))
         self.entries.append((head.box_pair_suppressor.bias, "clsb", (slice(K, K + 1),)))
         self.src = [e[0] for e in self.entries]
+        self.src_detached = [p.detach() for p in self.src]            # same storage as the live parameters
+        self.src_ptrs = [p.data_ptr() for p in self.src[:: 32]]       # spot check against re-pointed storage
         self.dst = [self.view(self.buf, e[1])[e[2]] for e in self.entries]
         self.ids = {id(p): k for k, p in enumerate(self.src)}
 
@@ -91,13 +93,30 @@ class Stacked:
         return flat[off:off + int(np.prod(shape))].view(*shape)
 
     def refresh(self):
+        if [p.data_ptr() for p in self.src[:: 32]] != self.src_ptrs:   # .data was re-pointed (rare): rebuild the aliases
+            self.src_detached = [p.detach() for p in self.src]
+            self.src_ptrs = [p.data_ptr() for p in self.src[:: 32]]
         with torch.no_grad():
-            torch._foreach_copy_(self.dst, [p.detach() for p in self.src])
+            torch._foreach_copy_(self.dst, self.src_detached)
         self.b3sum = self.view(self.buf, "b3").sum(dim=1)                 # [4, 1024]: fc_3 biases summed over branches
 
     def grad_views(self, garena):
-        """Views of a gradient arena (same layout) for the stacked parameters, in `entries` order."""
-        return [self.view(garena, e[1])[e[2]] for e in self.entries]
+        """Views of a gradient arena (same layout) for the stacked parameters, in `entries` order.  Built with one unbind
+        per (MBF, kind) -- 16 branch slices per call -- instead of 388 separate slicing calls."""
+        K = self.K
+        W2 = self.view(garena, "W2").view(4, 16, 64, 1024); b2 = self.view(garena, "b2").view(4, 16, 64)
+        b3 = self.view(garena, "b3")
+        out = []
+        for i in range(4):
+            w1 = self.view(garena, "W1_%d" % i).view(16, 64, self.in_dim[i]).unbind(0)
+            c1 = self.view(garena, "b1_%d" % i).view(16, 64).unbind(0)
+            w2 = W2[i].unbind(0); c2 = b2[i].unbind(0)
+            w3 = self.view(garena, "W3_%d" % i).unbind(0); c3 = b3[i].unbind(0)
+            for b in range(16):
+                out += [w1[b], c1[b], w2[b], c2[b], w3[b], c3[b]]
+        cw, cb = self.view(garena, "clsW"), self.view(garena, "clsb")
+        out += [cw[:K], cw[K:K + 1], cb[:K], cb[K:K + 1]]
+        return out
 
 
 def _lin(x, W, out, bias=None, relu=False, **kw):
@@ -284,7 +303,7 @@ class TrainJob:
         self.dlogits = torch.zeros_like(logits)
         self.cell_labels = torch.empty(max(Lt, 1), **f32)
         self.unary = torch.empty(max(Mp, 1), **f32)
-        partial = torch.empty(lay.n_active, 4, **f32)
+        partial = torch.empty(lay.n_active * _capi.LOSS_CHUNKS, 4, **f32)
         _check(lib.skg_hoi_loss_f32(logits.data_ptr(), logits.stride(0), K, self.meta.data_ptr(), lay.n_active, Lt,
                                     r["index"].data_ptr(), r["prediction"].data_ptr(), r["scores"].data_ptr(),
                                     self.labels.data_ptr(), self.cell_labels.data_ptr(), self.unary.data_ptr(),
@@ -490,7 +509,6 @@ def supported(head):
 def train_forward(head, eng, features, image_shapes, box_features, pre, targets):
     """InteractionHead.forward in training mode (HEAD:380-429) on the fused step.  Returns the reference's result list
     with the loss dict appended, or None when the batch has no image with pairs (the caller takes the generic path)."""
-    from concurrent.futures import ThreadPoolExecutor
     from . import dist as skd, transh
     lib = _capi.lib()
     gh = head.box_pair_head
@@ -571,19 +589,19 @@ def train_forward(head, eng, features, image_shapes, box_features, pre, targets)
     # The entity tables feed fc_head / fc_tail, so they are needed before the dense part; the permutations only after it.
     n_pos = npos_d.cpu().tolist()                                   # the step's host synchronisation
     ppi = [int(v) for v in lay.pairs_per_image]
-    tabs, perms = [], []
-    pool = ThreadPoolExecutor(max_workers=min(8, A))
-    for a in range(A):
-        tabs.append(transh.draw_tables(K, need_relations=True))
-        n_neg = ppi[a] * K - n_pos[a]
-        state = torch.get_rng_state()
-        if n_neg > 1:
-            torch.empty(n_neg - 1, dtype=torch.int32).random_()
-        perms.append(pool.submit(_perm, state, n_neg, n_pos[a]))
-    pool.shutdown(wait=False)
-    ent = torch.stack([t[0] for t in tabs]).to(dev, non_blocking=True)
-    rel = torch.stack([t[1] for t in tabs]).to(dev, non_blocking=True)
-    nrm = torch.stack([t[2] for t in tabs]).to(dev, non_blocking=True)
+    neg_cnt = [ppi[a] * K - n_pos[a] for a in range(A)]
+    ent_h, rel_h, nrm_h, perm_h = transh.draw_train(K, neg_cnt, n_pos, pin=True)      # tables + randperm heads, natively
+    ent = ent_h.to(dev, non_blocking=True); rel = rel_h.to(dev, non_blocking=True); nrm = nrm_h.to(dev, non_blocking=True)
+    pos_off_h = np.zeros(A + 1, np.int32); pos_off_h[1:] = np.cumsum(n_pos)
+    M_pos = int(pos_off_h[-1])
+    o_perm = (A + 1 + 1) // 2 * 2                                   # one staging block: pos_off | perm (int64, 8-byte aligned)
+    samp_d = torch.empty(o_perm + 2 * max(M_pos, 1), **i32)
+    sh = torch.empty(o_perm + 2 * max(M_pos, 1), dtype=torch.int32, pin_memory=True)
+    sh[:A + 1] = torch.from_numpy(pos_off_h)
+    sh[o_perm:o_perm + 2 * M_pos].view(torch.int64).copy_(perm_h)
+    samp_d.copy_(sh, non_blocking=True)
+    pos_off_d = samp_d[:A + 1]
+    perm_d = samp_d[o_perm:o_perm + 2 * max(M_pos, 1)].view(torch.int64)
     job.ent = ent
     gfeat = torch.nn.functional.adaptive_avg_pool2d(features["3"].float(), 1).flatten(start_dim=1)    # HEAD:811
     logits = HeadTrainFn.apply(job, box_features, gfeat, *params)
@@ -601,20 +619,15 @@ def train_forward(head, eng, features, image_shapes, box_features, pre, targets)
     scores_all = torch.empty(max(Mp, 1), K, **f32)
     _check(lib.skg_transh_scores_f32(ent.data_ptr(), rel.data_ptr(), nrm.data_ptr(), K, gh.human_idx, meta.data_ptr(), A,
                                      scores_all.data_ptr(), stream), "skg_transh_scores_f32")
-    labels_v = labels_all[:Mp]
-    pos_p, pos_k = torch.nonzero(labels_v).unbind(1)
-    zero_p, zero_k = torch.nonzero(labels_v == 0).unbind(1)
-    neg_cnt = [ppi[a] * K - n_pos[a] for a in range(A)]
-    neg_base = np.concatenate([[0], np.cumsum(neg_cnt)])
-    sel = torch.cat([perms[a].result() + int(neg_base[a]) for a in range(A)]).to(dev)
-    neg_p, neg_k = zero_p[sel], zero_k[sel]
-    score = torch.cat([scores_all[pos_p, pos_k], scores_all[neg_p, neg_k]])
-    half = len(score) // 2
-    p_ = score[:half].view(-1, half).permute(1, 0); n_ = score[half:].view(-1, half).permute(1, 0)
-    transh_loss = (torch.max(p_ - n_, torch.tensor([-1.0], device=dev)).mean() + 1.0) / norm[2]
+    pos_s = torch.empty(max(M_pos, 1), **f32); neg_s = torch.empty(max(M_pos, 1), **f32); mpart = torch.empty(A, **f32)
+    _check(lib.skg_transh_sample_f32(labels_all.data_ptr(), scores_all.data_ptr(), K, meta.data_ptr(), A,
+                                     pos_off_d.data_ptr(), perm_d.data_ptr(), 1.0, pos_s.data_ptr(), neg_s.data_ptr(),
+                                     mpart.data_ptr(), stream), "skg_transh_sample_f32")
+    # MarginLoss(margin = 1): mean(max(p - n, -margin)) + margin, divided by n_p (HEAD:228-234)
+    transh_loss = (mpart.sum() / float(max(M_pos, 1)) + 1.0) / norm[2]
     if eng.debug:                                                   # parity tests read these
-        head._last_train = dict(pair_features=job.S["PF"][:Mp], pos_scores=scores_all[pos_p, pos_k].split(n_pos),
-                                neg_scores=scores_all[neg_p, neg_k].split(n_pos), job=job)
+        head._last_train = dict(pair_features=job.S["PF"][:Mp], pos_scores=pos_s[:M_pos].split(n_pos),
+                                neg_scores=neg_s[:M_pos].split(n_pos), job=job)
     # ---- per-image result dicts (views of the packed arrays)
     results = head._results(lay, r, dev, train_extras=(job.cell_labels, job.unary))
     results.append(dict(hoi_loss=hoi_loss, interactiveness_loss=int_loss, transH_loss=transh_loss))

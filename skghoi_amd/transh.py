@@ -128,3 +128,36 @@ def draw_batch(K, n_images, need_relations=False, pin=False, out=None):
         if need_relations:
             rel[a] = r; nrm[a] = n
     return ent, rel, nrm
+
+
+def draw_train(K, n_neg, n_take, pin=False):
+    """Host RNG of a training forward for len(n_neg) processed images, in the reference's order: per image the TransH
+    tables (HEAD:574-580) then torch.randperm(n_neg[a])[:n_take[a]] (HEAD:938-939).  Returns ent [A,80,50], rel, nrm
+    [A,K,50] and the concatenated permutation heads (int64 CPU tensor).  Native (skg_transh_draw_train_f32) when the
+    probe against torch passed, through torch calls otherwise."""
+    A = len(n_neg)
+    ent = torch.empty(A, TRANSH_ENT, TRANSH_DIM, pin_memory=pin)
+    rel = torch.empty(A, K, TRANSH_DIM, pin_memory=pin)
+    nrm = torch.empty(A, K, TRANSH_DIM, pin_memory=pin)
+    perm = torch.empty(int(sum(n_take)), dtype=torch.int64)
+    if A == 0:
+        return ent, rel, nrm, perm
+    fused = native_path()
+    if fused is not False:
+        from . import _capi
+        nn_ = torch.tensor([int(v) for v in n_neg], dtype=torch.int64)
+        nt_ = torch.tensor([int(v) for v in n_take], dtype=torch.int64)
+        state = torch.get_rng_state()
+        _capi.check(_capi.lib().skg_transh_draw_train_f32(state.data_ptr(), state.numel(), A, K, fused, nn_.data_ptr(),
+                                                          nt_.data_ptr(), ent.data_ptr(), rel.data_ptr(), nrm.data_ptr(),
+                                                          perm.data_ptr()), "skg_transh_draw_train_f32")
+        torch.set_rng_state(state)
+        return ent, rel, nrm, perm
+    o = 0
+    for a in range(A):
+        e, r, n = _torch_draw_tables(K, True)
+        ent[a] = e; rel[a] = r; nrm[a] = n
+        m = int(n_take[a])
+        perm[o:o + m] = torch.randperm(int(n_neg[a]))[:m]
+        o += m
+    return ent, rel, nrm, perm
