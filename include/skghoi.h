@@ -381,13 +381,15 @@ int skg_hoi_loss_f32(const float* logits, int64_t ldl, int K, const skg_image_me
                      void* stream);
 
 /* TransH positive / negative sampling of the training step (HEAD:936-963) and the margin term (HEAD:207-235 as intended;
- * heads/MarginLoss.py:28-36): labels, scores [sumP, K]; pos_off [n_active + 1] = prefix of the positives per image (host
- * knows them from skg_associate_f32's npos); perm [sum m] = per image the first m entries of randperm(#zero cells)
- * (skg_transh_draw_train_f32).  pos_scores[i] = score of the i-th positive cell (row-major), neg_scores[i] = score of the
- * zero cell of rank perm[i]; partial[a] = sum_i max(pos_i - neg_i, -margin).  One workgroup per image.               */
+ * heads/MarginLoss.py:28-36): labels, scores [sumP, K]; pos_off [n_active + 1] = prefix of the positives per image and
+ * max_pos_per_image their maximum (the host knows them from skg_associate_f32's npos); perm [sum m] = per image the first
+ * m entries of randperm(#zero cells) (skg_transh_draw_train_f32); ws = skg_transh_sample_ws_ints(...) int32 of scratch.
+ * pos_scores[i] = score of the i-th positive cell (row-major), pos_cells[i] its cell index (pair * K + verb, local to the
+ * image), neg_scores[i] = score of the zero cell of rank perm[i]; partial[a] = sum_i max(pos_i - neg_i, -margin).     */
+int64_t skg_transh_sample_ws_ints(int n_active, int max_pos_per_image);
 int skg_transh_sample_f32(const float* labels, const float* scores, int K, const skg_image_meta* meta, int n_active,
-                          const int32_t* pos_off, const int64_t* perm, float margin, float* pos_scores,
-                          float* neg_scores, float* partial, void* stream);
+                          const int32_t* pos_off, int max_pos_per_image, const int64_t* perm, float margin, int32_t* ws,
+                          int32_t* pos_cells, float* pos_scores, float* neg_scores, float* partial, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Order-independent 64-bit checksum of the live parameters (bit patterns weighted by position) over a table of

@@ -279,6 +279,7 @@ class InteractionHead(Module):
             raise ValueError("precision must be 'fp32', 'fp16x2' or 'bf16'")
         self.precision = precision
         self.fused_training = True      # False: training through autograd over per-layer Functions (skghoi_amd/train_graph.py)
+        self.grad_mode = "autograd"     # "direct": the fused step writes p.grad itself (skghoi_amd/train_fused.py, HeadTrainFn)
         self._engine = None
 
     def engine(self) -> HeadEngine:

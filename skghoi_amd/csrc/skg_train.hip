@@ -497,72 +497,112 @@ extern "C" int skg_hoi_loss_f32(const float* logits, int64_t ldl, int K, const s
 // HEAD:936-963 + the intended MarginLoss (HEAD:207-235; heads/NegativeSampling.py:52-56, heads/MarginLoss.py:28-36):
 // per image the TransH scores of the positive cells (labels != 0, row-major over (pair, verb)) and of as many sampled
 // negatives -- the cells of rank perm[i] among the image's ZERO cells (nonzero(labels == 0)[randperm(#zeros)[:m]]).  The
-// reference materialises both index lists with nonzero(); here one workgroup per image counts, scans and selects:
-//   phase 1: every thread counts the positives of its contiguous span of cells, exclusive scan over the 256 spans
-//   phase 2: positives are emitted in order; the cell of zero-rank r is found by a binary search over the span prefixes
-//            and a walk inside one span
+// reference materialises both index lists with nonzero() over ~10^5 cells per image; positives are a few dozen, so:
+//   kernel 1 (image x SKG_SAMPLE_CHUNKS workgroups): every workgroup compacts the positive cells of its slice of the
+//            image, in order (wave ballots), into its own short list
+//   kernel 2 (one workgroup per image): concatenates the lists (= all positives in row-major order), emits their
+//            scores, and finds the zero cell of rank r as r + #(positives at or before it) by walking the positive list
 // Outputs pos_scores / neg_scores [sum m] (image a at pos_off[a]) and partial[a] = sum_i max(pos_i - neg_i, -margin).
-__global__ __launch_bounds__(256) void skg_transh_sample_kernel(const float* __restrict__ labels,
-                                                                const float* __restrict__ scores, int K,
-                                                                const skg_image_meta* __restrict__ meta,
+#define SKG_SAMPLE_CHUNKS 16
+
+__global__ __launch_bounds__(256) void skg_transh_compact_kernel(const float* __restrict__ labels, int K,
+                                                                 const skg_image_meta* __restrict__ meta, int cap,
+                                                                 int32_t* __restrict__ chunk_cells,
+                                                                 int32_t* __restrict__ chunk_count) {
+    __shared__ int wcnt[4];
+    __shared__ int base;
+    const int a = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const skg_image_meta mt = meta[a];
+    const int cells = mt.n_h * (mt.n - 1) * K;
+    const int per = ((cells + SKG_SAMPLE_CHUNKS - 1) / SKG_SAMPLE_CHUNKS + 255) / 256 * 256;
+    const int c0 = min(ch * per, cells), c1 = min(c0 + per, cells);
+    const float* lab = labels + (int64_t)mt.pair_off * K;
+    int32_t* out = chunk_cells + ((int64_t)a * SKG_SAMPLE_CHUNKS + ch) * cap;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int t0 = c0; t0 < c1; t0 += 256) {
+        const int c = t0 + tid;
+        const bool p = c < c1 && lab[c] != 0.f;
+        const unsigned long long bal = __ballot(p);
+        if (lane == 0) wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wv; ++w) off += wcnt[w];
+        const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
+        if (p && k < cap) out[k] = c;
+        __syncthreads();
+        if (tid == 0) base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) chunk_count[a * SKG_SAMPLE_CHUNKS + ch] = base;
+}
+
+__global__ __launch_bounds__(256) void skg_transh_sample_kernel(const float* __restrict__ scores, int K,
+                                                                const skg_image_meta* __restrict__ meta, int cap,
+                                                                const int32_t* __restrict__ chunk_cells,
+                                                                const int32_t* __restrict__ chunk_count,
                                                                 const int32_t* __restrict__ pos_off,
                                                                 const int64_t* __restrict__ perm, float margin,
+                                                                int32_t* __restrict__ pos_cells,
                                                                 float* __restrict__ pos_scores,
                                                                 float* __restrict__ neg_scores,
                                                                 float* __restrict__ partial) {
-    __shared__ int pbase[257];
+    __shared__ int cbase[SKG_SAMPLE_CHUNKS + 1];
     __shared__ float sred[4];
     const int a = blockIdx.x, tid = threadIdx.x;
     const skg_image_meta mt = meta[a];
-    const int64_t cells = (int64_t)mt.n_h * (mt.n - 1) * K;
-    const float* lab = labels + (int64_t)mt.pair_off * K;
     const float* sc = scores + (int64_t)mt.pair_off * K;
-    const int64_t span = (cells + 255) / 256;
-    const int64_t c0 = min((int64_t)tid * span, cells), c1 = min(c0 + span, cells);
-    int cnt = 0;
-    for (int64_t c = c0; c < c1; ++c) cnt += lab[c] != 0.f;
-    pbase[tid + 1] = cnt;
-    if (tid == 0) pbase[0] = 0;
-    __syncthreads();
-    if (tid == 0)
-        for (int t = 1; t <= 256; ++t) pbase[t] += pbase[t - 1];          // 256 additions: not worth a parallel scan
-    __syncthreads();
     const int o0 = pos_off[a], m = pos_off[a + 1] - o0;
-    int k = pbase[tid];
-    for (int64_t c = c0; c < c1; ++c)
-        if (lab[c] != 0.f) { if (k < m) pos_scores[o0 + k] = sc[c]; ++k; }
-    for (int i = tid; i < m; i += 256) {
-        const int64_t r = perm[o0 + i];
-        // zero cells in front of span t: min(t * span, cells) - pbase[t]; largest t whose count is <= r
-        int lo = 0, hi = 255;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            const int64_t z = min((int64_t)mid * span, cells) - pbase[mid];
-            if (z <= r) lo = mid; else hi = mid - 1;
+    if (tid == 0) {
+        cbase[0] = 0;
+        for (int c = 0; c < SKG_SAMPLE_CHUNKS; ++c) cbase[c + 1] = cbase[c] + chunk_count[a * SKG_SAMPLE_CHUNKS + c];
+    }
+    __syncthreads();
+    // positives in row-major order = the chunk lists back to back
+    for (int c = 0; c < SKG_SAMPLE_CHUNKS; ++c) {
+        const int n = cbase[c + 1] - cbase[c];
+        const int32_t* src = chunk_cells + ((int64_t)a * SKG_SAMPLE_CHUNKS + c) * cap;
+        for (int i = tid; i < n; i += 256) {
+            const int k = cbase[c] + i;
+            if (k < m) { const int cell = src[i]; pos_cells[o0 + k] = cell; pos_scores[o0 + k] = sc[cell]; }
         }
-        int64_t c = min((int64_t)lo * span, cells);
-        int64_t left = r - (c - pbase[lo]);
-        const int64_t ce = min(c + span, cells);
-        float v = 0.f;
-        for (; c < ce; ++c)
-            if (lab[c] == 0.f) { if (left == 0) { v = sc[c]; break; } --left; }
-        neg_scores[o0 + i] = v;
     }
     __threadfence_block();
     __syncthreads();
+    // zero cell of rank r: c = r + (number of positive cells <= c); the positive list is sorted
     float s = 0.f;
-    for (int i = tid; i < m; i += 256) s += fmaxf(pos_scores[o0 + i] - neg_scores[o0 + i], -margin);
+    for (int i = tid; i < m; i += 256) {
+        int64_t c = perm[o0 + i];
+        for (int j = 0; j < m; ++j) {
+            if ((int64_t)pos_cells[o0 + j] <= c) ++c; else break;
+        }
+        const float nv = sc[c];
+        neg_scores[o0 + i] = nv;
+        s += fmaxf(pos_scores[o0 + i] - nv, -margin);
+    }
     s = skg_block_sum256(s, sred);
     if (tid == 0) partial[a] = s;
 }
 
+extern "C" int64_t skg_transh_sample_ws_ints(int n_active, int max_pos_per_image) {
+    if (n_active < 0 || max_pos_per_image < 0) return SKG_E_ARG;
+    const int64_t cap = max_pos_per_image > 0 ? max_pos_per_image : 1;
+    return (int64_t)n_active * SKG_SAMPLE_CHUNKS * (cap + 1);
+}
+
 extern "C" int skg_transh_sample_f32(const float* labels, const float* scores, int K, const skg_image_meta* meta,
-                                     int n_active, const int32_t* pos_off, const int64_t* perm, float margin,
-                                     float* pos_scores, float* neg_scores, float* partial, void* stream) {
-    if (n_active < 0 || K <= 0) return SKG_E_ARG;
+                                     int n_active, const int32_t* pos_off, int max_pos_per_image, const int64_t* perm,
+                                     float margin, int32_t* ws, int32_t* pos_cells, float* pos_scores, float* neg_scores,
+                                     float* partial, void* stream) {
+    if (n_active < 0 || K <= 0 || max_pos_per_image < 0) return SKG_E_ARG;
     if (n_active == 0) return 0;
-    if (!labels || !scores || !meta || !pos_off || !perm || !pos_scores || !neg_scores || !partial) return SKG_E_ARG;
-    hipLaunchKernelGGL(skg_transh_sample_kernel, dim3(n_active), dim3(256), 0, (hipStream_t)stream, labels, scores, K, meta,
-                       pos_off, perm, margin, pos_scores, neg_scores, partial);
+    if (!labels || !scores || !meta || !pos_off || !perm || !ws || !pos_cells || !pos_scores || !neg_scores || !partial)
+        return SKG_E_ARG;
+    const int cap = max_pos_per_image > 0 ? max_pos_per_image : 1;
+    int32_t* counts = ws + (int64_t)n_active * SKG_SAMPLE_CHUNKS * cap;
+    hipLaunchKernelGGL(skg_transh_compact_kernel, dim3(n_active, SKG_SAMPLE_CHUNKS), dim3(256), 0, (hipStream_t)stream,
+                       labels, K, meta, cap, ws, counts);
+    hipLaunchKernelGGL(skg_transh_sample_kernel, dim3(n_active), dim3(256), 0, (hipStream_t)stream, scores, K, meta, cap,
+                       ws, counts, pos_off, perm, margin, pos_cells, pos_scores, neg_scores, partial);
     return skg_launch_status();
 }

@@ -458,6 +458,7 @@ class HeadEngine:
         self._pw = None
         self._vt = None
         self._det_off_cache = {}
+        self._gt_const = None
         self._cnt_host = None
         self._cnt_event = None
         self._cnt_host_dev = None
@@ -565,19 +566,30 @@ class HeadEngine:
         vt = self.verbs(dev)
         B = len(detections)
         bl, sl, ll, sizes = [], [], [], []
-        for b, det in enumerate(detections):
-            boxes, labels, scores = det["boxes"], det["labels"], det["scores"]
-            if append_gt:                                                        # HEAD:107-116
-                t = targets[b]
-                ng = t["boxes_h"].shape[0]
-                boxes = torch.cat([t["boxes_h"], t["boxes_o"], boxes])
-                scores = torch.cat([torch.ones(2 * ng, device=scores.device), scores])
-                labels = torch.cat([self.human_idx * torch.ones(ng, device=labels.device).long(), t["object"], labels])
-            bl.append(boxes.reshape(-1, 4)); sl.append(scores.reshape(-1)); ll.append(labels.reshape(-1))
-            sizes.append(int(boxes.shape[0]))
+        if append_gt:
+            # HEAD:107-116: ground-truth human and object boxes in front of the detections, score 1, labels human_idx /
+            # object.  The pieces of all images go into ONE concatenation per array (constants are slices of two cached
+            # tensors), instead of three concatenations and two fills per image.
+            ngs = [int(targets[b]["boxes_h"].shape[0]) for b in range(B)]
+            need = 2 * max(ngs, default=0)
+            if self._gt_const is None or self._gt_const[0].numel() < need or self._gt_const[0].device != dev:
+                n = max(need, 64)
+                self._gt_const = (torch.ones(n, device=dev), torch.full((n,), self.human_idx, dtype=torch.int64, device=dev))
+            ones, hum = self._gt_const
+            for b, det in enumerate(detections):
+                t, ng = targets[b], ngs[b]
+                bl += [t["boxes_h"].reshape(-1, 4), t["boxes_o"].reshape(-1, 4), det["boxes"].reshape(-1, 4)]
+                sl += [ones[:2 * ng], det["scores"].reshape(-1)]
+                ll += [hum[:ng], t["object"].reshape(-1), det["labels"].reshape(-1)]
+                sizes.append(2 * ng + int(det["boxes"].shape[0]))
+        else:
+            for b, det in enumerate(detections):
+                boxes, labels, scores = det["boxes"], det["labels"], det["scores"]
+                bl.append(boxes.reshape(-1, 4)); sl.append(scores.reshape(-1)); ll.append(labels.reshape(-1))
+                sizes.append(int(boxes.shape[0]))
         if max(sizes, default=0) > _capi.MAX_DET_PER_IMAGE:
             raise _capi.SkgError("more than %d detections in one image" % _capi.MAX_DET_PER_IMAGE)
-        if B == 1:                                   # the reference's evaluation mode: nothing to concatenate
+        if B == 1 and not append_gt:                 # the reference's evaluation mode: nothing to concatenate
             boxes, scores, labels = bl[0], sl[0], ll[0]
             if boxes.dtype != torch.float32 or not boxes.is_contiguous():
                 boxes = boxes.float().contiguous()

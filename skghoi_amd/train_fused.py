@@ -124,7 +124,13 @@ def _lin(x, W, out, bias=None, relu=False, **kw):
 
 
 class HeadTrainFn(torch.autograd.Function):
-    """(pooled box features, global features, 408 parameters) -> classifier logits [sumP, ld] of the kept pairs."""
+    """(pooled box features, global features, 408 parameters) -> classifier logits [sumP, ld] of the kept pairs.
+
+    grad_mode "autograd" (default): the parameters are inputs of the Function and their gradients are returned to the
+    autograd engine (hooks, DDP and torch.autograd.grad see them).  grad_mode "direct": the Function's only parameter-side
+    input is a one-element anchor; the backward writes `p.grad` itself (assign, or add to an existing gradient).  The
+    engine's per-leaf bookkeeping for 408 parameters costs ~1.2 ms of host time per step at which the GPU has nothing
+    queued -- a fifth of a batch-4 step; the single-process trainer (skghoi_amd/trainer.py) switches it on."""
 
     @staticmethod
     def forward(ctx, job, x0, gfeat, *params):
@@ -136,6 +142,15 @@ class HeadTrainFn(torch.autograd.Function):
     def backward(ctx, dlogits):
         job = ctx.job
         dx0, dgfeat, pgrads = job.backward(dlogits, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        if job.direct:
+            for p, g in zip(job.params, pgrads):
+                if g is None or not p.requires_grad:
+                    continue
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.add_(g)
+            return None, dx0, dgfeat, torch.zeros_like(job.anchor)
         return (None, dx0, dgfeat) + tuple(pgrads)
 
 
@@ -179,6 +194,35 @@ class TrainJob:
         return self.ibuf[o:o + l]
 
     # ------------------------------------------------------------------------------------------------ forward
+    def forward_a(self, x0, gfeat):
+        """The part of the forward that needs neither the TransH tables nor the label counts: parameter stacking,
+        box_head, the global branch's fc_1 and the spatial head.  The step driver enqueues it BEFORE its host
+        synchronisation, so that the GPU works through it while the host draws the tables."""
+        st, gh, lay, dev, S = self.st, self.gh, self.lay, self.dev, self.S
+        f32 = dict(device=dev, dtype=torch.float32)
+        NA, Mg = lay.sum_all, lay.sum_g
+        st.refresh()
+        W1g, b1g = st.view(st.buf, "W1_%d" % GL), st.view(st.buf, "b1_%d" % GL)
+        x0 = x0.detach().float().reshape(x0.shape[0], -1).contiguous()
+        gfeat = gfeat.detach().float().contiguous()
+        S["x0"], S["gfeat"] = x0, gfeat
+        Bf = gfeat.shape[0]
+        bh1, bh3 = gh.box_head[1], gh.box_head[3]
+        # ---- box_head (HEAD:812) and fc_1 of the global branch (HEAD:971)
+        E1 = torch.empty(NA, 1024, **f32); enc = torch.empty(NA, 1024, **f32); G1 = torch.empty(Bf, 1024, **f32)
+        gemmx.launch([_lin(x0, bh1.weight, E1, bh1.bias, True)])
+        gemmx.launch([_lin(E1, bh3.weight, enc, bh3.bias, True), _lin(gfeat, W1g, G1, b1g)])
+        S.update(E1=E1, enc=enc, G1=G1)
+        # ---- spatial head (HEAD:888) on the 46-d encodings the step driver produced with the pair enumeration
+        sp48 = S["sp48"]
+        sp = gh.spatial_head
+        s1 = torch.empty(Mg, 128, **f32); s2 = torch.empty(Mg, 256, **f32); Sp = torch.empty(Mg, 1024, **f32)
+        gemmx.launch([_lin(sp48, sp[0].weight, s1, sp[0].bias, True, K=46)])
+        gemmx.launch([_lin(s1, sp[2].weight, s2, sp[2].bias, True)])
+        gemmx.launch([_lin(s2, sp[4].weight, Sp, sp[4].bias, True)])
+        S.update(s1=s1, s2=s2, Sp=Sp)
+        self.part_a_done = True
+
     def forward(self, x0, gfeat):
         lib = _capi.lib()
         st, gh, lay, dev = self.st, self.gh, self.lay, self.dev
@@ -188,32 +232,20 @@ class TrainJob:
         S = self.S
         NA, Mg, Mp, Mh, Mn, A = lay.sum_all, lay.sum_g, lay.sum_p, lay.sum_h, lay.sum_n, lay.n_active
         K = self.K
-        st.refresh()
+        if not getattr(self, "part_a_done", False):
+            self.forward_a(x0, gfeat)
         W2, b2 = st.view(st.buf, "W2"), st.view(st.buf, "b2")
         W1 = [st.view(st.buf, "W1_%d" % i) for i in range(4)]
         b1 = [st.view(st.buf, "b1_%d" % i) for i in range(4)]
         W3 = [st.view(st.buf, "W3_%d" % i) for i in range(4)]
         b3 = st.b3sum
         blk = (6, 1024 * 64)
-        x0 = x0.detach().float().reshape(x0.shape[0], -1).contiguous()
-        gfeat = gfeat.detach().float().contiguous()
-        S["x0"], S["gfeat"] = x0, gfeat
+        x0, gfeat = S["x0"], S["gfeat"]
         Bf = gfeat.shape[0]
-        bh1, bh3 = gh.box_head[1], gh.box_head[3]
-        # ---- box_head (HEAD:812) and fc_1 of the global branch (HEAD:971)
-        E1 = torch.empty(NA, 1024, **f32); enc = torch.empty(NA, 1024, **f32); G1 = torch.empty(Bf, 1024, **f32)
-        gemmx.launch([_lin(x0, bh1.weight, E1, bh1.bias, True)])
-        gemmx.launch([_lin(E1, bh3.weight, enc, bh3.bias, True), _lin(gfeat, W1[GL], G1, b1[GL])])
-        S.update(E1=E1, enc=enc, G1=G1)
-        # ---- spatial head (HEAD:888) on the 46-d encodings the step driver produced with the pair enumeration
+        E1, enc, G1 = S["E1"], S["enc"], S["G1"]
+        s1, s2, Sp = S["s1"], S["s2"], S["Sp"]
         grid_h, grid_o, grid_pair, grid_img, pair_grid, pair_h, pair_o, sp48 = (
             S[k] for k in ("grid_h", "grid_o", "grid_pair", "grid_img", "pair_grid", "pair_h", "pair_o", "sp48"))
-        sp = gh.spatial_head
-        s1 = torch.empty(Mg, 128, **f32); s2 = torch.empty(Mg, 256, **f32); Sp = torch.empty(Mg, 1024, **f32)
-        gemmx.launch([_lin(sp48, sp[0].weight, s1, sp[0].bias, True, K=46)])
-        gemmx.launch([_lin(s1, sp[2].weight, s2, sp[2].bias, True)])
-        gemmx.launch([_lin(s2, sp[4].weight, Sp, sp[4].bias, True)])
-        S.update(s1=s1, s2=s2, Sp=Sp)
         # ---- fc_head / fc_tail on unique node rows (HEAD:884-885)
         Xhn = torch.empty(Mh + Mn, 1088, **f32)
         _check(lib.skg_concat_entity_f32(enc.data_ptr(), 1024, self.isl("enc_row_hn").data_ptr(), self.ent.data_ptr(),
@@ -585,9 +617,18 @@ def train_forward(head, eng, features, image_shapes, box_features, pre, targets)
                  pair_h=pair_h, pair_o=pair_o, x_keep=x_keep[:Mp], y_keep=y_keep[:Mp], sp48=sp48)
     job.pair_img, job.hum_of, job.node_of = isl("pair_img"), isl("hum_of"), isl("node_of")
     job.labels = labels_all
+    # the positive counts travel to the host behind the association kernel; the GPU goes on with the part of the
+    # forward that needs neither them nor the TransH tables while the host waits for the counts and draws the tables
+    npos_h = torch.empty(A, dtype=torch.int32, pin_memory=True)
+    npos_h.copy_(npos_d, non_blocking=True)
+    npos_ev = torch.cuda.Event(); npos_ev.record()
+    gfeat = torch.nn.functional.adaptive_avg_pool2d(features["3"].float(), 1).flatten(start_dim=1)    # HEAD:811
+    with torch.no_grad():
+        job.forward_a(box_features, gfeat)
     # host RNG in the reference's order: per image six TransH draws (HEAD:574-580), then randperm(#negatives) (HEAD:939).
     # The entity tables feed fc_head / fc_tail, so they are needed before the dense part; the permutations only after it.
-    n_pos = npos_d.cpu().tolist()                                   # the step's host synchronisation
+    npos_ev.synchronize()                                           # the step's host synchronisation
+    n_pos = npos_h.tolist()
     ppi = [int(v) for v in lay.pairs_per_image]
     neg_cnt = [ppi[a] * K - n_pos[a] for a in range(A)]
     ent_h, rel_h, nrm_h, perm_h = transh.draw_train(K, neg_cnt, n_pos, pin=True)      # tables + randperm heads, natively
@@ -603,8 +644,12 @@ def train_forward(head, eng, features, image_shapes, box_features, pre, targets)
     pos_off_d = samp_d[:A + 1]
     perm_d = samp_d[o_perm:o_perm + 2 * max(M_pos, 1)].view(torch.int64)
     job.ent = ent
-    gfeat = torch.nn.functional.adaptive_avg_pool2d(features["3"].float(), 1).flatten(start_dim=1)    # HEAD:811
-    logits = HeadTrainFn.apply(job, box_features, gfeat, *params)
+    job.direct = getattr(head, "grad_mode", "autograd") == "direct"
+    if job.direct:
+        job.anchor = torch.zeros(1, device=dev, requires_grad=True)      # a leaf that makes autograd call the backward
+        logits = HeadTrainFn.apply(job, box_features, gfeat, job.anchor)
+    else:
+        logits = HeadTrainFn.apply(job, box_features, gfeat, *params)
     # ---- scoring + result packing (HEAD:721-767, 237-337), on the detached logits
     g = dict(layout=lay, meta=meta, x_keep=x_keep[:Mp], y_keep=y_keep[:Mp])
     r = eng.score(logits.detach(), pre, g, True)
@@ -620,8 +665,11 @@ def train_forward(head, eng, features, image_shapes, box_features, pre, targets)
     _check(lib.skg_transh_scores_f32(ent.data_ptr(), rel.data_ptr(), nrm.data_ptr(), K, gh.human_idx, meta.data_ptr(), A,
                                      scores_all.data_ptr(), stream), "skg_transh_scores_f32")
     pos_s = torch.empty(max(M_pos, 1), **f32); neg_s = torch.empty(max(M_pos, 1), **f32); mpart = torch.empty(A, **f32)
+    max_pos = max(n_pos) if n_pos else 0
+    sws = torch.empty(int(lib.skg_transh_sample_ws_ints(A, max_pos)) + max(M_pos, 1), **i32)
     _check(lib.skg_transh_sample_f32(labels_all.data_ptr(), scores_all.data_ptr(), K, meta.data_ptr(), A,
-                                     pos_off_d.data_ptr(), perm_d.data_ptr(), 1.0, pos_s.data_ptr(), neg_s.data_ptr(),
+                                     pos_off_d.data_ptr(), max_pos, perm_d.data_ptr(), 1.0, sws.data_ptr(),
+                                     sws.data_ptr() + 4 * (sws.numel() - max(M_pos, 1)), pos_s.data_ptr(), neg_s.data_ptr(),
                                      mpart.data_ptr(), stream), "skg_transh_sample_f32")
     # MarginLoss(margin = 1): mean(max(p - n, -margin)) + margin, divided by n_p (HEAD:228-234)
     transh_loss = (mpart.sum() / float(max(M_pos, 1)) + 1.0) / norm[2]

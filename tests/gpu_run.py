@@ -178,7 +178,9 @@ def _run_train_fused(case, head, det, tg, feats, backward):
 
 def run_train_with_grads(case, fused=True):
     head = build_head(case)
-    head.fused_training = fused
+    head.fused_training = bool(fused)
+    if fused == "direct":
+        head.grad_mode = "direct"
     det = to_cuda(case["detections"]); tg = to_cuda(case["targets"])
     feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
     return _run_train(case, head, det, tg, feats, backward=True)

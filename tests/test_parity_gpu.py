@@ -173,8 +173,9 @@ def test_training_forward_matches_reference_golden(name, fused):
             assert np.array_equal(got["res%d.%s" % (b, k)], want["res%d.%s" % (b, k)]), (b, k)
 
 
-@pytest.mark.parametrize("fused,name", [(True, "train_tiny"), (True, "train_skips"), (False, "train_tiny")],
-                         ids=["fused-tiny", "fused-skips", "autograd-tiny"])
+@pytest.mark.parametrize("fused,name", [(True, "train_tiny"), (True, "train_skips"), ("direct", "train_tiny"),
+                                        (False, "train_tiny")],
+                         ids=["fused-tiny", "fused-skips", "fused-direct-grads", "autograd-tiny"])
 def test_training_gradients_match_oracle_autograd(fused, name):
     """Gradients of all 408 parameters vs CPU autograd of the oracle: the hand-written backward of the fused step
     (skghoi_amd/train_fused.py: skg_gemmx_f32 + skg_train.hip) and the autograd path over the per-layer Functions."""
