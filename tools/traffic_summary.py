@@ -27,7 +27,7 @@ def pmc(counter):
 fetch, write = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
 with open(os.path.join(d, tag + "_hbm_traffic.csv"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE   and   --pmc WRITE_SIZE  (separate passes) of: python3 bench.py "
-            "--steps 2 --warmup 1 --no-cpu-baseline --no-exact-leg --no-gemm-timer\n")
+            "--steps 2 --warmup 1 --no-cpu-baseline --no-legs --no-gemm-timer\n")
     f.write("# FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads "
             "(MI355X_MICROARCH.md, HBM): fetch_MB_corrected = 2*raw/1024\n")
     f.write("kernel,grid_size,launches,fetch_KB_raw_avg,fetch_MB_corrected_avg,write_MB_avg\n")
