@@ -1,4 +1,6 @@
-"""Thin data-parallel trainer shell for the interaction head.
+"""Data-parallel trainer shell for the interaction head: optimizer groups, schedule, DDP wrap, the train
+step, and -- below -- the data side (detection filter, horizontal flip, collate, distributed loader) and the epoch loop
+with the reference's checkpoint dictionary.
 
 Mirrors the reference's settings: AdamW with two parameter groups -- interaction head at `lr`, everything else (the
 detector backbone/neck when it is fine-tuned) at `lr * 0.1`, weight decay 1e-4
@@ -78,3 +80,144 @@ def train_step(net, optimizer, *inputs, targets):
     total.backward()
     optimizer.step()
     return {k: float(v.detach()) for k, v in loss_dict.items()}, out
+
+
+# ---------------------------------------------------------------------------------------------------- data side
+def seed_everything(seed: int = 42) -> None:
+    """main:67 ("Fix random seed for model synchronisation": every rank builds identical initial weights)."""
+    torch.manual_seed(seed)
+
+
+def filter_detections(detection: dict, human_idx: int, box_score_thresh_h: float = 0.2,
+                      box_score_thresh_o: float = 0.2) -> dict:
+    """DataFactory.filter_detections (utils.py:97-119): humans above their threshold first, then the other classes above
+    theirs, original order inside each group."""
+    boxes = torch.as_tensor(detection["boxes"]); labels = torch.as_tensor(detection["labels"])
+    scores = torch.as_tensor(detection["scores"])
+    idx = torch.nonzero(labels == human_idx).squeeze(1)
+    keep = idx[torch.nonzero(scores[idx] >= box_score_thresh_h).squeeze(1)]
+    idx = torch.nonzero(labels != human_idx).squeeze(1)
+    keep = torch.cat([keep, idx[torch.nonzero(scores[idx] >= box_score_thresh_o).squeeze(1)]])
+    return dict(boxes=boxes[keep].view(-1, 4), labels=labels[keep].view(-1), scores=scores[keep].view(-1))
+
+
+def horizontal_flip_boxes(w: float, boxes: torch.Tensor) -> torch.Tensor:
+    """pocket.ops.horizontal_flip_boxes(w, boxes) for 'coords' boxes (x1, y1, x2, y2): x1' = w - x2, x2' = w - x1."""
+    out = boxes.clone()
+    out[:, 0] = w - boxes[:, 2]
+    out[:, 2] = w - boxes[:, 0]
+    return out
+
+
+def hflip_sample(image_or_maps, detection: dict, target: dict, width: float):
+    """The horizontal-flip augmentation of DataFactory.__getitem__ (utils.py:85-86, 140-143): the image -- or, when
+    training from cached feature maps, every map [.., H, W] -- is mirrored along its last axis, and the detection and
+    ground-truth boxes with it.  Returns new objects (inputs are left untouched)."""
+    if torch.is_tensor(image_or_maps):
+        flipped = image_or_maps.flip(-1)
+    else:
+        flipped = type(image_or_maps)((k, v.flip(-1)) for k, v in image_or_maps.items())
+    det = dict(detection, boxes=horizontal_flip_boxes(width, detection["boxes"]))
+    tgt = dict(target, boxes_h=horizontal_flip_boxes(width, target["boxes_h"]),
+               boxes_o=horizontal_flip_boxes(width, target["boxes_o"]))
+    return flipped, det, tgt
+
+
+def draw_flips(n: int, flip: bool = True) -> torch.Tensor:
+    """DataFactory._flip (utils.py:85-86): one coin per sample, drawn once from the global CPU generator."""
+    return torch.randint(0, 2, (n,)) if flip else torch.zeros(n)
+
+
+def custom_collate(batch):
+    """utils.py:34-42."""
+    images, detections, targets = [], [], []
+    for im, det, tar in batch:
+        images.append(im); detections.append(det); targets.append(tar)
+    return images, detections, targets
+
+
+def make_loader(dataset, batch_size: int = 4, num_workers: int = 0, world_size: int = 1, rank: int = 0, shuffle=True):
+    """main:46-54: DataLoader over a DistributedSampler (shards the sample indices over the ranks, reshuffled per epoch
+    by sampler.set_epoch)."""
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    sampler = DistributedSampler(dataset, num_replicas=world_size, rank=rank, shuffle=shuffle)
+    return DataLoader(dataset=dataset, collate_fn=custom_collate, batch_size=batch_size, num_workers=num_workers,
+                      pin_memory=True, sampler=sampler)
+
+
+# ---------------------------------------------------------------------------------------------------- engine
+class Trainer:
+    """The training loop of the reference's CustomisedDLE / pocket DistributedLearningEngine, reduced to what the head's
+    training needs (utils.py:200-229, main:85-145): epochs over a (distributed) loader, the step of `train_step`,
+    LambdaLR stepped once per epoch, the NaN guard, and checkpoints carrying the reference's keys
+
+        {"iteration", "epoch", "model_state_dict", "optim_state_dict", "scheduler_state_dict"}
+
+    so that a checkpoint written by either side resumes on the other (main:85-93; the model keys are those of the
+    wrapped net without DDP's "module." prefix, as pocket saves `net.module.state_dict()`).
+
+    `step_fn(net, optimizer, batch) -> (loss_dict, results)` adapts the loader's batch to the net's call; the default
+    expects (features, detections, image_shapes, targets) batches and calls `train_step`."""
+
+    def __init__(self, net, optimizer, scheduler=None, train_loader=None, rank=0, cache_dir=None, step_fn=None,
+                 print_interval=0):
+        self.net, self.optimizer, self.scheduler = net, optimizer, scheduler
+        self.train_loader = train_loader
+        self.rank = rank
+        self.cache_dir = cache_dir
+        self.print_interval = print_interval
+        self.epoch = 0
+        self.iteration = 0
+        self.step_fn = step_fn or (lambda n, o, b: train_step(n, o, *b[:-1], targets=b[-1]))
+        self.history = []
+
+    # -- checkpoints (main:85-93, pocket engines' save_checkpoint)
+    def _module(self):
+        return self.net.module if isinstance(self.net, nn.parallel.DistributedDataParallel) else self.net
+
+    def state(self) -> dict:
+        return dict(iteration=self.iteration, epoch=self.epoch, model_state_dict=self._module().state_dict(),
+                    optim_state_dict=self.optimizer.state_dict(),
+                    scheduler_state_dict=(self.scheduler.state_dict() if self.scheduler is not None else None))
+
+    def save_checkpoint(self, path=None) -> str:
+        if path is None:
+            import os
+            os.makedirs(self.cache_dir, exist_ok=True)
+            path = os.path.join(self.cache_dir, "ckpt_{:05d}_{:02d}.pt".format(self.iteration, self.epoch))
+        torch.save(self.state(), path)
+        return path
+
+    def load_checkpoint(self, path_or_dict, map_location="cpu") -> None:
+        ckpt = torch.load(path_or_dict, map_location=map_location) if isinstance(path_or_dict, str) else path_or_dict
+        self._module().load_state_dict(ckpt["model_state_dict"])
+        if ckpt.get("optim_state_dict") is not None:
+            self.optimizer.load_state_dict(ckpt["optim_state_dict"])
+        if self.scheduler is not None and ckpt.get("scheduler_state_dict") is not None:
+            self.scheduler.load_state_dict(ckpt["scheduler_state_dict"])
+        self.epoch = int(ckpt.get("epoch", 0))
+        self.iteration = int(ckpt.get("iteration", 0))
+
+    # -- loop
+    def train_epoch(self) -> None:
+        sampler = getattr(self.train_loader, "sampler", None)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(self.epoch)                   # pocket: reshuffle the shards every epoch
+        self.net.train()
+        for batch in self.train_loader:
+            losses, _ = self.step_fn(self.net, self.optimizer, batch)
+            self.iteration += 1
+            self.history.append(losses)
+            if self.print_interval and self.rank == 0 and self.iteration % self.print_interval == 0:
+                print("Epoch %d iteration %d: %s" % (self.epoch, self.iteration,
+                                                     ", ".join("%s %.4f" % kv for kv in losses.items())))
+        self.epoch += 1
+        if self.scheduler is not None:
+            self.scheduler.step()
+
+    def __call__(self, num_epochs: int) -> None:
+        while self.epoch < num_epochs:
+            self.train_epoch()
+            if self.cache_dir is not None and self.rank == 0:
+                self.save_checkpoint()

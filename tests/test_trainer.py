@@ -105,3 +105,83 @@ def test_two_rank_ddp_train_step_on_one_gpu():
     for l in (l0, l1):
         assert all(np.isfinite(v) for v in l.values()) and set(l) == {"hoi_loss", "interactiveness_loss", "transH_loss"}
     assert np.array_equal(v0, v1)            # gradients were averaged: both replicas took the same step
+
+
+# ---------------------------------------------------------------------------------------------------- shell (CPU)
+def test_filter_flip_and_collate():
+    det = dict(boxes=[[10., 5., 50., 40.], [0., 0., 20., 20.], [30., 10., 90., 70.], [5., 5., 9., 9.]],
+               labels=[3, 49, 49, 7], scores=[0.9, 0.15, 0.6, 0.3])
+    f = trainer.filter_detections(det, human_idx=49, box_score_thresh_h=0.2, box_score_thresh_o=0.5)
+    assert f["labels"].tolist() == [49, 3] and f["scores"].tolist() == pytest.approx([0.6, 0.9])     # humans first
+    assert f["boxes"].shape == (2, 4)
+    b = torch.tensor([[10., 5., 50., 40.]])
+    fb = trainer.horizontal_flip_boxes(100., b)
+    assert fb.tolist() == [[50., 5., 90., 40.]] and b.tolist() == [[10., 5., 50., 40.]]             # input untouched
+    assert trainer.horizontal_flip_boxes(100., fb).tolist() == b.tolist()                           # an involution
+    maps = {"3": torch.arange(12.).reshape(1, 1, 3, 4)}
+    tgt = dict(boxes_h=b.clone(), boxes_o=b.clone() + 1, object=torch.tensor([3]), labels=torch.tensor([5]))
+    m2, d2, t2 = trainer.hflip_sample(maps, dict(boxes=b, labels=torch.tensor([49]), scores=torch.tensor([0.5])), tgt, 100.)
+    assert torch.equal(m2["3"][0, 0, 0], torch.tensor([3., 2., 1., 0.])) and d2["boxes"].tolist() == fb.tolist()
+    assert t2["boxes_o"].tolist() == [[49., 6., 89., 41.]] and t2["labels"] is tgt["labels"]
+    torch.manual_seed(42)
+    flips = trainer.draw_flips(8)
+    torch.manual_seed(42)
+    assert torch.equal(flips, torch.randint(0, 2, (8,))) and trainer.draw_flips(3, flip=False).sum() == 0
+    ims, dets, tgts = trainer.custom_collate([(1, 2, 3), (4, 5, 6)])
+    assert (ims, dets, tgts) == ([1, 4], [2, 5], [3, 6])
+
+
+class _ToyData(torch.utils.data.Dataset):
+    def __len__(self):
+        return 10
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(i)
+        return torch.randn(4, generator=g), dict(i=i), torch.randn(2, generator=g)
+
+
+def test_trainer_epochs_checkpoint_and_resume(tmp_path):
+    """Epoch loop over a DistributedSampler, LambdaLR per epoch, checkpoints with the reference's keys (main:85-93) and a
+    resumed run that continues bit-identically."""
+    def build():
+        trainer.seed_everything(42)
+        net = _Net()
+        opt = trainer.build_optimizer(net, lr=1e-2)
+        sch = trainer.build_scheduler(opt, milestone=2, lr_decay=0.1)
+        return net, opt, sch
+
+    def step_fn(net, opt, batch):
+        ims, _, tgts = batch
+        opt.zero_grad(set_to_none=True)
+        loss = (net.interaction_head(net.backbone(torch.stack(ims))) - torch.stack(tgts)).pow(2).mean()
+        loss.backward(); opt.step()
+        return {"hoi_loss": float(loss)}, None
+
+    loader = trainer.make_loader(_ToyData(), batch_size=4, world_size=2, rank=1)
+    assert len(loader.sampler) == 5 and len(loader) == 2                    # this rank's shard of the 10 samples
+    net, opt, sch = build()
+    tr = trainer.Trainer(net, opt, sch, loader, cache_dir=str(tmp_path), step_fn=step_fn)
+    tr(2)
+    assert tr.epoch == 2 and tr.iteration == 4 and opt.param_groups[0]["lr"] == pytest.approx(1e-3)
+    ck = torch.load(str(tmp_path / "ckpt_00004_02.pt"))
+    assert set(ck) == {"iteration", "epoch", "model_state_dict", "optim_state_dict", "scheduler_state_dict"}
+    assert ck["epoch"] == 2 and ck["iteration"] == 4
+    tr(3)                                                                    # one more epoch, uninterrupted
+    want = {k: v.clone() for k, v in net.state_dict().items()}
+    net2, opt2, sch2 = build()
+    tr2 = trainer.Trainer(net2, opt2, sch2, trainer.make_loader(_ToyData(), batch_size=4, world_size=2, rank=1),
+                          step_fn=step_fn)
+    tr2.load_checkpoint(str(tmp_path / "ckpt_00004_02.pt"))
+    assert (tr2.epoch, tr2.iteration) == (2, 4) and opt2.param_groups[0]["lr"] == pytest.approx(1e-3)
+    tr2(3)
+    for k, v in net2.state_dict().items():
+        assert torch.equal(v, want[k]), k                                    # same shuffles, same optimizer state
+
+
+def test_wrap_ddp_single_process_switches_direct_gradients():
+    from skghoi_amd import GraphHead, InteractionHead, synth
+    gh = GraphHead(8, 2, 1024, 1024, 117, 49, synth.hico_object_to_verb())
+    head = InteractionHead(nn.Identity(), gh, nn.Linear(2048, 1), nn.Linear(2048, 117), 49, 117)
+    wrapper = nn.Sequential(head)
+    assert head.grad_mode == "autograd"
+    assert trainer.wrap_ddp(wrapper) is wrapper and head.grad_mode == "direct"
