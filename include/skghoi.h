@@ -392,6 +392,27 @@ int skg_transh_sample_f32(const float* labels, const float* scores, int K, const
                           int32_t* pos_cells, float* pos_scores, float* neg_scores, float* partial, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Evaluation of the head's results on the device (utils.py:148-198): interaction = lut[object][verb]
+ * (hicodet/hicodet.py:139-153; lut [n_obj, n_verb] int32, -1 = invalid), box-pair association per interaction class at
+ * min_iou (pocket BoxPairAssociation: best min(IoU_h, IoU_o) ground-truth pair; per ground-truth pair the highest-scoring
+ * match is the true positive, ties to the earlier detection), for a BATCH of images laid out like the head's packed
+ * results: boxes_h / boxes_o / object [sumP], pair_off [n_images] (first pair of each image), index / pred / scores [L]
+ * (index local to the image), cell_off [n_images + 1]; ground truth gt_h / gt_o [Ng, 4], gt_hoi [Ng], gt_off
+ * [n_images + 1].  Outputs hoi_out [L], labels [L] (1 = true positive).  status (device int32, zero it first) receives
+ * the largest per-image ground-truth count if one exceeds the kernel's 2048 (that image's labels are all zero then).  */
+int skg_eval_associate_f32(const float* boxes_h, const float* boxes_o, const int64_t* object, const int32_t* pair_off,
+                           const int64_t* index, const int64_t* pred, const float* scores, const int32_t* cell_off,
+                           int n_images, const int32_t* lut, int n_obj, int n_verb, const float* gt_h, const float* gt_o,
+                           const int64_t* gt_hoi, const int32_t* gt_off, float min_iou, int32_t* hoi_out, float* labels,
+                           int32_t* status, void* stream);
+/* pocket DetectionAPMeter(algorithm = '11P'), float64: labels_sorted = labels of all detections sorted by class
+ * (ascending) and score (descending, stable); class_off [n_classes + 1]; num_gt [n_classes]; thresholds11 = the eleven
+ * recall thresholds (torch.linspace(0, 1, 11, float64): passed in so that host and device compare identical doubles).
+ * ap[c] = (1/11) sum_k max{precision_i : recall_i >= thresholds11[k]}; 0 without ground truth or detections.          */
+int skg_eval_ap11_f64(const float* labels_sorted, const int64_t* class_off, const int64_t* num_gt, int n_classes,
+                      const double* thresholds11, double* ap, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Order-independent 64-bit checksum of the live parameters (bit patterns weighted by position) over a table of
  * chunks: chunk c covers `count` fp32 words at `ptr` (16-byte aligned) whose first word has global index `first`.
  * The reference reads its nn.Linear / LayerNorm parameters afresh in every forward (HEAD:812-973, 410-411); the host

@@ -105,6 +105,9 @@ PROTOTYPES = {
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "skg_adjacency_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "skg_entity_rows_bwd_f32": (C.c_int, [_vp, _i64, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "skg_eval_associate_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp,
+                                         _vp, _vp, _f32, _vp, _vp, _vp, _vp]),
+    "skg_eval_ap11_f64": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "skg_transh_sample_ws_ints": (C.c_int64, [C.c_int, C.c_int]),
     "skg_transh_sample_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _f32, _vp, _vp, _vp, _vp, _vp,
                                         _vp]),

@@ -158,6 +158,92 @@ class HOIEvaluator:
         return out
 
 
+class DeviceHOIEvaluator:
+    """utils.test (utils.py:148-198) on the device, for batches of any size: interaction lookup + box-pair association in
+    one launch per batch (skg_eval_associate_f32), detections kept on the device, and at the end two stable device sorts
+    plus one launch for the 600 eleven-point APs (skg_eval_ap11_f64, float64).  Same numbers as HOIEvaluator (the host
+    restatement the oracle pins); use it when the head runs batched and the results should not travel to the host."""
+
+    def __init__(self, num_gt_test, object_n_verb_to_interaction=None, min_iou=0.5, num_anno_train=None, device="cuda"):
+        self.device = torch.device(device)
+        lut = object_n_verb_to_interaction if object_n_verb_to_interaction is not None \
+            else hico_object_n_verb_to_interaction()
+        self.n_obj, self.n_verb = lut.shape
+        self.num_cls = int(lut.max()) + 1
+        self.lut = lut.to(self.device, torch.int32).contiguous()
+        self.num_gt = torch.as_tensor([int(v) for v in num_gt_test], dtype=torch.int64, device=self.device)
+        self.min_iou = float(min_iou)
+        self.num_anno_train = None if num_anno_train is None else torch.as_tensor(num_anno_train)
+        self.thr = torch.linspace(0, 1, 11, dtype=torch.float64).to(self.device)
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._scores, self._hoi, self._labels = [], [], []
+
+    def add(self, outputs, targets):
+        """outputs: the head's result dicts of a batch (HEAD:317-322); targets: per image {boxes_h, boxes_o, hoi}.
+        Returns the per-image label tensors (views of one device tensor)."""
+        from . import _capi
+        from .engine import _stream
+        dev = self.device
+        n = len(outputs)
+        if n == 0:
+            return []
+        ppi = [int(o["boxes_h"].shape[0]) for o in outputs]; cpi = [int(o["scores"].shape[0]) for o in outputs]
+        cat = lambda k, dt=None: torch.cat([o[k].reshape(-1, *o[k].shape[1:]) for o in outputs]).to(dev).contiguous()
+        boxes_h = cat("boxes_h").float(); boxes_o = cat("boxes_o").float(); obj = cat("object").long()
+        index = cat("index").long(); pred = cat("prediction").long(); scores = cat("scores").float().contiguous()
+        gts = [int(t["boxes_h"].shape[0]) for t in targets]
+        gt_h = torch.cat([t["boxes_h"].reshape(-1, 4) for t in targets]).to(dev).float().contiguous()
+        gt_o = torch.cat([t["boxes_o"].reshape(-1, 4) for t in targets]).to(dev).float().contiguous()
+        gt_hoi = torch.cat([t["hoi"].reshape(-1) for t in targets]).to(dev).long().contiguous()
+        if gt_h.shape[0] == 0:
+            gt_h = torch.zeros(1, 4, device=dev); gt_o = torch.zeros(1, 4, device=dev)
+            gt_hoi = torch.full((1,), -1, dtype=torch.int64, device=dev)
+        offs = np.zeros(3 * (n + 1), np.int32)
+        offs[1:n + 1] = np.cumsum(ppi)                               # pair_off (n used) | cell_off | gt_off
+        offs[n + 2:2 * n + 2] = np.cumsum(cpi); offs[2 * n + 3:] = np.cumsum(gts)
+        offs_d = torch.from_numpy(offs).to(dev)
+        L = int(sum(cpi))
+        hoi = torch.empty(max(L, 1), dtype=torch.int32, device=dev); labels = torch.zeros(max(L, 1), device=dev)
+        pad4 = lambda t: t if t.shape[0] else torch.zeros((1,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        boxes_h, boxes_o, obj, index, pred, scores = map(pad4, (boxes_h, boxes_o, obj, index, pred, scores))
+        _capi.check(_capi.lib().skg_eval_associate_f32(
+            boxes_h.data_ptr(), boxes_o.data_ptr(), obj.data_ptr(), offs_d.data_ptr(), index.data_ptr(), pred.data_ptr(),
+            scores.data_ptr(), offs_d.data_ptr() + 4 * (n + 1), n, self.lut.data_ptr(), self.n_obj, self.n_verb,
+            gt_h.data_ptr(), gt_o.data_ptr(), gt_hoi.data_ptr(), offs_d.data_ptr() + 8 * (n + 1), self.min_iou,
+            hoi.data_ptr(), labels.data_ptr(), self.status.data_ptr(), _stream()), "skg_eval_associate_f32")
+        self._scores.append(scores[:L]); self._hoi.append(hoi[:L]); self._labels.append(labels[:L])
+        return list(labels[:L].split(cpi))
+
+    def summary(self):
+        from . import _capi
+        from .engine import _stream
+        dev = self.device
+        if int(self.status.item()):
+            raise _capi.SkgError("an image has %d ground-truth pairs; skg_eval_associate_f32 keeps at most 2048 per image"
+                                 % int(self.status.item()))
+        ap = torch.zeros(self.num_cls, dtype=torch.float64, device=dev)
+        if self._scores:
+            scores = torch.cat(self._scores); hoi = torch.cat(self._hoi).long(); labels = torch.cat(self._labels)
+            if (hoi < 0).any():
+                raise IndexError("a predicted (object, verb) pair is not a valid interaction")
+            o1 = torch.sort(scores, descending=True, stable=True).indices      # score descending, arrival order on ties
+            o2 = torch.sort(hoi[o1], stable=True).indices                      # ... then class ascending, order kept
+            order = o1[o2]
+            lab_sorted = labels[order].contiguous()
+            class_off = torch.zeros(self.num_cls + 1, dtype=torch.int64, device=dev)
+            class_off[1:] = torch.cumsum(torch.bincount(hoi, minlength=self.num_cls), 0)
+            _capi.check(_capi.lib().skg_eval_ap11_f64(lab_sorted.data_ptr(), class_off.data_ptr(), self.num_gt.data_ptr(),
+                                                      self.num_cls, self.thr.data_ptr(), ap.data_ptr(), _stream()),
+                        "skg_eval_ap11_f64")
+        ap = ap.cpu()
+        out = dict(ap=ap, full=float(ap.mean()))
+        if self.num_anno_train is not None:                      # test/..._test.py:30-33
+            rare = torch.nonzero(self.num_anno_train < 10).squeeze(1)
+            non_rare = torch.nonzero(self.num_anno_train >= 10).squeeze(1)
+            out["rare"] = float(ap[rare].mean()); out["non_rare"] = float(ap[non_rare].mean())
+        return out
+
+
 # ----------------------------------------------------------------------------------------------- exporters
 def hicodet_mat_cells(outputs, image_indices, n_images, lut=None, num_hoi=600):
     """cache.py:28-83: object array [num_hoi, n_images] whose cell (hoi, image) is [n, 9] = boxes_h | boxes_o | score

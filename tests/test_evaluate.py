@@ -80,3 +80,60 @@ def test_evaluator_and_exporters(tmp_path):
     back = pickle.load(open(tmp_path / "vcoco_results.pkl", "rb"))
     assert len(back) == 3 and back[1]["person_box"] == bh[0].tolist()
     assert type(back[0]).__module__ == "cache_template" and back[0]["carry_obj"] == [0., 0., .1, .1, 0.]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_device_evaluator_matches_host_and_oracle(seed):
+    """skg_eval_associate_f32 + skg_eval_ap11_f64 (DeviceHOIEvaluator) against the host evaluator (torch restatement) and,
+    per image and class, the loop-level oracle: labels bit-equal, the 600 APs equal in float64."""
+    rs = np.random.RandomState(seed)
+    lut = ev.hico_object_n_verb_to_interaction()
+    o2v = synth.hico_object_to_verb()
+    n_img = 5
+    num_gt = [0] * 600
+    outs, tgts = [], []
+    for b in range(n_img):
+        n_pairs = rs.randint(0, 14) if b != 3 else 0                 # one image without detections
+        bh = _rand_boxes(rs, n_pairs); bo = _rand_boxes(rs, n_pairs)
+        obj = torch.tensor(rs.randint(0, 80, n_pairs), dtype=torch.int64)
+        index, pred = [], []
+        for p in range(n_pairs):
+            vs = o2v[int(obj[p])]
+            for v in rs.choice(vs, size=min(len(vs), rs.randint(1, 4)), replace=False):
+                index.append(p); pred.append(int(v))
+        index = torch.tensor(index, dtype=torch.int64); pred = torch.tensor(pred, dtype=torch.int64)
+        scores = torch.tensor(np.round(rs.uniform(0, 1, len(index)), 1), dtype=torch.float32)      # many ties
+        # ground truth: jittered copies of some detected pairs (same class), some duplicated, plus unrelated ones
+        gh, go, ghoi = [], [], []
+        for c in rs.permutation(len(index))[:rs.randint(0, 6)]:
+            p = int(index[c])
+            for _ in range(rs.randint(1, 3)):
+                gh.append(bh[p] + float(rs.uniform(-4, 4))); go.append(bo[p] + float(rs.uniform(-4, 4)))
+                ghoi.append(int(lut[int(obj[p]), int(pred[c])]))
+        for _ in range(rs.randint(0, 3)):
+            gh.append(_rand_boxes(rs, 1)[0]); go.append(_rand_boxes(rs, 1)[0]); ghoi.append(int(rs.randint(0, 600)))
+        for h in ghoi:
+            num_gt[h] += 1
+        tgts.append(dict(boxes_h=torch.stack(gh) if gh else torch.zeros(0, 4), boxes_o=torch.stack(go) if go else torch.zeros(0, 4),
+                         hoi=torch.tensor(ghoi, dtype=torch.int64)))
+        outs.append(dict(boxes_h=bh, boxes_o=bo, index=index, prediction=pred, scores=scores, object=obj))
+    host = ev.HOIEvaluator(num_gt, num_anno_train=[5 if i % 3 else 50 for i in range(600)])
+    want_labels = [host.add(o, t) for o, t in zip(outs, tgts)]
+    dev = ev.DeviceHOIEvaluator(num_gt, num_anno_train=[5 if i % 3 else 50 for i in range(600)])
+    cu = lambda d: {k: v.cuda() for k, v in d.items()}
+    got = dev.add([cu(o) for o in outs[:2]], [cu(t) for t in tgts[:2]]) + dev.add([cu(o) for o in outs[2:]], tgts[2:])
+    for b in range(n_img):
+        assert torch.equal(got[b].cpu(), want_labels[b]), b
+        # and the oracle, class by class
+        o, t = outs[b], tgts[b]
+        inter = lut[o["object"][o["index"]], o["prediction"]]
+        for h in inter.unique().tolist():
+            det = torch.nonzero(inter == h).squeeze(1); g = torch.nonzero(t["hoi"] == h).squeeze(1)
+            if len(g):
+                w = EO.associate(t["boxes_h"][g].numpy(), t["boxes_o"][g].numpy(), o["boxes_h"][o["index"]][det].numpy(),
+                                 o["boxes_o"][o["index"]][det].numpy(), o["scores"][det].numpy())
+                assert np.array_equal(got[b].cpu().numpy()[det.numpy()], w), (b, h)
+    sh, sd = host.summary(), dev.summary()
+    assert torch.equal(sh["ap"], sd["ap"]) and sh["full"] == sd["full"] and sh["rare"] == sd["rare"]
+    assert float(sd["ap"].sum()) > 0
