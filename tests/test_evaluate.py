@@ -137,3 +137,42 @@ def test_device_evaluator_matches_host_and_oracle(seed):
     sh, sd = host.summary(), dev.summary()
     assert torch.equal(sh["ap"], sd["ap"]) and sh["full"] == sd["full"] and sh["rare"] == sd["rare"]
     assert float(sd["ap"].sum()) > 0
+
+
+VCOCO_ACTIONS = ["hold obj", "sit instr", "ride instr", "look obj", "hit instr", "hit obj", "eat obj", "eat instr",
+                 "jump instr", "lay instr", "talk_on_phone instr", "carry obj", "throw obj", "catch obj", "cut instr",
+                 "cut obj", "work_on_computer instr", "ski instr", "surf instr", "skateboard instr", "drink instr",
+                 "kick obj", "read obj", "snowboard instr"]           # VCOCO.actions (K = 24, cache.py:165-168)
+
+
+def test_vcoco_pickle_is_consumable_the_way_vsrl_eval_reads_it(tmp_path):
+    """the pickle goes through the reader of the external V-COCO toolkit (restated in
+    oracle/vsrl_consumer.py): 26 actions x roles per record, defaults for everything the record does not carry, and a
+    known-answer role AP computed from what was read."""
+    from oracle import vsrl_consumer as VC
+    bh = torch.tensor([[10., 10., 110., 210.], [300., 20., 380., 220.]]); bo = torch.tensor([[50., 60., 150., 160.], [200., 100., 320., 180.]])
+    a_hold, a_cut_i, a_cut_o = VCOCO_ACTIONS.index("hold obj"), VCOCO_ACTIONS.index("cut instr"), VCOCO_ACTIONS.index("cut obj")
+    out = dict(boxes_h=bh, boxes_o=bo, index=torch.tensor([0, 1, 1]), prediction=torch.tensor([a_hold, a_cut_i, a_cut_o]),
+               scores=torch.tensor([0.9, 0.6, 0.3]), object=torch.tensor([40, 44]))
+    res = ev.vcoco_results([out], [4711], VCOCO_ACTIONS)
+    ev.save_vcoco_pickle(res, str(tmp_path))
+    dets = pickle.load(open(tmp_path / "vcoco_results.pkl", "rb"))
+    for d in dets:                                                   # every key the reader asks for resolves
+        for action, roles in VC.ACTION_ROLES:
+            for r in roles:
+                v = d[action + "_" + r]
+                assert np.isscalar(v) if r == "agent" else len(v) == 5
+    assert {a.split()[0] for a in VCOCO_ACTIONS} <= {a for a, _ in VC.ACTION_ROLES}
+    agents, roles = VC.collect_detections_for_image(dets, 4711)
+    assert agents.shape == (3, 4 + 26) and roles.shape == (3, 130, 2)
+    hold, cut = 0, 14
+    assert agents[0, :4].tolist() == bh[0].tolist() and agents[0, 4 + hold] == pytest.approx(0.9)
+    assert roles[0, 5 * hold:5 * hold + 5, 0].tolist() == pytest.approx(bo[0].tolist() + [0.9])
+    assert agents[1, 4 + cut] == pytest.approx(0.6) and agents[2, 4 + cut] == pytest.approx(0.3)
+    assert roles[1, 5 * cut:5 * cut + 5, 0].tolist() == pytest.approx(bo[1].tolist() + [0.6])      # cut instr = role 1
+    assert roles[2, 5 * cut:5 * cut + 5, 1].tolist() == pytest.approx(bo[1].tolist() + [0.3])      # cut obj   = role 2
+    assert roles[0, 5 * cut:5 * cut + 5, 0].tolist() == pytest.approx([0., 0., .1, .1, 0.])        # template default
+    assert VC.collect_detections_for_image(dets, 1)[0].shape == (0, 30)
+    gt = [dict(image_id=4711, person_box=[12., 11., 108., 205.], role_box=[52., 58., 149., 161.])]
+    assert VC.role_ap(dets, gt, "hold", 1) == pytest.approx(1.0)                # found at rank 1
+    assert VC.role_ap(dets, gt, "cut", 2) == pytest.approx(0.0)                 # the cut detection is another pair
