@@ -13,7 +13,9 @@ b = torch.rand(N, generator=g).cuda(); C = torch.empty(M, N, device="cuda")
 kw = {}
 if os.environ.get("XA"):        # every A row gathers row 0: A always cache-hot
     kw["a_rows"] = torch.zeros(M, dtype=torch.int32, device="cuda")
-with SplitWeights():
+import contextlib
+ctx = contextlib.nullcontext if os.environ.get("EXACT") else SplitWeights      # EXACT=1: the exact fp32-MFMA loop
+with ctx():
     for _ in range(max(3, reps)):            # the shader clock needs ~50 ms of load to settle
         gemm(A, W, b, C, M, N, K, epi, **kw)
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
