@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SKG_ABI_VERSION 4
+#define SKG_ABI_VERSION 5
 #define SKG_E_ARG   (-1)   /* null pointer / negative size / unsupported shape            */
 #define SKG_E_ALIGN (-2)   /* pointer or leading dimension not 16-byte aligned            */
 #define SKG_E_LIMIT (-3)   /* exceeds a compiled-in limit (boxes per image, verbs, ...)   */
@@ -319,6 +319,10 @@ typedef struct {
 #define SKG_GEMMX_GROUP_MAX 8
 int64_t skg_gemmx_ws_floats(const skg_gemmx_desc* desc_host);
 int skg_gemmx_f32(const skg_gemmx_desc* descs_host, int n, void* stream);
+/* The same products with both operands rounded to bf16 (RNE) on their way to the matrix core and fp32 accumulation
+ * (v_mfma_f32_32x32x16_bf16); operands, results, bias gradient and epilogue stay fp32 in memory.  The dense layers of a
+ * precision="bf16" training step (BASELINE config 3: the reference under torch.autocast(bfloat16)).                  */
+int skg_gemmx_bf16(const skg_gemmx_desc* descs_host, int n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Non-GEMM stages of the fused TRAINING step (skg_train.hip): the forward pieces that keep what the backward needs and

@@ -89,6 +89,55 @@ __device__ __forceinline__ void xload(const XOperand& op, int row0, int k0, int 
     }
 }
 
+// Loop-invariant part of one thread's loads of one operand: the addresses along the operand's own index are formed
+// once, the main loop adds one k offset per tile and skips every bounds check on tiles that lie inside the slice
+// ("fast" tiles: all but possibly the last).  Quads that straddle the end of the operand take the generic path.
+struct XLane {
+    const float* p0; const float* p1; const float* p2; const float* p3;
+    int ok;              // bit u: quad u lies inside the operand along its own index
+    int straddle;        // row-contiguous quad crossing the operand's end
+    int kloc;
+};
+
+__device__ __forceinline__ float4 xld4(const float* p, bool ok) {
+    return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__device__ __forceinline__ void xprep(const XOperand& op, int row0, int tid, XLane& L) {
+    L.p1 = L.p2 = L.p3 = nullptr;
+    if (op.kcontig) {
+        const int r = row0 + (tid >> 2);
+        L.kloc = 4 * (tid & 3);
+        L.p0 = op.base + xoff(r, op.rshift, op.rstride, op.s_row);
+        L.p1 = op.base + xoff(r + 64, op.rshift, op.rstride, op.s_row);
+        L.ok = (r < op.rows ? 1 : 0) | (r + 64 < op.rows ? 2 : 0);
+        L.straddle = 0;
+    } else {
+        const int row = row0 + 4 * (tid & 31);
+        L.kloc = tid >> 5;
+        L.p0 = op.base + xoff(row, op.rshift, op.rstride, 1);
+        L.ok = row + 3 < op.rows ? 3 : 0;
+        L.straddle = row < op.rows && row + 3 >= op.rows;
+    }
+}
+
+// one 128 x 16 tile at k0 (fast when it lies inside [.., kend) and 16-byte loads are allowed)
+__device__ __forceinline__ void xtile(const XOperand& op, const XLane& L, int row0, int k0, int kend, int tid,
+                                      float4 (&v)[2]) {
+    if (op.vec && k0 + XBK <= kend && !L.straddle) {
+        if (op.kcontig) {
+            const int64_t ko = xoff(k0 + L.kloc, op.kshift, op.kstride, 1);
+            v[0] = xld4(L.p0 + ko, L.ok & 1);
+            v[1] = xld4(L.p1 + ko, L.ok & 2);
+        } else {
+            v[0] = xld4(L.p0 + xoff(k0 + L.kloc, op.kshift, op.kstride, op.s_k), L.ok & 1);
+            v[1] = xld4(L.p0 + xoff(k0 + L.kloc + 8, op.kshift, op.kstride, op.s_k), L.ok & 2);
+        }
+    } else {
+        xload(op, row0, k0, kend, tid, v);
+    }
+}
+
 __device__ __forceinline__ void xstore_lds(float* tile, bool kcontig, int tid, const float4 (&v)[2]) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -146,10 +195,13 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
     const bool do_rowsum = d.a_rowsum != nullptr && tn == 0 && tid < XBM;
     float rsum = 0.f;
 
+    XLane LA, LB;
+    xprep(A, m0, tid, LA);
+    xprep(B, n0, tid, LB);
     float4 va[2], vb[2];
     if (kt0 < kt1) {
-        xload(A, m0, kt0 * XBK, kend, tid, va);
-        xload(B, n0, kt0 * XBK, kend, tid, vb);
+        xtile(A, LA, m0, kt0 * XBK, kend, tid, va);
+        xtile(B, LB, n0, kt0 * XBK, kend, tid, vb);
         xstore_lds(smem, A.kcontig, tid, va);
         xstore_lds(smem + XTILE, B.kcontig, tid, vb);
     }
@@ -160,8 +212,8 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
         const float* Bs = As + XTILE;
         const bool more = kt + 1 < kt1;
         if (more) {
-            xload(A, m0, (kt + 1) * XBK, kend, tid, va);
-            xload(B, n0, (kt + 1) * XBK, kend, tid, vb);
+            xtile(A, LA, m0, (kt + 1) * XBK, kend, tid, va);
+            xtile(B, LB, n0, (kt + 1) * XBK, kend, tid, vb);
         }
 #pragma unroll
         for (int ks = 0; ks < XBK / 2; ++ks) {
@@ -239,6 +291,272 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
     }
 }
 
+// ------------------------------------------------------------------------------------------------ bf16 operands
+// Same products, same descriptors, same epilogue; the operands stay fp32 in HBM and are rounded to bf16 (RNE,
+// v_cvt_pk_bf16_f32) on their way into LDS, accumulation in fp32 on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).
+// This is what precision="bf16" training runs (BASELINE config 3: autocast of the reference's nn.Linear layers).
+//
+// 128x128x32 block tile, 4 waves (2x2) x (2x2) MFMA tiles.  LDS image of an operand tile: four k-planes (8 k each) of
+// [128 rows][8 bf16 = 16 B], plane stride 520 dwords, row slot XOR-swizzled (slot = row ^ ((row >> 3) & 3)): a lane's
+// MFMA fragment is ONE ds_read_b128, conflict-free, and both source layouts are written conflict-free too --
+//   k-contiguous source : a thread has 4 k of one row        -> one ds_write_b64
+//   row-contiguous source: a thread loads 4 rows x 4 k (four float4 along the rows), transposes in registers
+//                                                             -> four ds_write_b64 (one per row)
+// The bias gradient (row sums of A) is accumulated from the fp32 registers before rounding.
+#define YBK 32
+#define YPLANE 1040                          // bf16 elements per k-plane: 128 rows * 8 + 16 pad (520 dwords)
+#define YTILE (4 * YPLANE)
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 xbf2 __attribute__((ext_vector_type(2)));
+typedef float xf2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t ypack(float a, float b) {
+    const xf2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, xbf2));
+}
+__device__ __forceinline__ int yslot(int row) { return row ^ ((row >> 3) & 3); }
+
+// Four consecutive elements along the contiguous index `c` (extent cend) at fixed other index; zero outside.
+__device__ __forceinline__ float4 yquad(const float* p, int c, int cend, bool vec) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec && c + 3 < cend) {
+        t = *reinterpret_cast<const float4*>(p);
+    } else {
+        if (c < cend) t.x = p[0];
+        if (c + 1 < cend) t.y = p[1];
+        if (c + 2 < cend) t.z = p[2];
+        if (c + 3 < cend) t.w = p[3];
+    }
+    return t;
+}
+
+// One thread's share of a 128 x 32 operand tile: four quads (generic path: every bound checked).
+//   kcontig : quad u = 4 consecutive k (k0 + 4 (tid & 7)) of row (tid >> 3) + 32 u
+//   else    : quad u = rows 4 rq .. 4 rq + 3 at k = k0 + 4 kq4 + u,  rq = (tid & 7) | ((tid >> 4) & 3) << 3,
+//             kq4 = ((tid >> 3) & 1) | (tid >> 6) << 1
+__device__ __forceinline__ float4 yload1(const XOperand& op, int row0, int k0, int kend, int tid, int u) {
+    if (op.kcontig) {
+        const int row = row0 + (tid >> 3) + 32 * u, k = k0 + 4 * (tid & 7);
+        if (row >= op.rows || k >= kend) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return yquad(op.base + xoff(row, op.rshift, op.rstride, op.s_row) + xoff(k, op.kshift, op.kstride, 1), k, kend, op.vec);
+    }
+    const int rq = (tid & 7) | (((tid >> 4) & 3) << 3), kq4 = ((tid >> 3) & 1) | ((tid >> 6) << 1);
+    const int k = k0 + 4 * kq4 + u, row = row0 + 4 * rq;
+    if (k >= kend || row >= op.rows) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return yquad(op.base + xoff(k, op.kshift, op.kstride, op.s_k) + xoff(row, op.rshift, op.rstride, 1), row, op.rows, op.vec);
+}
+
+#define YLOAD(op, row0, k0, v)                                                                            \
+    do {                                                                                                  \
+        v##0 = yload1(op, row0, k0, kend, tid, 0); v##1 = yload1(op, row0, k0, kend, tid, 1);            \
+        v##2 = yload1(op, row0, k0, kend, tid, 2); v##3 = yload1(op, row0, k0, kend, tid, 3);            \
+    } while (0)
+
+__device__ __forceinline__ void yprep(const XOperand& op, int row0, int tid, XLane& L) {
+    L.p1 = L.p2 = L.p3 = nullptr;
+    if (op.kcontig) {
+        const int r = row0 + (tid >> 3);
+        L.kloc = 4 * (tid & 7);
+        L.p0 = op.base + xoff(r, op.rshift, op.rstride, op.s_row);
+        L.p1 = op.base + xoff(r + 32, op.rshift, op.rstride, op.s_row);
+        L.p2 = op.base + xoff(r + 64, op.rshift, op.rstride, op.s_row);
+        L.p3 = op.base + xoff(r + 96, op.rshift, op.rstride, op.s_row);
+        L.ok = (r < op.rows ? 1 : 0) | (r + 32 < op.rows ? 2 : 0) | (r + 64 < op.rows ? 4 : 0) | (r + 96 < op.rows ? 8 : 0);
+        L.straddle = 0;
+    } else {
+        const int rq = (tid & 7) | (((tid >> 4) & 3) << 3), kq4 = ((tid >> 3) & 1) | ((tid >> 6) << 1);
+        const int row = row0 + 4 * rq;
+        L.kloc = 4 * kq4;
+        L.p0 = op.base + xoff(row, op.rshift, op.rstride, 1);
+        L.ok = row + 3 < op.rows ? 15 : 0;
+        L.straddle = row < op.rows && row + 3 >= op.rows;
+    }
+}
+
+// one 128 x 32 tile at k0.  Fast tiles: one k offset per thread (a 4-aligned group of k never crosses a k block).
+#define YTILE_LOAD(op, L, row0, k0, v)                                                                    \
+    do {                                                                                                  \
+        if (op.vec && (k0) + YBK <= kend && !L.straddle) {                                                \
+            if (op.kcontig) {                                                                             \
+                const int64_t ko_ = xoff((k0) + L.kloc, op.kshift, op.kstride, 1);                        \
+                v##0 = xld4(L.p0 + ko_, L.ok & 1); v##1 = xld4(L.p1 + ko_, L.ok & 2);                     \
+                v##2 = xld4(L.p2 + ko_, L.ok & 4); v##3 = xld4(L.p3 + ko_, L.ok & 8);                     \
+            } else {                                                                                      \
+                const float* q_ = L.p0 + xoff((k0) + L.kloc, op.kshift, op.kstride, op.s_k);             \
+                v##0 = xld4(q_, L.ok & 1); v##1 = xld4(q_ + op.s_k, L.ok & 2);                            \
+                v##2 = xld4(q_ + 2 * op.s_k, L.ok & 4); v##3 = xld4(q_ + 3 * op.s_k, L.ok & 8);           \
+            }                                                                                             \
+        } else {                                                                                          \
+            YLOAD(op, row0, k0, v);                                                                       \
+        }                                                                                                 \
+    } while (0)
+
+__device__ __forceinline__ void ystore_lds(uint16_t* tile, bool kcontig, int tid, float4 v0, float4 v1, float4 v2, float4 v3) {
+    if (kcontig) {
+        const int kq4 = tid & 7, r = tid >> 3;
+        uint16_t* base = tile + (kq4 >> 1) * YPLANE + (kq4 & 1) * 4;
+        *reinterpret_cast<uint2*>(base + yslot(r) * 8) = make_uint2(ypack(v0.x, v0.y), ypack(v0.z, v0.w));
+        *reinterpret_cast<uint2*>(base + yslot(r + 32) * 8) = make_uint2(ypack(v1.x, v1.y), ypack(v1.z, v1.w));
+        *reinterpret_cast<uint2*>(base + yslot(r + 64) * 8) = make_uint2(ypack(v2.x, v2.y), ypack(v2.z, v2.w));
+        *reinterpret_cast<uint2*>(base + yslot(r + 96) * 8) = make_uint2(ypack(v3.x, v3.y), ypack(v3.z, v3.w));
+    } else {
+        const int rq = (tid & 7) | (((tid >> 4) & 3) << 3), kq4 = ((tid >> 3) & 1) | ((tid >> 6) << 1);
+        uint16_t* base = tile + (kq4 >> 1) * YPLANE + (kq4 & 1) * 4;
+        const int row = 4 * rq;
+        *reinterpret_cast<uint2*>(base + yslot(row + 0) * 8) = make_uint2(ypack(v0.x, v1.x), ypack(v2.x, v3.x));
+        *reinterpret_cast<uint2*>(base + yslot(row + 1) * 8) = make_uint2(ypack(v0.y, v1.y), ypack(v2.y, v3.y));
+        *reinterpret_cast<uint2*>(base + yslot(row + 2) * 8) = make_uint2(ypack(v0.z, v1.z), ypack(v2.z, v3.z));
+        *reinterpret_cast<uint2*>(base + yslot(row + 3) * 8) = make_uint2(ypack(v0.w, v1.w), ypack(v2.w, v3.w));
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_group g) {
+    __shared__ __attribute__((aligned(16))) uint16_t smem[4 * YTILE];      // A0 | B0 | A1 | B1
+    int gi = 0;
+#pragma unroll
+    for (int t = 1; t < SKG_GEMMX_GROUP_MAX; ++t)
+        if (t < g.n && (int)blockIdx.x >= g.start[t]) gi = t;
+    const skg_gemmx_desc& d = g.d[gi];
+    const int vecbits = g.vec[gi];
+    const int S = d.split_k > 1 ? d.split_k : 1;
+    const int nbn = (d.N + XBN - 1) / XBN;
+    int b = blockIdx.x - g.start[gi];
+    const int slice = b % S; b /= S;
+    const int tn = b % nbn, tm = b / nbn;
+    const int m0 = tm * XBM, n0 = tn * XBN;
+    const int nkt = (d.K + YBK - 1) / YBK;
+    const int per = (nkt + S - 1) / S;
+    const int kt0 = slice * per, kt1 = min(nkt, kt0 + per);
+    const int kend = min(d.K, kt1 * YBK);
+
+    XOperand A, B;
+    A.base = d.A; A.s_row = d.a_sm; A.s_k = d.a_sk; A.rshift = 0; A.kshift = 0; A.rstride = 0; A.kstride = 0;
+    A.rows = d.M; A.kcontig = d.a_sk == 1; A.vec = vecbits & 1;
+    B.base = d.B; B.s_row = d.b_sn; B.s_k = d.b_sk; B.rshift = d.b_nshift; B.kshift = d.b_kshift;
+    B.rstride = d.b_nstride; B.kstride = d.b_kstride; B.rows = d.N; B.kcontig = d.b_sk == 1; B.vec = (vecbits >> 1) & 1;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lk = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const bool do_rowsum = d.a_rowsum != nullptr && tn == 0;
+    float rs0 = 0.f, rs1 = 0.f, rs2 = 0.f, rs3 = 0.f;
+
+    // fragment addresses (bf16 elements) inside a tile, per k-step ks: + (2 ks) * YPLANE
+    int fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        fa[i] = lk * YPLANE + yslot(wm * 64 + i * 32 + li) * 8;
+        fb[i] = lk * YPLANE + yslot(wn * 64 + i * 32 + li) * 8;
+    }
+
+    float4 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
+    va0 = va1 = va2 = va3 = vb0 = vb1 = vb2 = vb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    XLane LA, LB;
+    yprep(A, m0, tid, LA);
+    yprep(B, n0, tid, LB);
+    if (kt0 < kt1) {
+        YTILE_LOAD(A, LA, m0, kt0 * YBK, va);
+        YTILE_LOAD(B, LB, n0, kt0 * YBK, vb);
+        ystore_lds(smem, A.kcontig, tid, va0, va1, va2, va3);
+        ystore_lds(smem + YTILE, B.kcontig, tid, vb0, vb1, vb2, vb3);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        const uint16_t* As = smem + cur * 2 * YTILE;
+        const uint16_t* Bs = As + YTILE;
+        const bool more = kt + 1 < kt1;
+        if (do_rowsum) {                                  // fp32 row sums of the tile now in LDS (registers still hold it)
+            if (A.kcontig) {
+                rs0 += (va0.x + va0.y) + (va0.z + va0.w); rs1 += (va1.x + va1.y) + (va1.z + va1.w);
+                rs2 += (va2.x + va2.y) + (va2.z + va2.w); rs3 += (va3.x + va3.y) + (va3.z + va3.w);
+            } else {
+                rs0 += (va0.x + va1.x) + (va2.x + va3.x); rs1 += (va0.y + va1.y) + (va2.y + va3.y);
+                rs2 += (va0.z + va1.z) + (va2.z + va3.z); rs3 += (va0.w + va1.w) + (va2.w + va3.w);
+            }
+        }
+        if (more) {
+            YTILE_LOAD(A, LA, m0, (kt + 1) * YBK, va);
+            YTILE_LOAD(B, LB, n0, (kt + 1) * YBK, vb);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[2], bq[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const bf16x8*>(As + 2 * ks * YPLANE + fa[i]);
+                bq[i] = *reinterpret_cast<const bf16x8*>(Bs + 2 * ks * YPLANE + fb[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            uint16_t* An = smem + (cur ^ 1) * 2 * YTILE;
+            ystore_lds(An, A.kcontig, tid, va0, va1, va2, va3);
+            ystore_lds(An + YTILE, B.kcontig, tid, vb0, vb1, vb2, vb3);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  acc[mi][ni][4*gq + t] = row m0 + wm*64 + mi*32 + 8*gq + 4*lk + t, column n0 + wn*64 + ni*32 + li.
+    const bool split = S > 1;
+    const int64_t MN = (int64_t)d.M * d.N;
+    float* ws = split ? d.split_ws + (int64_t)slice * (MN + d.M) : nullptr;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = m0 + wm * 64 + mi * 32 + 8 * gq + 4 * lk + t;
+                if (row >= d.M) continue;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int col = n0 + wn * 64 + ni * 32 + li;
+                    if (col >= d.N) continue;
+                    float v = acc[mi][ni][4 * gq + t];
+                    if (split) { ws[(int64_t)row * d.N + col] = v; continue; }
+                    if (d.bias) v += d.bias[col];
+                    if (d.relu) v = fmaxf(v, 0.f);
+                    float* p = d.C + xoff(col, d.c_nshift, d.c_nstride, 1) + (int64_t)row * d.ldc;
+                    if (d.accumulate) v += *p;
+                    if (d.mask && !(d.mask[(int64_t)row * d.ldmask + col] > 0.f)) v = 0.f;
+                    *p = v;
+                }
+            }
+    if (do_rowsum) {                                       // uniform per workgroup
+        float* part = reinterpret_cast<float*>(smem);      // [8][128] partial sums; the k loop ended on a barrier
+        if (A.kcontig) {
+            float* q = part + (tid & 7) * 128 + (tid >> 3);
+            q[0] = rs0; q[32] = rs1; q[64] = rs2; q[96] = rs3;
+        } else {
+            const int rq = (tid & 7) | (((tid >> 4) & 3) << 3), kq4 = ((tid >> 3) & 1) | ((tid >> 6) << 1);
+            float* q = part + kq4 * 128 + 4 * rq;
+            q[0] = rs0; q[1] = rs1; q[2] = rs2; q[3] = rs3;
+        }
+        __syncthreads();
+        if (tid < XBM && m0 + tid < d.M) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += part[q * 128 + tid];
+            if (split) ws[MN + m0 + tid] = s;
+            else d.a_rowsum[m0 + tid] = d.accumulate ? d.a_rowsum[m0 + tid] + s : s;
+        }
+    }
+}
+
 // Adds the split-K slices in slice order and applies the epilogue.  One thread per output element (coalesced along n).
 __global__ __launch_bounds__(256) void skg_gemmx_reduce_kernel(const skg_gemmx_group g) {
     int gi = 0;
@@ -288,7 +606,7 @@ extern "C" int64_t skg_gemmx_ws_floats(const skg_gemmx_desc* d) {
     return d->split_k > 1 ? (int64_t)d->split_k * ((int64_t)d->M * d->N + d->M) : 0;
 }
 
-extern "C" int skg_gemmx_f32(const skg_gemmx_desc* descs_host, int n, void* stream) {
+static int skg_gemmx_launch(const skg_gemmx_desc* descs_host, int n, void* stream, bool bf16) {
     if (!descs_host || n < 1 || n > SKG_GEMMX_GROUP_MAX) return SKG_E_ARG;
     skg_gemmx_group g, r;
     g.n = r.n = 0;
@@ -319,10 +637,19 @@ extern "C" int skg_gemmx_f32(const skg_gemmx_desc* descs_host, int n, void* stre
     }
     if (g.n == 0) return 0;
     for (int i = g.n; i <= SKG_GEMMX_GROUP_MAX; ++i) g.start[i] = (int)blocks;
-    hipLaunchKernelGGL(skg_gemmx_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    if (bf16) hipLaunchKernelGGL(skg_gemmx_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(skg_gemmx_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     if (r.n) {
         for (int i = r.n; i <= SKG_GEMMX_GROUP_MAX; ++i) r.start[i] = (int)rblocks;
         hipLaunchKernelGGL(skg_gemmx_reduce_kernel, dim3((unsigned)rblocks), dim3(256), 0, (hipStream_t)stream, r);
     }
     return skg_launch_status();
+}
+
+extern "C" int skg_gemmx_f32(const skg_gemmx_desc* descs_host, int n, void* stream) {
+    return skg_gemmx_launch(descs_host, n, stream, false);
+}
+
+extern "C" int skg_gemmx_bf16(const skg_gemmx_desc* descs_host, int n, void* stream) {
+    return skg_gemmx_launch(descs_host, n, stream, true);
 }

@@ -1,4 +1,4 @@
-"""Python face of skg_gemmx_f32 (include/skghoi.h): the free-layout fp32 MFMA GEMM of the training step.
+"""Python face of skg_gemmx_f32 / skg_gemmx_bf16 (include/skghoi.h): the free-layout MFMA GEMM of the training step.
 
     C(m, n) (+)= mask(relu(sum_k A(m, k) B(k, n) + bias[n]))
 
@@ -91,17 +91,19 @@ def weight_grad(dz, x, dW, db=None, accumulate=False, rows=None, n_out=None, k_i
     return op
 
 
-def pick_split(op, blocks_so_far=0, target=TARGET_BLOCKS):
+def pick_split(op, blocks_so_far=0, target=TARGET_BLOCKS, bk=16):
     tiles = ((op.M + 127) // 128) * ((op.N + 127) // 128)
-    kt = (op.K + 15) // 16
+    kt = (op.K + bk - 1) // bk
     if tiles == 0 or tiles >= target // 2 or kt < 8:
         return 1
     return int(max(1, min(-(-target // tiles), kt // 4, 64)))
 
 
-def launch(ops):
-    """Enqueues the products (one launch, plus one reduce launch when any of them is split along K)."""
+def launch(ops, bf16=False):
+    """Enqueues the products (one launch, plus one reduce launch when any of them is split along K).  bf16: operands
+    rounded to bf16 on the way to the matrix core (skg_gemmx_bf16), everything in memory stays fp32."""
     lib = _capi.lib()
+    fn, name, bk = (lib.skg_gemmx_bf16, "skg_gemmx_bf16", 32) if bf16 else (lib.skg_gemmx_f32, "skg_gemmx_f32", 16)
     ops = [o for o in ops if o.M > 0 and o.N > 0]
     for i0 in range(0, len(ops), _capi.GEMMX_GROUP_MAX):
         chunk = ops[i0:i0 + _capi.GEMMX_GROUP_MAX]
@@ -115,11 +117,11 @@ def launch(ops):
             d.accumulate = int(bool(o.accumulate))
             d.M, d.N, d.K, d.relu = o.M, o.N, o.K, int(bool(o.relu))
             d.bias = _p(o.bias); d.mask = _p(o.mask); d.ldmask = o.ldmask; d.a_rowsum = _p(o.a_rowsum)
-            sk = o.split_k or pick_split(o)
+            sk = o.split_k or pick_split(o, bk=bk)
             d.split_k = sk if sk > 1 else 0
             if sk > 1:
                 dev = o.keep[0].device if o.keep else torch.device("cuda")
                 ws = torch.empty(sk * (o.M * o.N + o.M), device=dev, dtype=torch.float32)
                 keep.append(ws)
                 d.split_ws = ws.data_ptr()
-        _capi.check(lib.skg_gemmx_f32(arr, len(chunk), _stream()), "skg_gemmx_f32[%d]" % len(chunk))
+        _capi.check(fn(arr, len(chunk), _stream()), "%s[%d]" % (name, len(chunk)))

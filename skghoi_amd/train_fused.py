@@ -188,6 +188,12 @@ class TrainJob:
         self.K = head.num_classes
         self.dev = pre.device
         self.S = {}
+        # precision="bf16": every dense layer of the step (forward, dX, dW) rounds its operands to bf16 on the way to
+        # the matrix core and accumulates in fp32 -- the reference under torch.autocast(bfloat16); tensors stay fp32.
+        self.bf16 = head.precision == "bf16"
+
+    def gx(self, ops):
+        gemmx.launch(ops, bf16=self.bf16)
 
     def isl(self, name):
         o, l = self.offs[name]
@@ -210,16 +216,16 @@ class TrainJob:
         bh1, bh3 = gh.box_head[1], gh.box_head[3]
         # ---- box_head (HEAD:812) and fc_1 of the global branch (HEAD:971)
         E1 = torch.empty(NA, 1024, **f32); enc = torch.empty(NA, 1024, **f32); G1 = torch.empty(Bf, 1024, **f32)
-        gemmx.launch([_lin(x0, bh1.weight, E1, bh1.bias, True)])
-        gemmx.launch([_lin(E1, bh3.weight, enc, bh3.bias, True), _lin(gfeat, W1g, G1, b1g)])
+        self.gx([_lin(x0, bh1.weight, E1, bh1.bias, True)])
+        self.gx([_lin(E1, bh3.weight, enc, bh3.bias, True), _lin(gfeat, W1g, G1, b1g)])
         S.update(E1=E1, enc=enc, G1=G1)
         # ---- spatial head (HEAD:888) on the 46-d encodings the step driver produced with the pair enumeration
         sp48 = S["sp48"]
         sp = gh.spatial_head
         s1 = torch.empty(Mg, 128, **f32); s2 = torch.empty(Mg, 256, **f32); Sp = torch.empty(Mg, 1024, **f32)
-        gemmx.launch([_lin(sp48, sp[0].weight, s1, sp[0].bias, True, K=46)])
-        gemmx.launch([_lin(s1, sp[2].weight, s2, sp[2].bias, True)])
-        gemmx.launch([_lin(s2, sp[4].weight, Sp, sp[4].bias, True)])
+        self.gx([_lin(sp48, sp[0].weight, s1, sp[0].bias, True, K=46)])
+        self.gx([_lin(s1, sp[2].weight, s2, sp[2].bias, True)])
+        self.gx([_lin(s2, sp[4].weight, Sp, sp[4].bias, True)])
         S.update(s1=s1, s2=s2, Sp=Sp)
         self.part_a_done = True
 
@@ -253,13 +259,13 @@ class TrainJob:
                                          Xhn.data_ptr(), 1088, stream), "skg_concat_entity_f32")
         GH = torch.empty(Mh, 1024, **f32); GO = torch.empty(Mn, 1024, **f32)
         fh, ft = gh.fc_head[0], gh.fc_tail[0]
-        gemmx.launch([_lin(Xhn[:Mh], fh.weight, GH, fh.bias, True, K=1074), _lin(Xhn[Mh:], ft.weight, GO, ft.bias, True, K=1074)])
+        self.gx([_lin(Xhn[:Mh], fh.weight, GH, fh.bias, True, K=1074), _lin(Xhn[Mh:], ft.weight, GO, ft.bias, True, K=1074)])
         S.update(Xhn=Xhn, GH=GH, GO=GO)
         # ---- fc_1 projections on node rows (HEAD:894-896 separable over [human | object]; HEAD:514, 524)
         A1h = torch.empty(Mh, 1024, **f32); A1o = torch.empty(Mn, 1024, **f32)
         C1o = torch.empty(Mn, 1024, **f32); C1h = torch.empty(Mh, 1024, **f32)
         Wa1 = W1[ATT]
-        gemmx.launch([_lin(GH, Wa1, A1h, K=1024), _lin(GO, Wa1[:, 1024:], A1o, K=1024),
+        self.gx([_lin(GH, Wa1, A1h, K=1024), _lin(GO, Wa1[:, 1024:], A1o, K=1024),
                       _lin(GO, W1[OS], C1o, b1[OS]), _lin(GH, W1[SO], C1h, b1[SO])])
         S.update(A1h=A1h, A1o=A1o, C1o=C1o, C1h=C1h)
         # ---- fc_2 on the grid rows with the fc_1 * fc_2 -> ReLU product in the epilogue; the raw fc_2 output is kept
@@ -270,14 +276,26 @@ class TrainJob:
         def fc2(i, out, **kw):
             gemm(Sp, W2, b2[1024 * i:1024 * i + 1024], out, Mg, 1024, 1024, _capi.EPI_MUL_RELU, W_off=1024 * 1024 * i,
                  C_raw=F[:, 1024 * i:], ldc_raw=4096, **kw)
-        fc2(ATT, T, P=A1h, p_idx=grid_h, ldp=1024, Q=A1o, q_idx=grid_o, ldq=1024, mbias=b1[ATT])
-        fc2(OS, Tos, P=C1o, p_idx=grid_o, ldp=1024)
-        fc2(SO, Tso, P=C1h, p_idx=grid_h, ldp=1024)
-        fc2(GL, Tg, P=G1, p_idx=grid_img, ldp=1024, out_rows=grid_pair)
+        def prod(P, p_idx, Q, q_idx, mbias, i, f_idx, rows, out):
+            _check(lib.skg_rows_mul_relu_f32(P.data_ptr(), p_idx.data_ptr(), 1024, _ptr(Q), _ptr(q_idx), 1024, _ptr(mbias),
+                                             F.data_ptr() + 4 * 1024 * i, _ptr(f_idx), 4096, rows, 1024, out.data_ptr(),
+                                             1024, stream), "skg_rows_mul_relu_f32")
+        if self.bf16:
+            # all four fc_2 as ONE product (N = 4096) on the bf16 matrix pipe, then the fc_1 * fc_2 -> ReLU rows
+            self.gx([_lin(Sp, W2, F, b2)])
+            prod(A1h, grid_h, A1o, grid_o, b1[ATT], ATT, None, Mg, T)
+            prod(C1o, grid_o, None, None, None, OS, None, Mg, Tos)
+            prod(C1h, grid_h, None, None, None, SO, None, Mg, Tso)
+            prod(G1, self.pair_img, None, None, None, GL, pair_grid, Mp, Tg)
+        else:
+            fc2(ATT, T, P=A1h, p_idx=grid_h, ldp=1024, Q=A1o, q_idx=grid_o, ldq=1024, mbias=b1[ATT])
+            fc2(OS, Tos, P=C1o, p_idx=grid_o, ldp=1024)
+            fc2(SO, Tso, P=C1h, p_idx=grid_h, ldp=1024)
+            fc2(GL, Tg, P=G1, p_idx=grid_img, ldp=1024, out_rows=grid_pair)
         S.update(F=F, T=T, Tos=Tos, Tso=Tso, Tg=Tg)
         # ---- attention fc_3 + ReLU, adjacency logits (HEAD:896-897)
         Wt = torch.empty(Mg, 1024, **f32)
-        gemmx.launch([_lin(T, W3[ATT], Wt, b3[ATT], True, w_blocks=blk)])
+        self.gx([_lin(T, W3[ATT], Wt, b3[ATT], True, w_blocks=blk)])
         adj_raw = torch.empty(Mg, **f32)
         wadj = gh.adjacency.weight.detach().reshape(-1)
         _check(lib.skg_rowdot_f32(Wt.data_ptr(), 1024, wadj.data_ptr(), Mg, 1024, adj_raw.data_ptr(), stream),
@@ -295,7 +313,7 @@ class TrainJob:
         S.update(Wt=Wt, U=U, V=V, alpha=alpha, beta=beta, adj=adj)
         # ---- message fc_3 + ReLU, residual, LayerNorm (HEAD:909-914, 916-925)
         M1 = torch.empty(Mh, 1024, **f32); M2 = torch.empty(Mn, 1024, **f32)
-        gemmx.launch([_lin(U, W3[OS], M1, b3[OS], True, w_blocks=blk), _lin(V, W3[SO], M2, b3[SO], True, w_blocks=blk)])
+        self.gx([_lin(U, W3[OS], M1, b3[OS], True, w_blocks=blk), _lin(V, W3[SO], M2, b3[SO], True, w_blocks=blk)])
         Hp = torch.empty(Mh, 1024, **f32); h_node = torch.empty(Mh, 1024, **f32); st_h = torch.empty(Mh, 2, **f32)
         Op = torch.empty(Mn, 1024, **f32); node = torch.empty(Mn, 1024, **f32); st_o = torch.empty(Mn, 2, **f32)
         nh, no = gh.norm_h, gh.norm_o
@@ -308,18 +326,18 @@ class TrainJob:
         S.update(M1=M1, M2=M2, Hp=Hp, Op=Op, h_node=h_node, node=node, st_h=st_h, st_o=st_o)
         # ---- read-out on the kept pairs (HEAD:966-973)
         B1h = torch.empty(Mh, 1024, **f32); B1o = torch.empty(Mn, 1024, **f32)
-        gemmx.launch([_lin(h_node, Wa1, B1h, K=1024), _lin(node, Wa1[:, 1024:], B1o, K=1024)])
+        self.gx([_lin(h_node, Wa1, B1h, K=1024), _lin(node, Wa1[:, 1024:], B1o, K=1024)])
         Tp = torch.empty(max(Mp, 1), 1024, **f32)
         _check(lib.skg_rows_mul_relu_f32(B1h.data_ptr(), pair_h.data_ptr(), 1024, B1o.data_ptr(), pair_o.data_ptr(), 1024,
                                          b1[ATT].data_ptr(), F.data_ptr(), pair_grid.data_ptr(), 4096, Mp, 1024,
                                          Tp.data_ptr(), 1024, stream), "skg_rows_mul_relu_f32")
         PF = torch.empty(max(Mp, 1), 2048, **f32)
-        gemmx.launch([_lin(Tp, W3[ATT], PF, b3[ATT], True, M=Mp, N=1024, w_blocks=blk),
+        self.gx([_lin(Tp, W3[ATT], PF, b3[ATT], True, M=Mp, N=1024, w_blocks=blk),
                       _lin(Tg, W3[GL], PF[:, 1024:], b3[GL], True, M=Mp, N=1024, w_blocks=blk)])
         # ---- classifier: predictor | suppressor as one product (HEAD:410-411)
         ld = (K + 1 + 3) // 4 * 4
         logits = torch.zeros(max(Mp, 1), ld, **f32)
-        gemmx.launch([_lin(PF, st.view(st.buf, "clsW"), logits, st.view(st.buf, "clsb"), M=Mp, N=K + 1)])
+        self.gx([_lin(PF, st.view(st.buf, "clsW"), logits, st.view(st.buf, "clsb"), M=Mp, N=K + 1)])
         S.update(B1h=B1h, B1o=B1o, Tp=Tp, PF=PF, logits=logits[:Mp])
         return S
 
@@ -368,11 +386,11 @@ class TrainJob:
         PF, Tp, Tg = S["PF"], S["Tp"], S["Tg"]
         # ---- classifier
         dPF = torch.empty(max(Mp, 1), 2048, **f32)
-        gemmx.launch([IG(dlogits, st.view(st.buf, "clsW"), dPF, mask=PF, M=Mp, N_in=2048, K_out=K + 1),
+        self.gx([IG(dlogits, st.view(st.buf, "clsW"), dPF, mask=PF, M=Mp, N_in=2048, K_out=K + 1),
                       WG(dlogits, PF, gv("clsW"), db=gv("clsb"), rows=Mp, n_out=K + 1, k_in=2048)])
         # ---- read-out fc_3 (both branches): dT = dPF W3 cut by the product's ReLU; dW3 = dPF^T T
         dTp = torch.empty(max(Mp, 1), 1024, **f32); dTg = torch.empty(max(Mp, 1), 1024, **f32)
-        gemmx.launch([IG(dPF, W3[ATT], dTp, mask=Tp, M=Mp, N_in=1024, K_out=1024, w_blocks=blk),
+        self.gx([IG(dPF, W3[ATT], dTp, mask=Tp, M=Mp, N_in=1024, K_out=1024, w_blocks=blk),
                       IG(dPF[:, 1024:], W3[GL], dTg, mask=Tg, M=Mp, N_in=1024, K_out=1024, w_blocks=blk),
                       WG(dPF, Tp, dW3[ATT], db=db3[ATT], rows=Mp, n_out=1024, k_in=1024, w_blocks=blk),
                       WG(dPF[:, 1024:], Tg, dW3[GL], db=db3[GL], rows=Mp, n_out=1024, k_in=1024, w_blocks=blk)])
@@ -399,7 +417,7 @@ class TrainJob:
         # ---- read-out fc_1 on the normalised nodes: dh_node, dnode; dW1[att] from both halves
         dh_node = torch.empty(Mh, 1024, **f32); dnode = torch.empty(Mn, 1024, **f32)
         Wa1, dWa1 = W1[ATT], dW1[ATT]
-        gemmx.launch([IG(dB1h, Wa1, dh_node, N_in=1024), IG(dB1o, Wa1[:, 1024:], dnode, N_in=1024),
+        self.gx([IG(dB1h, Wa1, dh_node, N_in=1024), IG(dB1o, Wa1[:, 1024:], dnode, N_in=1024),
                       WG(dB1h, S["h_node"], dWa1, k_in=1024), WG(dB1o, S["node"], dWa1[:, 1024:], k_in=1024)])
         # ---- LayerNorm + residual: dHp continues to the node, dHp cut by the message's ReLU goes to fc_3
         nh, no = gh.norm_h, gh.norm_o
@@ -414,7 +432,7 @@ class TrainJob:
                                          g_no[0].data_ptr(), g_no[1].data_ptr(), stream), "skg_layernorm_bwd_f32")
         # ---- message fc_3
         dU = torch.empty(Mh, 1024, **f32); dV = torch.empty(Mn, 1024, **f32)
-        gemmx.launch([IG(dHm, W3[OS], dU, N_in=1024, w_blocks=blk), IG(dOm, W3[SO], dV, N_in=1024, w_blocks=blk),
+        self.gx([IG(dHm, W3[OS], dU, N_in=1024, w_blocks=blk), IG(dOm, W3[SO], dV, N_in=1024, w_blocks=blk),
                       WG(dHm, S["U"], dW3[OS], db=db3[OS], w_blocks=blk), WG(dOm, S["V"], dW3[SO], db=db3[SO], w_blocks=blk)])
         # ---- aggregation + softmax
         dTos = torch.empty(Mg, 1024, **f32); dTso = torch.empty(Mg, 1024, **f32)
@@ -432,7 +450,7 @@ class TrainJob:
         g_adj_w = torch.empty(1, 1024, **f32); g_adj_b = torch.empty(1, **f32)
         dT = torch.empty(Mg, 1024, **f32)
         T = S["T"]
-        gemmx.launch([IG(dWt, W3[ATT], dT, mask=T, N_in=1024, w_blocks=blk),
+        self.gx([IG(dWt, W3[ATT], dT, mask=T, N_in=1024, w_blocks=blk),
                       WG(dWt, T, dW3[ATT], db=db3[ATT], accumulate=True, w_blocks=blk),
                       WG(dadj, S["Wt"], g_adj_w, db=g_adj_b)])
         # ---- in-loop fc_1 * fc_2 products
@@ -457,12 +475,12 @@ class TrainJob:
         # ---- fc_2 of all four MBFs: ONE product for the input gradient (K = 4096), one for the weights
         Sp = S["Sp"]
         dS = torch.empty(Mg, 1024, **f32)
-        gemmx.launch([IG(dF, W2, dS, mask=Sp, N_in=1024), WG(dF, Sp, gv("W2"), db=gv("b2"))])
+        self.gx([IG(dF, W2, dS, mask=Sp, N_in=1024), WG(dF, Sp, gv("W2"), db=gv("b2"))])
         # ---- fc_1 projections on node rows: gradients of the nodes accumulate on top of the residual path
         GH, GO = S["GH"], S["GO"]
-        gemmx.launch([IG(dA1h, Wa1, dHp, accumulate=True, N_in=1024), IG(dA1o, Wa1[:, 1024:], dOp, accumulate=True, N_in=1024),
+        self.gx([IG(dA1h, Wa1, dHp, accumulate=True, N_in=1024), IG(dA1o, Wa1[:, 1024:], dOp, accumulate=True, N_in=1024),
                       WG(dA1h, GH, dWa1, accumulate=True, k_in=1024), WG(dA1o, GO, dWa1[:, 1024:], accumulate=True, k_in=1024)])
-        gemmx.launch([IG(dC1h, W1[SO], dHp, mask=GH, accumulate=True), IG(dC1o, W1[OS], dOp, mask=GO, accumulate=True),
+        self.gx([IG(dC1h, W1[SO], dHp, mask=GH, accumulate=True), IG(dC1o, W1[OS], dOp, mask=GO, accumulate=True),
                       WG(dC1h, GH, dW1[SO], db=db1[SO]), WG(dC1o, GO, dW1[OS], db=db1[OS])])
         # ---- fc_head / fc_tail
         Xhn = S["Xhn"]
@@ -470,7 +488,7 @@ class TrainJob:
         dXhn = torch.empty(Mh + Mn, 1088, **f32)
         g_fh_w = torch.empty_like(fh.weight); g_fh_b = torch.empty_like(fh.bias)
         g_ft_w = torch.empty_like(ft.weight); g_ft_b = torch.empty_like(ft.bias)
-        gemmx.launch([IG(dHp, fh.weight, dXhn[:Mh], N_in=1074), IG(dOp, ft.weight, dXhn[Mh:], N_in=1074),
+        self.gx([IG(dHp, fh.weight, dXhn[:Mh], N_in=1074), IG(dOp, ft.weight, dXhn[Mh:], N_in=1074),
                       WG(dHp, Xhn[:Mh], g_fh_w, db=g_fh_b, k_in=1074), WG(dOp, Xhn[Mh:], g_ft_w, db=g_ft_b, k_in=1074)])
         d_enc = torch.empty(NA, 1024, **f32)
         _check(lib.skg_entity_rows_bwd_f32(dXhn.data_ptr(), 1088, self.hum_of.data_ptr(), self.node_of.data_ptr(), Mh, NA,
@@ -481,20 +499,20 @@ class TrainJob:
         dE1 = torch.empty(NA, 1024, **f32)
         g_bh3_w = torch.empty_like(bh3.weight); g_bh3_b = torch.empty_like(bh3.bias)
         g_bh1_w = torch.empty_like(bh1.weight); g_bh1_b = torch.empty_like(bh1.bias)
-        gemmx.launch([IG(d_enc, bh3.weight, dE1, mask=E1), WG(d_enc, E1, g_bh3_w, db=g_bh3_b)])
+        self.gx([IG(d_enc, bh3.weight, dE1, mask=E1), WG(d_enc, E1, g_bh3_w, db=g_bh3_b)])
         ops = [WG(dE1, x0, g_bh1_w, db=g_bh1_b)]
         dx0 = None
         if need_dx0:
             dx0 = torch.empty_like(x0)
             ops.append(IG(dE1, bh1.weight, dx0))
-        gemmx.launch(ops)
+        self.gx(ops)
         # ---- spatial head
         sp = gh.spatial_head
         s1, s2, sp48 = S["s1"], S["s2"], S["sp48"]
         ds2 = torch.empty(Mg, 256, **f32); ds1 = torch.empty(Mg, 128, **f32)
         g_sp = [(torch.empty_like(sp[i].weight), torch.empty_like(sp[i].bias)) for i in (0, 2, 4)]
-        gemmx.launch([IG(dS, sp[4].weight, ds2, mask=s2), WG(dS, s2, g_sp[2][0], db=g_sp[2][1])])
-        gemmx.launch([IG(ds2, sp[2].weight, ds1, mask=s1), WG(ds2, s1, g_sp[1][0], db=g_sp[1][1])])
+        self.gx([IG(dS, sp[4].weight, ds2, mask=s2), WG(dS, s2, g_sp[2][0], db=g_sp[2][1])])
+        self.gx([IG(ds2, sp[2].weight, ds1, mask=s1), WG(ds2, s1, g_sp[1][0], db=g_sp[1][1])])
         # ---- global branch fc_1 (HEAD:971) and the first spatial layer
         gfeat = S["gfeat"]
         ops = [WG(ds1, sp48, g_sp[0][0], db=g_sp[0][1], k_in=46), WG(dG1, gfeat, dW1[GL], db=db1[GL])]
@@ -502,7 +520,7 @@ class TrainJob:
         if need_dgfeat:
             dgfeat = torch.empty_like(gfeat)
             ops.append(IG(dG1, W1[GL], dgfeat))
-        gemmx.launch(ops)
+        self.gx(ops)
         # ---- the fc_3 bias of branch b is added once per row whatever b: every branch gets the MBF's bias gradient
         gv("b3").copy_(db3.unsqueeze(1).expand(4, 16, 1024))
         # ---- hand the gradients back in the order of the Function's parameter inputs
@@ -528,10 +546,11 @@ def _perm(state, n, m):
 
 
 def supported(head):
-    """The fused step covers the reference's configuration: fp32, message passing on (num_iter >= 1), plain Linear
-    predictor / suppressor.  Anything else takes the autograd path (skghoi_amd/train_graph.py)."""
+    """The fused step covers the reference's configuration -- message passing on (num_iter >= 1), plain Linear
+    predictor / suppressor -- in exact fp32 (the default) or with bf16 operands on every dense layer
+    (precision="bf16").  Anything else takes the autograd path (skghoi_amd/train_graph.py)."""
     gh = head.box_pair_head
-    return (head.precision == "fp32" and gh.num_iter > 0 and isinstance(head.box_pair_predictor, torch.nn.Linear)
+    return (head.precision in ("fp32", "bf16") and gh.num_iter > 0 and isinstance(head.box_pair_predictor, torch.nn.Linear)
             and isinstance(head.box_pair_suppressor, torch.nn.Linear)
             and head.box_pair_predictor.in_features == 2048 and head.box_pair_suppressor.in_features == 2048
             and head.box_pair_suppressor.out_features == 1 and head.box_pair_predictor.out_features == head.num_classes

@@ -1,6 +1,9 @@
-"""skg_gemmx_f32 (free operand layouts, fused backward epilogues) against float64 matmuls, through the C ABI.
-Tolerance: fp32 accumulation over K in a different order than the fp64 reference: <= 2e-6 * sqrt(K) * max|A| * max|B|
-per element would be generous; measured errors are ~1e-6 relative to the result's scale (asserted at 1e-5)."""
+"""skg_gemmx_f32 / skg_gemmx_bf16 (free operand layouts, fused backward epilogues) against float64 matmuls, through the
+C ABI.  Tolerance: fp32 accumulation over K in a different order than the fp64 reference: <= 2e-6 * sqrt(K) * max|A| *
+max|B| per element would be generous; measured errors are ~1e-6 relative to the result's scale (asserted at 1e-5).
+The bf16 entry point rounds both operands to bf16 (round to nearest even) and accumulates in fp32: its reference is
+the float64 product of the operands rounded the same way by torch, at the SAME tolerance -- bias, masks, accumulated
+values and the bias gradient are not rounded."""
 import numpy as np
 import pytest
 import torch
@@ -8,6 +11,16 @@ import torch
 from skghoi_amd import gemmx
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=[False, True], ids=["f32", "bf16"])
+def bf16(request):
+    return request.param
+
+
+def _q(t, bf16):
+    """The operand as the matrix core sees it, in float64."""
+    return (t.to(torch.bfloat16) if bf16 else t).double()
 
 
 def _rnd(*shape, seed=0):
@@ -30,97 +43,97 @@ def _blocked(W, blk=64):
 
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (37, 117, 50), (128, 128, 16), (1, 1024, 256), (513, 70, 1030)])
 @pytest.mark.parametrize("split", [0, 1, 5])
-def test_forward_layer(M, N, K, split):
+def test_forward_layer(M, N, K, split, bf16):
     x, W, b = _rnd(M, K, seed=1), _rnd(N, K, seed=2), _rnd(N, seed=3)
     out = torch.full((M, N), float("nan")).cuda()
     op = gemmx.forward(x, W, out, bias=b, relu=True)
     op.split_k = split
-    gemmx.launch([op])
-    _close(out, torch.relu(x.double() @ W.double().t() + b.double()), "forward")
+    gemmx.launch([op], bf16=bf16)
+    _close(out, torch.relu(_q(x, bf16) @ _q(W, bf16).t() + b.double()), "forward")
 
 
 @pytest.mark.parametrize("split", [0, 3])
-def test_forward_with_branch_major_weight(split):
+def test_forward_with_branch_major_weight(split, bf16):
     M, N, K = 200, 1024, 1024
     x, W, b = _rnd(M, K, seed=4), _rnd(N, K, seed=5) * 0.05, _rnd(N, seed=6)
     Wb = _blocked(W)
     out = torch.empty(M, N).cuda()
     op = gemmx.forward(x, Wb, out, bias=b, w_blocks=(6, N * 64))
     op.split_k = split
-    gemmx.launch([op])
-    _close(out, x.double() @ W.double().t() + b.double(), "forward blocked")
+    gemmx.launch([op], bf16=bf16)
+    _close(out, _q(x, bf16) @ _q(W, bf16).t() + b.double(), "forward blocked")
 
 
 @pytest.mark.parametrize("M,N_out,K_in", [(300, 256, 128), (45, 117, 2048), (130, 1024, 52)])
 @pytest.mark.parametrize("split", [0, 4])
-def test_input_grad_with_relu_mask_and_accumulate(M, N_out, K_in, split):
+def test_input_grad_with_relu_mask_and_accumulate(M, N_out, K_in, split, bf16):
     dz, W = _rnd(M, N_out, seed=7), _rnd(N_out, K_in, seed=8)
     y_prev = _rnd(M, K_in, seed=9)                      # the producing layer's output: ReLU mask source
     dx = _rnd(M, K_in, seed=10)
     before = dx.clone()
     op = gemmx.input_grad(dz, W, dx, mask=y_prev, accumulate=True)
     op.split_k = split
-    gemmx.launch([op])
-    want = (before.double() + dz.double() @ W.double()) * (y_prev > 0)      # accumulate first, mask last (see header)
+    gemmx.launch([op], bf16=bf16)
+    want = (before.double() + _q(dz, bf16) @ _q(W, bf16)) * (y_prev > 0)      # accumulate first, mask last (see header)
     _close(dx, want, "input grad")
 
 
-def test_input_grad_through_branch_major_weight():
+def test_input_grad_through_branch_major_weight(bf16):
     M, N, K = 150, 1024, 1024
     dz, W = _rnd(M, N, seed=11), _rnd(N, K, seed=12) * 0.05
     dx = torch.empty(M, K).cuda()
-    gemmx.launch([gemmx.input_grad(dz, _blocked(W), dx, w_blocks=(6, N * 64))])
-    _close(dx, dz.double() @ W.double(), "input grad blocked")
+    gemmx.launch([gemmx.input_grad(dz, _blocked(W), dx, w_blocks=(6, N * 64))], bf16=bf16)
+    _close(dx, _q(dz, bf16) @ _q(W, bf16), "input grad blocked")
 
 
 @pytest.mark.parametrize("rows,N_out,K_in", [(3200, 256, 128), (77, 117, 2048), (500, 1024, 48), (16, 64, 64)])
 @pytest.mark.parametrize("split", [0, 1, 7])
-def test_weight_and_bias_grad(rows, N_out, K_in, split):
+def test_weight_and_bias_grad(rows, N_out, K_in, split, bf16):
     dz, x = _rnd(rows, N_out, seed=13), _rnd(rows, K_in, seed=14)
     dW = torch.full((N_out, K_in), float("nan")).cuda(); db = torch.full((N_out,), float("nan")).cuda()
     op = gemmx.weight_grad(dz, x, dW, db=db)
     op.split_k = split
-    gemmx.launch([op])
-    _close(dW, dz.double().t() @ x.double(), "dW")
+    gemmx.launch([op], bf16=bf16)
+    _close(dW, _q(dz, bf16).t() @ _q(x, bf16), "dW")
     _close(db, dz.double().sum(0), "db")
     # accumulation into existing gradients (a weight used at two call sites)
     op = gemmx.weight_grad(dz, x, dW, db=db, accumulate=True)
     op.split_k = split
-    gemmx.launch([op])
-    _close(dW, 2 * (dz.double().t() @ x.double()), "dW accumulate")
+    gemmx.launch([op], bf16=bf16)
+    _close(dW, 2 * (_q(dz, bf16).t() @ _q(x, bf16)), "dW accumulate")
     _close(db, 2 * dz.double().sum(0), "db accumulate")
 
 
-def test_weight_grad_into_branch_major_storage():
+def test_weight_grad_into_branch_major_storage(bf16):
     rows, N, K = 700, 1024, 1024
     dz, x = _rnd(rows, N, seed=15), _rnd(rows, K, seed=16)
     dWb = torch.empty(16, N, 64).cuda()
-    gemmx.launch([gemmx.weight_grad(dz, x, dWb, w_blocks=(6, N * 64))])
-    want = dz.double().t() @ x.double()
+    gemmx.launch([gemmx.weight_grad(dz, x, dWb, w_blocks=(6, N * 64))], bf16=bf16)
+    want = _q(dz, bf16).t() @ _q(x, bf16)
     _close(dWb, _blocked(want.float()).double(), "dW blocked")       # same permutation of the fp64 result
 
 
-def test_grouped_launch_of_a_layers_backward():
+def test_grouped_launch_of_a_layers_backward(bf16):
     """dX and dW of one layer (different shapes and layouts) in ONE launch, strided views as operands."""
     rows, N_out, K_in = 900, 1024, 1088
     big = _rnd(rows, 2 * N_out, seed=17)
     dz = big[:, N_out:]                                  # a column view: leading dimension 2048
     x, W, y_prev = _rnd(rows, K_in, seed=18), _rnd(N_out, K_in, seed=19) * 0.05, _rnd(rows, K_in, seed=20)
     dx = torch.empty(rows, K_in).cuda(); dW = torch.empty(N_out, K_in).cuda(); db = torch.empty(N_out).cuda()
-    gemmx.launch([gemmx.input_grad(dz, W, dx, mask=y_prev), gemmx.weight_grad(dz, x, dW, db=db)])
-    _close(dx, (dz.double() @ W.double()) * (y_prev > 0), "grouped dx")
-    _close(dW, dz.double().t() @ x.double(), "grouped dW")
+    gemmx.launch([gemmx.input_grad(dz, W, dx, mask=y_prev), gemmx.weight_grad(dz, x, dW, db=db)], bf16=bf16)
+    _close(dx, (_q(dz, bf16) @ _q(W, bf16)) * (y_prev > 0), "grouped dx")
+    _close(dW, _q(dz, bf16).t() @ _q(x, bf16), "grouped dW")
     _close(db, dz.double().sum(0), "grouped db")
 
 
-def test_many_small_products_one_call():
+def test_many_small_products_one_call(bf16):
     ops, wants, outs = [], [], []
     for i in range(11):                                  # more than one group's worth: launch() cuts it into groups
         M, N, K = 20 + 7 * i, 64 + 32 * (i % 3), 1024
         x, W = _rnd(M, K, seed=30 + i), _rnd(N, K, seed=50 + i)
         out = torch.empty(M, N).cuda()
-        ops.append(gemmx.forward(x, W, out)); outs.append(out); wants.append(x.double() @ W.double().t())
-    gemmx.launch(ops)
+        ops.append(gemmx.forward(x, W, out)); outs.append(out); wants.append(_q(x, bf16) @ _q(W, bf16).t())
+    gemmx.launch(ops, bf16=bf16)
     for o, w in zip(outs, wants):
         _close(o, w, "small product")
 
@@ -138,3 +151,5 @@ def test_argument_validation():
     d.a_sk = 1; d.M = 0
     assert lib.skg_gemmx_f32(ctypes.byref(d), 1, None) == 0            # empty product: nothing launched
     assert lib.skg_gemmx_f32(ctypes.byref(d), 9, None) == -1           # more than SKG_GEMMX_GROUP_MAX
+    assert lib.skg_gemmx_bf16(None, 1, None) == -1
+    assert lib.skg_gemmx_bf16(ctypes.byref(d), 1, None) == 0

@@ -197,12 +197,14 @@ def test_training_gradients_match_oracle_autograd(fused, name):
     print("max relative gradient error %.3e over %d tensors" % (worst, len(want)))
 
 
-def test_bf16_training_tracks_fp32():
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "autograd"])
+def test_bf16_training_tracks_fp32(fused):
     """BASELINE config 3 (bf16): bf16 operands on the matrix cores, fp32 accumulation / master weights.  Losses within
-    2 % of the fp32 path, gradient direction preserved (cosine > 0.97 per large tensor, > 0.99 on average)."""
+    2 % of the fp32 path, gradient direction preserved (cosine > 0.97 per large tensor, > 0.99 on average).  Both
+    training paths: the fused step (skg_gemmx_bf16 on every dense layer) and autograd over per-layer Functions."""
     case = cases.build_case("train_tiny")
     flat32, g32 = gpu_run.run_train_with_grads(case)
-    head = gpu_run.build_head(case); head.precision = "bf16"
+    head = gpu_run.build_head(case); head.precision = "bf16"; head.fused_training = fused
     from collections import OrderedDict
     det = gpu_run.to_cuda(case["detections"]); tg = gpu_run.to_cuda(case["targets"])
     feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")

@@ -1,5 +1,5 @@
 """Developer aid (GPU box): skg_gemmx_f32 throughput on the training step's shapes (batch 4: 3200 grid rows).
-usage: gemmx_microbench.py [rows=3200]"""
+usage: gemmx_microbench.py [rows=3200] [bf16]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.dont_write_bytecode = True
@@ -7,17 +7,18 @@ import torch
 from skghoi_amd import gemmx
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 3200
+BF16 = len(sys.argv) > 2 and sys.argv[2] == "bf16"
 
 
 def bench(name, mk, flops, n=30):
     ops = mk()
     for _ in range(5):
-        gemmx.launch(ops)
+        gemmx.launch(ops, bf16=BF16)
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
-        gemmx.launch(ops)
+        gemmx.launch(ops, bf16=BF16)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     print("%-46s %8.3f ms  %7.1f TFLOP/s" % (name, ms, flops / ms / 1e9))
