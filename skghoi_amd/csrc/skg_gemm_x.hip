@@ -1,4 +1,4 @@
-// skg_gemm_x.hip -- fp32 MFMA GEMM with free operand layouts, for the TRAINING step of the interaction head.
+// skg_gemm_x.hip -- MFMA GEMM with free operand layouts, for the TRAINING step of the interaction head.
 //
 //   C(m, n) (+)= epilogue( sum_k A(m, k) * B(k, n) )
 //
@@ -14,15 +14,16 @@
 // gradient as row sums of the A operand (db = dZ^T 1).  Up to SKG_GEMMX_GROUP_MAX independent products share one
 // launch (dX and dW of a layer; the node-row GEMMs of the graph), with split-K for long contractions and small outputs.
 //
-// Design (gfx950): 128x128x16 block tile, 4 waves (2x2), each 64x64 = 2x2 v_mfma_f32_32x32x2_f32 tiles (exact fp32,
-// bit-for-bit an fmaf chain).  Both operand tiles live in LDS K-MAJOR ([16 k][128 rows], row stride 130 dwords): a
-// lane's fragment is ONE ds_read_b64 = two adjacent rows at its k (the rows a MFMA tile covers are interleaved -- the
-// tile does not care which rows it is given -- so no operand is ever transposed on its way to the matrix core).
-// Operands contiguous along their own index are copied into that image as they are (512-byte coalesced rows);
-// operands contiguous along k are loaded as 16-byte k-quads and written transposed (bank-conflict free: 130 = 2 mod 32
-// spreads the four k-quads of a row over four bank groups).  Double-buffered LDS, register prefetch of the next tile
-// across the MFMA loop, one barrier per k-tile.  The fp32 MFMA is slow enough (64 cycles per 32x32x2) that LDS and
-// VALU work hide behind it.
+// Two kernels, same descriptors and epilogue:
+//   skg_gemmx_kernel       exact fp32: v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain), 128x128x16 tiles
+//   skg_gemmx_bf16_kernel  operands rounded to bf16 on their way into LDS, fp32 accumulation on
+//                          v_mfma_f32_32x32x16_bf16, 128x128x32 tiles (precision="bf16" training)
+// Both: 4 waves (2x2), each 64x64 = 2x2 MFMA tiles; double-buffered LDS, register prefetch of the next tile across
+// the MFMA loop, one barrier per k-tile.  The operand layouts are COMPILE-TIME cases of the main loop (the workgroup
+// picks its case once, uniformly), and the loop over the k-tiles that lie fully inside the slice has no bounds checks,
+// no branches and one address addition per load -- all loads of a tile are in flight together (a loop that decides
+// per quad serialises them behind s_waitcnt and runs at a fraction of the speed).  A ragged last tile, operands
+// without 16-byte alignment and row-contiguous operands whose extent is not a multiple of 4 take the generic loop.
 #include "skg_common.h"
 
 #define XBM 128
@@ -50,108 +51,188 @@ struct XOperand {
     int rshift, kshift;          // power-of-two blocking of either index (0 = none)
     int64_t rstride, kstride;
     int rows;                    // extent of the own index (M or N)
-    bool kcontig, vec;
+    bool vec;                    // 16-byte loads allowed
 };
 
-// One thread's share of a 128 x 16 operand tile: two quads.  kcontig: quad = 4 consecutive k of one row; otherwise
-// quad = 4 consecutive rows at one k.  Out-of-range elements read as zero.
-__device__ __forceinline__ void xload(const XOperand& op, int row0, int k0, int kend, int tid, float4 (&v)[2]) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int f = tid + 256 * u;
-        float r[4] = {0.f, 0.f, 0.f, 0.f};
-        if (op.kcontig) {
-            const int row = row0 + (f >> 2), k = k0 + 4 * (f & 3);
-            if (row < op.rows && k < kend) {
-                const float* p = op.base + xoff(row, op.rshift, op.rstride, op.s_row) + xoff(k, op.kshift, op.kstride, 1);
-                if (op.vec && k + 3 < kend) {
-                    const float4 t = *reinterpret_cast<const float4*>(p);
-                    r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) if (k + c < kend) r[c] = p[c];
-                }
-            }
-        } else {
-            const int k = k0 + (f >> 5), row = row0 + 4 * (f & 31);
-            if (k < kend && row < op.rows) {
-                const float* p = op.base + xoff(k, op.kshift, op.kstride, op.s_k) + xoff(row, op.rshift, op.rstride, 1);
-                if (op.vec && row + 3 < op.rows) {
-                    const float4 t = *reinterpret_cast<const float4*>(p);
-                    r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) if (row + c < op.rows) r[c] = p[c];
-                }
-            }
-        }
-        v[u] = make_float4(r[0], r[1], r[2], r[3]);
-    }
-}
-
-// Loop-invariant part of one thread's loads of one operand: the addresses along the operand's own index are formed
-// once, the main loop adds one k offset per tile and skips every bounds check on tiles that lie inside the slice
-// ("fast" tiles: all but possibly the last).  Quads that straddle the end of the operand take the generic path.
+// Loop-invariant part of one thread's loads of one operand (fast tiles).  Addresses along the operand's own index are
+// formed once; rows outside the operand are clamped to a valid row and their values zeroed after the load.
 struct XLane {
     const float* p0; const float* p1; const float* p2; const float* p3;
     int ok;              // bit u: quad u lies inside the operand along its own index
-    int straddle;        // row-contiguous quad crossing the operand's end
     int kloc;
 };
 
-__device__ __forceinline__ float4 xld4(const float* p, bool ok) {
-    return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+struct XQ2 { float4 a, b; };
+
+__device__ __forceinline__ float4 xzero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 xsel(bool ok, float4 v) { return ok ? v : xzero4(); }
+__device__ __forceinline__ float4 xld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// Four consecutive elements along the contiguous index c (extent cend); zero outside.
+__device__ __forceinline__ float4 xquad(const float* p, int c, int cend, bool vec) {
+    float4 t = xzero4();
+    if (vec && c + 3 < cend) {
+        t = xld4(p);
+    } else {
+        if (c < cend) t.x = p[0];
+        if (c + 1 < cend) t.y = p[1];
+        if (c + 2 < cend) t.z = p[2];
+        if (c + 3 < cend) t.w = p[3];
+    }
+    return t;
 }
 
+// Generic quad: KC -- 4 consecutive k of `row`; otherwise 4 consecutive rows at `k`.  Every bound checked.
+template <bool KC>
+__device__ __forceinline__ float4 xgen(const XOperand& op, int row, int k, int kend) {
+    if (row >= op.rows || k >= kend) return xzero4();
+    if (KC)
+        return xquad(op.base + xoff(row, op.rshift, op.rstride, op.s_row) + xoff(k, op.kshift, op.kstride, 1), k, kend,
+                     op.vec);
+    return xquad(op.base + xoff(k, op.kshift, op.kstride, op.s_k) + xoff(row, op.rshift, op.rstride, 1), row, op.rows,
+                 op.vec);
+}
+
+// An operand may take the fast loop from row0 when 16-byte loads are allowed and no row-contiguous quad straddles its end.
+template <bool KC>
+__device__ __forceinline__ bool xfast_ok(const XOperand& op, int row0) {
+    return op.vec && (KC || (op.rows & 3) == 0 || row0 + 128 <= op.rows);
+}
+
+// ================================================================================================ exact fp32
+// Operand tiles live in LDS K-MAJOR ([16 k][128 rows], row stride 130 dwords): a lane's fragment is ONE ds_read_b64 =
+// two adjacent rows at its k (the rows a MFMA tile covers are interleaved -- the tile does not care which rows it is
+// given -- so no operand is ever transposed on its way to the matrix core).  Operands contiguous along their own index
+// are copied into that image as they are (512-byte coalesced rows); operands contiguous along k are loaded as 16-byte
+// k-quads and written transposed (130 = 2 mod 32 spreads the four k-quads of a row over four bank groups).
+//   thread -> quads of a 128 x 16 tile:   KC : quad u = k0 + 4 (tid & 3) .. +3 of row (tid >> 2) + 64 u
+//                                          RC : quad u = rows 4 (tid & 31) .. +3 at k = k0 + (tid >> 5) + 8 u
+template <bool KC>
 __device__ __forceinline__ void xprep(const XOperand& op, int row0, int tid, XLane& L) {
-    L.p1 = L.p2 = L.p3 = nullptr;
-    if (op.kcontig) {
-        const int r = row0 + (tid >> 2);
+    L.p2 = L.p3 = nullptr;
+    if (KC) {
+        const int r = row0 + (tid >> 2), last = op.rows - 1;
         L.kloc = 4 * (tid & 3);
-        L.p0 = op.base + xoff(r, op.rshift, op.rstride, op.s_row);
-        L.p1 = op.base + xoff(r + 64, op.rshift, op.rstride, op.s_row);
+        L.p0 = op.base + xoff(min(r, last), op.rshift, op.rstride, op.s_row);
+        L.p1 = op.base + xoff(min(r + 64, last), op.rshift, op.rstride, op.s_row);
         L.ok = (r < op.rows ? 1 : 0) | (r + 64 < op.rows ? 2 : 0);
-        L.straddle = 0;
     } else {
         const int row = row0 + 4 * (tid & 31);
         L.kloc = tid >> 5;
-        L.p0 = op.base + xoff(row, op.rshift, op.rstride, 1);
+        L.p0 = op.base + xoff(max(0, min(row, op.rows - 4)), op.rshift, op.rstride, 1);
+        L.p1 = nullptr;
         L.ok = row + 3 < op.rows ? 3 : 0;
-        L.straddle = row < op.rows && row + 3 >= op.rows;
     }
 }
 
-// one 128 x 16 tile at k0 (fast when it lies inside [.., kend) and 16-byte loads are allowed)
-__device__ __forceinline__ void xtile(const XOperand& op, const XLane& L, int row0, int k0, int kend, int tid,
-                                      float4 (&v)[2]) {
-    if (op.vec && k0 + XBK <= kend && !L.straddle) {
-        if (op.kcontig) {
+template <bool KC, bool FAST>
+__device__ __forceinline__ XQ2 xtile(const XOperand& op, const XLane& L, int row0, int k0, int kend, int tid) {
+    XQ2 v;
+    if (FAST) {
+        if (KC) {
             const int64_t ko = xoff(k0 + L.kloc, op.kshift, op.kstride, 1);
-            v[0] = xld4(L.p0 + ko, L.ok & 1);
-            v[1] = xld4(L.p1 + ko, L.ok & 2);
+            v.a = xld4(L.p0 + ko); v.b = xld4(L.p1 + ko);
         } else {
-            v[0] = xld4(L.p0 + xoff(k0 + L.kloc, op.kshift, op.kstride, op.s_k), L.ok & 1);
-            v[1] = xld4(L.p0 + xoff(k0 + L.kloc + 8, op.kshift, op.kstride, op.s_k), L.ok & 2);
+            v.a = xld4(L.p0 + xoff(k0 + L.kloc, op.kshift, op.kstride, op.s_k));
+            v.b = xld4(L.p0 + xoff(k0 + L.kloc + 8, op.kshift, op.kstride, op.s_k));
         }
+    } else if (KC) {
+        v.a = xgen<true>(op, row0 + (tid >> 2), k0 + 4 * (tid & 3), kend);
+        v.b = xgen<true>(op, row0 + (tid >> 2) + 64, k0 + 4 * (tid & 3), kend);
     } else {
-        xload(op, row0, k0, kend, tid, v);
+        v.a = xgen<false>(op, row0 + 4 * (tid & 31), k0 + (tid >> 5), kend);
+        v.b = xgen<false>(op, row0 + 4 * (tid & 31), k0 + (tid >> 5) + 8, kend);
+    }
+    return v;
+}
+
+__device__ __forceinline__ void xmask2(int ok, XQ2& v) { v.a = xsel(ok & 1, v.a); v.b = xsel(ok & 2, v.b); }
+
+template <bool KC>
+__device__ __forceinline__ void xstore_lds(float* tile, int tid, const XQ2& v) {
+    if (KC) {
+        float* p = tile + (4 * (tid & 3)) * XLD + (tid >> 2);
+        p[0] = v.a.x; p[XLD] = v.a.y; p[2 * XLD] = v.a.z; p[3 * XLD] = v.a.w;
+        p += 64;
+        p[0] = v.b.x; p[XLD] = v.b.y; p[2 * XLD] = v.b.z; p[3 * XLD] = v.b.w;
+    } else {
+        float2* p = reinterpret_cast<float2*>(tile + (tid >> 5) * XLD + 4 * (tid & 31));
+        p[0] = make_float2(v.a.x, v.a.y); p[1] = make_float2(v.a.z, v.a.w);
+        p = reinterpret_cast<float2*>(tile + ((tid >> 5) + 8) * XLD + 4 * (tid & 31));
+        p[0] = make_float2(v.b.x, v.b.y); p[1] = make_float2(v.b.z, v.b.w);
     }
 }
 
-__device__ __forceinline__ void xstore_lds(float* tile, bool kcontig, int tid, const float4 (&v)[2]) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int f = tid + 256 * u;
-        if (kcontig) {
-            const int r = f >> 2, kq = f & 3;
-            float* p = tile + (4 * kq) * XLD + r;
-            p[0] = v[u].x; p[XLD] = v[u].y; p[2 * XLD] = v[u].z; p[3 * XLD] = v[u].w;
-        } else {
-            const int kk = f >> 5, rq = f & 31;
-            float2* p = reinterpret_cast<float2*>(tile + kk * XLD + 4 * rq);
-            p[0] = make_float2(v[u].x, v[u].y); p[1] = make_float2(v[u].z, v[u].w);
+struct XCtx {
+    int m0, n0, kend, tid, wm, wn, li, lk;
+    bool do_rowsum;
+};
+
+// k-tiles [ka, kb) of one workgroup.  `par` = LDS buffer the first tile goes to (flips per tile).
+template <bool AK, bool BK_, bool FAST>
+__device__ __forceinline__ void xrun(const XOperand& A, const XOperand& B, const XLane& LA, const XLane& LB, const XCtx& c,
+                                     int ka, int kb, int& par, float* smem, f32x16 (&acc)[2][2], float& rsum) {
+    if (ka >= kb) return;
+    const int tid = c.tid;
+    XQ2 va = xtile<AK, FAST>(A, LA, c.m0, ka * XBK, c.kend, tid);
+    XQ2 vb = xtile<BK_, FAST>(B, LB, c.n0, ka * XBK, c.kend, tid);
+    if (FAST) { xmask2(LA.ok, va); xmask2(LB.ok, vb); }
+    xstore_lds<AK>(smem + par * 2 * XTILE, tid, va);
+    xstore_lds<BK_>(smem + par * 2 * XTILE + XTILE, tid, vb);
+    __syncthreads();
+    for (int kt = ka; kt < kb; ++kt) {
+        const float* As = smem + par * 2 * XTILE;
+        const float* Bs = As + XTILE;
+        const bool more = kt + 1 < kb;
+        if (more) {
+            va = xtile<AK, FAST>(A, LA, c.m0, (kt + 1) * XBK, c.kend, tid);
+            vb = xtile<BK_, FAST>(B, LB, c.n0, (kt + 1) * XBK, c.kend, tid);
         }
+#pragma unroll
+        for (int ks = 0; ks < XBK / 2; ++ks) {
+            const int kk = 2 * ks + c.lk;
+            const float2 a = *reinterpret_cast<const float2*>(As + kk * XLD + c.wm * 64 + 2 * c.li);
+            const float2 bq = *reinterpret_cast<const float2*>(Bs + kk * XLD + c.wn * 64 + 2 * c.li);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.y, acc[1][1], 0, 0, 0);
+        }
+        if (c.do_rowsum && tid < XBM) {
+#pragma unroll
+            for (int kk = 0; kk < XBK; ++kk) rsum += As[kk * XLD + tid];
+        }
+        if (more) {
+            float* An = smem + (par ^ 1) * 2 * XTILE;
+            // rows outside the operand were loaded from a clamped address: zeroed here, AFTER the MFMAs, so that the
+            // loads stay in flight across them (a select right behind the load makes the wave wait for it first)
+            if (FAST) { xmask2(LA.ok, va); xmask2(LB.ok, vb); }
+            xstore_lds<AK>(An, tid, va);
+            xstore_lds<BK_>(An + XTILE, tid, vb);
+        }
+        __syncthreads();
+        par ^= 1;
     }
+}
+
+template <bool AK, bool BK_>
+__device__ __forceinline__ void xmain(const XOperand& A, const XOperand& B, const XCtx& c, int kt0, int kt1, float* smem,
+                                      f32x16 (&acc)[2][2], float& rsum) {
+    XLane LA, LB;
+    xprep<AK>(A, c.m0, c.tid, LA);
+    xprep<BK_>(B, c.n0, c.tid, LB);
+    int ktf = kt0;                                         // [kt0, ktf): tiles inside the slice, fast loop
+    if (xfast_ok<AK>(A, c.m0) && xfast_ok<BK_>(B, c.n0) && kt1 > kt0) ktf = (c.kend == kt1 * XBK) ? kt1 : kt1 - 1;
+    int par = 0;
+    xrun<AK, BK_, true>(A, B, LA, LB, c, kt0, ktf, par, smem, acc, rsum);
+    xrun<AK, BK_, false>(A, B, LA, LB, c, ktf, kt1, par, smem, acc, rsum);
+}
+
+__device__ __forceinline__ void xoperands(const skg_gemmx_desc& d, int vecbits, XOperand& A, XOperand& B) {
+    A.base = d.A; A.s_row = d.a_sm; A.s_k = d.a_sk; A.rshift = 0; A.kshift = 0; A.rstride = 0; A.kstride = 0;
+    A.rows = d.M; A.vec = vecbits & 1;
+    B.base = d.B; B.s_row = d.b_sn; B.s_k = d.b_sk; B.rshift = d.b_nshift; B.kshift = d.b_kshift;
+    B.rstride = d.b_nstride; B.kstride = d.b_kstride; B.rows = d.N; B.vec = (vecbits >> 1) & 1;
 }
 
 __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group g) {
@@ -164,26 +245,23 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
     const int vecbits = g.vec[gi];
     const int S = d.split_k > 1 ? d.split_k : 1;
     const int nbn = (d.N + XBN - 1) / XBN;
-    const int nbm = (d.M + XBM - 1) / XBM;
     int b = blockIdx.x - g.start[gi];
     const int slice = b % S; b /= S;
     const int tn = b % nbn, tm = b / nbn;                 // consecutive blocks walk N: they share the A panel in L2
-    const int m0 = tm * XBM, n0 = tn * XBN;
     // k range of this slice, in whole k-tiles
     const int nkt = (d.K + XBK - 1) / XBK;
     const int per = (nkt + S - 1) / S;
     const int kt0 = slice * per, kt1 = min(nkt, kt0 + per);
-    const int kend = min(d.K, kt1 * XBK);
 
     XOperand A, B;
-    A.base = d.A; A.s_row = d.a_sm; A.s_k = d.a_sk; A.rshift = 0; A.kshift = 0; A.rstride = 0; A.kstride = 0;
-    A.rows = d.M; A.kcontig = d.a_sk == 1; A.vec = vecbits & 1;
-    B.base = d.B; B.s_row = d.b_sn; B.s_k = d.b_sk; B.rshift = d.b_nshift; B.kshift = d.b_kshift;
-    B.rstride = d.b_nstride; B.kstride = d.b_kstride; B.rows = d.N; B.kcontig = d.b_sk == 1; B.vec = (vecbits >> 1) & 1;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int li = lane & 31, lk = lane >> 5;
+    xoperands(d, vecbits, A, B);
+    XCtx c;
+    c.m0 = tm * XBM; c.n0 = tn * XBN; c.kend = min(d.K, kt1 * XBK);
+    c.tid = threadIdx.x;
+    const int lane = c.tid & 63, wave = c.tid >> 6;
+    c.wm = wave >> 1; c.wn = wave & 1; c.li = lane & 31; c.lk = lane >> 5;
+    c.do_rowsum = d.a_rowsum != nullptr && tn == 0;
+    const int m0 = c.m0, n0 = c.n0, tid = c.tid, wm = c.wm, wn = c.wn, li = c.li, lk = c.lk;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -192,49 +270,13 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    const bool do_rowsum = d.a_rowsum != nullptr && tn == 0 && tid < XBM;
     float rsum = 0.f;
-
-    XLane LA, LB;
-    xprep(A, m0, tid, LA);
-    xprep(B, n0, tid, LB);
-    float4 va[2], vb[2];
-    if (kt0 < kt1) {
-        xtile(A, LA, m0, kt0 * XBK, kend, tid, va);
-        xtile(B, LB, n0, kt0 * XBK, kend, tid, vb);
-        xstore_lds(smem, A.kcontig, tid, va);
-        xstore_lds(smem + XTILE, B.kcontig, tid, vb);
-    }
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        const float* As = smem + cur * 2 * XTILE;
-        const float* Bs = As + XTILE;
-        const bool more = kt + 1 < kt1;
-        if (more) {
-            xtile(A, LA, m0, (kt + 1) * XBK, kend, tid, va);
-            xtile(B, LB, n0, (kt + 1) * XBK, kend, tid, vb);
-        }
-#pragma unroll
-        for (int ks = 0; ks < XBK / 2; ++ks) {
-            const int kk = 2 * ks + lk;
-            const float2 a = *reinterpret_cast<const float2*>(As + kk * XLD + wm * 64 + 2 * li);
-            const float2 bq = *reinterpret_cast<const float2*>(Bs + kk * XLD + wn * 64 + 2 * li);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.y, acc[1][1], 0, 0, 0);
-        }
-        if (do_rowsum) {
-#pragma unroll
-            for (int kk = 0; kk < XBK; ++kk) rsum += As[kk * XLD + tid];
-        }
-        if (more) {
-            float* An = smem + (cur ^ 1) * 2 * XTILE;
-            xstore_lds(An, A.kcontig, tid, va);
-            xstore_lds(An + XTILE, B.kcontig, tid, vb);
-        }
-        __syncthreads();
+    if (d.a_sk == 1) {
+        if (d.b_sk == 1) xmain<true, true>(A, B, c, kt0, kt1, smem, acc, rsum);
+        else xmain<true, false>(A, B, c, kt0, kt1, smem, acc, rsum);
+    } else {
+        if (d.b_sk == 1) xmain<false, true>(A, B, c, kt0, kt1, smem, acc, rsum);
+        else xmain<false, false>(A, B, c, kt0, kt1, smem, acc, rsum);
     }
 
     // ---- epilogue.  Lane (li, lk) of wave (wm, wn) holds, in acc[mb][nb][4*gq + t], the element
@@ -285,23 +327,26 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
                     }
                 }
             }
-    if (do_rowsum && m0 + tid < d.M) {
+    if (c.do_rowsum && tid < XBM && m0 + tid < d.M) {
         if (split) ws[MN + m0 + tid] = rsum;
         else d.a_rowsum[m0 + tid] = d.accumulate ? d.a_rowsum[m0 + tid] + rsum : rsum;
     }
 }
 
-// ------------------------------------------------------------------------------------------------ bf16 operands
+// ================================================================================================ bf16 operands
 // Same products, same descriptors, same epilogue; the operands stay fp32 in HBM and are rounded to bf16 (RNE,
 // v_cvt_pk_bf16_f32) on their way into LDS, accumulation in fp32 on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).
 // This is what precision="bf16" training runs (BASELINE config 3: autocast of the reference's nn.Linear layers).
 //
-// 128x128x32 block tile, 4 waves (2x2) x (2x2) MFMA tiles.  LDS image of an operand tile: four k-planes (8 k each) of
-// [128 rows][8 bf16 = 16 B], plane stride 520 dwords, row slot XOR-swizzled (slot = row ^ ((row >> 3) & 3)): a lane's
-// MFMA fragment is ONE ds_read_b128, conflict-free, and both source layouts are written conflict-free too --
-//   k-contiguous source : a thread has 4 k of one row        -> one ds_write_b64
+// 128x128x32 block tile.  LDS image of an operand tile: four k-planes (8 k each) of [128 rows][8 bf16 = 16 B], plane
+// stride 520 dwords, row slot XOR-swizzled (slot = row ^ ((row >> 3) & 3)): a lane's MFMA fragment is ONE
+// ds_read_b128, conflict-free, and both source layouts are written conflict-free too --
+//   k-contiguous source  : a thread has 4 k of one row        -> one ds_write_b64
 //   row-contiguous source: a thread loads 4 rows x 4 k (four float4 along the rows), transposes in registers
-//                                                             -> four ds_write_b64 (one per row)
+//                                                              -> four ds_write_b64 (one per row)
+//   thread -> quads of a 128 x 32 tile:   KC : quad u = k0 + 4 (tid & 7) .. +3 of row (tid >> 3) + 32 u
+//                                          RC : quad u = rows 4 rq .. +3 at k = k0 + 4 kq4 + u,
+//                                               rq = (tid & 7) | ((tid >> 4) & 3) << 3,  kq4 = ((tid >> 3) & 1) | (tid >> 6) << 1
 // The bias gradient (row sums of A) is accumulated from the fp32 registers before rounding.
 #define YBK 32
 #define YPLANE 1040                          // bf16 elements per k-plane: 128 rows * 8 + 16 pad (520 dwords)
@@ -316,98 +361,157 @@ __device__ __forceinline__ uint32_t ypack(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, xbf2));
 }
 __device__ __forceinline__ int yslot(int row) { return row ^ ((row >> 3) & 3); }
+__device__ __forceinline__ int yrq(int tid) { return (tid & 7) | (((tid >> 4) & 3) << 3); }
+__device__ __forceinline__ int ykq4(int tid) { return ((tid >> 3) & 1) | ((tid >> 6) << 1); }
 
-// Four consecutive elements along the contiguous index `c` (extent cend) at fixed other index; zero outside.
-__device__ __forceinline__ float4 yquad(const float* p, int c, int cend, bool vec) {
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (vec && c + 3 < cend) {
-        t = *reinterpret_cast<const float4*>(p);
-    } else {
-        if (c < cend) t.x = p[0];
-        if (c + 1 < cend) t.y = p[1];
-        if (c + 2 < cend) t.z = p[2];
-        if (c + 3 < cend) t.w = p[3];
-    }
-    return t;
-}
-
-// One thread's share of a 128 x 32 operand tile: four quads (generic path: every bound checked).
-//   kcontig : quad u = 4 consecutive k (k0 + 4 (tid & 7)) of row (tid >> 3) + 32 u
-//   else    : quad u = rows 4 rq .. 4 rq + 3 at k = k0 + 4 kq4 + u,  rq = (tid & 7) | ((tid >> 4) & 3) << 3,
-//             kq4 = ((tid >> 3) & 1) | (tid >> 6) << 1
-__device__ __forceinline__ float4 yload1(const XOperand& op, int row0, int k0, int kend, int tid, int u) {
-    if (op.kcontig) {
-        const int row = row0 + (tid >> 3) + 32 * u, k = k0 + 4 * (tid & 7);
-        if (row >= op.rows || k >= kend) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return yquad(op.base + xoff(row, op.rshift, op.rstride, op.s_row) + xoff(k, op.kshift, op.kstride, 1), k, kend, op.vec);
-    }
-    const int rq = (tid & 7) | (((tid >> 4) & 3) << 3), kq4 = ((tid >> 3) & 1) | ((tid >> 6) << 1);
-    const int k = k0 + 4 * kq4 + u, row = row0 + 4 * rq;
-    if (k >= kend || row >= op.rows) return make_float4(0.f, 0.f, 0.f, 0.f);
-    return yquad(op.base + xoff(k, op.kshift, op.kstride, op.s_k) + xoff(row, op.rshift, op.rstride, 1), row, op.rows, op.vec);
-}
-
-#define YLOAD(op, row0, k0, v)                                                                            \
-    do {                                                                                                  \
-        v##0 = yload1(op, row0, k0, kend, tid, 0); v##1 = yload1(op, row0, k0, kend, tid, 1);            \
-        v##2 = yload1(op, row0, k0, kend, tid, 2); v##3 = yload1(op, row0, k0, kend, tid, 3);            \
-    } while (0)
-
+template <bool KC>
 __device__ __forceinline__ void yprep(const XOperand& op, int row0, int tid, XLane& L) {
-    L.p1 = L.p2 = L.p3 = nullptr;
-    if (op.kcontig) {
-        const int r = row0 + (tid >> 3);
+    if (KC) {
+        const int r = row0 + (tid >> 3), last = op.rows - 1;
         L.kloc = 4 * (tid & 7);
-        L.p0 = op.base + xoff(r, op.rshift, op.rstride, op.s_row);
-        L.p1 = op.base + xoff(r + 32, op.rshift, op.rstride, op.s_row);
-        L.p2 = op.base + xoff(r + 64, op.rshift, op.rstride, op.s_row);
-        L.p3 = op.base + xoff(r + 96, op.rshift, op.rstride, op.s_row);
+        L.p0 = op.base + xoff(min(r, last), op.rshift, op.rstride, op.s_row);
+        L.p1 = op.base + xoff(min(r + 32, last), op.rshift, op.rstride, op.s_row);
+        L.p2 = op.base + xoff(min(r + 64, last), op.rshift, op.rstride, op.s_row);
+        L.p3 = op.base + xoff(min(r + 96, last), op.rshift, op.rstride, op.s_row);
         L.ok = (r < op.rows ? 1 : 0) | (r + 32 < op.rows ? 2 : 0) | (r + 64 < op.rows ? 4 : 0) | (r + 96 < op.rows ? 8 : 0);
-        L.straddle = 0;
     } else {
-        const int rq = (tid & 7) | (((tid >> 4) & 3) << 3), kq4 = ((tid >> 3) & 1) | ((tid >> 6) << 1);
-        const int row = row0 + 4 * rq;
-        L.kloc = 4 * kq4;
-        L.p0 = op.base + xoff(row, op.rshift, op.rstride, 1);
+        const int row = row0 + 4 * yrq(tid);
+        L.kloc = 4 * ykq4(tid);
+        L.p0 = op.base + xoff(max(0, min(row, op.rows - 4)), op.rshift, op.rstride, 1);
+        L.p1 = L.p2 = L.p3 = nullptr;
         L.ok = row + 3 < op.rows ? 15 : 0;
-        L.straddle = row < op.rows && row + 3 >= op.rows;
     }
 }
 
-// one 128 x 32 tile at k0.  Fast tiles: one k offset per thread (a 4-aligned group of k never crosses a k block).
-#define YTILE_LOAD(op, L, row0, k0, v)                                                                    \
-    do {                                                                                                  \
-        if (op.vec && (k0) + YBK <= kend && !L.straddle) {                                                \
-            if (op.kcontig) {                                                                             \
-                const int64_t ko_ = xoff((k0) + L.kloc, op.kshift, op.kstride, 1);                        \
-                v##0 = xld4(L.p0 + ko_, L.ok & 1); v##1 = xld4(L.p1 + ko_, L.ok & 2);                     \
-                v##2 = xld4(L.p2 + ko_, L.ok & 4); v##3 = xld4(L.p3 + ko_, L.ok & 8);                     \
-            } else {                                                                                      \
-                const float* q_ = L.p0 + xoff((k0) + L.kloc, op.kshift, op.kstride, op.s_k);             \
-                v##0 = xld4(q_, L.ok & 1); v##1 = xld4(q_ + op.s_k, L.ok & 2);                            \
-                v##2 = xld4(q_ + 2 * op.s_k, L.ok & 4); v##3 = xld4(q_ + 3 * op.s_k, L.ok & 8);           \
-            }                                                                                             \
-        } else {                                                                                          \
-            YLOAD(op, row0, k0, v);                                                                       \
-        }                                                                                                 \
-    } while (0)
+template <bool KC, bool FAST>
+__device__ __forceinline__ void ytile(const XOperand& op, const XLane& L, int row0, int k0, int kend, int tid, float4& va,
+                                      float4& vb, float4& vc, float4& vd) {
+    if (FAST) {
+        if (KC) {
+            const int64_t ko = xoff(k0 + L.kloc, op.kshift, op.kstride, 1);
+            va = xld4(L.p0 + ko); vb = xld4(L.p1 + ko); vc = xld4(L.p2 + ko); vd = xld4(L.p3 + ko);
+        } else {                                           // a 4-aligned group of k never crosses a k block
+            const float* q = L.p0 + xoff(k0 + L.kloc, op.kshift, op.kstride, op.s_k);
+            va = xld4(q); vb = xld4(q + op.s_k); vc = xld4(q + 2 * op.s_k); vd = xld4(q + 3 * op.s_k);
+        }
+    } else if (KC) {
+        const int r = row0 + (tid >> 3), k = k0 + 4 * (tid & 7);
+        va = xgen<true>(op, r, k, kend); vb = xgen<true>(op, r + 32, k, kend);
+        vc = xgen<true>(op, r + 64, k, kend); vd = xgen<true>(op, r + 96, k, kend);
+    } else {
+        const int row = row0 + 4 * yrq(tid), k = k0 + 4 * ykq4(tid);
+        va = xgen<false>(op, row, k, kend); vb = xgen<false>(op, row, k + 1, kend);
+        vc = xgen<false>(op, row, k + 2, kend); vd = xgen<false>(op, row, k + 3, kend);
+    }
+}
 
-__device__ __forceinline__ void ystore_lds(uint16_t* tile, bool kcontig, int tid, float4 v0, float4 v1, float4 v2, float4 v3) {
-    if (kcontig) {
+__device__ __forceinline__ void ymask4(int ok, float4& a, float4& b, float4& c, float4& d) {
+    a = xsel(ok & 1, a); b = xsel(ok & 2, b); c = xsel(ok & 4, c); d = xsel(ok & 8, d);
+}
+
+template <bool KC>
+__device__ __forceinline__ void ystore_lds(uint16_t* tile, int tid, float4 va, float4 vb, float4 vc, float4 vd) {
+    if (KC) {
         const int kq4 = tid & 7, r = tid >> 3;
         uint16_t* base = tile + (kq4 >> 1) * YPLANE + (kq4 & 1) * 4;
-        *reinterpret_cast<uint2*>(base + yslot(r) * 8) = make_uint2(ypack(v0.x, v0.y), ypack(v0.z, v0.w));
-        *reinterpret_cast<uint2*>(base + yslot(r + 32) * 8) = make_uint2(ypack(v1.x, v1.y), ypack(v1.z, v1.w));
-        *reinterpret_cast<uint2*>(base + yslot(r + 64) * 8) = make_uint2(ypack(v2.x, v2.y), ypack(v2.z, v2.w));
-        *reinterpret_cast<uint2*>(base + yslot(r + 96) * 8) = make_uint2(ypack(v3.x, v3.y), ypack(v3.z, v3.w));
+        *reinterpret_cast<uint2*>(base + yslot(r) * 8) = make_uint2(ypack(va.x, va.y), ypack(va.z, va.w));
+        *reinterpret_cast<uint2*>(base + yslot(r + 32) * 8) = make_uint2(ypack(vb.x, vb.y), ypack(vb.z, vb.w));
+        *reinterpret_cast<uint2*>(base + yslot(r + 64) * 8) = make_uint2(ypack(vc.x, vc.y), ypack(vc.z, vc.w));
+        *reinterpret_cast<uint2*>(base + yslot(r + 96) * 8) = make_uint2(ypack(vd.x, vd.y), ypack(vd.z, vd.w));
     } else {
-        const int rq = (tid & 7) | (((tid >> 4) & 3) << 3), kq4 = ((tid >> 3) & 1) | ((tid >> 6) << 1);
+        const int kq4 = ykq4(tid), row = 4 * yrq(tid);
         uint16_t* base = tile + (kq4 >> 1) * YPLANE + (kq4 & 1) * 4;
-        const int row = 4 * rq;
-        *reinterpret_cast<uint2*>(base + yslot(row + 0) * 8) = make_uint2(ypack(v0.x, v1.x), ypack(v2.x, v3.x));
-        *reinterpret_cast<uint2*>(base + yslot(row + 1) * 8) = make_uint2(ypack(v0.y, v1.y), ypack(v2.y, v3.y));
-        *reinterpret_cast<uint2*>(base + yslot(row + 2) * 8) = make_uint2(ypack(v0.z, v1.z), ypack(v2.z, v3.z));
-        *reinterpret_cast<uint2*>(base + yslot(row + 3) * 8) = make_uint2(ypack(v0.w, v1.w), ypack(v2.w, v3.w));
+        *reinterpret_cast<uint2*>(base + yslot(row + 0) * 8) = make_uint2(ypack(va.x, vb.x), ypack(vc.x, vd.x));
+        *reinterpret_cast<uint2*>(base + yslot(row + 1) * 8) = make_uint2(ypack(va.y, vb.y), ypack(vc.y, vd.y));
+        *reinterpret_cast<uint2*>(base + yslot(row + 2) * 8) = make_uint2(ypack(va.z, vb.z), ypack(vc.z, vd.z));
+        *reinterpret_cast<uint2*>(base + yslot(row + 3) * 8) = make_uint2(ypack(va.w, vb.w), ypack(vc.w, vd.w));
+    }
+}
+
+// fp32 row sums of the thread's share of an A tile (before rounding)
+template <bool KC>
+__device__ __forceinline__ void yrowsum(float4 va, float4 vb, float4 vc, float4 vd, float4& rs) {
+    if (KC) {
+        rs.x += (va.x + va.y) + (va.z + va.w); rs.y += (vb.x + vb.y) + (vb.z + vb.w);
+        rs.z += (vc.x + vc.y) + (vc.z + vc.w); rs.w += (vd.x + vd.y) + (vd.z + vd.w);
+    } else {
+        rs.x += (va.x + vb.x) + (vc.x + vd.x); rs.y += (va.y + vb.y) + (vc.y + vd.y);
+        rs.z += (va.z + vb.z) + (vc.z + vd.z); rs.w += (va.w + vb.w) + (vc.w + vd.w);
+    }
+}
+
+template <bool AK, bool BK_, bool FAST>
+__device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const XLane& LA, const XLane& LB, const XCtx& c,
+                                     int ka, int kb, int& par, uint16_t* smem, f32x16 (&acc)[2][2], float4& rs) {
+    if (ka >= kb) return;
+    const int tid = c.tid;
+    // fragment addresses (bf16 elements) inside a tile; k-step ks adds 2 ks planes
+    const int fa0 = c.lk * YPLANE + yslot(c.wm * 64 + c.li) * 8, fa1 = c.lk * YPLANE + yslot(c.wm * 64 + 32 + c.li) * 8;
+    const int fb0 = c.lk * YPLANE + yslot(c.wn * 64 + c.li) * 8, fb1 = c.lk * YPLANE + yslot(c.wn * 64 + 32 + c.li) * 8;
+    float4 a0, a1, a2, a3, b0, b1, b2, b3;
+    ytile<AK, FAST>(A, LA, c.m0, ka * YBK, c.kend, tid, a0, a1, a2, a3);
+    ytile<BK_, FAST>(B, LB, c.n0, ka * YBK, c.kend, tid, b0, b1, b2, b3);
+    if (FAST) { ymask4(LA.ok, a0, a1, a2, a3); ymask4(LB.ok, b0, b1, b2, b3); }
+    if (c.do_rowsum) yrowsum<AK>(a0, a1, a2, a3, rs);
+    ystore_lds<AK>(smem + par * 2 * YTILE, tid, a0, a1, a2, a3);
+    ystore_lds<BK_>(smem + par * 2 * YTILE + YTILE, tid, b0, b1, b2, b3);
+    __syncthreads();
+    for (int kt = ka; kt < kb; ++kt) {
+        const uint16_t* As = smem + par * 2 * YTILE;
+        const uint16_t* Bs = As + YTILE;
+        const bool more = kt + 1 < kb;
+        if (more) {
+            ytile<AK, FAST>(A, LA, c.m0, (kt + 1) * YBK, c.kend, tid, a0, a1, a2, a3);
+            ytile<BK_, FAST>(B, LB, c.n0, (kt + 1) * YBK, c.kend, tid, b0, b1, b2, b3);
+        }
+        const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(As + fa0), a01 = *reinterpret_cast<const bf16x8*>(As + fa1);
+        const bf16x8 b00 = *reinterpret_cast<const bf16x8*>(Bs + fb0), b01 = *reinterpret_cast<const bf16x8*>(Bs + fb1);
+        const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(As + 2 * YPLANE + fa0);
+        const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(As + 2 * YPLANE + fa1);
+        const bf16x8 b10 = *reinterpret_cast<const bf16x8*>(Bs + 2 * YPLANE + fb0);
+        const bf16x8 b11 = *reinterpret_cast<const bf16x8*>(Bs + 2 * YPLANE + fb1);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, b00, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, b01, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, b00, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, b01, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, b10, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, b11, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, b10, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, b11, acc[1][1], 0, 0, 0);
+        if (more) {
+            uint16_t* An = smem + (par ^ 1) * 2 * YTILE;
+            // zeroing of clamped rows AFTER the MFMAs: the loads stay in flight across them
+            if (FAST) { ymask4(LA.ok, a0, a1, a2, a3); ymask4(LB.ok, b0, b1, b2, b3); }
+            if (c.do_rowsum) yrowsum<AK>(a0, a1, a2, a3, rs);
+            ystore_lds<AK>(An, tid, a0, a1, a2, a3);
+            ystore_lds<BK_>(An + YTILE, tid, b0, b1, b2, b3);
+        }
+        __syncthreads();
+        par ^= 1;
+    }
+}
+
+template <bool AK, bool BK_>
+__device__ __forceinline__ void ymain(const XOperand& A, const XOperand& B, const XCtx& c, int kt0, int kt1, uint16_t* smem,
+                                      f32x16 (&acc)[2][2], float4& rs) {
+    XLane LA, LB;
+    yprep<AK>(A, c.m0, c.tid, LA);
+    yprep<BK_>(B, c.n0, c.tid, LB);
+    int ktf = kt0;
+    if (xfast_ok<AK>(A, c.m0) && xfast_ok<BK_>(B, c.n0) && kt1 > kt0) ktf = (c.kend == kt1 * YBK) ? kt1 : kt1 - 1;
+    int par = 0;
+    yrun<AK, BK_, true>(A, B, LA, LB, c, kt0, ktf, par, smem, acc, rs);
+    yrun<AK, BK_, false>(A, B, LA, LB, c, ktf, kt1, par, smem, acc, rs);
+    if (c.do_rowsum) {                                     // uniform per workgroup; the k loop ended on a barrier
+        float* part = reinterpret_cast<float*>(smem);      // [8][128] partial sums
+        if (AK) {
+            float* q = part + (c.tid & 7) * 128 + (c.tid >> 3);
+            q[0] = rs.x; q[32] = rs.y; q[64] = rs.z; q[96] = rs.w;
+        } else {
+            float* q = part + ykq4(c.tid) * 128 + 4 * yrq(c.tid);
+            q[0] = rs.x; q[1] = rs.y; q[2] = rs.z; q[3] = rs.w;
+        }
+        __syncthreads();
     }
 }
 
@@ -424,21 +528,19 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_
     int b = blockIdx.x - g.start[gi];
     const int slice = b % S; b /= S;
     const int tn = b % nbn, tm = b / nbn;
-    const int m0 = tm * XBM, n0 = tn * XBN;
     const int nkt = (d.K + YBK - 1) / YBK;
     const int per = (nkt + S - 1) / S;
     const int kt0 = slice * per, kt1 = min(nkt, kt0 + per);
-    const int kend = min(d.K, kt1 * YBK);
 
     XOperand A, B;
-    A.base = d.A; A.s_row = d.a_sm; A.s_k = d.a_sk; A.rshift = 0; A.kshift = 0; A.rstride = 0; A.kstride = 0;
-    A.rows = d.M; A.kcontig = d.a_sk == 1; A.vec = vecbits & 1;
-    B.base = d.B; B.s_row = d.b_sn; B.s_k = d.b_sk; B.rshift = d.b_nshift; B.kshift = d.b_kshift;
-    B.rstride = d.b_nstride; B.kstride = d.b_kstride; B.rows = d.N; B.kcontig = d.b_sk == 1; B.vec = (vecbits >> 1) & 1;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int li = lane & 31, lk = lane >> 5;
+    xoperands(d, vecbits, A, B);
+    XCtx c;
+    c.m0 = tm * XBM; c.n0 = tn * XBN; c.kend = min(d.K, kt1 * YBK);
+    c.tid = threadIdx.x;
+    const int lane = c.tid & 63, wave = c.tid >> 6;
+    c.wm = wave >> 1; c.wn = wave & 1; c.li = lane & 31; c.lk = lane >> 5;
+    c.do_rowsum = d.a_rowsum != nullptr && tn == 0;
+    const int m0 = c.m0, n0 = c.n0, tid = c.tid, wm = c.wm, wn = c.wn, li = c.li, lk = c.lk;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -447,67 +549,13 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    const bool do_rowsum = d.a_rowsum != nullptr && tn == 0;
-    float rs0 = 0.f, rs1 = 0.f, rs2 = 0.f, rs3 = 0.f;
-
-    // fragment addresses (bf16 elements) inside a tile, per k-step ks: + (2 ks) * YPLANE
-    int fa[2], fb[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        fa[i] = lk * YPLANE + yslot(wm * 64 + i * 32 + li) * 8;
-        fb[i] = lk * YPLANE + yslot(wn * 64 + i * 32 + li) * 8;
-    }
-
-    float4 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
-    va0 = va1 = va2 = va3 = vb0 = vb1 = vb2 = vb3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    XLane LA, LB;
-    yprep(A, m0, tid, LA);
-    yprep(B, n0, tid, LB);
-    if (kt0 < kt1) {
-        YTILE_LOAD(A, LA, m0, kt0 * YBK, va);
-        YTILE_LOAD(B, LB, n0, kt0 * YBK, vb);
-        ystore_lds(smem, A.kcontig, tid, va0, va1, va2, va3);
-        ystore_lds(smem + YTILE, B.kcontig, tid, vb0, vb1, vb2, vb3);
-    }
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        const uint16_t* As = smem + cur * 2 * YTILE;
-        const uint16_t* Bs = As + YTILE;
-        const bool more = kt + 1 < kt1;
-        if (do_rowsum) {                                  // fp32 row sums of the tile now in LDS (registers still hold it)
-            if (A.kcontig) {
-                rs0 += (va0.x + va0.y) + (va0.z + va0.w); rs1 += (va1.x + va1.y) + (va1.z + va1.w);
-                rs2 += (va2.x + va2.y) + (va2.z + va2.w); rs3 += (va3.x + va3.y) + (va3.z + va3.w);
-            } else {
-                rs0 += (va0.x + va1.x) + (va2.x + va3.x); rs1 += (va0.y + va1.y) + (va2.y + va3.y);
-                rs2 += (va0.z + va1.z) + (va2.z + va3.z); rs3 += (va0.w + va1.w) + (va2.w + va3.w);
-            }
-        }
-        if (more) {
-            YTILE_LOAD(A, LA, m0, (kt + 1) * YBK, va);
-            YTILE_LOAD(B, LB, n0, (kt + 1) * YBK, vb);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[2], bq[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = *reinterpret_cast<const bf16x8*>(As + 2 * ks * YPLANE + fa[i]);
-                bq[i] = *reinterpret_cast<const bf16x8*>(Bs + 2 * ks * YPLANE + fb[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], acc[i][j], 0, 0, 0);
-        }
-        if (more) {
-            uint16_t* An = smem + (cur ^ 1) * 2 * YTILE;
-            ystore_lds(An, A.kcontig, tid, va0, va1, va2, va3);
-            ystore_lds(An + YTILE, B.kcontig, tid, vb0, vb1, vb2, vb3);
-        }
-        __syncthreads();
+    float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.a_sk == 1) {
+        if (d.b_sk == 1) ymain<true, true>(A, B, c, kt0, kt1, smem, acc, rs);
+        else ymain<true, false>(A, B, c, kt0, kt1, smem, acc, rs);
+    } else {
+        if (d.b_sk == 1) ymain<false, true>(A, B, c, kt0, kt1, smem, acc, rs);
+        else ymain<false, false>(A, B, c, kt0, kt1, smem, acc, rs);
     }
 
     // ---- epilogue.  acc[mi][ni][4*gq + t] = row m0 + wm*64 + mi*32 + 8*gq + 4*lk + t, column n0 + wn*64 + ni*32 + li.
@@ -536,24 +584,13 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_
                     *p = v;
                 }
             }
-    if (do_rowsum) {                                       // uniform per workgroup
-        float* part = reinterpret_cast<float*>(smem);      // [8][128] partial sums; the k loop ended on a barrier
-        if (A.kcontig) {
-            float* q = part + (tid & 7) * 128 + (tid >> 3);
-            q[0] = rs0; q[32] = rs1; q[64] = rs2; q[96] = rs3;
-        } else {
-            const int rq = (tid & 7) | (((tid >> 4) & 3) << 3), kq4 = ((tid >> 3) & 1) | ((tid >> 6) << 1);
-            float* q = part + kq4 * 128 + 4 * rq;
-            q[0] = rs0; q[1] = rs1; q[2] = rs2; q[3] = rs3;
-        }
-        __syncthreads();
-        if (tid < XBM && m0 + tid < d.M) {
-            float s = 0.f;
+    if (c.do_rowsum && tid < XBM && m0 + tid < d.M) {
+        const float* part = reinterpret_cast<const float*>(smem);
+        float s = 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) s += part[q * 128 + tid];
-            if (split) ws[MN + m0 + tid] = s;
-            else d.a_rowsum[m0 + tid] = d.accumulate ? d.a_rowsum[m0 + tid] + s : s;
-        }
+        for (int q = 0; q < 8; ++q) s += part[q * 128 + tid];
+        if (split) ws[MN + m0 + tid] = s;
+        else d.a_rowsum[m0 + tid] = d.accumulate ? d.a_rowsum[m0 + tid] + s : s;
     }
 }
 
