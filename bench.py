@@ -125,18 +125,21 @@ def run_train(B, precision, steps, warmup, device, rank, world, dist_on):
     net = trainer.wrap_ddp(head, device)
     opt = trainer.build_optimizer(net, lr=1e-4)
     torch.manual_seed(1234 + rank)
+    # lazy=True: the losses stay on the device (no per-step .item() / isnan round trip); all the work of the K steps is
+    # still inside the timed region -- it ends on a device synchronisation -- and the losses are read and NaN-checked after
     for _ in range(warmup):
-        losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets)
+        losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True)
     torch.cuda.synchronize()
     if dist_on:
         torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets)
+        losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True)
     torch.cuda.synchronize()
     if dist_on:
         torch.distributed.barrier()
-    return time.perf_counter() - t0, losses
+    elapsed = time.perf_counter() - t0
+    return elapsed, trainer.read_losses(losses)
 
 
 def train_mode(args, device, rank, world, dist_on):

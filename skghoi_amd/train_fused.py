@@ -66,6 +66,7 @@ class Stacked:
         add("W2", 4096, 1024); add("b2", 4096)
         add("clsW", self.K + 1, 2048); add("clsb", self.K + 1)
         self.seg, self.total = seg, off
+        self.numel = {k: int(np.prod(v[1])) for k, v in seg.items()}
         self.buf = torch.empty(off, device=device, dtype=torch.float32)
         # (live parameter, segment, selector inside the segment's view) in a fixed order
         self.entries = []
@@ -90,7 +91,26 @@ class Stacked:
 
     def view(self, flat, name):
         off, shape = self.seg[name]
-        return flat[off:off + int(np.prod(shape))].view(*shape)
+        return flat[off:off + self.numel[name]].view(shape)
+
+    def grad_arena(self):
+        """(arena, per-entry views) for one backward.  The arena of the previous step and its 392 view objects are reused
+        when nothing else holds them any more -- zero_grad(set_to_none=True) has dropped every p.grad (C++ side: the
+        tensors' use counts) and no caller kept a gradient tensor (Python side: the reference counts of the cached view
+        objects) -- which saves ~0.4 ms of view construction per step; otherwise (gradient accumulation, a caller
+        holding on to a gradient, autograd still owning one) a fresh arena is made."""
+        c = getattr(self, "_ga", None)
+        if c is not None and self._holders(c[1]) == c[2]:
+            return c[0], c[1]
+        ga = torch.empty(self.total, device=self.device, dtype=torch.float32)
+        views = self.grad_views(ga)
+        self._ga = (ga, views, self._holders(views))
+        return ga, views
+
+    @staticmethod
+    def _holders(views):
+        import sys
+        return sum(map(sys.getrefcount, views)) + sum(map(torch.Tensor._use_count, views))
 
     def refresh(self):
         if [p.data_ptr() for p in self.src[:: 32]] != self.src_ptrs:   # .data was re-pointed (rare): rebuild the aliases
@@ -214,19 +234,16 @@ class TrainJob:
         S["x0"], S["gfeat"] = x0, gfeat
         Bf = gfeat.shape[0]
         bh1, bh3 = gh.box_head[1], gh.box_head[3]
-        # ---- box_head (HEAD:812) and fc_1 of the global branch (HEAD:971)
+        # ---- box_head (HEAD:812), fc_1 of the global branch (HEAD:971) and the first two layers of the spatial head
+        #      (HEAD:888, on the 46-d encodings the step driver produced with the pair enumeration): two grouped launches
         E1 = torch.empty(NA, 1024, **f32); enc = torch.empty(NA, 1024, **f32); G1 = torch.empty(Bf, 1024, **f32)
-        self.gx([_lin(x0, bh1.weight, E1, bh1.bias, True)])
-        self.gx([_lin(E1, bh3.weight, enc, bh3.bias, True), _lin(gfeat, W1g, G1, b1g)])
-        S.update(E1=E1, enc=enc, G1=G1)
-        # ---- spatial head (HEAD:888) on the 46-d encodings the step driver produced with the pair enumeration
         sp48 = S["sp48"]
         sp = gh.spatial_head
-        s1 = torch.empty(Mg, 128, **f32); s2 = torch.empty(Mg, 256, **f32); Sp = torch.empty(Mg, 1024, **f32)
-        self.gx([_lin(sp48, sp[0].weight, s1, sp[0].bias, True, K=46)])
-        self.gx([_lin(s1, sp[2].weight, s2, sp[2].bias, True)])
-        self.gx([_lin(s2, sp[4].weight, Sp, sp[4].bias, True)])
-        S.update(s1=s1, s2=s2, Sp=Sp)
+        s1 = torch.empty(Mg, 128, **f32); s2 = torch.empty(Mg, 256, **f32)
+        self.gx([_lin(x0, bh1.weight, E1, bh1.bias, True), _lin(sp48, sp[0].weight, s1, sp[0].bias, True, K=46)])
+        self.gx([_lin(E1, bh3.weight, enc, bh3.bias, True), _lin(gfeat, W1g, G1, b1g),
+                 _lin(s1, sp[2].weight, s2, sp[2].bias, True)])
+        S.update(E1=E1, enc=enc, G1=G1, s1=s1, s2=s2)
         self.part_a_done = True
 
     def forward(self, x0, gfeat):
@@ -249,7 +266,7 @@ class TrainJob:
         x0, gfeat = S["x0"], S["gfeat"]
         Bf = gfeat.shape[0]
         E1, enc, G1 = S["E1"], S["enc"], S["G1"]
-        s1, s2, Sp = S["s1"], S["s2"], S["Sp"]
+        s1, s2 = S["s1"], S["s2"]
         grid_h, grid_o, grid_pair, grid_img, pair_grid, pair_h, pair_o, sp48 = (
             S[k] for k in ("grid_h", "grid_o", "grid_pair", "grid_img", "pair_grid", "pair_h", "pair_o", "sp48"))
         # ---- fc_head / fc_tail on unique node rows (HEAD:884-885)
@@ -257,10 +274,12 @@ class TrainJob:
         _check(lib.skg_concat_entity_f32(enc.data_ptr(), 1024, self.isl("enc_row_hn").data_ptr(), self.ent.data_ptr(),
                                          self.isl("img_hn").data_ptr(), self.isl("ent_row_hn").data_ptr(), Mh + Mn,
                                          Xhn.data_ptr(), 1088, stream), "skg_concat_entity_f32")
-        GH = torch.empty(Mh, 1024, **f32); GO = torch.empty(Mn, 1024, **f32)
+        GH = torch.empty(Mh, 1024, **f32); GO = torch.empty(Mn, 1024, **f32); Sp = torch.empty(Mg, 1024, **f32)
         fh, ft = gh.fc_head[0], gh.fc_tail[0]
-        self.gx([_lin(Xhn[:Mh], fh.weight, GH, fh.bias, True, K=1074), _lin(Xhn[Mh:], ft.weight, GO, ft.bias, True, K=1074)])
-        S.update(Xhn=Xhn, GH=GH, GO=GO)
+        sp = gh.spatial_head
+        self.gx([_lin(Xhn[:Mh], fh.weight, GH, fh.bias, True, K=1074), _lin(Xhn[Mh:], ft.weight, GO, ft.bias, True, K=1074),
+                 _lin(s2, sp[4].weight, Sp, sp[4].bias, True)])           # + the last spatial layer (HEAD:888)
+        S.update(Xhn=Xhn, GH=GH, GO=GO, Sp=Sp)
         # ---- fc_1 projections on node rows (HEAD:894-896 separable over [human | object]; HEAD:514, 524)
         A1h = torch.empty(Mh, 1024, **f32); A1o = torch.empty(Mn, 1024, **f32)
         C1o = torch.empty(Mn, 1024, **f32); C1h = torch.empty(Mh, 1024, **f32)
@@ -371,7 +390,7 @@ class TrainJob:
         K = self.K
         blk = (6, 1024 * 64)
         IG, WG = gemmx.input_grad, gemmx.weight_grad
-        ga = torch.empty(st.total, **f32)                       # gradient arena of the stacked parameters
+        ga, sviews = st.grad_arena()                            # gradient arena of the stacked parameters + p.grad views
         gv = lambda name: st.view(ga, name)
         W2 = st.view(st.buf, "W2")
         W1 = [st.view(st.buf, "W1_%d" % i) for i in range(4)]
@@ -476,20 +495,35 @@ class TrainJob:
         Sp = S["Sp"]
         dS = torch.empty(Mg, 1024, **f32)
         self.gx([IG(dF, W2, dS, mask=Sp, N_in=1024), WG(dF, Sp, gv("W2"), db=gv("b2"))])
-        # ---- fc_1 projections on node rows: gradients of the nodes accumulate on top of the residual path
+        # ---- fc_1 projections on node rows: gradients of the nodes accumulate on top of the residual path.  The spatial
+        #      head's backward (dS -> ds2 -> ds1 -> first layer) is independent of the node chain: its three steps ride in
+        #      the same grouped launches.
         GH, GO = S["GH"], S["GO"]
+        sp = gh.spatial_head
+        s1, s2, sp48 = S["s1"], S["s2"], S["sp48"]
+        ds2 = torch.empty(Mg, 256, **f32); ds1 = torch.empty(Mg, 128, **f32)
+        g_sp = [(torch.empty_like(sp[i].weight), torch.empty_like(sp[i].bias)) for i in (0, 2, 4)]
         self.gx([IG(dA1h, Wa1, dHp, accumulate=True, N_in=1024), IG(dA1o, Wa1[:, 1024:], dOp, accumulate=True, N_in=1024),
-                      WG(dA1h, GH, dWa1, accumulate=True, k_in=1024), WG(dA1o, GO, dWa1[:, 1024:], accumulate=True, k_in=1024)])
+                 WG(dA1h, GH, dWa1, accumulate=True, k_in=1024), WG(dA1o, GO, dWa1[:, 1024:], accumulate=True, k_in=1024),
+                 IG(dS, sp[4].weight, ds2, mask=s2), WG(dS, s2, g_sp[2][0], db=g_sp[2][1])])
         self.gx([IG(dC1h, W1[SO], dHp, mask=GH, accumulate=True), IG(dC1o, W1[OS], dOp, mask=GO, accumulate=True),
-                      WG(dC1h, GH, dW1[SO], db=db1[SO]), WG(dC1o, GO, dW1[OS], db=db1[OS])])
-        # ---- fc_head / fc_tail
+                 WG(dC1h, GH, dW1[SO], db=db1[SO]), WG(dC1o, GO, dW1[OS], db=db1[OS]),
+                 IG(ds2, sp[2].weight, ds1, mask=s1), WG(ds2, s1, g_sp[1][0], db=g_sp[1][1])])
+        # ---- fc_head / fc_tail, with the first spatial layer and the global branch's fc_1 (HEAD:971)
         Xhn = S["Xhn"]
         fh, ft = gh.fc_head[0], gh.fc_tail[0]
         dXhn = torch.empty(Mh + Mn, 1088, **f32)
         g_fh_w = torch.empty_like(fh.weight); g_fh_b = torch.empty_like(fh.bias)
         g_ft_w = torch.empty_like(ft.weight); g_ft_b = torch.empty_like(ft.bias)
-        self.gx([IG(dHp, fh.weight, dXhn[:Mh], N_in=1074), IG(dOp, ft.weight, dXhn[Mh:], N_in=1074),
-                      WG(dHp, Xhn[:Mh], g_fh_w, db=g_fh_b, k_in=1074), WG(dOp, Xhn[Mh:], g_ft_w, db=g_ft_b, k_in=1074)])
+        gfeat = S["gfeat"]
+        ops = [IG(dHp, fh.weight, dXhn[:Mh], N_in=1074), IG(dOp, ft.weight, dXhn[Mh:], N_in=1074),
+               WG(dHp, Xhn[:Mh], g_fh_w, db=g_fh_b, k_in=1074), WG(dOp, Xhn[Mh:], g_ft_w, db=g_ft_b, k_in=1074),
+               WG(ds1, sp48, g_sp[0][0], db=g_sp[0][1], k_in=46), WG(dG1, gfeat, dW1[GL], db=db1[GL])]
+        dgfeat = None
+        if need_dgfeat:
+            dgfeat = torch.empty_like(gfeat)
+            ops.append(IG(dG1, W1[GL], dgfeat))
+        self.gx(ops)
         d_enc = torch.empty(NA, 1024, **f32)
         _check(lib.skg_entity_rows_bwd_f32(dXhn.data_ptr(), 1088, self.hum_of.data_ptr(), self.node_of.data_ptr(), Mh, NA,
                                            S["enc"].data_ptr(), d_enc.data_ptr(), stream), "skg_entity_rows_bwd_f32")
@@ -506,21 +540,6 @@ class TrainJob:
             dx0 = torch.empty_like(x0)
             ops.append(IG(dE1, bh1.weight, dx0))
         self.gx(ops)
-        # ---- spatial head
-        sp = gh.spatial_head
-        s1, s2, sp48 = S["s1"], S["s2"], S["sp48"]
-        ds2 = torch.empty(Mg, 256, **f32); ds1 = torch.empty(Mg, 128, **f32)
-        g_sp = [(torch.empty_like(sp[i].weight), torch.empty_like(sp[i].bias)) for i in (0, 2, 4)]
-        self.gx([IG(dS, sp[4].weight, ds2, mask=s2), WG(dS, s2, g_sp[2][0], db=g_sp[2][1])])
-        self.gx([IG(ds2, sp[2].weight, ds1, mask=s1), WG(ds2, s1, g_sp[1][0], db=g_sp[1][1])])
-        # ---- global branch fc_1 (HEAD:971) and the first spatial layer
-        gfeat = S["gfeat"]
-        ops = [WG(ds1, sp48, g_sp[0][0], db=g_sp[0][1], k_in=46), WG(dG1, gfeat, dW1[GL], db=db1[GL])]
-        dgfeat = None
-        if need_dgfeat:
-            dgfeat = torch.empty_like(gfeat)
-            ops.append(IG(dG1, W1[GL], dgfeat))
-        self.gx(ops)
         # ---- the fc_3 bias of branch b is added once per row whatever b: every branch gets the MBF's bias gradient
         gv("b3").copy_(db3.unsqueeze(1).expand(4, 16, 1024))
         # ---- hand the gradients back in the order of the Function's parameter inputs
@@ -530,7 +549,6 @@ class TrainJob:
                   id(sp[0].weight): g_sp[0][0], id(sp[0].bias): g_sp[0][1], id(sp[2].weight): g_sp[1][0],
                   id(sp[2].bias): g_sp[1][1], id(sp[4].weight): g_sp[2][0], id(sp[4].bias): g_sp[2][1],
                   id(fh.weight): g_fh_w, id(fh.bias): g_fh_b, id(ft.weight): g_ft_w, id(ft.bias): g_ft_b}
-        sviews = st.grad_views(ga)
         out = []
         for p in self.params:
             k = st.ids.get(id(p))
@@ -628,8 +646,7 @@ def train_forward(head, eng, features, image_shapes, box_features, pre, targets)
                                  float(gh.fg_iou_thresh), labels_all.data_ptr(), npos_d.data_ptr(), stream),
            "skg_associate_f32")
     # ---- the dense part does not depend on the sampling below: enqueue it first, then pay the one host sync of the step
-    params = list(head.box_pair_head.parameters()) + list(head.box_pair_suppressor.parameters()) + \
-        list(head.box_pair_predictor.parameters())
+    params = _head_params(head)
     job = TrainJob(head, eng, st, lay, pre, ibuf, offs, None, meta)
     job.params = params
     job.S.update(grid_h=grid_h, grid_o=grid_o, grid_pair=grid_pair, grid_img=grid_img, pair_grid=pair_grid,
@@ -699,6 +716,18 @@ def train_forward(head, eng, features, image_shapes, box_features, pre, targets)
     results = head._results(lay, r, dev, train_extras=(job.cell_labels, job.unary))
     results.append(dict(hoi_loss=hoi_loss, interactiveness_loss=int_loss, transH_loss=transh_loss))
     return results
+
+
+def _head_params(head):
+    """box_pair_head | suppressor | predictor parameters in registration order; the module walk (~0.7 ms for 408
+    tensors) is redone only after a module / parameter registration anywhere (engine.module_registration_hook)."""
+    ep = _reg_epoch()
+    c = getattr(head, "_train_params", None)
+    if c is None or c[0] != ep:
+        c = (ep, list(head.box_pair_head.parameters()) + list(head.box_pair_suppressor.parameters()) +
+             list(head.box_pair_predictor.parameters()))
+        head._train_params = c
+    return c[1]
 
 
 def _reg_epoch():

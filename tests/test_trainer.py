@@ -185,3 +185,77 @@ def test_wrap_ddp_single_process_switches_direct_gradients():
     wrapper = nn.Sequential(head)
     assert head.grad_mode == "autograd"
     assert trainer.wrap_ddp(wrapper) is wrapper and head.grad_mode == "direct"
+
+
+@pytest.mark.gpu
+def test_cached_fused_adamw_matches_stock_bit_for_bit():
+    """trainer.CachedFusedAdamW = torch.optim.AdamW(fused=True) without the per-step state walk: identical parameters
+    after several steps (fresh gradient tensors every step, as the fused training step hands them over), through a
+    state_dict round trip, a changed learning rate, and a step in which one parameter has no gradient."""
+    torch.manual_seed(0)
+    dev = torch.device("cuda")
+
+    def make():
+        torch.manual_seed(1)
+        return torch.nn.Sequential(torch.nn.Linear(33, 65), torch.nn.ReLU(), torch.nn.Linear(65, 7)).to(dev)
+    a, b = make(), make()
+    oa = trainer.build_optimizer(a, lr=1e-3)
+    assert isinstance(oa, trainer.CachedFusedAdamW)
+    ob = torch.optim.AdamW(b.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+
+    def step(k, skip=False):
+        g = torch.Generator(device="cpu").manual_seed(100 + k)
+        for net, opt in ((a, oa), (b, ob)):
+            opt.zero_grad(set_to_none=True)
+            for i, p in enumerate(net.parameters()):
+                if skip and i == 1:
+                    continue
+                gg = torch.Generator(device="cpu").manual_seed(1000 * k + i)
+                p.grad = torch.randn(p.shape, generator=gg).to(dev)
+            opt.step()
+    for k in range(4):
+        step(k)
+    assert oa._lists, "fast path not taken"
+    step(4, skip=True)                                   # a parameter without gradient: stock path, same result
+    for g in oa.param_groups + ob.param_groups:
+        g["lr"] = 3e-4
+    step(5)
+    sd = oa.state_dict()
+    oa2 = trainer.build_optimizer(a, lr=1e-3)
+    oa2.load_state_dict(sd)
+    oa = oa2
+    for k in range(6, 9):
+        step(k)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)
+    for (ka, va), (kb, vb) in zip(oa.state_dict()["state"].items(), ob.state_dict()["state"].items()):
+        assert torch.equal(va["exp_avg"], vb["exp_avg"]) and torch.equal(va["exp_avg_sq"], vb["exp_avg_sq"])
+        assert float(va["step"]) == float(vb["step"]) == (8.0 if ka == 1 else 9.0)     # parameter 1 sat one step out
+
+
+def test_lazy_losses_read_back_with_nan_guard(capsys):
+    """Trainer(lazy_losses=True): step functions hand back device tensors, floats appear at the print interval and at
+    the end of the epoch, and the reference's NaN guard (utils.py:219) fires at the read."""
+    lazy = {"hoi_loss": torch.tensor(0.25), "interactiveness_loss": torch.tensor(1.5)}
+    assert trainer.read_losses(lazy) == {"hoi_loss": 0.25, "interactiveness_loss": 1.5}
+    with pytest.raises(ValueError, match="NaN"):
+        trainer.read_losses({"hoi_loss": torch.tensor(float("nan")), "transH_loss": torch.tensor(1.0)})
+
+    trainer.seed_everything(3)
+    net = _Net()
+    opt = trainer.build_optimizer(net, lr=1e-2)
+    seen = []
+
+    def step_fn(n, o, batch):
+        ims, _, tgts = batch
+        o.zero_grad(set_to_none=True)
+        loss = (n.interaction_head(n.backbone(torch.stack(ims))) - torch.stack(tgts)).pow(2).mean()
+        loss.backward(); o.step()
+        seen.append(float(loss))
+        return {"hoi_loss": loss.detach()}, None
+
+    tr = trainer.Trainer(net, opt, None, trainer.make_loader(_ToyData(), batch_size=4), step_fn=step_fn, print_interval=2,
+                         lazy_losses=True)
+    tr(1)
+    assert [h["hoi_loss"] for h in tr.history] == pytest.approx(seen) and all(isinstance(h["hoi_loss"], float) for h in tr.history)
+    assert "iteration 2" in capsys.readouterr().out

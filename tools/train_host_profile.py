@@ -1,0 +1,66 @@
+"""Developer aid (GPU box): cProfile of the host side of the training step at batch 4.
+usage: train_host_profile.py [precision=bf16] [batch=4]"""
+import cProfile, os, pstats, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.dont_write_bytecode = True
+import torch
+import bench
+from skghoi_amd import synth, trainer
+
+prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+LAZY = not (len(sys.argv) > 3 and sys.argv[3] == "eager")
+trainer.limit_host_threads()
+device = torch.device("cuda:0")
+head = bench.build_head(device).train()
+head.precision = prec
+dets, pooled, feats, shapes = bench.make_inputs(B, 0, device)
+o2v = synth.hico_object_to_verb()
+cpu_dets = [dict(boxes=d["boxes"].cpu(), labels=d["labels"].cpu(), scores=d["scores"].cpu()) for d in dets]
+targets = [{k: v.to(device) for k, v in synth.make_targets(d, 49, o2v, 500 + i, n_gt=4).items()} for i, d in enumerate(cpu_dets)]
+
+
+class Pool(torch.nn.Module):
+    def forward(self, features, boxes, image_shapes):
+        n = sum(len(b) for b in boxes)
+        reps = (n + pooled.shape[0] - 1) // pooled.shape[0]
+        return pooled.repeat(reps, 1, 1, 1)[:n]
+
+
+head.box_roi_pool = Pool()
+net = trainer.wrap_ddp(head, device)
+opt = trainer.build_optimizer(net, lr=1e-4)
+for _ in range(5):
+    trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=LAZY)
+torch.cuda.synchronize()
+N = 30
+t0 = time.perf_counter()
+for _ in range(N):
+    trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=LAZY)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("host %.3f ms/step, with final sync %.3f ms/step" % ((t1 - t0) / N * 1e3, (t2 - t0) / N * 1e3))
+# the backward runs on autograd's own thread: profile it there
+from skghoi_amd import train_fused
+_orig = train_fused.TrainJob.backward
+bpr = cProfile.Profile()
+def _wrapped(self, *a, **k):
+    bpr.enable()
+    try:
+        return _orig(self, *a, **k)
+    finally:
+        bpr.disable()
+train_fused.TrainJob.backward = _wrapped
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(N):
+    trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=LAZY)
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(35)
+st.sort_stats("cumulative").print_stats(45)
+
+print("=" * 30, "TrainJob.backward (autograd thread)")
+pstats.Stats(bpr).sort_stats("tottime").print_stats(25)
