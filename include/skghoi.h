@@ -177,6 +177,9 @@ int skg_gemm_group_tile(const skg_gemm_desc* descs_host, int n);
 /* Developer switch: which 64 x 64 main loop the small launches take (3 = 64-k steps, register staged: the default;
  * 1 = 16-k steps, DMA staged).  Returns the previous setting; other values only query.                              */
 int skg_gemm_small_mode(int mode);
+/* Developer switch: a launch / group takes the 64 x 64 tiles below this many 128 x 128 tiles (default 384); returns the
+ * previous bound, tiles <= 0 only queries.                                                                          */
+int skg_gemm_small_tiles(int tiles);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * fc_head / fc_tail input rows (HEAD:884-885): out[r] = [ enc[enc_row[r], 0:1024] | ent[ent_img[r], ent_row[r], 0:50]

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "skg_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
     "skg_gemm_group_tile": (C.c_int, [C.POINTER(GemmDesc), C.c_int]),
     "skg_gemm_small_mode": (C.c_int, [C.c_int]),
+    "skg_gemm_small_tiles": (C.c_int, [C.c_int]),
     "skg_gemmx_ws_floats": (C.c_int64, [C.POINTER(GemmXDesc)]),
     "skg_gemmx_f32": (C.c_int, [C.POINTER(GemmXDesc), C.c_int, _vp]),
     "skg_gemmx_bf16": (C.c_int, [C.POINTER(GemmXDesc), C.c_int, _vp]),
@@ -139,6 +140,8 @@ def lib():
         raise SkgError("libskghoi_hip.so ABI %d != binding ABI %d" % (l.skg_abi_version(), ABI_VERSION))
     if os.environ.get("SKG_SMALL_MODE"):                 # developer switch: 64 x 64 main loop of the small launches
         l.skg_gemm_small_mode(int(os.environ["SKG_SMALL_MODE"]))
+    if os.environ.get("SKG_SMALL_TILES"):                # developer switch: bound of the 64 x 64-tile launches
+        l.skg_gemm_small_tiles(int(os.environ["SKG_SMALL_TILES"]))
     _LIB = l
     return l
 

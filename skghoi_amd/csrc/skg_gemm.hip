@@ -903,6 +903,14 @@ extern "C" int skg_gemm_small_mode(int mode) {
     return old;
 }
 
+// A launch (or group) counts as small -- 64 x 64 tiles -- below this many 128 x 128 tiles (split-K slices included).
+static int g_small_tiles = 384;
+extern "C" int skg_gemm_small_tiles(int tiles) {
+    const int old = g_small_tiles;
+    if (tiles > 0) g_small_tiles = tiles;
+    return old;
+}
+
 // 64 x 64 tiles when the 128 x 128 grid would leave most CUs idle (small M: low-batch inference); needs the DMA path.
 static int skg_gemm_tile_scale(const skg_gemm_desc* d) {
     const bool glds = SKG_USE_GLDS && BK == 16 && (d->K % BK) == 0 && !d->a_rows &&
@@ -910,7 +918,7 @@ static int skg_gemm_tile_scale(const skg_gemm_desc* d) {
     const int64_t tiles128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * (d->split_k > 1 ? d->split_k : 1);
     if (d->w_split && (d->K % 16) == 0 && d->w_scale > 0.f) return 2;
     // M <= 64: a 128-row tile would spend half of its MFMAs on padding rows whatever the grid size (box_head at one image)
-    return (glds && (tiles128 < 384 || d->M <= 64)) ? 1 : 2;
+    return (glds && (tiles128 < g_small_tiles || d->M <= 64)) ? 1 : 2;
 }
 
 extern "C" int skg_gemm_dot_partials(const skg_gemm_desc* dh) {
@@ -953,7 +961,7 @@ static bool skg_gemm_group_small(const skg_gemm_desc* descs, int n) {
         if (!glds || (d.w_split && d.w_scale > 0.f)) return false;
         tiles128 += (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128);
     }
-    return tiles128 < 384;
+    return tiles128 < g_small_tiles;
 }
 
 extern "C" int skg_gemm_group_tile(const skg_gemm_desc* descs_host, int n) {
