@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SKG_ABI_VERSION 5
+#define SKG_ABI_VERSION 6
 #define SKG_E_ARG   (-1)   /* null pointer / negative size / unsupported shape            */
 #define SKG_E_ALIGN (-2)   /* pointer or leading dimension not 16-byte aligned            */
 #define SKG_E_LIMIT (-3)   /* exceeds a compiled-in limit (boxes per image, verbs, ...)   */
@@ -147,7 +147,16 @@ typedef struct {
      * fp32 grade); tiles whose result is not finite (fp16 range exceeded, inf / nan inputs) are recomputed with the
      * exact fp32 loop, for which W is still required. */
     const void* w_split;
+    /* optional with w_split: one exponent per A row (after the a_rows gather), from skg_row_exponents_f32 for THIS operand.
+     * Row r then travels as 2^-a_exp[r] * A[r, :] (its max |.| in [2^11, 2^12)) and the result row is multiplied back by
+     * 2^a_exp[r] in the epilogue -- both exact: the split keeps its 22 significant bits whatever the magnitude of the
+     * activations (without it the absolute error floor is 2^-25: fine for O(1) activations, 3 % at a gain of 2^-20),
+     * and an outlier row does not cost the others their precision.  NULL = no scaling.                               */
+    const int32_t* a_exp;
 } skg_gemm_desc;
+/* exp_out[r] = floor(log2(max_k |A[r, k]|)) - 11, clamped to [-126, 126]; 0 for all-zero rows and for rows holding
+ * inf / nan (their tile is recomputed exactly anyway).  Rows are gathered through a_rows when given (negative = zero row). */
+int skg_row_exponents_f32(const float* A, int64_t lda, const int32_t* a_rows, int M, int K, int32_t* exp_out, void* stream);
 
 int skg_gemm_f32(const skg_gemm_desc* desc_host, void* stream);
 

@@ -12,7 +12,7 @@ MAX_NODES = 160
 SPATIAL_LD = 48
 TRANSH_DIM = 50
 TRANSH_ENT = 80
-ABI_VERSION = 5
+ABI_VERSION = 6
 GEMM_GROUP_MAX = 4
 CHECKSUM_PARTIALS = 1024
 LOSS_CHUNKS = 16
@@ -29,7 +29,8 @@ class GemmDesc(C.Structure):
                 ("M", _i32), ("N", _i32), ("K", _i32), ("epilogue", _i32), ("a_rows", _vp), ("out_rows", _vp),
                 ("P", _vp), ("p_idx", _vp), ("ldp", _i64), ("Q", _vp), ("q_idx", _vp), ("ldq", _i64),
                 ("mbias", _vp), ("C_raw", _vp), ("ldc_raw", _i64), ("dot_w", _vp), ("dot_partial", _vp),
-                ("res", _vp), ("ldres", _i64), ("split_k", _i32), ("w_scale", _f32), ("split_ws", _vp), ("w_split", _vp)]
+                ("res", _vp), ("ldres", _i64), ("split_k", _i32), ("w_scale", _f32), ("split_ws", _vp), ("w_split", _vp),
+                ("a_exp", _vp)]
 
 
 class GemmXDesc(C.Structure):
@@ -75,6 +76,7 @@ PROTOTYPES = {
     "skg_split_weights_f16x2": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _f32, _vp, _vp]),
     "skg_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
     "skg_gemm_group_tile": (C.c_int, [C.POINTER(GemmDesc), C.c_int]),
+    "skg_row_exponents_f32": (C.c_int, [_vp, C.c_int64, _vp, C.c_int, C.c_int, _vp, _vp]),
     "skg_gemm_small_mode": (C.c_int, [C.c_int]),
     "skg_gemm_small_tiles": (C.c_int, [C.c_int]),
     "skg_gemmx_ws_floats": (C.c_int64, [C.POINTER(GemmXDesc)]),

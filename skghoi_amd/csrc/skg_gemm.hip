@@ -30,6 +30,9 @@
 #include "skg_common.h"
 #include <type_traits>
 
+// 2^e for e in [-126, 127], exactly
+__device__ __forceinline__ float skg_exp2i(int e) { return __uint_as_float((uint32_t)(127 + e) << 23); }
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -328,11 +331,17 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
         // lane-linear ds_read_b128.  fp16 overflows at 65504: a tile whose accumulators come out non-finite (overflow,
         // inf / nan inputs) is recomputed by the exact loop, so those cases behave as in fp32 arithmetic.
         char* sm = reinterpret_cast<char*>(smem);
+        // Power-of-two scale of every A row (optional, d.a_exp: exponents from skg_row_exponents_f32): row r travels as
+        // 2^-e_r * A[r, :] -- max |.| in [2^11, 2^12) -- and the result row is multiplied back by 2^e_r with the weight's
+        // scale in the epilogue, both exact: the h + m pair keeps its 22 significant bits at any activation magnitude
+        // (un-scaled, m turns subnormal below |x| = 2^-3 and the error floor is 2^-25 absolute), and an outlier row does
+        // not cost the other rows their precision.  Rows holding inf / nan keep e = 0; their tile takes the exact loop.
         constexpr int NC = 2, NCB = NC * 1024;
         constexpr int BUF = 8 * NCB, WOFF = 4 * NCB;                  // per buffer: A planes | W planes, 4 row tiles each
         const int q = tid & 3, r = tid >> 2;                          // staging: rows r, r + 64; k quad q
         const float* pa[2];
         bool va[2];
+        float asc[2];
         uint32_t aw[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -340,6 +349,7 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
             int src = -1;
             if (row < d.M) src = d.a_rows ? d.a_rows[row] : row;
             va[i] = src >= 0 || row >= d.M;                           // rows past M: any readable data, never stored
+            asc[i] = (d.a_exp && row < d.M) ? skg_exp2i(-min(max(d.a_exp[row], -126), 126)) : 1.f;
             pa[i] = d.A + (int64_t)(src >= 0 ? src : 0) * d.lda + q * 4;
             aw[i] = (uint32_t)((((r >> 5) + 2 * i) * NC) * 1024 + (q >> 1) * 512 + (r & 31) * 16 + (q & 1) * 8);
         }
@@ -372,7 +382,7 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
                 h16x2 hp[2], mp[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const float x0 = va[i] ? ra[st][i][2 * e] : 0.f, x1 = va[i] ? ra[st][i][2 * e + 1] : 0.f;
+                    const float x0 = va[i] ? ra[st][i][2 * e] * asc[i] : 0.f, x1 = va[i] ? ra[st][i][2 * e + 1] * asc[i] : 0.f;
                     const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;                       // round to nearest even
                     hp[e] = h16x2{h0, h1};
                     mp[e] = h16x2{(_Float16)(x0 - (float)h0), (_Float16)(x1 - (float)h1)};    // x - h is exact
@@ -463,6 +473,23 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
                     bad = fmaf(acc[mi][ni][rr], 0.f, bad);
                     acc[mi][ni][rr] *= d.w_scale;
                 }
+        if (d.a_exp) {
+            // acc[mi][ni][4 g + t] is row m0 + wr*64 + mi*32 + 8 g + 4 (lane >> 5) + t: four consecutive rows per g
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = m0 + wr * 64 + mi * 32 + 8 * g + 4 * (lane >> 5);
+                    float un[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        un[t] = row + t < d.M ? skg_exp2i(min(max(d.a_exp[row + t], -126), 126)) : 1.f;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[mi][ni][4 * g + t] *= un[t];
+                }
+        }
         if (__syncthreads_or(bad != bad)) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
@@ -890,6 +917,44 @@ extern "C" int skg_split_weights_f16x2(const float* W, int N, int K, int64_t ldw
     const int64_t total = (int64_t)((N + 31) >> 5) * 32 * ((K + 15) >> 4) * 4;
     hipLaunchKernelGGL(skg_split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        W, N, K, ldw, scale, reinterpret_cast<char*>(out));
+    return skg_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ row exponents of an operand
+// exp_out[r] = floor(log2(max |A[r, :]|)) - 11 (0 for an all-zero row and for rows holding inf / nan), clamped to
+// [-126, 126]: the power of two the split-operand loop divides row r by.  One wave per row, 16-byte loads.
+__global__ __launch_bounds__(256) void skg_row_exponents_kernel(const float* __restrict__ A, int64_t lda,
+                                                                const int32_t* __restrict__ a_rows, int M, int K,
+                                                                int32_t* __restrict__ exp_out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int src = a_rows ? a_rows[row] : row;
+    uint32_t mx = 0u;
+    if (src >= 0) {
+        const float* p = A + (int64_t)src * lda;
+        for (int k = 4 * lane; k < K; k += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(p + k);
+            mx = max(max(mx, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
+            mx = max(max(mx, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+    if (lane == 0) {
+        const int E = (int)(mx >> 23);
+        exp_out[row] = (mx == 0u || E == 255) ? 0 : min(max(E - 127 - 11, -126), 126);
+    }
+}
+
+extern "C" int skg_row_exponents_f32(const float* A, int64_t lda, const int32_t* a_rows, int M, int K, int32_t* exp_out,
+                                     void* stream) {
+    if (M < 0 || K <= 0 || (K & 3) || (lda & 3)) return SKG_E_ARG;
+    if (M == 0) return 0;
+    if (!A || !exp_out) return SKG_E_ARG;
+    if (!skg_aligned16(A)) return SKG_E_ALIGN;
+    hipLaunchKernelGGL(skg_row_exponents_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, A, lda, a_rows, M, K,
+                       exp_out);
     return skg_launch_status();
 }
 

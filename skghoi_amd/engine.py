@@ -256,6 +256,28 @@ def gemm_desc(A, W, bias, C_out, M, N, K, epilogue, lda=None, ldw=None, ldc=None
     return d
 
 
+# ---- row exponents of the split-operand (fp16x2) GEMMs' A operands (power-of-two row scale, include/skghoi.h): one small
+# pass per operand in front of its GEMM, on the same stream.  The buffer comes from the caching allocator (stream-ordered:
+# it may be handed out again only to later work of this stream); inside a graph capture the buffers are kept by the plan,
+# because the capture's two branches share one pool.
+AMAX_CAPTURE_KEEP = None        # set to a list by small.py while a plan is captured
+
+
+def enqueue_row_exponents(d, device):
+    """For a descriptor that takes the split-operand loop (w_split set): enqueues the exponent pass of its A operand on
+    the current stream and points d.a_exp at the result.  Returns the buffer (keep it until the GEMM is enqueued)."""
+    if not d.w_split or d.M <= 0:
+        d.a_exp = 0
+        return None
+    t = torch.empty(d.M, device=device, dtype=torch.int32)
+    if AMAX_CAPTURE_KEEP is not None:
+        AMAX_CAPTURE_KEEP.append(t)
+    _capi.check(_capi.lib().skg_row_exponents_f32(d.A, d.lda, d.a_rows, d.M, d.K, t.data_ptr(), _stream()),
+                "skg_row_exponents_f32")
+    d.a_exp = t.data_ptr()
+    return t
+
+
 def pick_split_k(M, N, K, target_blocks=1024):
     """Split-K factor for a plain layer whose M x N tile grid would leave most of the 256 CUs idle while each
     workgroup walks a long K (box_head: K = 12544).  Slices keep >= 16 k-tiles (256 k) each."""
@@ -284,6 +306,7 @@ def dot_partials(M, N, K, lda, ldw):
 def gemm(A, W, bias, C_out, M, N, K, epilogue, **kw):
     """One skg_gemm_f32 launch (see gemm_desc for the keywords)."""
     d = gemm_desc(A, W, bias, C_out, M, N, K, epilogue, **kw)
+    keep_exp = enqueue_row_exponents(d, A.device) if d.w_split else None
     timed = GEMM_TIMER is not None and (GEMM_TIMER_EPI is None or epilogue in GEMM_TIMER_EPI)
     if timed:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -309,8 +332,11 @@ def gemm_group(specs):
     n = len(specs)
     arr = (_capi.GemmDesc * n)()
     flops = 0.0
+    keep_exp = []
     for i, (a, kw) in enumerate(specs):
         gemm_desc(*a, d=arr[i], **kw)
+        if arr[i].w_split:
+            keep_exp.append(enqueue_row_exponents(arr[i], a[0].device))
         flops += 2.0 * a[4] * a[5] * a[6]
     lib = _capi.lib()
     if lib.skg_gemm_group_tile(arr, n) == 1:

@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 from . import _capi, layout, transh
-from .engine import Preprocessed, gemm_desc, gemm_group, pick_split_k, _stream
+from .engine import Preprocessed, enqueue_row_exponents, gemm_desc, gemm_group, pick_split_k, _stream
 
 META_WORDS = layout.META_DTYPE.itemsize // 4
 
@@ -169,10 +169,13 @@ class SmallBatchRunner:
         import gc
         gc_on = gc.isenabled()
         gc.disable()
+        from . import engine as _engine
+        _engine.AMAX_CAPTURE_KEEP = p.amax_keep = []
         try:
             with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
                 p.out = self._body(p)
         finally:
+            _engine.AMAX_CAPTURE_KEEP = None
             if gc_on:
                 gc.enable()
         p.graph = g
@@ -248,6 +251,8 @@ class SmallBatchRunner:
                 p.bh1_desc = gemm_desc(x0, pw.bh1_w, pw.bh1_b, p.enc1, lay.sum_all, 1024, x0.shape[1],
                                        _capi.EPI_BIAS_RELU, split_k=p.sk, split_ws=p.ws)
         p.bh1_desc.A = x0.data_ptr()               # the one field that changes from call to call
+        if p.bh1_desc.w_split:
+            p.bh1_exp = enqueue_row_exponents(p.bh1_desc, x0.device)
         _capi.check(lib.skg_gemm_f32(C.byref(p.bh1_desc), _stream()), "skg_gemm_f32[box_head 1]")
         # per-call records: meta (image sizes, result offsets), cell count, TransH entity tables
         if p.h2d_done is not None:

@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_struct_mirrors_match_header():
-    assert ctypes.sizeof(_capi.GemmDesc) == 216
+    assert ctypes.sizeof(_capi.GemmDesc) == 224
     assert layout.META_DTYPE.itemsize == 48
     hdr = open(os.path.join(ROOT, "include", "skghoi.h")).read()
     body = hdr[hdr.index("typedef struct {\n    int32_t image"):hdr.index("} skg_image_meta;")]

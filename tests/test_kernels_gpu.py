@@ -156,6 +156,65 @@ def test_gemm_split_operands_precision_range_and_nonfinite():
     assert rel < 1e-5, rel
 
 
+def test_row_exponents_of_an_operand():
+    """skg_row_exponents_f32: floor(log2(max |row|)) - 11 per (gathered) row; 0 for zero rows, gathered -1 rows and rows
+    holding inf / nan."""
+    M, K = 300, 1088
+    src = _rand(200, K, seed=3) * torch.exp2(torch.randint(-30, 30, (200, 1), generator=torch.Generator().manual_seed(5)).float()).cuda()
+    src[7] = 0.0; src[9, 100] = float("inf"); src[11, 5] = float("nan"); src[13, 0] = -3.0e38; src[15, 1] = 1e-40
+    src[15, 2:] = 0.0; src[15, 0] = 0.0
+    rows = torch.randint(-1, 200, (M,), generator=torch.Generator().manual_seed(6)).int().cuda()
+    rows[:20] = torch.arange(20, dtype=torch.int32)
+    out = torch.full((M,), 99, dtype=torch.int32, device="cuda")
+    lib = _capi.lib()
+    assert lib.skg_row_exponents_f32(src.data_ptr(), K, rows.data_ptr(), M, K, out.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    g = torch.where(rows[:, None] >= 0, src[rows.clamp(min=0).long()], torch.zeros(1, device="cuda"))
+    amax = g.abs().amax(dim=1)
+    want = torch.floor(torch.log2(amax.double().clamp(min=1e-300))).int() - 11
+    want = want.clamp(-126, 126)
+    want[(amax == 0) | ~torch.isfinite(amax)] = 0
+    sub = (amax > 0) & (amax < 2.0 ** -126)                 # subnormal maxima: exponent field 0 -> clamped at -126
+    want[sub] = -126
+    assert torch.equal(out, want), (out[out != want][:8], want[out != want][:8])
+    # ungathered, ragged row count (one wave per row, four rows per workgroup)
+    out2 = torch.empty(199, dtype=torch.int32, device="cuda")
+    assert lib.skg_row_exponents_f32(src.data_ptr(), K, None, 199, K, out2.data_ptr(), None) == 0
+    a2 = src[:199].abs().amax(dim=1)
+    w2 = (torch.floor(torch.log2(a2.double().clamp(min=1e-300))).int() - 11).clamp(-126, 126)
+    w2[(a2 == 0) | ~torch.isfinite(a2)] = 0
+    w2[(a2 > 0) & (a2 < 2.0 ** -126)] = -126
+    assert torch.equal(out2, w2)
+
+
+@pytest.mark.parametrize("gain_log2", [-40, -20, -6, 0, 10, 20, 60])
+def test_gemm_split_operands_keep_fp32_grade_at_any_activation_scale(gain_log2):
+    """fp16x2 loop with the power-of-two ROW scale (engine.gemm enqueues skg_row_exponents_f32 and sets desc.a_exp): the
+    result stays within 2e-6 of the row's scale for activations at gains 2^-40 .. 2^60, for rows of very different
+    magnitude in one operand (each row its own power of two on top of the gain), with an outlier row next to them --
+    un-scaled the split's error floor of 2^-25 absolute is 3 % of an activation at a gain of 2^-20."""
+    M, N, K = 300, 256, 512
+    gen = torch.Generator().manual_seed(11)
+    row_pow = torch.randint(-12, 13, (M, 1), generator=gen).float()
+    A = (_rand(M, K, seed=1).cpu() * torch.exp2(row_pow + gain_log2)).cuda()
+    A[5] *= 2.0 ** 15                                            # an outlier row
+    W = _rand(N, K, seed=2) * 3; b = _rand(N, seed=3) * 2.0 ** gain_log2
+    C = torch.empty(M, N, device="cuda")
+    with SplitWeights():
+        gemm(A, W, b, C, M, N, K, _capi.EPI_BIAS)
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double().t() + b.double()
+    assert torch.isfinite(C).all()
+    scale = ref.abs().amax(dim=1, keepdim=True)
+    rel = ((C.double() - ref).abs() / scale).max().item()
+    assert rel <= 2e-6, rel
+    # the exact path on the same operands, for comparison of the grade
+    C0 = torch.empty(M, N, device="cuda")
+    gemm(A, W, b, C0, M, N, K, _capi.EPI_BIAS)
+    rel0 = ((C0.double() - ref).abs() / scale).max().item()
+    assert rel <= 8 * max(rel0, 2.0 ** -24), (rel, rel0)
+
+
 def test_gemm_large_gather_scatter_and_fallback():
     """A grid of several thousand tiles: gathered A rows (incl. -1 = zero row), scattered output rows, a ragged N, and
     the per-tile exact fallback of the fp16x2 loop in tiles far apart."""
