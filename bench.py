@@ -289,8 +289,12 @@ def main():
         raise SystemExit("--precision bf16 is a training configuration (use --mode train)")
     if args.chunk:
         head.engine().chunk_images = args.chunk
-    if args.streams:
-        head.engine().n_streams = args.streams
+    # The timed region runs the chunks on ONE stream: with the engine's default of two, GEMMs of neighbouring chunks
+    # time-share the CUs (+1-2 % images/s) and the HIP events around a launch then time both of them -- the per-launch
+    # durations of the roofline record would read twice what the kernel takes (and what rocprofv3, which serialises
+    # kernels, reports).  The two-stream figure is reported next to it ("two_stream_chunks").
+    default_streams = head.engine().n_streams
+    head.engine().n_streams = args.streams or 1
 
     def step():
         with torch.no_grad():
@@ -371,6 +375,16 @@ def main():
 
     # ---- extra legs, same run, one GPU only (the N-GPU runs of the scaling curve stay headline-only)
     if world == 1 and not args.no_legs:
+        if not args.streams and default_streams > 1:
+            head.engine().n_streams = default_streams
+            for _ in range(2):
+                step()
+            ks = max(2, min(args.steps, 5))
+            els, _ = timed_infer(step, barrier, ks, False)
+            out["two_stream_chunks"] = dict(value=round(args.batch * ks / els, 2), unit="images/s", steps=ks,
+                                            ms_per_step=round(els / ks * 1e3, 3), n_streams=default_streams,
+                                            note="HeadEngine's default: chunks alternate over two HIP streams")
+            head.engine().n_streams = 1
         if head.precision == "fp32":
             # (a) opt-in fp16x2 path on the same inputs, with its own roofline
             head.precision = "fp16x2"

@@ -223,6 +223,47 @@ def test_bf16_training_tracks_fp32(fused):
     assert len(coss) > 20 and float(np.mean(coss)) > 0.99
 
 
+@pytest.mark.parametrize("mode", ["direct", "autograd"])
+def test_fused_step_gradient_arena_reuse_is_safe(mode):
+    """The fused backward reuses its gradient arena (and the p.grad view objects) from step to step ONLY when nothing
+    holds them: (1) steps separated by zero_grad(set_to_none=True) reuse it and give identical gradients; (2) a second
+    backward WITHOUT zero_grad accumulates (2 x the gradients) instead of aliasing the arena it adds to; (3) a gradient
+    tensor a caller kept across zero_grad is not overwritten by the next step."""
+    case = cases.build_case("train_tiny")
+    head = gpu_run.build_head(case)
+    head.fused_training = True
+    head.grad_mode = mode
+    det = gpu_run.to_cuda(case["detections"]); tg = gpu_run.to_cuda(case["targets"])
+    from collections import OrderedDict
+    feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
+    names = ["box_pair_head.attention_head.fc_3.5.weight", "box_pair_head.obj_to_sub.fc_1.0.bias",
+             "box_pair_predictor.weight", "box_pair_head.box_head.3.weight", "box_pair_head.norm_h.weight"]
+    params = dict(head.named_parameters())
+
+    def step(zero=True):
+        if zero:
+            head.zero_grad(set_to_none=True)
+        torch.manual_seed(case["rng_seed"])
+        out = head(feats, det, case["shapes"], tg)
+        sum(out[-1].values()).backward()
+        return {n: params[n].grad.detach().clone() for n in names}
+
+    g1 = step()
+    st = head._train_stack if hasattr(head, "_train_stack") else None
+    g2 = step()                                                     # (1) same inputs, same RNG: identical gradients
+    for n in names:
+        assert torch.equal(g1[n], g2[n]), n
+    g3 = step(zero=False)                                           # (2) accumulation on top of step 2
+    for n in names:
+        assert torch.allclose(g3[n], 2 * g2[n], rtol=1e-6, atol=1e-12), n
+    held = {n: params[n].grad for n in names}                       # (3) a caller keeps the tensors themselves
+    snap = {n: held[n].clone() for n in names}
+    g4 = step()
+    for n in names:
+        assert torch.equal(held[n], snap[n]), "held gradient of %s was overwritten" % n
+        assert torch.equal(g4[n], g1[n]), n
+
+
 def test_eval_with_targets_consumes_rng_like_reference():
     """Validation mode: labels in the results and the host RNG advanced exactly as the reference does
     (tables + randperm per image), checked by drawing from the generator after the call on both sides."""
