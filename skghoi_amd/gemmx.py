@@ -15,7 +15,6 @@ import torch
 from . import _capi
 from .engine import _stream
 
-TARGET_BLOCKS = 512
 
 
 class Op:
@@ -91,12 +90,18 @@ def weight_grad(dz, x, dW, db=None, accumulate=False, rows=None, n_out=None, k_i
     return op
 
 
-def pick_split(op, blocks_so_far=0, target=TARGET_BLOCKS, bk=16):
+def pick_split(op, blocks_so_far=0, target=None, bk=16):
+    """Split-K factor of one product.  Measured on MI355X (tools/gemmx_split_sweep.py, training shapes at 3200 grid
+    rows): the exact fp32 loop is best at ~1000 workgroups (its k-tiles are long: 32 MFMAs of 64 cycles), the bf16 loop
+    at ~450; slices keep >= 128 k; products with more than ~1.5x fewer tiles than the target are not split."""
     tiles = ((op.M + 127) // 128) * ((op.N + 127) // 128)
     kt = (op.K + bk - 1) // bk
-    if tiles == 0 or tiles >= target // 2 or kt < 8:
+    if target is None:
+        target = 1000 if bk == 16 else 448
+    cap = min(kt * bk // 128, 64)
+    if tiles == 0 or cap < 2:
         return 1
-    return int(max(1, min(-(-target // tiles), kt // 4, 64)))
+    return int(max(1, min(int(target / tiles + 0.5), cap)))
 
 
 def launch(ops, bf16=False):
