@@ -49,6 +49,20 @@ class SmallBatchRunner:
         self.hits = self.misses = 0
         self.side = None                   # second stream of the plan bodies (second branch of the captured graphs)
         self.epoch = engine.plan_epoch
+        self.retired = []                  # dropped plans: destroyed only on an idle device, never next to a capture
+
+    def _retire(self, plans):
+        self.retired.extend(plans)
+
+    def _bury_retired(self):
+        """Destroys dropped plans (their hipGraphExec, pool blocks, events, pinned staging) -- with the device idle and
+        before anything of a new capture exists.  Tearing graphs down while the next one is being captured or replayed
+        on the same streams and pool is where the runtime has crashed (rarely) in hipGraphLaunch."""
+        if self.retired:
+            torch.cuda.synchronize()
+            self.retired.clear()
+            import gc
+            gc.collect()                   # dead cycles holding graphs / events go now, not in the middle of a capture
 
     # ------------------------------------------------------------------------------------------------ plan
     def _build_plan(self, key, pre, lay, pw, feat3, pooled):
@@ -155,9 +169,12 @@ class SmallBatchRunner:
             eng.score(logits, p.pre, g, False, out=p.r, L_dev=p.lt_dev)
         # everything both branches touched stays referenced until the plan dies: a block handed back to the allocator
         # inside the capture could be given to the other branch while this one still uses it
-        return dict(logits=logits, pair_features=PF[:Mp], x_keep=x_keep[:Mp], y_keep=y_keep[:Mp], enc=enc, _cx=cx, _G1=G1)
+        # (the fork / join events too: a captured graph must not outlive anything its capture touched)
+        return dict(logits=logits, pair_features=PF[:Mp], x_keep=x_keep[:Mp], y_keep=y_keep[:Mp], enc=enc, _cx=cx, _G1=G1,
+                    _events=(fork, s_ready, g1_ready, g_done))
 
     def _capture(self, p):
+        self._bury_retired()
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
         p.out = self._body(p)                      # eager once: first-use work (weight twins, lazy module init) happens here
@@ -195,6 +212,7 @@ class SmallBatchRunner:
         if not pw.fused_cls:
             return self._fallback(head, pre, features, image_shapes)
         if self.epoch != eng.plan_epoch:           # the packed weights were rebuilt: every plan points into the old copies
+            self._retire(self.plans.values())
             self.plans.clear()
             self.epoch = eng.plan_epoch
         feat3 = features["3"]
@@ -223,7 +241,7 @@ class SmallBatchRunner:
             p = self._build_plan(key, pre, lay, pw, feat3, pooled)
             p.boxes.copy_(pre.boxes); p.scores.copy_(pre.scores); p.labels.copy_(pre.labels)
             while len(self.plans) >= self.max_plans:
-                self.plans.popitem(last=False)
+                self._retire([self.plans.popitem(last=False)[1]])
             self.plans[key] = p
         else:
             self.hits += 1
