@@ -331,9 +331,9 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
         // lane-linear ds_read_b128.  fp16 overflows at 65504: a tile whose accumulators come out non-finite (overflow,
         // inf / nan inputs) is recomputed by the exact loop, so those cases behave as in fp32 arithmetic.
         char* sm = reinterpret_cast<char*>(smem);
-        // Power-of-two scale of every A row (optional, d.a_exp: exponents from skg_row_exponents_f32): row r travels as
-        // 2^-e_r * A[r, :] -- max |.| in [2^11, 2^12) -- and the result row is multiplied back by 2^e_r with the weight's
-        // scale in the epilogue, both exact: the h + m pair keeps its 22 significant bits at any activation magnitude
+        // Power-of-two scale of every A row: row r travels as 2^-e_r * A[r, :] and the result row is multiplied back by
+        // 2^e_r with the weight's scale in the epilogue, both exact.  e_r comes from d.a_exp (skg_row_exponents_f32: the
+        // row's true maximum lands in [2^11, 2^12)) or, without it, from the workgroup's own estimate below: the h + m pair keeps its 22 significant bits at any activation magnitude
         // (un-scaled, m turns subnormal below |x| = 2^-3 and the error floor is 2^-25 absolute), and an outlier row does
         // not cost the other rows their precision.  Rows holding inf / nan keep e = 0; their tile takes the exact loop.
         constexpr int NC = 2, NCB = NC * 1024;
@@ -443,6 +443,29 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
         load_tile(I1{}, clampk(kt_begin + 1));
         load_tile(I2{}, clampk(kt_begin + 2));
         load_tile(I3{}, clampk(kt_begin + 3));
+        if (!d.a_exp) {
+            // No exponents given: every workgroup estimates its rows' scale from the first 64 k it walks (the four tiles
+            // now in registers; 16 values per thread, 4 threads per row).  The estimate can only be LOW (it is the maximum
+            // of a part of the row): values up to 2^7 times larger still fit fp16, beyond that the tile overflows and is
+            // recomputed by the exact loop -- never a wrong result, and no separate pass over the operand.  A row whose
+            // first 64 k are all zero stays un-scaled.
+            int* rowexp = reinterpret_cast<int*>(sm + 2 * BUF);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                uint32_t mx = 0u;
+#pragma unroll
+                for (int st = 0; st < NST; ++st)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mx = max(mx, __float_as_uint(ra[st][i][e]) & 0x7fffffffu);
+                if (!va[i]) mx = 0u;
+                mx = max(mx, (uint32_t)__shfl_xor((int)mx, 1, 64));
+                mx = max(mx, (uint32_t)__shfl_xor((int)mx, 2, 64));
+                const int E = (int)(mx >> 23);
+                const int ex = (mx == 0u || E == 255) ? 0 : min(max(E - 127 - 9, -126), 126);
+                asc[i] = skg_exp2i(-ex);
+                if (q == 0) rowexp[r + 64 * i] = ex;
+            }
+        }
         store_tile(I0{}, 0);
         store_tile(I1{}, 1);
         load_tile(I0{}, clampk(kt_begin + 4));
@@ -473,17 +496,22 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
                     bad = fmaf(acc[mi][ni][rr], 0.f, bad);
                     acc[mi][ni][rr] *= d.w_scale;
                 }
-        if (d.a_exp) {
-            // acc[mi][ni][4 g + t] is row m0 + wr*64 + mi*32 + 8 g + 4 (lane >> 5) + t: four consecutive rows per g
+        {
+            // acc[mi][ni][4 g + t] is row m0 + wr*64 + mi*32 + 8 g + 4 (lane >> 5) + t: four consecutive rows per g.
+            // (rowexp was written before the first barrier of the loop; the tiles never reach that part of the LDS)
+            const int* rowexp = reinterpret_cast<const int*>(sm + 2 * BUF);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int row = m0 + wr * 64 + mi * 32 + 8 * g + 4 * (lane >> 5);
+                    const int lrow = wr * 64 + mi * 32 + 8 * g + 4 * (lane >> 5);
                     float un[4];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        un[t] = row + t < d.M ? skg_exp2i(min(max(d.a_exp[row + t], -126), 126)) : 1.f;
+                    for (int t = 0; t < 4; ++t) {
+                        const int row = m0 + lrow + t;
+                        const int ex = d.a_exp ? (row < d.M ? d.a_exp[row] : 0) : rowexp[lrow + t];
+                        un[t] = skg_exp2i(min(max(ex, -126), 126));
+                    }
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll

@@ -261,12 +261,16 @@ def gemm_desc(A, W, bias, C_out, M, N, K, epilogue, lda=None, ldw=None, ldc=None
 # it may be handed out again only to later work of this stream); inside a graph capture the buffers are kept by the plan,
 # because the capture's two branches share one pool.
 AMAX_CAPTURE_KEEP = None        # set to a list by small.py while a plan is captured
+# False (default): the GEMM workgroups estimate each row's scale from the first 64 k they walk (no extra pass; a low
+# estimate costs at worst an exact re-run of a tile).  True: one skg_row_exponents_f32 pass per operand gives the row's
+# true maximum (+10 % step time at batch 256) -- for operands whose rows start with long runs of zeros.
+EXACT_ROW_SCALE = False
 
 
 def enqueue_row_exponents(d, device):
     """For a descriptor that takes the split-operand loop (w_split set): enqueues the exponent pass of its A operand on
     the current stream and points d.a_exp at the result.  Returns the buffer (keep it until the GEMM is enqueued)."""
-    if not d.w_split or d.M <= 0:
+    if not d.w_split or d.M <= 0 or not EXACT_ROW_SCALE:
         d.a_exp = 0
         return None
     t = torch.empty(d.M, device=device, dtype=torch.int32)

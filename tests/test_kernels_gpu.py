@@ -187,12 +187,16 @@ def test_row_exponents_of_an_operand():
     assert torch.equal(out2, w2)
 
 
+@pytest.mark.parametrize("exact_pass", [False, True], ids=["estimated", "exact-pass"])
 @pytest.mark.parametrize("gain_log2", [-40, -20, -6, 0, 10, 20, 60])
-def test_gemm_split_operands_keep_fp32_grade_at_any_activation_scale(gain_log2):
-    """fp16x2 loop with the power-of-two ROW scale (engine.gemm enqueues skg_row_exponents_f32 and sets desc.a_exp): the
-    result stays within 2e-6 of the row's scale for activations at gains 2^-40 .. 2^60, for rows of very different
-    magnitude in one operand (each row its own power of two on top of the gain), with an outlier row next to them --
-    un-scaled the split's error floor of 2^-25 absolute is 3 % of an activation at a gain of 2^-20."""
+def test_gemm_split_operands_keep_fp32_grade_at_any_activation_scale(gain_log2, exact_pass, monkeypatch):
+    """fp16x2 loop with the power-of-two ROW scale -- estimated by the workgroups from the first 64 k of their rows
+    (default) or from an exact skg_row_exponents_f32 pass (engine.EXACT_ROW_SCALE): the result stays within 2e-6 of the
+    row's scale for activations at gains 2^-40 .. 2^60, for rows of very different magnitude in one operand (each row
+    its own power of two on top of the gain), with an outlier row next to them -- un-scaled the split's error floor of
+    2^-25 absolute is 3 % of an activation at a gain of 2^-20."""
+    from skghoi_amd import engine as _engine
+    monkeypatch.setattr(_engine, "EXACT_ROW_SCALE", exact_pass)
     M, N, K = 300, 256, 512
     gen = torch.Generator().manual_seed(11)
     row_pow = torch.randint(-12, 13, (M, 1), generator=gen).float()
@@ -213,6 +217,27 @@ def test_gemm_split_operands_keep_fp32_grade_at_any_activation_scale(gain_log2):
     gemm(A, W, b, C0, M, N, K, _capi.EPI_BIAS)
     rel0 = ((C0.double() - ref).abs() / scale).max().item()
     assert rel <= 8 * max(rel0, 2.0 ** -24), (rel, rel0)
+
+
+def test_gemm_split_operands_low_scale_estimate_falls_back_exactly():
+    """The workgroups' estimate sees the first 64 k of a row only.  Rows whose values grow past 2^7 times that estimate
+    overflow fp16 and their tiles are recomputed by the exact loop; rows that start with zeros stay un-scaled: the
+    result is right in every case (compared with the exact path)."""
+    M, N, K = 260, 192, 1024
+    A = _rand(M, K, seed=1)
+    A[:, 64:] *= 2.0 ** 14                                # 16 000 times the prefix: overflow -> exact re-run
+    A[3, :200] = 0.0                                      # zero prefix, O(2^14) tail
+    A[200:, :] = _rand(60, K, seed=4) * 2.0 ** -18
+    A[200:, :64] = 0.0                                    # zero prefix, tiny tail: un-scaled (2^-25 absolute floor)
+    W = _rand(N, K, seed=2); b = _rand(N, seed=3)
+    C0 = torch.empty(M, N, device="cuda"); C1 = torch.empty(M, N, device="cuda")
+    gemm(A, W, b, C0, M, N, K, _capi.EPI_BIAS)
+    with SplitWeights():
+        gemm(A, W, b, C1, M, N, K, _capi.EPI_BIAS)
+    torch.cuda.synchronize()
+    assert torch.isfinite(C1).all()
+    scale = (A.abs().amax(dim=1, keepdim=True) * K ** 0.5).clamp(min=1.0)
+    assert ((C1 - C0).abs() / scale).max().item() <= 2e-6
 
 
 def test_gemm_large_gather_scatter_and_fallback():
