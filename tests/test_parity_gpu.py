@@ -249,7 +249,6 @@ def test_fused_step_gradient_arena_reuse_is_safe(mode):
         return {n: params[n].grad.detach().clone() for n in names}
 
     g1 = step()
-    st = head._train_stack if hasattr(head, "_train_stack") else None
     g2 = step()                                                     # (1) same inputs, same RNG: identical gradients
     for n in names:
         assert torch.equal(g1[n], g2[n]), n
