@@ -25,6 +25,7 @@
 // per quad serialises them behind s_waitcnt and runs at a fraction of the speed).  A ragged last tile, operands
 // without 16-byte alignment and row-contiguous operands whose extent is not a multiple of 4 take the generic loop.
 #include "skg_common.h"
+#include <type_traits>
 
 #define XBM 128
 #define XBN 128
@@ -169,25 +170,37 @@ struct XCtx {
 };
 
 // k-tiles [ka, kb) of one workgroup.  `par` = LDS buffer the first tile goes to (flips per tile).
+// k-tiles [ka, kb) of one workgroup.  `par` = LDS buffer the first tile goes to (flips per tile).
+// XNST register stages: the loads of tile t + XNST are issued while tile t is multiplied, so a tile has XNST steps
+// (~1 us each) to arrive -- one stage (the first version) left the HBM / L2 round trip exposed in every step.
+#define XNST 3
 template <bool AK, bool BK_, bool FAST>
 __device__ __forceinline__ void xrun(const XOperand& A, const XOperand& B, const XLane& LA, const XLane& LB, const XCtx& c,
                                      int ka, int kb, int& par, float* smem, f32x16 (&acc)[2][2], float& rsum) {
     if (ka >= kb) return;
     const int tid = c.tid;
-    XQ2 va = xtile<AK, FAST>(A, LA, c.m0, ka * XBK, c.kend, tid);
-    XQ2 vb = xtile<BK_, FAST>(B, LB, c.n0, ka * XBK, c.kend, tid);
-    if (FAST) { xmask2(LA.ok, va); xmask2(LB.ok, vb); }
-    xstore_lds<AK>(smem + par * 2 * XTILE, tid, va);
-    xstore_lds<BK_>(smem + par * 2 * XTILE + XTILE, tid, vb);
+    XQ2 sa[XNST], sb[XNST];
+    auto load = [&](XQ2& a, XQ2& b, int t) {              // past the end: the last tile again (never stored)
+        const int tt = min(t, kb - 1);
+        a = xtile<AK, FAST>(A, LA, c.m0, tt * XBK, c.kend, tid);
+        b = xtile<BK_, FAST>(B, LB, c.n0, tt * XBK, c.kend, tid);
+    };
+    auto store = [&](XQ2& a, XQ2& b, int buf) {
+        // rows outside the operand were loaded from a clamped address: zeroed here, long after the load was issued (a
+        // select right behind the load makes the wave wait for it first)
+        if (FAST) { xmask2(LA.ok, a); xmask2(LB.ok, b); }
+        xstore_lds<AK>(smem + buf * 2 * XTILE, tid, a);
+        xstore_lds<BK_>(smem + buf * 2 * XTILE + XTILE, tid, b);
+    };
+#pragma unroll
+    for (int j = 0; j < XNST; ++j) load(sa[j], sb[j], ka + j);
+    store(sa[0], sb[0], par);
+    load(sa[0], sb[0], ka + XNST);
     __syncthreads();
-    for (int kt = ka; kt < kb; ++kt) {
+    auto step = [&](auto J, int kt) {                      // tile kt is in LDS[par]; tile kt + 1 in stage (J + 1) % XNST
+        constexpr int nx = (decltype(J)::value + 1) % XNST;
         const float* As = smem + par * 2 * XTILE;
         const float* Bs = As + XTILE;
-        const bool more = kt + 1 < kb;
-        if (more) {
-            va = xtile<AK, FAST>(A, LA, c.m0, (kt + 1) * XBK, c.kend, tid);
-            vb = xtile<BK_, FAST>(B, LB, c.n0, (kt + 1) * XBK, c.kend, tid);
-        }
 #pragma unroll
         for (int ks = 0; ks < XBK / 2; ++ks) {
             const int kk = 2 * ks + c.lk;
@@ -202,17 +215,23 @@ __device__ __forceinline__ void xrun(const XOperand& A, const XOperand& B, const
 #pragma unroll
             for (int kk = 0; kk < XBK; ++kk) rsum += As[kk * XLD + tid];
         }
-        if (more) {
-            float* An = smem + (par ^ 1) * 2 * XTILE;
-            // rows outside the operand were loaded from a clamped address: zeroed here, AFTER the MFMAs, so that the
-            // loads stay in flight across them (a select right behind the load makes the wave wait for it first)
-            if (FAST) { xmask2(LA.ok, va); xmask2(LB.ok, vb); }
-            xstore_lds<AK>(An, tid, va);
-            xstore_lds<BK_>(An + XTILE, tid, vb);
-        }
+        if (kt + 1 < kb) store(sa[nx], sb[nx], par ^ 1);
+        load(sa[nx], sb[nx], kt + 1 + XNST);
         __syncthreads();
         par ^= 1;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    static_assert(XNST == 3, "the step sequence below is written for three stages");
+    int kt = ka;
+    for (; kt + XNST <= kb; kt += XNST) {
+        step(I0{}, kt);
+        step(I1{}, kt + 1);
+        step(I2{}, kt + 2);
     }
+    if (kt < kb) step(I0{}, kt);
+    if (kt + 1 < kb) step(I1{}, kt + 1);
 }
 
 template <bool AK, bool BK_>
