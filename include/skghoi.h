@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SKG_ABI_VERSION 6
+#define SKG_ABI_VERSION 7
 #define SKG_E_ARG   (-1)   /* null pointer / negative size / unsupported shape            */
 #define SKG_E_ALIGN (-2)   /* pointer or leading dimension not 16-byte aligned            */
 #define SKG_E_LIMIT (-3)   /* exceeds a compiled-in limit (boxes per image, verbs, ...)   */
@@ -443,6 +443,22 @@ typedef struct {
     uint32_t    first;     /* global word index of ptr[0] */
 } skg_param_chunk;
 int skg_param_checksum(const skg_param_chunk* chunks, int n_chunks, uint64_t* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * AdamW over ALL parameters of the step in ONE launch (SURVEY 8(f)-4 "fused ... optimizer kernels"; the reference
+ * uses torch.optim.AdamW, lr 1e-4, weight decay 1e-4, main:109-127).  chunks[c] = up to SKG_ADAMW_CHUNK consecutive
+ * elements of one tensor: parameter, gradient, exp_avg, exp_avg_sq (fp32, the four at the same element offset).
+ * Per element, torch's decoupled rule:  p *= 1 - lr * weight_decay;  m += (g - m)(1 - beta1);
+ * v = beta2 v + (1 - beta2) g^2;  p -= (lr / bias1) * m / (sqrt(v) / sqrt(bias2) + eps),  bias_k = 1 - beta_k^step
+ * (bias1, bias2 are passed in: the step count lives on the host; the scalar
+ * factors are formed in double and rounded once, like torch's).  HBM-bound: 28 bytes per parameter.               */
+#define SKG_ADAMW_CHUNK 16384
+typedef struct {
+    float* p; const float* g; float* m; float* v;
+    uint32_t count, reserved;
+} skg_adamw_chunk;
+int skg_adamw_f32(const skg_adamw_chunk* chunks, int n_chunks, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, double bias1, double bias2, void* stream);
 
 #ifdef __cplusplus
 }

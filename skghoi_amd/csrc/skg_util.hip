@@ -7,6 +7,7 @@
 //                        nn.Linear weights afresh in every forward (heads/adamixer_transH_spatial_r50_head.py:812-973),
 //                        so a stale packed copy would be a silent parity bug.  HBM-bound: 118 MB read once
 //                        (the bytes of the parameters), one 16-byte load per lane and step.
+//   skg_adamw          : AdamW over every parameter of the training step in one launch (chunk table).
 #include "skg_common.h"
 
 #define CK_THREADS 256
@@ -57,5 +58,57 @@ extern "C" int skg_param_checksum(const skg_param_chunk* chunks, int n_chunks, u
     if ((((uintptr_t)out) & 7u) != 0) return SKG_E_ALIGN;
     hipLaunchKernelGGL(skg_param_checksum_kernel, dim3(SKG_CHECKSUM_PARTIALS), dim3(CK_THREADS), 0, (hipStream_t)stream,
                        chunks, n_chunks, reinterpret_cast<unsigned long long*>(out));
+    return skg_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ AdamW, one launch
+// One workgroup per chunk (<= SKG_ADAMW_CHUNK elements of one tensor).  16-byte accesses when the four pointers allow it
+// (uniform per workgroup), scalar otherwise (a bias slice that starts at an odd element).
+__device__ __forceinline__ void skg_adamw_one(float& p, float g, float& m, float& v, float decay, float c1, float beta2,
+                                              float c2, float step_size, float inv_sqrt_b2, float eps) {
+    p *= decay;
+    m += (g - m) * c1;
+    v = beta2 * v + c2 * g * g;
+    p -= step_size * (m / (sqrtf(v) * inv_sqrt_b2 + eps));
+}
+
+__global__ __launch_bounds__(256) void skg_adamw_kernel(const skg_adamw_chunk* __restrict__ chunks, float decay, float c1,
+                                                        float beta2, float c2, float step_size, float inv_sqrt_b2,
+                                                        float eps) {
+    const skg_adamw_chunk c = chunks[blockIdx.x];
+    const uint32_t n = c.count;
+    const bool vec = ((((uintptr_t)c.p) | ((uintptr_t)c.g) | ((uintptr_t)c.m) | ((uintptr_t)c.v)) & 15u) == 0;
+    uint32_t done = 0;
+    if (vec) {
+        const uint32_t n4 = n >> 2;
+        float4* p4 = reinterpret_cast<float4*>(c.p); const float4* g4 = reinterpret_cast<const float4*>(c.g);
+        float4* m4 = reinterpret_cast<float4*>(c.m); float4* v4 = reinterpret_cast<float4*>(c.v);
+        for (uint32_t i = threadIdx.x; i < n4; i += 256) {
+            float4 p = p4[i], m = m4[i], v = v4[i];
+            const float4 g = g4[i];
+            skg_adamw_one(p.x, g.x, m.x, v.x, decay, c1, beta2, c2, step_size, inv_sqrt_b2, eps);
+            skg_adamw_one(p.y, g.y, m.y, v.y, decay, c1, beta2, c2, step_size, inv_sqrt_b2, eps);
+            skg_adamw_one(p.z, g.z, m.z, v.z, decay, c1, beta2, c2, step_size, inv_sqrt_b2, eps);
+            skg_adamw_one(p.w, g.w, m.w, v.w, decay, c1, beta2, c2, step_size, inv_sqrt_b2, eps);
+            p4[i] = p; m4[i] = m; v4[i] = v;
+        }
+        done = 4u * n4;
+    }
+    for (uint32_t i = done + threadIdx.x; i < n; i += 256) {
+        float p = c.p[i], m = c.m[i], v = c.v[i];
+        skg_adamw_one(p, c.g[i], m, v, decay, c1, beta2, c2, step_size, inv_sqrt_b2, eps);
+        c.p[i] = p; c.m[i] = m; c.v[i] = v;
+    }
+}
+
+// The scalar factors are formed in double on the host and rounded once (1 - beta2 in float arithmetic is 1.3e-5 off).
+extern "C" int skg_adamw_f32(const skg_adamw_chunk* chunks, int n_chunks, double lr, double beta1, double beta2, double eps,
+                             double weight_decay, double bias1, double bias2, void* stream) {
+    if (n_chunks < 0 || (n_chunks > 0 && !chunks)) return SKG_E_ARG;
+    if (!(bias1 > 0.0) || !(bias2 > 0.0) || !(eps >= 0.0)) return SKG_E_ARG;
+    if (n_chunks == 0) return 0;
+    hipLaunchKernelGGL(skg_adamw_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, chunks,
+                       (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                       (float)(lr / bias1), (float)(1.0 / sqrt(bias2)), (float)eps);
     return skg_launch_status();
 }

@@ -199,8 +199,8 @@ def test_cached_fused_adamw_matches_stock_bit_for_bit():
         torch.manual_seed(1)
         return torch.nn.Sequential(torch.nn.Linear(33, 65), torch.nn.ReLU(), torch.nn.Linear(65, 7)).to(dev)
     a, b = make(), make()
-    oa = trainer.build_optimizer(a, lr=1e-3)
-    assert isinstance(oa, trainer.CachedFusedAdamW)
+    oa = trainer.CachedFusedAdamW(a.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+    assert isinstance(trainer.build_optimizer(a, lr=1e-3), trainer.SkgAdamW)        # what the trainer shell hands out on a GPU
     ob = torch.optim.AdamW(b.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
 
     def step(k, skip=False):
@@ -221,7 +221,7 @@ def test_cached_fused_adamw_matches_stock_bit_for_bit():
         g["lr"] = 3e-4
     step(5)
     sd = oa.state_dict()
-    oa2 = trainer.build_optimizer(a, lr=1e-3)
+    oa2 = trainer.CachedFusedAdamW(a.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
     oa2.load_state_dict(sd)
     oa = oa2
     for k in range(6, 9):
@@ -259,3 +259,64 @@ def test_lazy_losses_read_back_with_nan_guard(capsys):
     tr(1)
     assert [h["hoi_loss"] for h in tr.history] == pytest.approx(seen) and all(isinstance(h["hoi_loss"], float) for h in tr.history)
     assert "iteration 2" in capsys.readouterr().out
+
+
+@pytest.mark.gpu
+def test_one_launch_adamw_matches_torch_fused():
+    """trainer.SkgAdamW (skg_adamw_f32: all parameters in one launch) against torch.optim.AdamW(fused=True): parameters
+    and moments agree to rounding after ten steps with fresh gradient tensors every step, sizes that are no multiple of
+    the chunk or of 4, a parameter living at an odd element offset of a larger buffer (scalar path), two parameter groups
+    with different learning rates, a changed lr, a state_dict round trip into the stock optimizer and back, and a step
+    with a missing gradient (stock path, then back on the kernel)."""
+    dev = torch.device("cuda")
+    shapes = [(1024, 1088), (117, 2048), (117,), (1,), (64, 46), (3, 5, 7), (40000,)]
+
+    def make():
+        g = torch.Generator().manual_seed(3)
+        ps = [torch.nn.Parameter(torch.randn(*sh, generator=g).to(dev)) for sh in shapes]
+        big = torch.randn(300, generator=g).to(dev)
+        odd = torch.nn.Parameter(torch.empty(0, device=dev))
+        odd.data = big[1:118]                                   # 4-byte aligned only
+        return ps + [odd]
+    pa, pb = make(), make()
+    oa = trainer.SkgAdamW([{"params": pa[:4]}, {"params": pa[4:], "lr": 3e-4}], lr=1e-3, weight_decay=1e-2, fused=True)
+    ob = torch.optim.AdamW([{"params": pb[:4]}, {"params": pb[4:], "lr": 3e-4}], lr=1e-3, weight_decay=1e-2, fused=True)
+
+    def step(k, skip=None):
+        for ps, opt in ((pa, oa), (pb, ob)):
+            opt.zero_grad(set_to_none=True)
+            for i, p in enumerate(ps):
+                if i == skip:
+                    continue
+                gg = torch.Generator().manual_seed(1000 * k + i)
+                p.grad = (torch.randn(p.shape, generator=gg) * (1.0 + i)).to(dev)
+            opt.step()
+
+    def check(tag):
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            assert torch.allclose(x, y, rtol=2e-6, atol=1e-7), (tag, i, (x - y).abs().max().item())
+        for x, y in zip(pa, pb):
+            sx, sy = oa.state[x], ob.state[y]
+            # (moments near zero are differences of O(|g|) numbers: one ulp of the gradient's scale, absolute)
+            assert torch.allclose(sx["exp_avg"], sy["exp_avg"], rtol=1e-5, atol=1e-5)
+            assert torch.allclose(sx["exp_avg_sq"], sy["exp_avg_sq"], rtol=1e-5, atol=1e-6)
+            assert float(sx["step"]) == float(sy["step"])
+    for k in range(5):
+        step(k)
+    assert oa._plans and all(pl["ok"] for pl in oa._plans.values()), "kernel path not taken"
+    check("five steps")
+    for g in oa.param_groups + ob.param_groups:
+        g["lr"] = g["lr"] * 0.1
+    step(5)
+    step(6, skip=2)                                             # a missing gradient: stock path, steps diverge
+    step(7)                                                     # different step counts in group 0: stays on the stock path
+    check("after a skipped gradient")
+    sd = oa.state_dict()
+    oc = torch.optim.AdamW([{"params": pa[:4]}, {"params": pa[4:], "lr": 3e-4}], lr=1e-3, weight_decay=1e-2, fused=True)
+    oc.load_state_dict(sd)                                      # the stock optimizer accepts the state
+    oa2 = trainer.SkgAdamW([{"params": pa[:4]}, {"params": pa[4:], "lr": 3e-4}], lr=1e-3, weight_decay=1e-2, fused=True)
+    oa2.load_state_dict(oc.state_dict())
+    oa = oa2
+    for k in range(8, 11):
+        step(k)
+    check("after the state_dict round trip")
