@@ -1,11 +1,11 @@
 """Developer aid: per-launch timeline of the last training step in a rocprofv3 kernel trace.
-usage: step_timeline.py <dir with *_kernel_trace.csv> [adam launches per step = 12]"""
+usage: step_timeline.py <dir with *_kernel_trace.csv> [optimizer launches per step = 1 (skg_adamw; torch's fused AdamW: 12)]"""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True)[0]
-per = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+per = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'FusedAdam' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'FusedAdam' in r['Kernel_Name'] or 'skg_adamw' in r['Kernel_Name']]
 seg = rows[idx[-per - 1] + 1: idx[-1] + 1]
 t0 = int(seg[0]['Start_Timestamp'])
 tot = 0
