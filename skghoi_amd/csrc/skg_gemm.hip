@@ -273,35 +273,44 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
             s_begin = split_slice * per;
             s_end = s_begin + per < s_end ? s_begin + per : s_end;
         }
-        float4 ra[4], rw[4];
-        auto gload3 = [&](int st) {
+        // Two register stages: the loads of step st + 2 are issued while step st is multiplied, so a tile has two steps
+        // (~1 us each: 32 MFMAs of 64 cycles per wave) to arrive.  With one stage the round trip to L2 / HBM stuck out of
+        // every step by ~0.7 us (2 us per step measured at one image).
+        float4 ra[2][4], rw[2][4];
+        auto gload3 = [&](auto S, int st) {
+            constexpr int sg = decltype(S)::value;
             const int k = st * BK3 + lc;
             const int kk = (k < d.K) ? k : 0;        // clamped, masked when written to LDS (K % 4 == 0: whole quads)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                ra[i] = *reinterpret_cast<const float4*>(pa[i] + kk);
-                rw[i] = *reinterpret_cast<const float4*>(pw[i] + kk);
+                ra[sg][i] = *reinterpret_cast<const float4*>(pa[i] + kk);
+                rw[sg][i] = *reinterpret_cast<const float4*>(pw[i] + kk);
             }
         };
-        auto lstore3 = [&](int st) {
+        auto lstore3 = [&](auto S, int st) {
+            constexpr int sg = decltype(S)::value;
             const bool kin = st * BK3 + lc < d.K;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool ma = kin && va[i], mw = kin && vw[i];
-                const float4 x = ra[i], w = rw[i];
+                const float4 x = ra[sg][i], w = rw[sg][i];
                 *reinterpret_cast<float4*>(a_s3 + (lr + 16 * i) * LD3 + lc) =
                     make_float4(ma ? x.x : 0.f, ma ? x.y : 0.f, ma ? x.z : 0.f, ma ? x.w : 0.f);
                 *reinterpret_cast<float4*>(b_s3 + (lr + 16 * i) * LD3 + lc) =
                     make_float4(mw ? w.x : 0.f, mw ? w.y : 0.f, mw ? w.z : 0.f, mw ? w.w : 0.f);
             }
         };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
         if (s_begin < s_end) {
-            gload3(s_begin);
-            lstore3(s_begin);
+            gload3(S0{}, s_begin);
+            gload3(S1{}, s_begin + 1);               // (past the slice: a readable tile that is never stored)
+            lstore3(S0{}, s_begin);
+            gload3(S0{}, s_begin + 2);
         }
         __syncthreads();
-        for (int st = s_begin; st < s_end; ++st) {
-            if (st + 1 < s_end) gload3(st + 1);
+        // one step: tile st is in LDS, tile st + 1 in stage NX, tile st + 2 in flight into the other stage
+        auto step3 = [&](auto NX, int st) {
             const float* ap = a_s3 + (wr * 32 + li) * LD3 + 4 * lh;
             const float* bp = b_s3 + (wc * 32 + li) * LD3 + 4 * lh;
 #pragma unroll
@@ -315,10 +324,17 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
             }
             __syncthreads();                          // every wave is done reading this step's tile
             if (st + 1 < s_end) {
-                lstore3(st + 1);
+                lstore3(NX, st + 1);
+                gload3(NX, st + 3);
                 __syncthreads();
             }
+        };
+        int st = s_begin;
+        for (; st + 1 < s_end; st += 2) {
+            step3(S1{}, st);
+            step3(S0{}, st + 1);
         }
+        if (st < s_end) step3(S1{}, st);
     } else if constexpr (MODE == 2) {
         // ---- fp32-grade result from the fp16 matrix pipe (3 MFMA passes instead of the 8 of the fp32 MFMA per 16 k).
         // Every operand value x is carried as h + m with h = fp16(x), m = fp16(x - h): 22 significant bits, i.e.
