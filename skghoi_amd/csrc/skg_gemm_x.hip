@@ -459,8 +459,12 @@ __device__ __forceinline__ void yrowsum(float4 va, float4 vb, float4 vc, float4 
     }
 }
 
+// One register stage (the next tile in flight across the MFMAs): kept for products whose operands are both contiguous
+// along their own index (dW = dZ^T X) -- measured, a second stage costs them a third of their rate at 102400 rows
+// (475 -> 295 TFLOP/s: eight more 16-byte loads per thread in flight, two 512-byte segments each), while it gains the
+// k-contiguous layouts 15-35 %.
 template <bool AK, bool BK_, bool FAST>
-__device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const XLane& LA, const XLane& LB, const XCtx& c,
+__device__ __forceinline__ void yrun1(const XOperand& A, const XOperand& B, const XLane& LA, const XLane& LB, const XCtx& c,
                                      int ka, int kb, int& par, uint16_t* smem, f32x16 (&acc)[2][2], float4& rs) {
     if (ka >= kb) return;
     const int tid = c.tid;
@@ -510,6 +514,71 @@ __device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const
     }
 }
 
+// YNST register stages of global prefetch (see xrun): here a step's MFMAs take 256 cycles, so the loop is a pure memory
+// round trip per step unless several tiles are in flight; two stages (64 VGPRs) are what the register budget of two
+// waves per SIMD leaves next to the 64 accumulators.
+#define YNST 2
+template <bool AK, bool BK_, bool FAST>
+__device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const XLane& LA, const XLane& LB, const XCtx& c,
+                                     int ka, int kb, int& par, uint16_t* smem, f32x16 (&acc)[2][2], float4& rs) {
+    if (ka >= kb) return;
+    const int tid = c.tid;
+    // fragment addresses (bf16 elements) inside a tile; k-step ks adds 2 ks planes
+    const int fa0 = c.lk * YPLANE + yslot(c.wm * 64 + c.li) * 8, fa1 = c.lk * YPLANE + yslot(c.wm * 64 + 32 + c.li) * 8;
+    const int fb0 = c.lk * YPLANE + yslot(c.wn * 64 + c.li) * 8, fb1 = c.lk * YPLANE + yslot(c.wn * 64 + 32 + c.li) * 8;
+    float4 sa[YNST][4], sb[YNST][4];
+    auto load = [&](auto S, int t) {                      // past the end: the last tile again (never stored)
+        constexpr int g = decltype(S)::value;
+        const int tt = min(t, kb - 1);
+        ytile<AK, FAST>(A, LA, c.m0, tt * YBK, c.kend, tid, sa[g][0], sa[g][1], sa[g][2], sa[g][3]);
+        ytile<BK_, FAST>(B, LB, c.n0, tt * YBK, c.kend, tid, sb[g][0], sb[g][1], sb[g][2], sb[g][3]);
+    };
+    auto store = [&](auto S, int buf) {
+        constexpr int g = decltype(S)::value;
+        // zeroing of clamped rows long after the load was issued: the loads stay in flight across the MFMAs
+        if (FAST) { ymask4(LA.ok, sa[g][0], sa[g][1], sa[g][2], sa[g][3]); ymask4(LB.ok, sb[g][0], sb[g][1], sb[g][2], sb[g][3]); }
+        if (c.do_rowsum) yrowsum<AK>(sa[g][0], sa[g][1], sa[g][2], sa[g][3], rs);
+        ystore_lds<AK>(smem + buf * 2 * YTILE, tid, sa[g][0], sa[g][1], sa[g][2], sa[g][3]);
+        ystore_lds<BK_>(smem + buf * 2 * YTILE + YTILE, tid, sb[g][0], sb[g][1], sb[g][2], sb[g][3]);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    static_assert(YNST == 2, "the step sequence below is written for two stages");
+    load(I0{}, ka);
+    load(I1{}, ka + 1);
+    store(I0{}, par);
+    load(I0{}, ka + 2);
+    __syncthreads();
+    auto step = [&](auto NX, int kt) {                     // tile kt is in LDS[par]; tile kt + 1 in stage NX
+        const uint16_t* As = smem + par * 2 * YTILE;
+        const uint16_t* Bs = As + YTILE;
+        const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(As + fa0), a01 = *reinterpret_cast<const bf16x8*>(As + fa1);
+        const bf16x8 b00 = *reinterpret_cast<const bf16x8*>(Bs + fb0), b01 = *reinterpret_cast<const bf16x8*>(Bs + fb1);
+        const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(As + 2 * YPLANE + fa0);
+        const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(As + 2 * YPLANE + fa1);
+        const bf16x8 b10 = *reinterpret_cast<const bf16x8*>(Bs + 2 * YPLANE + fb0);
+        const bf16x8 b11 = *reinterpret_cast<const bf16x8*>(Bs + 2 * YPLANE + fb1);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, b00, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, b01, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, b00, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, b01, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, b10, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, b11, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, b10, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, b11, acc[1][1], 0, 0, 0);
+        if (kt + 1 < kb) store(NX, par ^ 1);
+        load(NX, kt + 1 + YNST);
+        __syncthreads();
+        par ^= 1;
+    };
+    int kt = ka;
+    for (; kt + 1 < kb; kt += 2) {
+        step(I1{}, kt);
+        step(I0{}, kt + 1);
+    }
+    if (kt < kb) step(I1{}, kt);
+}
+
 template <bool AK, bool BK_>
 __device__ __forceinline__ void ymain(const XOperand& A, const XOperand& B, const XCtx& c, int kt0, int kt1, uint16_t* smem,
                                       f32x16 (&acc)[2][2], float4& rs) {
@@ -519,8 +588,13 @@ __device__ __forceinline__ void ymain(const XOperand& A, const XOperand& B, cons
     int ktf = kt0;
     if (xfast_ok<AK>(A, c.m0) && xfast_ok<BK_>(B, c.n0) && kt1 > kt0) ktf = (c.kend == kt1 * YBK) ? kt1 : kt1 - 1;
     int par = 0;
-    yrun<AK, BK_, true>(A, B, LA, LB, c, kt0, ktf, par, smem, acc, rs);
-    yrun<AK, BK_, false>(A, B, LA, LB, c, ktf, kt1, par, smem, acc, rs);
+    if (!AK && !BK_) {
+        yrun1<AK, BK_, true>(A, B, LA, LB, c, kt0, ktf, par, smem, acc, rs);
+        yrun1<AK, BK_, false>(A, B, LA, LB, c, ktf, kt1, par, smem, acc, rs);
+    } else {
+        yrun<AK, BK_, true>(A, B, LA, LB, c, kt0, ktf, par, smem, acc, rs);
+        yrun<AK, BK_, false>(A, B, LA, LB, c, ktf, kt1, par, smem, acc, rs);
+    }
     if (c.do_rowsum) {                                     // uniform per workgroup; the k loop ended on a barrier
         float* part = reinterpret_cast<float*>(smem);      // [8][128] partial sums
         if (AK) {
