@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SKG_ABI_VERSION 7
+#define SKG_ABI_VERSION 8
 #define SKG_E_ARG   (-1)   /* null pointer / negative size / unsupported shape            */
 #define SKG_E_ALIGN (-2)   /* pointer or leading dimension not 16-byte aligned            */
 #define SKG_E_LIMIT (-3)   /* exceeds a compiled-in limit (boxes per image, verbs, ...)   */
@@ -100,6 +100,13 @@ int skg_roi_align_f32(const float* const* feats_host, const int32_t* H_host, con
                       const float* scales_host, int n_levels, int C, int k_min, int k_max, float canonical_scale,
                       int canonical_level, const float* boxes, const int32_t* box_image, int n_rois, int pooled,
                       int sampling, float* out, void* stream);
+/* Backward of skg_roi_align_f32 with respect to the feature maps (torchvision's roi_align backward; no gradient for the
+ * boxes): dfeats_host[l] points at a ZEROED [B, C, H_l, W_l] gradient map per level, dout is [n_rois, C, pooled, pooled].
+ * Float atomics: the order of the additions into a pixel is not fixed (as in torchvision's kernel).               */
+int skg_roi_align_bwd_f32(float* const* dfeats_host, const int32_t* H_host, const int32_t* W_host,
+                          const float* scales_host, int n_levels, int C, int k_min, int k_max, float canonical_scale,
+                          int canonical_level, const float* boxes, const int32_t* box_image, int n_rois, int pooled,
+                          int sampling, const float* dout, void* stream);
 
 /* AdaptiveAvgPool2d(1) of features['3'] (HEAD:811): in [B, C, HW] -> out [B, C]. */
 int skg_global_avgpool_f32(const float* in, int B, int C, int HW, float* out, void* stream);

@@ -12,7 +12,7 @@ MAX_NODES = 160
 SPATIAL_LD = 48
 TRANSH_DIM = 50
 TRANSH_ENT = 80
-ABI_VERSION = 7
+ABI_VERSION = 8
 GEMM_GROUP_MAX = 4
 CHECKSUM_PARTIALS = 1024
 LOSS_CHUNKS = 16
@@ -67,6 +67,8 @@ PROTOTYPES = {
     "skg_pairs_spatial_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int,
                                         _vp]),
     "skg_roi_align_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp,
+                                    C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "skg_roi_align_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp,
                                     C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "skg_global_avgpool_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "skg_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _vp]),

@@ -5,7 +5,9 @@ Drop-in for `torchvision.ops.MultiScaleRoIAlign` as the reference builds it
 sampling_ratio 2) and calls it (heads/adamixer_transH_spatial_r50_head.py:387):
     box_features = box_roi_pool(features: Dict[str, Tensor[B,C,H,W]], boxes: List[Tensor[N,4]], image_shapes)
 torchvision is absent from the image; its published algorithm is restated (scale inference 2**round(log2(feat/img)),
-LevelMapper with canonical scale 224 / level 4 / eps 1e-6, roi_align with aligned=False).
+LevelMapper with canonical scale 224 / level 4 / eps 1e-6, roi_align with aligned=False).  Differentiable with respect to
+the feature maps (`skg_roi_align_bwd_f32`): the reference trains the detector's backbone and neck through this pooling
+(configures/hicodet/adamixer_transH_spatial_r50_main.py:109-127 gives them lr * 0.1).
 """
 import ctypes as C
 import math
@@ -17,6 +19,44 @@ from torch import nn, Tensor
 
 from . import _capi
 from .engine import _stream
+
+
+def _level_args(feats, scales):
+    L = len(feats)
+    return ((C.c_void_p * L)(*[f.data_ptr() for f in feats]),
+            (C.c_int32 * L)(*[int(f.shape[2]) for f in feats]), (C.c_int32 * L)(*[int(f.shape[3]) for f in feats]),
+            (C.c_float * L)(*scales))
+
+
+class _RoIAlignFn(torch.autograd.Function):
+    """out = MultiScaleRoIAlign(feats...); backward scatters d out into zeroed feature gradients (float atomics)."""
+
+    @staticmethod
+    def forward(ctx, cfg, rois, img, *feats):
+        scales, k_min, k_max, canon_s, canon_l, pooled, sampling = cfg
+        fs = [f.float().contiguous() for f in feats]
+        n_rois, Cc = rois.shape[0], fs[0].shape[1]
+        out = torch.empty(n_rois, Cc, pooled, pooled, device=rois.device, dtype=torch.float32)
+        ptrs, Hs, Ws, sc = _level_args(fs, scales)
+        _capi.check(_capi.lib().skg_roi_align_f32(ptrs, Hs, Ws, sc, len(fs), Cc, k_min, k_max, float(canon_s), int(canon_l),
+                                                  rois.data_ptr(), img.data_ptr(), n_rois, pooled, sampling,
+                                                  out.data_ptr(), _stream()), "skg_roi_align_f32")
+        ctx.cfg, ctx.rois, ctx.img = cfg, rois, img
+        ctx.shapes = [tuple(f.shape) for f in fs]
+        ctx.dtypes = [f.dtype for f in feats]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        scales, k_min, k_max, canon_s, canon_l, pooled, sampling = ctx.cfg
+        dout = dout.float().contiguous()
+        dfs = [torch.zeros(sh, device=dout.device, dtype=torch.float32) for sh in ctx.shapes]
+        ptrs, Hs, Ws, sc = _level_args(dfs, scales)
+        _capi.check(_capi.lib().skg_roi_align_bwd_f32(ptrs, Hs, Ws, sc, len(dfs), ctx.shapes[0][1], k_min, k_max,
+                                                      float(canon_s), int(canon_l), ctx.rois.data_ptr(), ctx.img.data_ptr(),
+                                                      ctx.rois.shape[0], pooled, sampling, dout.data_ptr(), _stream()),
+                    "skg_roi_align_bwd_f32")
+        return (None, None, None) + tuple(d.to(t) for d, t in zip(dfs, ctx.dtypes))
 
 
 class MultiScaleRoIAlign(nn.Module):
@@ -58,20 +98,19 @@ class MultiScaleRoIAlign(nn.Module):
         n_per = [int(b.shape[0]) for b in boxes]
         n_rois = sum(n_per)
         Cc = feats[0].shape[1]
-        out = torch.empty(n_rois, Cc, self.output_size, self.output_size, device=dev, dtype=torch.float32)
         if n_rois == 0:
-            return out
-        feats = [f.float().contiguous() for f in feats]
-        rois = torch.cat([b.reshape(-1, 4) for b in boxes]).float().contiguous()
+            return torch.empty(0, Cc, self.output_size, self.output_size, device=dev, dtype=torch.float32)
+        rois = torch.cat([b.reshape(-1, 4) for b in boxes]).detach().float().contiguous()
         img = torch.repeat_interleave(torch.arange(len(boxes), dtype=torch.int32),
                                       torch.tensor(n_per)).to(dev, non_blocking=True)
         L = len(feats)
-        ptrs = (C.c_void_p * L)(*[f.data_ptr() for f in feats])
-        Hs = (C.c_int32 * L)(*[int(f.shape[2]) for f in feats]); Ws = (C.c_int32 * L)(*[int(f.shape[3]) for f in feats])
-        sc = (C.c_float * L)(*self.scales)
         k_min, k_max = (self.k_min, self.k_max) if L > 1 else (0, 0)
-        _capi.check(_capi.lib().skg_roi_align_f32(ptrs, Hs, Ws, sc, L, Cc, k_min, k_max, float(self.canonical_scale),
-                                                  int(self.canonical_level), rois.data_ptr(), img.data_ptr(), n_rois,
-                                                  self.output_size, self.sampling_ratio, out.data_ptr(), _stream()),
-                    "skg_roi_align_f32")
-        return out
+        cfg = (list(self.scales), k_min, k_max, self.canonical_scale, self.canonical_level, self.output_size,
+               self.sampling_ratio)
+        if torch.is_grad_enabled() and any(f.requires_grad for f in feats):
+            return _RoIAlignFn.apply(cfg, rois, img, *feats)
+        return _RoIAlignFn.forward(_NoCtx(), cfg, rois, img, *feats)
+
+
+class _NoCtx:
+    """Stand-in for the autograd context on the no-gradient path (the forward stores three attributes on it)."""

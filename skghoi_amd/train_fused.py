@@ -156,12 +156,20 @@ class HeadTrainFn(torch.autograd.Function):
     def forward(ctx, job, x0, gfeat, *params):
         S = job.forward(x0, gfeat)
         ctx.job = job
+        ctx.in_meta = ((x0.shape, x0.dtype), (gfeat.shape, gfeat.dtype))
         return S["logits"]
 
     @staticmethod
     def backward(ctx, dlogits):
         job = ctx.job
         dx0, dgfeat, pgrads = job.backward(dlogits, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        # the step works on flattened fp32 copies of its inputs: hand the gradients back in the inputs' own shape / dtype
+        # (pooled box features arrive as [N, 256, 7, 7] when the RoI pooling in front is differentiable)
+        (s0, t0), (s1, t1) = ctx.in_meta
+        if dx0 is not None:
+            dx0 = dx0.reshape(s0).to(t0)
+        if dgfeat is not None:
+            dgfeat = dgfeat.reshape(s1).to(t1)
         if job.direct:
             for p, g in zip(job.params, pgrads):
                 if g is None or not p.requires_grad:

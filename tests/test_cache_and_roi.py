@@ -62,6 +62,34 @@ def test_multiscale_roi_align_matches_oracle():
 
 
 @pytest.mark.gpu
+def test_multiscale_roi_align_backward_matches_oracle_autograd():
+    """Gradient with respect to the four feature maps (the reference trains the detector through this pooling) against
+    CPU autograd of the oracle's loop restatement, boxes on all four levels, partly outside the image, one degenerate."""
+    from oracle import roi_align_oracle as RO
+    from skghoi_amd.roi_pool import MultiScaleRoIAlign
+    g = torch.Generator().manual_seed(1)
+    shapes = [(200, 320), (192, 256)]
+    feats = [torch.randn(2, 3, 200 // s, 320 // s, generator=g) for s in (4, 8, 16, 32)]
+    boxes = [torch.tensor([[10.3, 20.1, 150.7, 180.2], [0., 0., 319., 199.], [100., 50., 104., 53.], [5., 5., 5.5, 5.2]]),
+             torch.tensor([[30., 40., 90., 160.], [-5., -3., 40., 30.], [200., 150., 330., 210.]])]
+    dout = torch.randn(7, 3, 7, 7, generator=g)
+    fr = [f.clone().requires_grad_(True) for f in feats]
+    RO.multiscale_roi_align(fr, boxes, shapes, 7, 2).backward(dout)
+    fd = [f.cuda().requires_grad_(True) for f in feats]
+    pool = MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
+    out = pool({str(i): f for i, f in enumerate(fd)}, [b.cuda() for b in boxes], shapes)
+    assert out.requires_grad
+    out.backward(dout.cuda())
+    for l, (a, b) in enumerate(zip(fd, fr)):
+        want = b.grad if b.grad is not None else torch.zeros_like(b)
+        assert a.grad is not None and (a.grad.cpu() - want).abs().max().item() <= 2e-5, l
+    assert sum(float(b.grad.abs().sum()) > 0 for b in fr if b.grad is not None) >= 3      # several levels really used
+    # without gradients requested nothing is recorded
+    with torch.no_grad():
+        assert not pool({str(i): f for i, f in enumerate(fd)}, [b.cuda() for b in boxes], shapes).requires_grad
+
+
+@pytest.mark.gpu
 def test_cached_pipeline_equals_direct(tmp_path):
     """feature maps -> MultiScaleRoIAlign -> head   ==   producer -> shard on disk -> reader -> head (fp32, bit-equal)."""
     from collections import OrderedDict

@@ -223,6 +223,56 @@ def test_bf16_training_tracks_fp32(fused):
     assert len(coss) > 20 and float(np.mean(coss)) > 0.99
 
 
+@pytest.mark.parametrize("name", ["train_tiny", "train_skips"])
+def test_fused_step_input_gradients_match_oracle_autograd(name):
+    """Gradients with respect to the head's INPUTS -- the pooled box features [N, C, p, p] (they feed the detector's
+    backbone through the RoI pooling: the reference trains it, main:109-127) and features['3'] (global average pool) --
+    against CPU autograd of the oracle, in the inputs' own shapes."""
+    from oracle import skg_oracle as O
+    from skghoi_amd import synth
+    case = cases.build_case(name)
+    cfg = case["cfg"]
+    # oracle side
+    sd = synth.make_state_dict(cfg["K"], case["C"], case["p"], seed=case["weight_seed"])
+    feat3_o = case["feat3"].clone().requires_grad_(True)
+    pooled_o = {}
+
+    def pool_o(coords):
+        t = cases.pooled_for(case, sum(len(c) for c in coords)).requires_grad_(True)
+        pooled_o["t"] = t
+        return t
+    torch.manual_seed(case["rng_seed"])
+    _, extras = O.interaction_head_forward(
+        sd, feat3_o, case["detections"], case["shapes"], pool_o, cfg["K"], cfg["human_idx"], case["o2v"],
+        targets=case["targets"], training=True, max_human=case["max_human"], max_object=case["max_object"],
+        box_nms_thresh=case["box_nms_thresh"], box_score_thresh=case["box_score_thresh"], num_iter=case["num_iter"])
+    sum(extras["losses"].values()).backward()
+    # device side
+    head = gpu_run.build_head(case)
+    head.fused_training = True
+    pooled_d = {}
+
+    class Pool(torch.nn.Module):
+        def forward(self, features, boxes, image_shapes):
+            t = cases.pooled_for(case, sum(len(b) for b in boxes)).cuda().requires_grad_(True)
+            pooled_d["t"] = t
+            return t
+    head.box_roi_pool = Pool()
+    from collections import OrderedDict
+    feat3_d = case["feat3"].cuda().requires_grad_(True)
+    feats = OrderedDict((k, feat3_d) for k in "0123")
+    torch.manual_seed(case["rng_seed"])
+    out = head(feats, gpu_run.to_cuda(case["detections"]), case["shapes"], gpu_run.to_cuda(case["targets"]))
+    sum(out[-1].values()).backward()
+    for what, got, want in (("pooled box features", pooled_d["t"].grad, pooled_o["t"].grad),
+                            ("features['3']", feat3_d.grad, feat3_o.grad)):
+        assert got is not None and want is not None, what
+        assert got.shape == want.shape, (what, got.shape, want.shape)
+        scale = max(want.abs().max().item(), 1e-9)
+        err = (got.cpu() - want).abs().max().item() / scale
+        assert err <= 1e-4, "%s: relative error %.3e (scale %.3e)" % (what, err, scale)
+
+
 @pytest.mark.parametrize("mode", ["direct", "autograd"])
 def test_fused_step_gradient_arena_reuse_is_safe(mode):
     """The fused backward reuses its gradient arena (and the p.grad view objects) from step to step ONLY when nothing
