@@ -6,10 +6,11 @@ first MI355X version kept autograd and only replaced nn.Linear (skghoi_amd/train
 launches per step (gathers, products, masks, transposes, segment softmax, LayerNorm, the losses), host-bound at 13 ms for
 four images.  Here the differentiable part of the step is ONE autograd.Function:
 
-    forward   ~35 launches: every dense layer on skg_gemmx_f32 / skg_gemm_f32 (MBF fc_1 * fc_2 fused in the fc_2
-              epilogue; the 16 branch weights of every MBF are gathered once per step into stacked copies, fc_3
+    forward   ~32 launches: every dense layer on skg_gemmx_f32 (precision "bf16": skg_gemmx_bf16 -- operands rounded to
+              bf16 on the way to the matrix core, everything in memory fp32) / skg_gemm_f32 (MBF fc_1 * fc_2 fused in the
+              fc_2 epilogue; the 16 branch weights of every MBF are gathered once per step into stacked copies, fc_3
               branch-major), message aggregation, add + LayerNorm, read-out, classifier
-    backward  ~55 launches: dX and dW (+ bias gradient as row sums) of a layer in ONE grouped launch with the ReLU mask
+    backward  ~50 launches: dX and dW (+ bias gradient as row sums) of a layer in ONE grouped launch with the ReLU mask
               of the layer below in its epilogue -- no transposes, no mask kernels; the graph stages by the kernels of
               skg_train.hip (per-destination reductions, deterministic)
     losses    one kernel: both focal terms forward + d/dlogits (skg_hoi_loss_f32)
