@@ -140,3 +140,23 @@ def test_plans_are_dropped_when_weights_change():
     assert torch.allclose(lb[:, :K] - bias, 2.0 * (la[:, :K] - bias), rtol=1e-4, atol=1e-5)
     want, lw, _ = _run(head, case, 5, small=False)
     _same(b, want)
+
+
+def test_graph_path_with_exact_row_exponent_passes(monkeypatch):
+    """fp16x2 with engine.EXACT_ROW_SCALE: every split-operand GEMM of the captured plan has a row-exponent pass in front
+    of it, writing into a buffer the plan keeps (the capture's two branches share one pool).  Capturing call and replays
+    must equal the eager path bit for bit."""
+    from skghoi_amd import engine as _engine
+    monkeypatch.setattr(_engine, "EXACT_ROW_SCALE", True)
+    monkeypatch.setattr(gpu_run, "PRECISION", "fp16x2")
+    case = cases.build_case("tiny")
+    head = gpu_run.build_head(case).eval()
+    assert head.precision == "fp16x2"
+    for seed in (21, 22, 23):
+        want, wl, _ = _run(head, case, seed, small=False)
+        got, gl, _ = _run(head, case, seed, small=True)
+        _same(got, want)
+        if wl is not None:
+            assert torch.equal(gl, wl)
+    plans = list(head.engine()._small.plans.values())
+    assert plans and all(len(p.amax_keep) > 0 for p in plans)
