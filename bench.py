@@ -13,8 +13,10 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline     : dominant kernel (the fp32-MFMA GEMM) algorithmic FLOP/s from HIP-event timings of every launch
   cpu_baseline : the CPU oracle (faithful restatement of the reference head, oracle/skg_oracle.py) timed on this
                  box's host cores on a bounded sample (rank 0, N=1 only)
-and, at N=1, extra legs of the same run: fp16x2 (the opt-in split-operand GEMM path, own roofline), b1_latency_ms /
-b4_latency_ms (the reference evaluates one image per forward), train (the batch-4 training step, fp32 and bf16).
+and, at N=1, extra legs of the same run: two_stream_chunks (the engine's default stream setting; the timed region itself
+runs the chunks on one stream so that the per-launch HIP-event durations of the roofline record are those of un-shared
+launches), fp16x2 (the opt-in split-operand GEMM path, own roofline), b1_latency_ms / b4_latency_ms (the reference
+evaluates one image per forward), train (the batch-4 training step: forward + backward + AdamW, fp32 and bf16 operands).
 The headline value / dtype / roofline are the exact fp32 path (precision="fp32", the head's default).
 """
 import argparse
