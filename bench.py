@@ -75,32 +75,57 @@ def build_head(device):
     return head.to(device).eval()
 
 
-def cpu_baseline(n_images):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(budget_s=40.0):
     """The oracle (kind 'port': loop-for-loop restatement of the reference head, incl. its Python row loop) on the
-    host cores, same synthetic workload, batch 1 per forward like the reference's inference (utils.py:166-167)."""
+    host cores, same synthetic workload, batch 1 per forward like the reference's inference (utils.py:166-167).
+    Protocol of SURVEY 8(d): all cores of the process's share AND one thread; 2 warm-up images, then 5 timed images per
+    thread setting (fewer only if the time budget runs out); min and median reported; CPU model printed."""
     from oracle import skg_oracle as O
     from skghoi_amd import synth
     sd = synth.make_state_dict(117, C_FEAT, POOL, seed=0)
     o2v = synth.hico_object_to_verb()
     cores = torch.get_num_threads()               # set in main() to the process's CPU share
+    t_start = time.perf_counter()
 
-    times = []
-    with torch.no_grad():
-        for i in range(n_images + 1):
-            im = synth.make_image(1000 + i, n_h=N_H, n_o=N_O, out_channels=C_FEAT, pool=POOL)
-            det = [dict(boxes=im["boxes"], labels=im["labels"], scores=im["scores"])]
-            torch.manual_seed(i)
-            t0 = time.perf_counter()
-            O.interaction_head_forward(sd, im["feat3"], det, [im["hw"]], lambda c: im["pooled"], 117, 49, o2v,
-                                       max_human=N_H, max_object=N_O, row_loop=True)
-            dt = time.perf_counter() - t0
-            if i > 0:                       # first image = warm-up
-                times.append(dt)
-            if sum(times) > 25.0:
-                break
-    return dict(value=round(len(times) / sum(times), 4), unit="images/s", cores=cores, kind="port",
-                sample="%d images (20x20), batch 1 per forward, fp32 torch CPU, %d threads, after 1 warm-up; "
-                       "median %.3f s/image" % (len(times), cores, float(np.median(times))))
+    def leg(threads, deadline):
+        torch.set_num_threads(threads)
+        times = []
+        with torch.no_grad():
+            for i in range(2 + 5):
+                im = synth.make_image(1000 + i, n_h=N_H, n_o=N_O, out_channels=C_FEAT, pool=POOL)
+                det = [dict(boxes=im["boxes"], labels=im["labels"], scores=im["scores"])]
+                torch.manual_seed(i)
+                t0 = time.perf_counter()
+                O.interaction_head_forward(sd, im["feat3"], det, [im["hw"]], lambda c: im["pooled"], 117, 49, o2v,
+                                           max_human=N_H, max_object=N_O, row_loop=True)
+                dt = time.perf_counter() - t0
+                if i >= 2:                      # two warm-up images
+                    times.append(dt)
+                if len(times) >= 2 and time.perf_counter() > deadline:
+                    break
+        return dict(threads=threads, images=len(times), min_s=round(min(times), 4),
+                    median_s=round(float(np.median(times)), 4), value=round(1.0 / float(np.median(times)), 4))
+    try:
+        full = leg(cores, t_start + 0.4 * budget_s)
+        one = leg(1, t_start + budget_s)
+    finally:
+        torch.set_num_threads(cores)
+    return dict(value=full["value"], unit="images/s", cores=cores, kind="port", cpu_model=cpu_model(),
+                all_cores=full, one_thread=one,
+                sample="20x20 synthetic images, batch 1 per forward, fp32 torch CPU; per thread setting 2 warm-up images "
+                       "then %d / %d timed images (%d threads / 1 thread); value = 1 / median seconds per image on %d "
+                       "threads" % (full["images"], one["images"], cores, cores))
 
 
 def run_train(B, precision, steps, warmup, device, rank, world, dist_on):
@@ -161,7 +186,7 @@ def train_mode(args, device, rank, world, dist_on):
                               config=dict(workload="train step: fwd + bwd + AdamW, NegativeSampling + MarginLoss + "
                                                    "two focal terms, 20x20 synthetic images with GT appended",
                                           batch_per_gpu=B, parallelism="dp%d" % world),
-                              losses=losses)))
+                              losses=losses, dist=dist_info(world))))
     if dist_on:
         dist.destroy_process_group()
 
@@ -236,6 +261,89 @@ def small_batch_latency(head, dets, pooled, feats, shapes, B, iters=200, warmup=
         head.box_roi_pool = old_pool
 
 
+def launch_ranks(n, argv):
+    """Starts `n` fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment,
+    rendezvous on 127.0.0.1), relays rank 0's stdout (the ONE JSON line) and returns the worst exit code.  The parent
+    never initialises the GPU and never replaces itself: the ranks are ordinary children.  A rank that dies takes the
+    others down with it (by PID) instead of leaving them waiting in a collective."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    rc = 0
+    alive = list(procs)
+    out0 = b""
+    try:
+        while alive:
+            for p in list(alive):
+                try:
+                    if p is procs[0]:
+                        out0 += p.communicate(timeout=0.5)[0] or b""
+                    else:
+                        p.wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                alive.remove(p)
+                if p.returncode != 0:
+                    rc = rc or p.returncode
+                    for q in alive:                      # a dead rank leaves the others hanging in their next collective
+                        q.terminate()
+    finally:
+        for q in alive:
+            q.kill()
+    for line in out0.decode(errors="replace").splitlines():      # stdout carries the JSON line only; library chatter
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")      # (gloo / RCCL banners) goes to stderr
+    sys.stdout.flush()
+    return rc if rc >= 0 else 128 - rc
+
+
+def dry_run(args, rank, world):
+    """Launcher rehearsal (no GPU, no head): the same rendezvous, barriers, max-over-ranks timing and count gather as the
+    real run around an empty step."""
+    import torch.distributed as dist
+    from skghoi_amd import dist as skd
+    if world > 1:
+        dist.init_process_group(os.environ.get("SKG_BENCH_BACKEND", "gloo"))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    if os.environ.get("SKG_BENCH_FAIL_RANK") == str(rank):      # test hook: this rank dies after the rendezvous
+        os._exit(3)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    barrier()
+    elapsed = skd.max_over_ranks(time.perf_counter() - t0)
+    counts = skd.gather_counts(args.batch * args.steps)
+    if rank == 0:
+        print(json.dumps(dict(metric="images/sec through interaction head (20x20 pairs)", value=None, unit="images/s",
+                              n_gpus=world, steps=args.steps, warmup=args.warmup,
+                              ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
+                              vs_baseline=None, dtype="f32", data="synthetic", dry_run=True,
+                              config=dict(workload="launcher rehearsal: no head, empty steps",
+                                          images_counted=sum(counts), batch_per_gpu=args.batch),
+                              dist=dist_info(world))))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def dist_info(world):
+    """What the process group itself reports (not what the flags asked for)."""
+    import torch.distributed as dist
+    if world > 1 and dist.is_initialized():
+        return dict(world_size=dist.get_world_size(), backend=dist.get_backend(),
+                    launcher=os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run" or "bench.py --gpus N")
+    return dict(world_size=1, backend=None, launcher=None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,12 +362,24 @@ def main():
                     help="headline only: skip the extra legs (fp16x2, small-batch latency, training step)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="train: NegativeSampling+MarginLoss training step (fwd+bwd+AdamW) as the headline instead")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher rehearsal on a box without a GPU: the ranks rendezvous (SKG_BENCH_BACKEND=gloo), run the "
+                         "barrier / max-over-ranks / gather plumbing around an empty step and print the line; no head, no "
+                         "throughput claim (value is null)")
     args = ap.parse_args()
 
+    # ---- `bench.py --gpus N` launches its N ranks itself (the reference does: mp.spawn(main, nprocs=world_size),
+    # configures/hicodet/adamixer_transH_spatial_r50_main.py:175-179).  Nothing in this process has touched the GPU yet.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     dist_on = world > 1
+    if args.dry_run:
+        return dry_run(args, rank, world)
     local = local % max(torch.cuda.device_count(), 1)          # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -373,7 +493,7 @@ def main():
                                            "InteractionHead from cached AdaMixer-R50 box features [40,256,7,7]/image",
                                   batch_per_gpu=args.batch, images_per_step=args.batch * world,
                                   parallelism="dp%d (independent image shards, no data-path collective)" % world),
-                      roofline=roofline)
+                      roofline=roofline, dist=dist_info(world))
 
     # ---- extra legs, same run, one GPU only (the N-GPU runs of the scaling curve stay headline-only)
     if world == 1 and not args.no_legs:
@@ -422,7 +542,7 @@ def main():
         out["train"] = train
         torch.set_num_threads(max(1, host_cpu_share() // world))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(12)
+        out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out))
     if dist_on:

@@ -47,6 +47,47 @@ def test_struct_mirrors_match_header():
     assert flat == [f[0] for f in _capi.META_FIELDS]
 
 
+def _header_struct_fields(hdr, name):
+    """[(field, kind)] of `typedef struct { ... } name;` in include/skghoi.h, kind in {ptr, i64, i32, f32}."""
+    end = hdr.index("} %s;" % name)
+    body = hdr[hdr.rindex("typedef struct {", 0, end):end]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for stmt in body.split(";"):
+        stmt = stmt.replace("typedef struct {", "").strip()
+        m = re.match(r"(?:const\s+)?(void|float|int32_t|int64_t)\s*(\*?)\s*(.+)$", stmt, flags=re.S)
+        if not m:
+            continue
+        base, star, rest = m.groups()
+        for nm in rest.split(","):
+            nm = nm.strip()
+            ptr = bool(star) or nm.startswith("*")
+            kind = "ptr" if ptr else {"float": "f32", "int32_t": "i32", "int64_t": "i64"}[base]
+            out.append((nm.lstrip("* "), kind))
+    return out
+
+
+_CT_KIND = {ctypes.c_void_p: "ptr", ctypes.c_int64: "i64", ctypes.c_int32: "i32", ctypes.c_float: "f32"}
+
+
+def test_gemm_desc_mirrors_match_header_field_by_field():
+    """skg_gemm_desc in the header == _capi.GemmDesc == the stub INTEGRATION.md publishes (names, order, kinds): a
+    mirror that stops short makes the library read past the caller's struct (round-2 finding: the document lacked a_exp)."""
+    hdr = open(os.path.join(ROOT, "include", "skghoi.h")).read()
+    want = _header_struct_fields(hdr, "skg_gemm_desc")
+    assert want[0] == ("A", "ptr") and want[-1] == ("a_exp", "ptr") and len(want) == 31
+    assert [(n, _CT_KIND[t]) for n, t in _capi.GemmDesc._fields_] == want
+    wantx = _header_struct_fields(hdr, "skg_gemmx_desc")
+    assert [(n, _CT_KIND[t]) for n, t in _capi.GemmXDesc._fields_] == wantx
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class GemmDesc(C.Structure)"):]
+    stub = stub[:stub.index("]\n") + 1]
+    fields = re.findall(r'\("(\w+)",\s*C\.(c_\w+)\)', stub)
+    kinds = {"c_void_p": "ptr", "c_int64": "i64", "c_int32": "i32", "c_float": "f32"}
+    assert [(n, kinds[t]) for n, t in fields] == want
+    assert "C.sizeof(GemmDesc) == %d" % ctypes.sizeof(_capi.GemmDesc) in doc
+
+
 def test_argument_validation_without_gpu(lib):
     d = _capi.GemmDesc()
     assert lib.skg_gemm_f32(None, None) == -1

@@ -91,3 +91,46 @@ def test_single_process_fallbacks():
     assert h.work is None and h.get().tolist() == [4.0, 2.0, 2.0]
     res = [_fake_result(0), _fake_result(1)]
     assert skd.gather_image_results(res) == res
+
+
+def _run_bench(args, env_extra, timeout=180):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_gpus_n_launches_its_ranks_itself():
+    """`python bench.py --gpus 2` (no launcher, the form the driver uses) starts two rank processes before touching the
+    GPU, and rank 0's ONE line says what the process group saw.  Reference: mp.spawn(main, nprocs=world_size)
+    (configures/hicodet/adamixer_transH_spatial_r50_main.py:175-179).  CPU rehearsal: gloo, empty steps."""
+    import json
+    r = _run_bench(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1", "--batch", "8"],
+                   {"SKG_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dist"] == dict(world_size=2, backend="gloo", launcher="bench.py --gpus N")
+    assert out["config"]["images_counted"] == 2 * 3 * 8 and out["scaling"] == "weak"
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_launcher_propagates_a_rank_failure():
+    """A rank that dies must fail the whole run (non-zero exit), not leave the others waiting in a collective."""
+    r = _run_bench(["--gpus", "2", "--dry-run", "--steps", "2"], {"SKG_BENCH_BACKEND": "gloo", "SKG_BENCH_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
