@@ -123,6 +123,13 @@ def build_case(name):
     elif name == "train_tiny":
         imgs = _grid_images([(3, 4), (2, 3)], 8, 2, 49, 80, 700)
         c.update(training=True)
+    elif name == "train_full20x4":
+        # BASELINE config 3 at full size: the reference's per-GPU training batch (main:158) of four full-width 20 x 20
+        # images with ground truth appended (M ~ 3200 grid rows: the 128 x 128 tiles, split-K targets, grouped dX|dW
+        # launches and the N = 4096 fc_2 product of the fused step).  Output-only fixture + gradient samples taken from
+        # the live reference's autograd.
+        imgs = _grid_images([(20, 20)] * 4, 256, 7, 49, 80, 1500)
+        c.update(C=256, p=7, max_human=20, max_object=20, weight_seed=0, training=True, n_gt=4)
     else:
         raise KeyError(name)
     c["cfg"] = cfg
@@ -131,14 +138,24 @@ def build_case(name):
     c["feat3"] = torch.cat([i["feat3"] for i in imgs])
     c["shapes"] = [i["hw"] for i in imgs]
     if c["training"] or c.get("eval_targets"):
-        c["targets"] = [synth.make_targets(d, cfg["human_idx"], c["o2v"], 900 + k, n_gt=3)
+        c["targets"] = [synth.make_targets(d, cfg["human_idx"], c["o2v"], 900 + k, n_gt=c.get("n_gt", 3))
                         for k, d in enumerate(c["detections"])]
     return c
 
 
 EVAL_CASES = ["tiny", "ragged3", "skips_eval", "nanbox", "vcoco", "nms", "iter1", "iter0", "full20", "full15x2",
               "eval_targets", "full20x3", "many8", "many12"]
-OUTPUT_ONLY = ["full20", "full15x2", "full20x3", "many8", "many12"]      # fixtures without the bulky intermediates
+OUTPUT_ONLY = ["full20", "full15x2", "full20x3", "many8", "many12", "train_full20x4"]   # no bulky intermediates
 TRAIN_CASES = ["train_tiny", "train_skips"]
+FULL_TRAIN_CASE = "train_full20x4"        # full-size training step: losses / labels / samples + gradient samples
+GRAD_SAMPLES = 512                        # entries kept per parameter gradient in that fixture (evenly strided)
 RAISING_CASES = ["skips_raise"]
-ALL_CASES = EVAL_CASES + TRAIN_CASES
+ALL_CASES = EVAL_CASES + TRAIN_CASES + [FULL_TRAIN_CASE]
+
+
+def grad_sample(flat_grad):
+    """The fixed sample of a parameter gradient the full-size fixture stores: GRAD_SAMPLES evenly strided entries of the
+    flattened tensor (all of it when smaller)."""
+    n = flat_grad.shape[0]
+    stride = max(1, n // GRAD_SAMPLES)
+    return flat_grad[::stride][:GRAD_SAMPLES]

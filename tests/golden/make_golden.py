@@ -24,6 +24,27 @@ from skghoi_amd import synth
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
+class StableTies:
+    """The reference orders the kept detections with `torch.argsort(scores, descending=True)` (HEAD:131), which is not
+    a stable sort: with more than a handful of elements the order of EQUAL scores is whatever the installed torch build
+    and device happen to produce (the ground-truth boxes appended in training all score 1.0, HEAD:113 -- every training
+    batch has ties).  The fixtures pin the one order that is defined -- ties in ascending input index -- by making that
+    call stable while the reference runs; nothing in the reference's files is touched.  (The small fixtures are
+    bit-identical with and without this: torch's sort is stable at their sizes.)"""
+
+    def __enter__(self):
+        self._orig = torch.argsort
+
+        def argsort(x, dim=-1, descending=False, stable=False):
+            return self._orig(x, dim=dim, descending=descending, stable=True)
+        torch.argsort = argsort
+        return self
+
+    def __exit__(self, *exc):
+        torch.argsort = self._orig
+        return False
+
+
 def run_reference(case):
     """Returns a flat {key: ndarray} of the reference's outputs for `case`."""
     ref = ref_import.load_reference()
@@ -47,8 +68,9 @@ def run_reference(case):
     hooks = [gh.adjacency.register_forward_hook(lambda m, i, o: cap["adjacency"].append(o.detach().clone())),
              gh.norm_h.register_forward_hook(lambda m, i, o: cap["norm_h"].append(o.detach().clone())),
              gh.norm_o.register_forward_hook(lambda m, i, o: cap["norm_o"].append(o.detach().clone()))]
+    want_grads = case["name"] == cases.FULL_TRAIN_CASE     # gradient samples from the reference's own autograd
     try:
-        with torch.no_grad():
+        with torch.set_grad_enabled(want_grads), StableTies():
             det = head.preprocess(case["detections"], case["targets"], append_gt=case["training"])
             n_rows = sum(len(d["boxes"]) for d in det)
             pooled = cases.pooled_for(case, n_rows)
@@ -87,6 +109,16 @@ def run_reference(case):
                         out["timg%d.pos_scores" % i] = pos[i]; out["timg%d.neg_scores" % i] = neg[i]
                         out["timg%d.head_ent" % i] = he[i]; out["timg%d.tail_ent" % i] = te[i]
                         out["timg%d.rel" % i] = re[i]; out["timg%d.rel_norm" % i] = rne[i]
+                    if want_grads:
+                        head.zero_grad()
+                        (out["hoi_loss"] + out["interactiveness_loss"] + out["transH_loss"]).backward()
+                        for k, prm in head.named_parameters():
+                            if prm.grad is None:
+                                continue
+                            g = prm.grad.detach().reshape(-1)
+                            out["grad." + k + ".sample"] = cases.grad_sample(g).clone()
+                            out["grad." + k + ".absmax"] = g.abs().max()
+                            out["grad." + k + ".norm"] = g.double().norm()
     finally:
         ref.compute_spatial_ratio_encodings = orig_sp
         for h in hooks:
@@ -117,10 +149,11 @@ def main(names):
         if name in cases.OUTPUT_ONLY:
             # output-only fixture: drop the bulky intermediates, keep what pins the result
             keep = ("logits_p", "logits_s", "n_results", "n_tables")
+            keep += ("hoi_loss", "interactiveness_loss", "transH_loss")
             flat = {k: v for k, v in flat.items()
                     if k in keep or k.endswith((".ent", ".scores", ".index", ".prediction", ".labels", ".adjacency",
-                                                ".weights"))
-                    or k.startswith("pre")}
+                                                ".weights", ".pos_scores", ".neg_scores", ".unary_labels"))
+                    or k.startswith(("pre", "grad."))}
         path = os.path.join(OUT, name + ".npz")
         np.savez_compressed(path, **flat)
         print("%-12s %4d arrays  %8.1f KB" % (name, len(flat), os.path.getsize(path) / 1024))

@@ -101,18 +101,24 @@ def compare_flat(got, want, atol=1e-6, rtol=1e-5, skip=(), only_common=False):
     return worst
 
 
-def oracle_train_grads(case):
-    """Oracle training forward + backward of (hoi + interactiveness + transH) on CPU: {param name: grad}."""
+def oracle_train_grads(case, with_flat=False):
+    """Oracle training forward + backward of (hoi + interactiveness + transH) on CPU: {param name: grad}, losses
+    (+ the flattened forward outputs when with_flat)."""
     cfg = case["cfg"]
     sd = synth.make_state_dict(cfg["K"], case["C"], case["p"], seed=case["weight_seed"])
     sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    cap = {}
     torch.manual_seed(case["rng_seed"])
     results, extras = O.interaction_head_forward(
         sd, case["feat3"], case["detections"], case["shapes"],
         lambda coords: cases.pooled_for(case, sum(len(c) for c in coords)),
         cfg["K"], cfg["human_idx"], case["o2v"], targets=case["targets"], training=True,
         max_human=case["max_human"], max_object=case["max_object"], box_nms_thresh=case["box_nms_thresh"],
-        box_score_thresh=case["box_score_thresh"], num_iter=case["num_iter"])
+        box_score_thresh=case["box_score_thresh"], num_iter=case["num_iter"], capture=cap)
     total = sum(extras["losses"].values())
     total.backward()
-    return {k: v.grad.numpy() for k, v in sd.items() if v.grad is not None}, {k: float(v) for k, v in extras["losses"].items()}
+    grads = {k: v.grad.numpy() for k, v in sd.items() if v.grad is not None}
+    losses = {k: float(v) for k, v in extras["losses"].items()}
+    if with_flat:
+        return grads, losses, flatten_oracle(case, results, extras, cap)
+    return grads, losses
