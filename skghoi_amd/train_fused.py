@@ -84,9 +84,8 @@ class Stacked:
         self.entries.append((head.box_pair_suppressor.weight, "clsW", (slice(K, K + 1),)))
         self.entries.append((head.box_pair_predictor.bias, "clsb", (slice(0, K),)))
         self.entries.append((head.box_pair_suppressor.bias, "clsb", (slice(K, K + 1),)))
-        self.src = [e[0] for e in self.entries]
-        self.src_detached = [p.detach() for p in self.src]            # same storage as the live parameters
-        self.src_ptrs = [p.data_ptr() for p in self.src[:: 32]]       # spot check against re-pointed storage
+        self.src = [e[0] for e in self.entries]                       # the LIVE parameters (never cached aliases: a
+                                                                      # re-pointed p.data must be seen by the next step)
         self.dst = [self.view(self.buf, e[1])[e[2]] for e in self.entries]
         self.ids = {id(p): k for k, p in enumerate(self.src)}
 
@@ -114,11 +113,8 @@ class Stacked:
         return sum(map(sys.getrefcount, views)) + sum(map(torch.Tensor._use_count, views))
 
     def refresh(self):
-        if [p.data_ptr() for p in self.src[:: 32]] != self.src_ptrs:   # .data was re-pointed (rare): rebuild the aliases
-            self.src_detached = [p.detach() for p in self.src]
-            self.src_ptrs = [p.data_ptr() for p in self.src[:: 32]]
         with torch.no_grad():
-            torch._foreach_copy_(self.dst, self.src_detached)
+            torch._foreach_copy_(self.dst, self.src)
         self.b3sum = self.view(self.buf, "b3").sum(dim=1)                 # [4, 1024]: fc_3 biases summed over branches
 
     def grad_views(self, garena):
@@ -163,6 +159,10 @@ class HeadTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         job = ctx.job
+        if job.S is None:
+            raise RuntimeError("Trying to backward through the fused interaction-head step a second time: its saved "
+                               "activations are freed by the first backward (retain_graph is not supported by the "
+                               "fused step; use head.fused_training = False for repeated backward passes)")
         dx0, dgfeat, pgrads = job.backward(dlogits, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         # the step works on flattened fp32 copies of its inputs: hand the gradients back in the inputs' own shape / dtype
         # (pooled box features arrive as [N, 256, 7, 7] when the RoI pooling in front is differentiable)
@@ -196,11 +196,14 @@ class HoiLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g1, g2):
         job = ctx.job
-        d = job.dlogits
         K = job.K
-        # columns < K belong to the cell loss, column K to the pair loss (the pair weight is detached in the scores)
-        d[:, :K].mul_(g1)
-        d[:, K:K + 1].mul_(g2)
+        # columns < K belong to the cell loss, column K to the pair loss (the pair weight is detached in the scores).
+        # Out of place: job.dlogits stays the unscaled d(sum)/dlogits, so a second backward through this node (e.g.
+        # autograd.grad followed by .backward()) scales it once again from the same values, not twice.
+        src = job.dlogits
+        d = torch.empty_like(src)
+        torch.mul(src[:, :K], g1, out=d[:, :K])
+        torch.mul(src[:, K:], g2, out=d[:, K:])          # suppressor column + zero padding
         return None, d
 
 

@@ -405,3 +405,37 @@ def test_full_size_bf16_training_step_tracks_the_reference(full_train_oracle):
             assert abs(np.linalg.norm(a) / np.linalg.norm(r) - 1.0) < 0.05, k
             coss.append(cos)
     assert len(coss) > 20 and float(np.mean(coss)) > 0.99
+
+
+def test_fused_step_sees_repointed_parameter_storage_and_refuses_a_second_backward():
+    """(1) `p.data = new` on ONE mid-list branch weight (an EMA swap, manual weight loading) must reach the next fused
+    step: the stacked copies are refreshed from the live Parameters, not from cached aliases of their old storage
+    (round-2 advisor finding).  (2) A second backward through the same step raises a clear RuntimeError instead of
+    scaling d(loss)/d(logits) twice or dying on freed activations."""
+    case = cases.build_case("train_tiny")
+    head = gpu_run.build_head(case)
+    head.fused_training = True
+    det = gpu_run.to_cuda(case["detections"]); tg = gpu_run.to_cuda(case["targets"])
+    from collections import OrderedDict
+    feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
+
+    def losses():
+        torch.manual_seed(case["rng_seed"])
+        out = head(feats, det, case["shapes"], tg)
+        return out[-1]
+
+    base = float(sum(losses().values()))
+    w = head.box_pair_head.attention_head.fc_2[7].weight           # entry 7 * 6 + 2 of the stacked list: never spot-checked
+    w.data = torch.zeros_like(w.data)                               # new storage
+    l2 = losses()
+    changed = float(sum(l2.values()))
+    assert changed != base
+    ref = gpu_run.build_head(case); ref.fused_training = False      # the autograd path reads the live parameters directly
+    ref.load_state_dict(head.state_dict())
+    torch.manual_seed(case["rng_seed"])
+    want = float(sum(ref(feats, det, case["shapes"], tg)[-1].values()))
+    assert abs(changed - want) <= 1e-5 * max(1.0, abs(want))
+    total = sum(l2.values())
+    total.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        total.backward()
