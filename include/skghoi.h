@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SKG_ABI_VERSION 8
+#define SKG_ABI_VERSION 9
 #define SKG_E_ARG   (-1)   /* null pointer / negative size / unsupported shape            */
 #define SKG_E_ALIGN (-2)   /* pointer or leading dimension not 16-byte aligned            */
 #define SKG_E_LIMIT (-3)   /* exceeds a compiled-in limit (boxes per image, verbs, ...)   */
@@ -466,6 +466,65 @@ typedef struct {
 } skg_adamw_chunk;
 int skg_adamw_f32(const skg_adamw_chunk* chunks, int n_chunks, double lr, double beta1, double beta2, double eps,
                   double weight_decay, double bias1, double bias2, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Native launch plan of the fused TRAINING step's dense part: GraphHead.forward in training mode (HEAD:769-993; the
+ * classifier HEAD:410-411) and its backward -- what the reference leaves to eager PyTorch + autograd inside
+ * `net(...)` / `loss.backward()` (utils.py:213-229) -- as ONE host call per phase.  The call enqueues the whole launch
+ * sequence (every dense layer on skg_gemmx_f32 / skg_gemmx_bf16 / skg_gemm_f32, the graph stages of skg_train.hip) on
+ * `stream`; nothing allocates or synchronises.
+ *
+ * Parameters and gradients live in two flat fp32 ARENAS with the same layout (skghoi_amd/train_fused.py, Stacked):
+ * seg_off[s] = offset in floats of segment s.  Shapes: W1_m [1024, in_m] (in = 2048, 1024, 1024, Cf for m = attention_head,
+ * obj_to_sub, sub_to_obj, attention_head_g: the 16 fc_1 branch weights as row blocks), b1_m [1024], W3_m [16][1024][64]
+ * (branch-major fc_3), b3 [4][16][1024], W2 [4 x 1024, 1024] / b2 [4 x 1024] (fc_2 of the four MBFs back to back), CLS_W
+ * [K + 1, 2048] (predictor rows, then the suppressor row) / CLS_B [K + 1], and the plain layers in their nn.Linear /
+ * LayerNorm shapes (box_head BH1 [1024, x0_k], BH3; spatial_head SP0 [128, 46], SP2, SP4; fc_head FH / fc_tail FT
+ * [1024, 1074]; adjacency ADJ [1, 1024]; norm_h NH, norm_o NO).
+ * Row spaces (skg_image_meta): NA selected boxes, Mh humans, Mn nodes, Mg grid rows, Mp kept pairs of the A active images.
+ * Index arrays are the ones skg_pairs_spatial_f32 and the host layout produce (skghoi_amd/layout.py).                  */
+enum {
+    SKG_SEG_W1_0 = 0, SKG_SEG_W1_1, SKG_SEG_W1_2, SKG_SEG_W1_3, SKG_SEG_B1_0, SKG_SEG_B1_1, SKG_SEG_B1_2, SKG_SEG_B1_3,
+    SKG_SEG_W3_0, SKG_SEG_W3_1, SKG_SEG_W3_2, SKG_SEG_W3_3, SKG_SEG_B3, SKG_SEG_W2, SKG_SEG_B2, SKG_SEG_CLS_W, SKG_SEG_CLS_B,
+    SKG_SEG_NH_W, SKG_SEG_NH_B, SKG_SEG_NO_W, SKG_SEG_NO_B, SKG_SEG_ADJ_W, SKG_SEG_ADJ_B, SKG_SEG_SP0_W, SKG_SEG_SP0_B,
+    SKG_SEG_SP2_W, SKG_SEG_SP2_B, SKG_SEG_SP4_W, SKG_SEG_SP4_B, SKG_SEG_FH_W, SKG_SEG_FH_B, SKG_SEG_FT_W, SKG_SEG_FT_B,
+    SKG_SEG_BH3_W, SKG_SEG_BH3_B, SKG_SEG_BH1_W, SKG_SEG_BH1_B, SKG_TRAIN_SEGS
+};
+#define SKG_TRAIN_BWD_STAGES 12
+typedef struct {
+    int32_t NA, Mg, Mp, Mh, Mn, A, K, Bf, Cf;   /* row-space sizes, verbs, feature maps [Bf, Cf] after the global pool   */
+    int32_t x0_k;                               /* columns of the flattened pooled box features (256 * 7 * 7)            */
+    int32_t bf16;                               /* 0: exact fp32 products; 1: operands rounded to bf16 (skg_gemmx_bf16)  */
+    int32_t ld_logits;                          /* (K + 1) rounded up to a multiple of 4                                 */
+    const float* params; float* grads;          /* the two arenas                                                        */
+    int64_t seg_off[SKG_TRAIN_SEGS];
+    const float* x0;                            /* [NA, x0_k] pooled box features (MultiScaleRoIAlign output, flattened)  */
+    const float* gfeat;                         /* [Bf, Cf] globally pooled features['3'] (HEAD:811)                     */
+    const float* sp48;                          /* [Mg, 48] spatial encodings (skg_pairs_spatial_f32)                    */
+    const float* ent;                           /* [A, 80, 50] TransH entity tables of the step (part 1 only)            */
+    const skg_image_meta* meta;
+    const int32_t *enc_row_hn, *img_hn, *ent_row_hn, *hum_img, *node_img;      /* host layout (layout.pack_int_arrays) */
+    const int32_t *grid_h, *grid_o, *grid_pair, *grid_img, *pair_grid, *pair_h, *pair_o;   /* skg_pairs_spatial_f32   */
+    const int32_t *pair_img, *hum_of, *node_of;
+    float* ws; int64_t ws_floats;               /* activations + scratch: skg_train_ws_floats(plan) floats               */
+    float* pair_features;                       /* out [max(Mp, 1), 2048] (HEAD:966-973)                                 */
+    float* logits;                              /* out [max(Mp, 1), ld_logits], ZERO-FILLED by the caller                */
+    const float* dlogits;                       /* backward in: [max(Mp, 1), ld_logits]                                  */
+    float* dx0; float* dgfeat;                  /* backward out, optional: gradients of x0 / gfeat                       */
+} skg_train_plan;
+/* Floats of workspace the plan needs (activations kept for the backward, backward temporaries, split-K scratch);
+ * < 0: rejected plan.  Only the sizes, bf16 and params (non-null) are read.                                              */
+int64_t skg_train_ws_floats(const skg_train_plan* plan_host);
+/* part 0: everything that needs neither the TransH tables nor the label counts (box_head, fc_1 of the global branch, two
+ * spatial layers) -- enqueue it before the step's host synchronisation; part 1: the rest, down to the logits.           */
+int skg_train_forward_f32(const skg_train_plan* plan_host, int part, void* stream);
+/* Backward stages [first_stage, last_stage) of SKG_TRAIN_BWD_STAGES, from dlogits to the gradient arena (and dx0 /
+ * dgfeat).  After stage s the arena prefix of the segments whose gradients that stage completes is final (the order of
+ * the segments in the arena follows the stages: read-out layers first, box_head last), so a data-parallel caller can
+ * exchange the arena chunk by chunk between calls.                                                                      */
+int skg_train_backward_f32(const skg_train_plan* plan_host, int first_stage, int last_stage, void* stream);
+/* Offset (floats) of a saved activation inside ws, for tests: 0 enc, 1 h_node, 2 node, 3 adjacency logits, 4 raw fc_2.   */
+int64_t skg_train_ws_offset(const skg_train_plan* plan_host, int which);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ MAX_NODES = 160
 SPATIAL_LD = 48
 TRANSH_DIM = 50
 TRANSH_ENT = 80
-ABI_VERSION = 8
+ABI_VERSION = 9
 GEMM_GROUP_MAX = 4
 CHECKSUM_PARTIALS = 1024
 LOSS_CHUNKS = 16
@@ -51,6 +51,24 @@ class GemmBf16Desc(C.Structure):
     _fields_ = [("A", _vp), ("lda", _i64), ("W", _vp), ("ldw", _i64), ("bias", _vp), ("C", _vp), ("ldc", _i64),
                 ("M", _i32), ("N", _i32), ("K", _i32), ("relu", _i32), ("out_bf16", _i32), ("split_k", _i32),
                 ("split_ws", _vp)]
+
+
+TRAIN_SEGS = ("W1_0", "W1_1", "W1_2", "W1_3", "b1_0", "b1_1", "b1_2", "b1_3", "W3_0", "W3_1", "W3_2", "W3_3", "b3", "W2",
+              "b2", "clsW", "clsb", "nh_w", "nh_b", "no_w", "no_b", "adj_w", "adj_b", "sp0_w", "sp0_b", "sp2_w", "sp2_b",
+              "sp4_w", "sp4_b", "fh_w", "fh_b", "ft_w", "ft_b", "bh3_w", "bh3_b", "bh1_w", "bh1_b")    # SKG_SEG_* order
+TRAIN_BWD_STAGES = 12
+
+
+class TrainPlan(C.Structure):
+    """Mirror of skg_train_plan."""
+    _fields_ = [(n, _i32) for n in ("NA", "Mg", "Mp", "Mh", "Mn", "A", "K", "Bf", "Cf", "x0_k", "bf16", "ld_logits")] + \
+               [("params", _vp), ("grads", _vp), ("seg_off", _i64 * len(TRAIN_SEGS)),
+                ("x0", _vp), ("gfeat", _vp), ("sp48", _vp), ("ent", _vp), ("meta", _vp)] + \
+               [(n, _vp) for n in ("enc_row_hn", "img_hn", "ent_row_hn", "hum_img", "node_img", "grid_h", "grid_o",
+                                   "grid_pair", "grid_img", "pair_grid", "pair_h", "pair_o", "pair_img", "hum_of",
+                                   "node_of")] + \
+               [("ws", _vp), ("ws_floats", _i64), ("pair_features", _vp), ("logits", _vp), ("dlogits", _vp),
+                ("dx0", _vp), ("dgfeat", _vp)]
 
 
 # numpy dtype of skg_image_meta (12 x 4 bytes)
@@ -120,6 +138,10 @@ PROTOTYPES = {
     "skg_transh_sample_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _f32, _vp, _vp, _vp, _vp, _vp,
                                         _vp]),
     "skg_hoi_loss_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "skg_train_ws_floats": (C.c_int64, [C.POINTER(TrainPlan)]),
+    "skg_train_forward_f32": (C.c_int, [C.POINTER(TrainPlan), C.c_int, _vp]),
+    "skg_train_backward_f32": (C.c_int, [C.POINTER(TrainPlan), C.c_int, C.c_int, _vp]),
+    "skg_train_ws_offset": (C.c_int64, [C.POINTER(TrainPlan), C.c_int]),
 }
 
 _LIB = None

@@ -1,0 +1,565 @@
+// skg_train_plan.hip -- native launch plan of the fused TRAINING step's dense part (include/skghoi.h, skg_train_plan).
+//
+// The reference's training step is `zero_grad -> net -> backward -> step` (utils.py:213-229) over eager PyTorch: autograd
+// issues ~1000 launches for GraphHead.forward (HEAD:769-993) and its backward.  The first MI355X version cut that to ~130
+// launches but issued them from Python (descriptor objects, ~100 tensor allocations, ctypes marshalling): ~3.4 ms of
+// host time per batch-4 step in front of 2.1 ms of GPU work.  Here the whole launch sequence of the forward (after the
+// step's one host synchronisation) and of the backward is ONE C call each: descriptors are plain structs on the stack,
+// every activation lives at a fixed offset of one caller-provided workspace, split-K scratch is a single region reused
+// by consecutive launches of the stream.  The sequence itself -- which kernels, in which order, on which operands -- is
+// the one skghoi_amd/train_fused.py (TrainJob) describes; the algebra is DESIGN.md section 3.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include "skghoi.h"
+
+namespace {
+
+struct Mat {                      // a row-major fp32 matrix view
+    float* p; int64_t ld; int rows, cols;
+    Mat() : p(nullptr), ld(0), rows(0), cols(0) {}
+    Mat(float* p_, int r, int c) : p(p_), ld(c), rows(r), cols(c) {}
+    Mat(float* p_, int r, int c, int64_t ld_) : p(p_), ld(ld_), rows(r), cols(c) {}
+    Mat from_col(int c0) const { return Mat(p + c0, rows, cols - c0, ld); }
+    Mat row_range(int r0, int n) const { return Mat(p + (int64_t)r0 * ld, n, cols, ld); }
+};
+static inline Mat cm(const float* p, int r, int c) { return Mat(const_cast<float*>(p), r, c); }
+
+constexpr int BLK_SHIFT = 6;                 // fc_3 weights are stored branch-major [16][1024][64]
+constexpr int64_t BLK_STRIDE = 1024 * 64;
+
+struct Ctx {
+    const skg_train_plan* P;
+    hipStream_t stream;
+    bool dry;                    // sizing pass: nothing is launched, the scratch high-water mark is recorded
+    int64_t scratch_need;        // floats
+    float* scratch;              // split-K partials (one region, reused by consecutive launches of the stream)
+    int rc;
+};
+
+// ---- skg_gemmx descriptor builders (skghoi_amd/gemmx.py: forward / input_grad / weight_grad)
+static skg_gemmx_desc op_zero() { skg_gemmx_desc d; memset(&d, 0, sizeof(d)); return d; }
+
+static skg_gemmx_desc FWD(const Mat& x, const Mat& W, const Mat& out, const float* bias, bool relu, int M = -1, int K = -1,
+                          int N = -1, bool blocks = false) {
+    skg_gemmx_desc d = op_zero();
+    d.A = x.p; d.a_sm = x.ld; d.a_sk = 1;
+    d.B = W.p; d.b_sk = 1;
+    d.C = out.p; d.ldc = out.ld;
+    d.M = M < 0 ? x.rows : M; d.K = K < 0 ? x.cols : K; d.N = N < 0 ? out.cols : N;
+    d.bias = bias; d.relu = relu ? 1 : 0;
+    if (!blocks) d.b_sn = W.ld;
+    else { d.b_kshift = BLK_SHIFT; d.b_kstride = BLK_STRIDE; d.b_sn = 1 << BLK_SHIFT; }
+    return d;
+}
+static skg_gemmx_desc IG(const Mat& dz, const Mat& W, const Mat& dx, const Mat* mask, bool accumulate, int M = -1,
+                         int N_in = -1, int K_out = -1, bool blocks = false) {
+    skg_gemmx_desc d = op_zero();
+    d.A = dz.p; d.a_sm = dz.ld; d.a_sk = 1;
+    d.B = W.p; d.b_sn = 1;
+    d.C = dx.p; d.ldc = dx.ld;
+    d.M = M < 0 ? dz.rows : M; d.N = N_in < 0 ? dx.cols : N_in; d.K = K_out < 0 ? dz.cols : K_out;
+    if (mask) { d.mask = mask->p; d.ldmask = mask->ld; }
+    d.accumulate = accumulate ? 1 : 0;
+    if (!blocks) d.b_sk = W.ld;
+    else { d.b_nshift = BLK_SHIFT; d.b_nstride = BLK_STRIDE; d.b_sk = 1 << BLK_SHIFT; }
+    return d;
+}
+static skg_gemmx_desc WG(const Mat& dz, const Mat& x, const Mat& dW, float* db, bool accumulate, int rows = -1,
+                         int n_out = -1, int k_in = -1, bool blocks = false) {
+    skg_gemmx_desc d = op_zero();
+    d.A = dz.p; d.a_sm = 1; d.a_sk = dz.ld;
+    d.B = x.p; d.b_sn = 1; d.b_sk = x.ld;
+    d.C = dW.p;
+    d.M = n_out < 0 ? dz.cols : n_out; d.N = k_in < 0 ? x.cols : k_in; d.K = rows < 0 ? dz.rows : rows;
+    d.a_rowsum = db; d.accumulate = accumulate ? 1 : 0;
+    if (!blocks) d.ldc = dW.ld;
+    else { d.c_nshift = BLK_SHIFT; d.c_nstride = BLK_STRIDE; d.ldc = 1 << BLK_SHIFT; }
+    return d;
+}
+
+// Split-K factor of one product: measured on MI355X at the training shapes (tools/gemmx_split_sweep.py) -- the exact fp32
+// loop is best at ~1000 workgroups, the bf16 loop at ~450; slices keep >= 128 k.
+static int pick_split(const skg_gemmx_desc& o, int bk) {
+    int64_t tiles = (int64_t)((o.M + 127) / 128) * ((o.N + 127) / 128);
+    int kt = (o.K + bk - 1) / bk;
+    int target = bk == 16 ? 1000 : 448;
+    int cap = kt * bk / 128; if (cap > 64) cap = 64;
+    if (tiles == 0 || cap < 2) return 1;
+    int sk = (int)((double)target / (double)tiles + 0.5);
+    if (sk > cap) sk = cap;
+    return sk < 1 ? 1 : sk;
+}
+
+static void launch(Ctx& c, skg_gemmx_desc* ops, int n) {
+    if (c.rc) return;
+    const bool bf16 = c.P->bf16 != 0;
+    const int bk = bf16 ? 32 : 16;
+    skg_gemmx_desc live[16];
+    int m = 0;
+    for (int i = 0; i < n; ++i)
+        if (ops[i].M > 0 && ops[i].N > 0) live[m++] = ops[i];
+    for (int i0 = 0; i0 < m; i0 += SKG_GEMMX_GROUP_MAX) {
+        int cnt = m - i0 < SKG_GEMMX_GROUP_MAX ? m - i0 : SKG_GEMMX_GROUP_MAX;
+        int64_t used = 0;
+        for (int i = 0; i < cnt; ++i) {
+            skg_gemmx_desc& d = live[i0 + i];
+            int sk = pick_split(d, bk);
+            d.split_k = sk > 1 ? sk : 0;
+            if (sk > 1) {
+                int64_t need = (int64_t)sk * ((int64_t)d.M * d.N + d.M);
+                need = (need + 3) & ~(int64_t)3;
+                d.split_ws = c.scratch ? c.scratch + used : nullptr;
+                used += need;
+            }
+        }
+        if (used > c.scratch_need) c.scratch_need = used;
+        if (c.dry) continue;
+        int rc = bf16 ? skg_gemmx_bf16(live + i0, cnt, c.stream) : skg_gemmx_f32(live + i0, cnt, c.stream);
+        if (rc) { c.rc = rc; return; }
+    }
+}
+#define CK(call) do { if (!c.rc && !c.dry) { int rc__ = (call); if (rc__) c.rc = rc__; } } while (0)
+
+// ---- tiny kernels of the plan ------------------------------------------------------------------------------------------
+__global__ void b3sum_kernel(const float* __restrict__ b3, float* __restrict__ out) {      // [4][16][1024] -> [4][1024]
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * 1024) return;
+    int m = i >> 10, col = i & 1023;
+    float s = 0.f;
+    for (int b = 0; b < 16; ++b) s += b3[((int64_t)m * 16 + b) * 1024 + col];
+    out[i] = s;
+}
+__global__ void b3bcast_kernel(const float* __restrict__ db3, float* __restrict__ out) {    // [4][1024] -> [4][16][1024]
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * 16 * 1024) return;
+    int m = i >> 14, col = i & 1023;
+    out[i] = db3[m * 1024 + col];
+}
+// out[c] = sum_r X[r, c] + sum_r Y[r, c]  (gradient of attention_head.fc_1's bias: added once per row of both uses)
+__global__ void colsum2_kernel(const float* __restrict__ X, int rx, const float* __restrict__ Y, int ry,
+                               float* __restrict__ out) {
+    __shared__ float red[4][64];
+    int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    int part = threadIdx.x >> 6;
+    float s = 0.f;
+    for (int r = part; r < rx; r += 4) s += X[(int64_t)r * 1024 + col];
+    float t = 0.f;
+    for (int r = part; r < ry; r += 4) t += Y[(int64_t)r * 1024 + col];
+    red[part][threadIdx.x & 63] = s + t;
+    __syncthreads();
+    if (part == 0) out[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---- workspace ---------------------------------------------------------------------------------------------------------
+struct Ws {
+    // forward, kept for the backward
+    float *E1, *enc, *G1, *s1, *s2, *Xhn, *GH, *GO, *Sp, *A1h, *A1o, *C1o, *C1h, *F, *T, *Tos, *Tso, *Tg, *Wt, *adj_raw,
+          *U, *V, *adj, *alpha, *beta, *M1, *M2, *Hp, *h_node, *st_h, *Op, *node, *st_o, *B1h, *B1o, *Tp, *b3sum;
+    // backward temporaries
+    float *dPF, *dTp, *dTg, *dF, *dB1h, *dB1o, *dG1, *dh_node, *dnode, *dHp, *dHm, *dOp, *dOm, *dU, *dV, *dTos, *dTso,
+          *da, *dadj, *dWt, *dT, *dA1h, *dA1o, *dC1o, *dC1h, *dS, *ds2, *ds1, *dXhn, *d_enc, *dE1, *db3;
+    float* scratch;
+    int64_t total;               // floats, scratch excluded
+};
+
+static void layout_ws(const skg_train_plan* P, float* base, Ws& w) {
+    int64_t off = 0;
+    auto take = [&](int64_t rows, int64_t cols) -> float* {
+        int64_t n = rows * cols; if (n < 4) n = 4;
+        n = (n + 3) & ~(int64_t)3;
+        float* p = base ? base + off : nullptr;
+        off += n;
+        return p;
+    };
+    const int64_t NA = P->NA, Mg = P->Mg, Mp = P->Mp > 0 ? P->Mp : 1, Mh = P->Mh, Mn = P->Mn, Bf = P->Bf;
+    w.E1 = take(NA, 1024); w.enc = take(NA, 1024); w.G1 = take(Bf, 1024); w.s1 = take(Mg, 128); w.s2 = take(Mg, 256);
+    w.Xhn = take(Mh + Mn, 1088); w.GH = take(Mh, 1024); w.GO = take(Mn, 1024); w.Sp = take(Mg, 1024);
+    w.A1h = take(Mh, 1024); w.A1o = take(Mn, 1024); w.C1o = take(Mn, 1024); w.C1h = take(Mh, 1024);
+    w.F = take(Mg, 4096); w.T = take(Mg, 1024); w.Tos = take(Mg, 1024); w.Tso = take(Mg, 1024); w.Tg = take(Mp, 1024);
+    w.Wt = take(Mg, 1024); w.adj_raw = take(Mg, 1); w.U = take(Mh, 1024); w.V = take(Mn, 1024);
+    w.adj = take(Mg, 1); w.alpha = take(Mg, 1); w.beta = take(Mg, 1);
+    w.M1 = take(Mh, 1024); w.M2 = take(Mn, 1024); w.Hp = take(Mh, 1024); w.h_node = take(Mh, 1024); w.st_h = take(Mh, 2);
+    w.Op = take(Mn, 1024); w.node = take(Mn, 1024); w.st_o = take(Mn, 2); w.B1h = take(Mh, 1024); w.B1o = take(Mn, 1024);
+    w.Tp = take(Mp, 1024); w.b3sum = take(4, 1024);
+    w.dPF = take(Mp, 2048); w.dTp = take(Mp, 1024); w.dTg = take(Mp, 1024); w.dF = take(Mg, 4096);
+    w.dB1h = take(Mh, 1024); w.dB1o = take(Mn, 1024); w.dG1 = take(Bf, 1024); w.dh_node = take(Mh, 1024);
+    w.dnode = take(Mn, 1024); w.dHp = take(Mh, 1024); w.dHm = take(Mh, 1024); w.dOp = take(Mn, 1024); w.dOm = take(Mn, 1024);
+    w.dU = take(Mh, 1024); w.dV = take(Mn, 1024); w.dTos = take(Mg, 1024); w.dTso = take(Mg, 1024); w.da = take(4, Mg);
+    w.dadj = take(Mg, 1); w.dWt = take(Mg, 1024); w.dT = take(Mg, 1024); w.dA1h = take(Mh, 1024); w.dA1o = take(Mn, 1024);
+    w.dC1o = take(Mn, 1024); w.dC1h = take(Mh, 1024); w.dS = take(Mg, 1024); w.ds2 = take(Mg, 256); w.ds1 = take(Mg, 128);
+    w.dXhn = take(Mh + Mn, 1088); w.d_enc = take(NA, 1024); w.dE1 = take(NA, 1024); w.db3 = take(4, 1024);
+    w.total = off;
+    w.scratch = base ? base + off : nullptr;
+}
+
+// ---- parameter / gradient segments -------------------------------------------------------------------------------------
+struct Seg {
+    const skg_train_plan* P; float* base;
+    float* at(int s) const { return base + P->seg_off[s]; }
+};
+
+static int check_plan(const skg_train_plan* P) {
+    if (!P || !P->params || !P->meta) return SKG_E_ARG;
+    if (P->NA <= 0 || P->Mg <= 0 || P->Mh <= 0 || P->Mn <= 0 || P->A <= 0 || P->K <= 0 || P->Bf <= 0 || P->Cf <= 0 ||
+        P->x0_k <= 0 || P->Mp < 0)
+        return SKG_E_ARG;
+    if (P->ld_logits < P->K + 1 || (P->ld_logits & 3)) return SKG_E_ARG;
+    return 0;
+}
+
+// ---- forward -----------------------------------------------------------------------------------------------------------
+// part 0: what needs neither the TransH tables nor the label counts (parameter-side sums, box_head, the global branch's
+//         fc_1, two spatial layers) -- the step driver enqueues it BEFORE its host synchronisation;  part 1: the rest.
+static void forward(Ctx& c, const Ws& w, int part) {
+    const skg_train_plan* P = c.P;
+    Seg W{P, const_cast<float*>(P->params)};
+    const int NA = P->NA, Mg = P->Mg, Mp = P->Mp, Mh = P->Mh, Mn = P->Mn, A = P->A, K = P->K, Bf = P->Bf, Cf = P->Cf;
+    const int kx = P->x0_k;
+    Mat x0 = cm(P->x0, NA, kx), gfeat = cm(P->gfeat, Bf, Cf), sp48 = cm(P->sp48, Mg, SKG_SPATIAL_LD);
+    Mat E1(w.E1, NA, 1024), enc(w.enc, NA, 1024), G1(w.G1, Bf, 1024), s1(w.s1, Mg, 128), s2(w.s2, Mg, 256);
+    Mat bh1_w(W.at(SKG_SEG_BH1_W), 1024, kx), bh3_w(W.at(SKG_SEG_BH3_W), 1024, 1024);
+    Mat sp0_w(W.at(SKG_SEG_SP0_W), 128, 46), sp2_w(W.at(SKG_SEG_SP2_W), 256, 128), sp4_w(W.at(SKG_SEG_SP4_W), 1024, 256);
+    Mat W1[4] = {Mat(W.at(SKG_SEG_W1_0), 1024, 2048), Mat(W.at(SKG_SEG_W1_1), 1024, 1024),
+                 Mat(W.at(SKG_SEG_W1_2), 1024, 1024), Mat(W.at(SKG_SEG_W1_3), 1024, Cf)};
+    float* b1[4] = {W.at(SKG_SEG_B1_0), W.at(SKG_SEG_B1_1), W.at(SKG_SEG_B1_2), W.at(SKG_SEG_B1_3)};
+    Mat W3[4] = {Mat(W.at(SKG_SEG_W3_0), 1024, 1024), Mat(W.at(SKG_SEG_W3_1), 1024, 1024),
+                 Mat(W.at(SKG_SEG_W3_2), 1024, 1024), Mat(W.at(SKG_SEG_W3_3), 1024, 1024)};
+    enum { ATT = 0, OS = 1, SO = 2, GL = 3 };
+    if (part == 0) {
+        if (!c.dry)
+            hipLaunchKernelGGL(b3sum_kernel, dim3(16), dim3(256), 0, c.stream, W.at(SKG_SEG_B3), w.b3sum);
+        // ---- box_head (HEAD:812), fc_1 of the global branch (HEAD:971), the first two spatial layers (HEAD:888)
+        skg_gemmx_desc l1[2] = {FWD(x0, bh1_w, E1, W.at(SKG_SEG_BH1_B), true),
+                                FWD(sp48, sp0_w, s1, W.at(SKG_SEG_SP0_B), true, -1, 46)};
+        launch(c, l1, 2);
+        skg_gemmx_desc l2[3] = {FWD(E1, bh3_w, enc, W.at(SKG_SEG_BH3_B), true), FWD(gfeat, W1[GL], G1, b1[GL], false),
+                                FWD(s1, sp2_w, s2, W.at(SKG_SEG_SP2_B), true)};
+        launch(c, l2, 3);
+        return;
+    }
+    const float* b3 = w.b3sum;
+    const int Mp1 = Mp > 0 ? Mp : 1;
+    // ---- fc_head / fc_tail on unique node rows (HEAD:884-885)
+    Mat Xhn(w.Xhn, Mh + Mn, 1088), GH(w.GH, Mh, 1024), GO(w.GO, Mn, 1024), Sp(w.Sp, Mg, 1024);
+    CK(skg_concat_entity_f32(w.enc, 1024, P->enc_row_hn, P->ent, P->img_hn, P->ent_row_hn, Mh + Mn, w.Xhn, 1088, c.stream));
+    Mat fh_w(W.at(SKG_SEG_FH_W), 1024, 1074), ft_w(W.at(SKG_SEG_FT_W), 1024, 1074);
+    {
+        skg_gemmx_desc l[3] = {FWD(Xhn.row_range(0, Mh), fh_w, GH, W.at(SKG_SEG_FH_B), true, -1, 1074),
+                               FWD(Xhn.row_range(Mh, Mn), ft_w, GO, W.at(SKG_SEG_FT_B), true, -1, 1074),
+                               FWD(s2, sp4_w, Sp, W.at(SKG_SEG_SP4_B), true)};           // + the last spatial layer
+        launch(c, l, 3);
+    }
+    // ---- fc_1 projections on node rows (HEAD:894-896 separable over [human | object]; HEAD:514, 524)
+    Mat A1h(w.A1h, Mh, 1024), A1o(w.A1o, Mn, 1024), C1o(w.C1o, Mn, 1024), C1h(w.C1h, Mh, 1024);
+    Mat Wa1 = W1[ATT];
+    {
+        skg_gemmx_desc l[4] = {FWD(GH, Wa1, A1h, nullptr, false, -1, 1024), FWD(GO, Wa1.from_col(1024), A1o, nullptr, false, -1, 1024),
+                               FWD(GO, W1[OS], C1o, b1[OS], false), FWD(GH, W1[SO], C1h, b1[SO], false)};
+        launch(c, l, 4);
+    }
+    // ---- fc_2 on the grid rows; the raw fc_2 output F = [F2 | F_os | F_so | F_g] (ld 4096) is kept for the backward
+    Mat F(w.F, Mg, 4096), T(w.T, Mg, 1024), Tos(w.Tos, Mg, 1024), Tso(w.Tso, Mg, 1024), Tg(w.Tg, Mp1, 1024);
+    const float* W2 = W.at(SKG_SEG_W2); const float* b2 = W.at(SKG_SEG_B2);
+    if (P->bf16) {
+        skg_gemmx_desc l[1] = {FWD(Sp, cm(W2, 4096, 1024), F, b2, false)};            // all four fc_2 as ONE N = 4096 product
+        launch(c, l, 1);
+        CK(skg_rows_mul_relu_f32(w.A1h, P->grid_h, 1024, w.A1o, P->grid_o, 1024, b1[ATT], w.F, nullptr, 4096, Mg, 1024,
+                                 w.T, 1024, c.stream));
+        CK(skg_rows_mul_relu_f32(w.C1o, P->grid_o, 1024, nullptr, nullptr, 1024, nullptr, w.F + 1024, nullptr, 4096, Mg,
+                                 1024, w.Tos, 1024, c.stream));
+        CK(skg_rows_mul_relu_f32(w.C1h, P->grid_h, 1024, nullptr, nullptr, 1024, nullptr, w.F + 2048, nullptr, 4096, Mg,
+                                 1024, w.Tso, 1024, c.stream));
+        if (Mp > 0)
+            CK(skg_rows_mul_relu_f32(w.G1, P->pair_img, 1024, nullptr, nullptr, 1024, nullptr, w.F + 3072, P->pair_grid,
+                                     4096, Mp, 1024, w.Tg, 1024, c.stream));
+    } else {
+        // exact fp32: the eval kernel with the fc_1 * fc_2 -> ReLU product fused in its epilogue, raw output stored too
+        for (int i = 0; i < 4; ++i) {
+            skg_gemm_desc d; memset(&d, 0, sizeof(d));
+            d.A = w.Sp; d.lda = 1024; d.W = W2 + (int64_t)1024 * 1024 * i; d.ldw = 1024; d.bias = b2 + 1024 * i;
+            d.ldc = 1024; d.M = Mg; d.N = 1024; d.K = 1024; d.epilogue = SKG_EPI_MUL_RELU;
+            d.C_raw = w.F + 1024 * i; d.ldc_raw = 4096;
+            if (i == ATT) { d.C = w.T; d.P = w.A1h; d.p_idx = P->grid_h; d.ldp = 1024; d.Q = w.A1o; d.q_idx = P->grid_o;
+                            d.ldq = 1024; d.mbias = b1[ATT]; }
+            else if (i == OS) { d.C = w.Tos; d.P = w.C1o; d.p_idx = P->grid_o; d.ldp = 1024; }
+            else if (i == SO) { d.C = w.Tso; d.P = w.C1h; d.p_idx = P->grid_h; d.ldp = 1024; }
+            else { d.C = w.Tg; d.P = w.G1; d.p_idx = P->grid_img; d.ldp = 1024; d.out_rows = P->grid_pair; }
+            CK(skg_gemm_f32(&d, c.stream));
+        }
+    }
+    // ---- attention fc_3 + ReLU, adjacency logits (HEAD:896-897)
+    Mat Wt(w.Wt, Mg, 1024);
+    {
+        skg_gemmx_desc l[1] = {FWD(T, W3[ATT], Wt, b3 + 1024 * ATT, true, -1, -1, -1, true)};
+        launch(c, l, 1);
+    }
+    CK(skg_rowdot_f32(w.Wt, 1024, W.at(SKG_SEG_ADJ_W), Mg, 1024, w.adj_raw, c.stream));
+    // ---- softmax-weighted aggregation before the linear fc_3 (HEAD:907-922); the adjacency bias cancels in the softmax
+    CK(skg_graph_aggregate_train_f32(w.adj_raw, 1, Mg, 0.0f, P->meta, A, P->hum_img, P->node_img, Mh, Mn, w.Tos, w.Tso,
+                                     1024, 1024, w.U, w.V, 1024, w.adj, w.alpha, w.beta, c.stream));
+    // ---- message fc_3 + ReLU, residual, LayerNorm (HEAD:909-914, 916-925)
+    Mat U(w.U, Mh, 1024), V(w.V, Mn, 1024), M1(w.M1, Mh, 1024), M2(w.M2, Mn, 1024);
+    {
+        skg_gemmx_desc l[2] = {FWD(U, W3[OS], M1, b3 + 1024 * OS, true, -1, -1, -1, true),
+                               FWD(V, W3[SO], M2, b3 + 1024 * SO, true, -1, -1, -1, true)};
+        launch(c, l, 2);
+    }
+    CK(skg_add_layernorm_f32(w.GH, 1024, w.M1, 1024, W.at(SKG_SEG_NH_W), W.at(SKG_SEG_NH_B), Mh, 1e-5f, w.Hp, w.h_node,
+                             w.st_h, c.stream));
+    CK(skg_add_layernorm_f32(w.GO, 1024, w.M2, 1024, W.at(SKG_SEG_NO_W), W.at(SKG_SEG_NO_B), Mn, 1e-5f, w.Op, w.node,
+                             w.st_o, c.stream));
+    // ---- read-out on the kept pairs (HEAD:966-973)
+    Mat h_node(w.h_node, Mh, 1024), node(w.node, Mn, 1024), B1h(w.B1h, Mh, 1024), B1o(w.B1o, Mn, 1024);
+    {
+        skg_gemmx_desc l[2] = {FWD(h_node, Wa1, B1h, nullptr, false, -1, 1024),
+                               FWD(node, Wa1.from_col(1024), B1o, nullptr, false, -1, 1024)};
+        launch(c, l, 2);
+    }
+    if (Mp > 0)
+        CK(skg_rows_mul_relu_f32(w.B1h, P->pair_h, 1024, w.B1o, P->pair_o, 1024, b1[ATT], w.F, P->pair_grid, 4096, Mp,
+                                 1024, w.Tp, 1024, c.stream));
+    Mat Tp(w.Tp, Mp1, 1024), PF(P->pair_features, Mp1, 2048);
+    {
+        skg_gemmx_desc l[2] = {FWD(Tp, W3[ATT], PF, b3 + 1024 * ATT, true, Mp, -1, 1024, true),
+                               FWD(Tg, W3[GL], PF.from_col(1024), b3 + 1024 * GL, true, Mp, -1, 1024, true)};
+        launch(c, l, 2);
+    }
+    // ---- classifier: predictor | suppressor as one product (HEAD:410-411); the caller zero-filled `logits`
+    {
+        Mat logits(P->logits, Mp1, P->ld_logits);
+        skg_gemmx_desc l[1] = {FWD(PF, Mat(W.at(SKG_SEG_CLS_W), K + 1, 2048), logits, W.at(SKG_SEG_CLS_B), false, Mp, -1, K + 1)};
+        launch(c, l, 1);
+    }
+}
+
+// ---- backward ----------------------------------------------------------------------------------------------------------
+// stages [first, last): 0 classifier + read-out ... 11 box_head; the gradient arena prefix that is final after stage s
+// is skghoi_amd/train_fused.py's Stacked.milestone_end (the data-parallel exchange runs behind it).
+static void backward(Ctx& c, const Ws& w, int first, int last) {
+    const skg_train_plan* P = c.P;
+    Seg W{P, const_cast<float*>(P->params)}, G{P, P->grads};
+    const int NA = P->NA, Mg = P->Mg, Mp = P->Mp, Mh = P->Mh, Mn = P->Mn, A = P->A, K = P->K, Bf = P->Bf, Cf = P->Cf;
+    const int kx = P->x0_k, Mp1 = Mp > 0 ? Mp : 1;
+    enum { ATT = 0, OS = 1, SO = 2, GL = 3 };
+    Mat W1[4] = {Mat(W.at(SKG_SEG_W1_0), 1024, 2048), Mat(W.at(SKG_SEG_W1_1), 1024, 1024),
+                 Mat(W.at(SKG_SEG_W1_2), 1024, 1024), Mat(W.at(SKG_SEG_W1_3), 1024, Cf)};
+    Mat dW1[4] = {Mat(G.at(SKG_SEG_W1_0), 1024, 2048), Mat(G.at(SKG_SEG_W1_1), 1024, 1024),
+                  Mat(G.at(SKG_SEG_W1_2), 1024, 1024), Mat(G.at(SKG_SEG_W1_3), 1024, Cf)};
+    float* b1[4] = {W.at(SKG_SEG_B1_0), W.at(SKG_SEG_B1_1), W.at(SKG_SEG_B1_2), W.at(SKG_SEG_B1_3)};
+    float* db1[4] = {G.at(SKG_SEG_B1_0), G.at(SKG_SEG_B1_1), G.at(SKG_SEG_B1_2), G.at(SKG_SEG_B1_3)};
+    Mat W3[4] = {Mat(W.at(SKG_SEG_W3_0), 1024, 1024), Mat(W.at(SKG_SEG_W3_1), 1024, 1024),
+                 Mat(W.at(SKG_SEG_W3_2), 1024, 1024), Mat(W.at(SKG_SEG_W3_3), 1024, 1024)};
+    Mat dW3[4] = {Mat(G.at(SKG_SEG_W3_0), 1024, 1024), Mat(G.at(SKG_SEG_W3_1), 1024, 1024),
+                  Mat(G.at(SKG_SEG_W3_2), 1024, 1024), Mat(G.at(SKG_SEG_W3_3), 1024, 1024)};
+    float* db3 = w.db3;
+    Mat dlogits = cm(P->dlogits, Mp1, P->ld_logits);
+    Mat PF(P->pair_features, Mp1, 2048), Tp(w.Tp, Mp1, 1024), Tg(w.Tg, Mp1, 1024);
+    Mat dPF(w.dPF, Mp1, 2048), dTp(w.dTp, Mp1, 1024), dTg(w.dTg, Mp1, 1024);
+    Mat Wa1 = W1[ATT], dWa1 = dW1[ATT];
+    Mat dB1h(w.dB1h, Mh, 1024), dB1o(w.dB1o, Mn, 1024), dG1(w.dG1, Bf, 1024);
+    Mat dh_node(w.dh_node, Mh, 1024), dnode(w.dnode, Mn, 1024), h_node(w.h_node, Mh, 1024), node(w.node, Mn, 1024);
+    Mat dHp(w.dHp, Mh, 1024), dHm(w.dHm, Mh, 1024), dOp(w.dOp, Mn, 1024), dOm(w.dOm, Mn, 1024);
+    Mat dU(w.dU, Mh, 1024), dV(w.dV, Mn, 1024), U(w.U, Mh, 1024), V(w.V, Mn, 1024);
+    Mat dWt(w.dWt, Mg, 1024), dT(w.dT, Mg, 1024), T(w.T, Mg, 1024), Wt(w.Wt, Mg, 1024), dadj(w.dadj, Mg, 1);
+    Mat dA1h(w.dA1h, Mh, 1024), dA1o(w.dA1o, Mn, 1024), dC1o(w.dC1o, Mn, 1024), dC1h(w.dC1h, Mh, 1024);
+    Mat GH(w.GH, Mh, 1024), GO(w.GO, Mn, 1024), Sp(w.Sp, Mg, 1024), dS(w.dS, Mg, 1024), dF(w.dF, Mg, 4096);
+    Mat s1(w.s1, Mg, 128), s2(w.s2, Mg, 256), ds1(w.ds1, Mg, 128), ds2(w.ds2, Mg, 256), sp48 = cm(P->sp48, Mg, SKG_SPATIAL_LD);
+    Mat sp0_w(W.at(SKG_SEG_SP0_W), 128, 46), sp2_w(W.at(SKG_SEG_SP2_W), 256, 128), sp4_w(W.at(SKG_SEG_SP4_W), 1024, 256);
+    Mat g_sp0(G.at(SKG_SEG_SP0_W), 128, 46), g_sp2(G.at(SKG_SEG_SP2_W), 256, 128), g_sp4(G.at(SKG_SEG_SP4_W), 1024, 256);
+    Mat Xhn(w.Xhn, Mh + Mn, 1088), dXhn(w.dXhn, Mh + Mn, 1088);
+    Mat fh_w(W.at(SKG_SEG_FH_W), 1024, 1074), ft_w(W.at(SKG_SEG_FT_W), 1024, 1074);
+    Mat g_fh(G.at(SKG_SEG_FH_W), 1024, 1074), g_ft(G.at(SKG_SEG_FT_W), 1024, 1074);
+    Mat gfeat = cm(P->gfeat, Bf, Cf), x0 = cm(P->x0, NA, kx);
+    Mat E1(w.E1, NA, 1024), dE1(w.dE1, NA, 1024), d_enc(w.d_enc, NA, 1024);
+    Mat bh1_w(W.at(SKG_SEG_BH1_W), 1024, kx), bh3_w(W.at(SKG_SEG_BH3_W), 1024, 1024);
+    Mat g_bh1(G.at(SKG_SEG_BH1_W), 1024, kx), g_bh3(G.at(SKG_SEG_BH3_W), 1024, 1024);
+    for (int st = first; st < last && !c.rc; ++st) switch (st) {
+    case 0: {
+        // ---- classifier
+        Mat clsW(W.at(SKG_SEG_CLS_W), K + 1, 2048), g_clsW(G.at(SKG_SEG_CLS_W), K + 1, 2048);
+        skg_gemmx_desc l[2] = {IG(dlogits, clsW, dPF, &PF, false, Mp, 2048, K + 1),
+                               WG(dlogits, PF, g_clsW, G.at(SKG_SEG_CLS_B), false, Mp, K + 1, 2048)};
+        launch(c, l, 2);
+    } break;
+    case 1: {
+        // ---- read-out fc_3 (both branches): dT = dPF W3 cut by the product's ReLU; dW3 = dPF^T T
+        skg_gemmx_desc l[4] = {IG(dPF, W3[ATT], dTp, &Tp, false, Mp, 1024, 1024, true),
+                               IG(dPF.from_col(1024), W3[GL], dTg, &Tg, false, Mp, 1024, 1024, true),
+                               WG(dPF, Tp, dW3[ATT], db3 + 1024 * ATT, false, Mp, 1024, 1024, true),
+                               WG(dPF.from_col(1024), Tg, dW3[GL], db3 + 1024 * GL, false, Mp, 1024, 1024, true)};
+        launch(c, l, 4);
+        // ---- read-out fc_1 * fc_2 products: dF at the pairs' grid rows (self-pair rows stay zero), dm in place
+        if (!c.dry) {
+            hipError_t e = hipMemsetAsync(w.dF, 0, sizeof(float) * (size_t)Mg * 4096, c.stream);
+            if (e == hipSuccess) e = hipMemsetAsync(w.dG1, 0, sizeof(float) * (size_t)Bf * 1024, c.stream);
+            if (e != hipSuccess) { c.rc = (int)e; break; }
+        }
+        if (Mp > 0) {
+            CK(skg_mul_bwd_f32(w.dTp, 1024, w.F, P->pair_grid, 4096, w.B1h, P->pair_h, 1024, w.B1o, P->pair_o, 1024,
+                               b1[ATT], Mp, w.dF, 4096, 0, c.stream));
+            CK(skg_mul_bwd_f32(w.dTg, 1024, w.F + 3072, P->pair_grid, 4096, w.G1, P->pair_img, 1024, nullptr, nullptr, 0,
+                               nullptr, Mp, w.dF + 3072, 4096, 0, c.stream));
+        }
+        CK(skg_segment_sum_f32(w.dTp, 1024, P->meta, A, P->hum_img, P->node_img, Mh, Mn, 1, w.dB1h, w.dB1o, 0, c.stream));
+        CK(skg_segment_sum_f32(w.dTg, 1024, P->meta, A, nullptr, nullptr, 0, 0, 2, w.dG1, nullptr, 0, c.stream));
+        // ---- read-out fc_1 on the normalised nodes: dh_node, dnode; dW1[att] from both halves
+        skg_gemmx_desc l2[4] = {IG(dB1h, Wa1, dh_node, nullptr, false, -1, 1024), IG(dB1o, Wa1.from_col(1024), dnode, nullptr, false, -1, 1024),
+                                WG(dB1h, h_node, dWa1, nullptr, false, -1, -1, 1024),
+                                WG(dB1o, node, dWa1.from_col(1024), nullptr, false, -1, -1, 1024)};
+        launch(c, l2, 4);
+    } break;
+    case 2: {
+        // ---- LayerNorm + residual: dHp continues to the node, dHp cut by the message's ReLU goes to fc_3
+        CK(skg_layernorm_bwd_f32(w.dh_node, 1024, w.Hp, w.st_h, W.at(SKG_SEG_NH_W), Mh, w.dHp, w.M1, w.dHm,
+                                 G.at(SKG_SEG_NH_W), G.at(SKG_SEG_NH_B), c.stream));
+        CK(skg_layernorm_bwd_f32(w.dnode, 1024, w.Op, w.st_o, W.at(SKG_SEG_NO_W), Mn, w.dOp, w.M2, w.dOm,
+                                 G.at(SKG_SEG_NO_W), G.at(SKG_SEG_NO_B), c.stream));
+    } break;
+    case 3: {
+        // ---- message fc_3
+        skg_gemmx_desc l[4] = {IG(dHm, W3[OS], dU, nullptr, false, -1, 1024, -1, true), IG(dOm, W3[SO], dV, nullptr, false, -1, 1024, -1, true),
+                               WG(dHm, U, dW3[OS], db3 + 1024 * OS, false, -1, -1, -1, true),
+                               WG(dOm, V, dW3[SO], db3 + 1024 * SO, false, -1, -1, -1, true)};
+        launch(c, l, 4);
+    } break;
+    case 4: {
+        // ---- aggregation + softmax, adjacency Linear(1024 -> 1) over relu(fc_3(T)), attention fc_3
+        float* da = w.da;
+        CK(skg_aggregate_bwd_f32(w.dU, w.dV, w.Tos, w.Tso, w.alpha, w.beta, P->grid_h, P->grid_o, Mg, P->meta, P->hum_img,
+                                 P->node_img, Mh, Mn, w.dTos, w.dTso, da, da + Mg, da + 2 * (int64_t)Mg, da + 3 * (int64_t)Mg,
+                                 c.stream));
+        CK(skg_adjacency_bwd_f32(da + 2 * (int64_t)Mg, da + 3 * (int64_t)Mg, W.at(SKG_SEG_ADJ_W), w.Wt, Mg, w.dadj, w.dWt,
+                                 c.stream));
+        skg_gemmx_desc l[3] = {IG(dWt, W3[ATT], dT, &T, false, -1, 1024, -1, true),
+                               WG(dWt, T, dW3[ATT], db3 + 1024 * ATT, true, -1, -1, -1, true),
+                               WG(dadj, Wt, Mat(G.at(SKG_SEG_ADJ_W), 1, 1024), G.at(SKG_SEG_ADJ_B), false)};
+        launch(c, l, 3);
+    } break;
+    case 5: {
+        // ---- in-loop fc_1 * fc_2 products
+        CK(skg_mul_bwd_f32(w.dT, 1024, w.F, nullptr, 4096, w.A1h, P->grid_h, 1024, w.A1o, P->grid_o, 1024, b1[ATT], Mg,
+                           w.dF, 4096, 1, c.stream));
+        CK(skg_mul_bwd_f32(w.dTos, 1024, w.F + 1024, nullptr, 4096, w.C1o, P->grid_o, 1024, nullptr, nullptr, 0, nullptr, Mg,
+                           w.dF + 1024, 4096, 0, c.stream));
+        CK(skg_mul_bwd_f32(w.dTso, 1024, w.F + 2048, nullptr, 4096, w.C1h, P->grid_h, 1024, nullptr, nullptr, 0, nullptr, Mg,
+                           w.dF + 2048, 4096, 0, c.stream));
+        CK(skg_segment_sum_f32(w.dT, 1024, P->meta, A, P->hum_img, P->node_img, Mh, Mn, 0, w.dA1h, w.dA1o, 0, c.stream));
+        CK(skg_segment_sum_f32(w.dTos, 1024, P->meta, A, P->hum_img, P->node_img, Mh, Mn, 0, nullptr, w.dC1o, 0, c.stream));
+        CK(skg_segment_sum_f32(w.dTso, 1024, P->meta, A, P->hum_img, P->node_img, Mh, Mn, 0, w.dC1h, nullptr, 0, c.stream));
+        // the multiplier bias of attention_head's fc_1 is added once per row: its gradient is the sum over all rows
+        if (!c.dry)
+            hipLaunchKernelGGL(colsum2_kernel, dim3(16), dim3(256), 0, c.stream, w.dA1h, Mh, w.dB1h, Mh, db1[ATT]);
+    } break;
+    case 6: {
+        // ---- fc_2 of all four MBFs: ONE product for the input gradient (K = 4096), one for the weights
+        Mat W2(W.at(SKG_SEG_W2), 4096, 1024), g_W2(G.at(SKG_SEG_W2), 4096, 1024);
+        skg_gemmx_desc l[2] = {IG(dF, W2, dS, &Sp, false, -1, 1024), WG(dF, Sp, g_W2, G.at(SKG_SEG_B2), false)};
+        launch(c, l, 2);
+    } break;
+    case 7: {
+        // ---- fc_1 projections on node rows (gradients accumulate on top of the residual path) + spatial layer 3
+        skg_gemmx_desc l[6] = {IG(dA1h, Wa1, dHp, nullptr, true, -1, 1024), IG(dA1o, Wa1.from_col(1024), dOp, nullptr, true, -1, 1024),
+                               WG(dA1h, GH, dWa1, nullptr, true, -1, -1, 1024),
+                               WG(dA1o, GO, dWa1.from_col(1024), nullptr, true, -1, -1, 1024),
+                               IG(dS, sp4_w, ds2, &s2, false), WG(dS, s2, g_sp4, G.at(SKG_SEG_SP4_B), false)};
+        launch(c, l, 6);
+    } break;
+    case 8: {
+        skg_gemmx_desc l[6] = {IG(dC1h, W1[SO], dHp, &GH, true), IG(dC1o, W1[OS], dOp, &GO, true),
+                               WG(dC1h, GH, dW1[SO], db1[SO], false), WG(dC1o, GO, dW1[OS], db1[OS], false),
+                               IG(ds2, sp2_w, ds1, &s1, false), WG(ds2, s1, g_sp2, G.at(SKG_SEG_SP2_B), false)};
+        launch(c, l, 6);
+    } break;
+    case 9: {
+        // ---- fc_head / fc_tail, the first spatial layer and the global branch's fc_1 (HEAD:971)
+        skg_gemmx_desc l[7] = {IG(dHp, fh_w, dXhn.row_range(0, Mh), nullptr, false, -1, 1074),
+                               IG(dOp, ft_w, dXhn.row_range(Mh, Mn), nullptr, false, -1, 1074),
+                               WG(dHp, Xhn.row_range(0, Mh), g_fh, G.at(SKG_SEG_FH_B), false, -1, -1, 1074),
+                               WG(dOp, Xhn.row_range(Mh, Mn), g_ft, G.at(SKG_SEG_FT_B), false, -1, -1, 1074),
+                               WG(ds1, sp48, g_sp0, G.at(SKG_SEG_SP0_B), false, -1, -1, 46),
+                               WG(dG1, gfeat, dW1[GL], db1[GL], false), skg_gemmx_desc()};
+        int n = 6;
+        if (P->dgfeat) l[n++] = IG(dG1, W1[GL], Mat(P->dgfeat, Bf, Cf), nullptr, false);
+        launch(c, l, n);
+        CK(skg_entity_rows_bwd_f32(w.dXhn, 1088, P->hum_of, P->node_of, Mh, NA, w.enc, w.d_enc, c.stream));
+    } break;
+    case 10: {
+        // ---- box_head layer 2
+        skg_gemmx_desc l[2] = {IG(d_enc, bh3_w, dE1, &E1, false), WG(d_enc, E1, g_bh3, G.at(SKG_SEG_BH3_B), false)};
+        launch(c, l, 2);
+    } break;
+    case 11: {
+        // ---- box_head layer 1; every fc_3 branch gets its MBF's bias gradient (the bias is added once per row)
+        skg_gemmx_desc l[2] = {WG(dE1, x0, g_bh1, G.at(SKG_SEG_BH1_B), false), skg_gemmx_desc()};
+        int n = 1;
+        if (P->dx0) l[n++] = IG(dE1, bh1_w, Mat(P->dx0, NA, kx), nullptr, false);
+        launch(c, l, n);
+        if (!c.dry)
+            hipLaunchKernelGGL(b3bcast_kernel, dim3(256), dim3(256), 0, c.stream, w.db3, G.at(SKG_SEG_B3));
+    } break;
+    default: break;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t skg_train_ws_floats(const skg_train_plan* P) {
+    int rc = check_plan(P);
+    if (rc) return rc;
+    Ws w; layout_ws(P, nullptr, w);
+    Ctx c{P, nullptr, true, 0, nullptr, 0};
+    forward(c, w, 0); forward(c, w, 1); backward(c, w, 0, SKG_TRAIN_BWD_STAGES);
+    return w.total + c.scratch_need + 4;
+}
+
+int skg_train_forward_f32(const skg_train_plan* P, int part, void* stream) {
+    int rc = check_plan(P);
+    if (rc) return rc;
+    if (!P->ws || !P->x0 || !P->gfeat || !P->sp48 || part < 0 || part > 1) return SKG_E_ARG;
+    if (part == 1 && (!P->ent || !P->logits || !P->pair_features)) return SKG_E_ARG;
+    Ws w; layout_ws(P, P->ws, w);
+    if (w.total > P->ws_floats) return SKG_E_LIMIT;
+    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0};
+    // bound the scratch: the sizing pass told the caller how much the largest launch needs
+    Ctx d{P, nullptr, true, 0, nullptr, 0};
+    forward(d, w, part);
+    if (w.total + d.scratch_need > P->ws_floats) return SKG_E_LIMIT;
+    forward(c, w, part);
+    if (!c.rc) { hipError_t e = hipGetLastError(); if (e != hipSuccess) c.rc = (int)e; }
+    return c.rc;
+}
+
+int skg_train_backward_f32(const skg_train_plan* P, int first_stage, int last_stage, void* stream) {
+    int rc = check_plan(P);
+    if (rc) return rc;
+    if (!P->ws || !P->grads || !P->dlogits || !P->pair_features || first_stage < 0 || last_stage > SKG_TRAIN_BWD_STAGES ||
+        first_stage > last_stage)
+        return SKG_E_ARG;
+    Ws w; layout_ws(P, P->ws, w);
+    Ctx d{P, nullptr, true, 0, nullptr, 0};
+    backward(d, w, first_stage, last_stage);
+    if (w.total + d.scratch_need > P->ws_floats) return SKG_E_LIMIT;
+    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0};
+    backward(c, w, first_stage, last_stage);
+    if (!c.rc) { hipError_t e = hipGetLastError(); if (e != hipSuccess) c.rc = (int)e; }
+    return c.rc;
+}
+
+/* offset (floats) of a saved activation inside the workspace: 0 = pair-independent debug reads (tests) */
+int64_t skg_train_ws_offset(const skg_train_plan* P, int which) {
+    if (check_plan(P)) return -1;
+    Ws w; layout_ws(P, reinterpret_cast<float*>(16), w);       // non-null dummy base: offsets = pointer differences
+    float* base = reinterpret_cast<float*>(16);
+    switch (which) {
+    case 0: return w.enc - base;
+    case 1: return w.h_node - base;
+    case 2: return w.node - base;
+    case 3: return w.adj - base;
+    case 4: return w.F - base;
+    default: return -1;
+    }
+}
+
+}  // extern "C"

@@ -37,38 +37,74 @@ def _check(rc, what):
     _capi.check(rc, what)
 
 
-class Stacked:
-    """Stacked copies of the MBF / classifier parameters (refreshed from the live parameters once per step by one
-    multi-tensor copy) and the matching views of a gradient arena.
+# Plain (un-stacked) parameters of the head, by arena segment name: (owner path, attribute)
+_PLAIN = (("nh_w", ("norm_h", "weight")), ("nh_b", ("norm_h", "bias")), ("no_w", ("norm_o", "weight")),
+          ("no_b", ("norm_o", "bias")), ("adj_w", ("adjacency", "weight")), ("adj_b", ("adjacency", "bias")),
+          ("sp4_w", ("spatial_head", 4, "weight")), ("sp4_b", ("spatial_head", 4, "bias")),
+          ("sp2_w", ("spatial_head", 2, "weight")), ("sp2_b", ("spatial_head", 2, "bias")),
+          ("fh_w", ("fc_head", 0, "weight")), ("fh_b", ("fc_head", 0, "bias")),
+          ("ft_w", ("fc_tail", 0, "weight")), ("ft_b", ("fc_tail", 0, "bias")),
+          ("sp0_w", ("spatial_head", 0, "weight")), ("sp0_b", ("spatial_head", 0, "bias")),
+          ("bh3_w", ("box_head", 3, "weight")), ("bh3_b", ("box_head", 3, "bias")),
+          ("bh1_w", ("box_head", 1, "weight")), ("bh1_b", ("box_head", 1, "bias")))
 
-    Segments (fp32, one flat buffer):  per MBF m: W1[m] [1024, in_m] (16 x [64, in_m] row blocks), b1[m] [1024],
-    W3[m] [16][1024][64] (branch-major: branch b is the contiguous fc_3[b].weight), b3[m] [16][1024];
-    W2 [4 x 1024, 1024] and b2 [4 x 1024] of all four MBFs back to back (one GEMM for their input gradient);
-    classifier [K + 1, 2048] = predictor rows then the suppressor row, bias [K + 1]."""
+# Arena order = the order in which the backward FINISHES the gradients (read-out layers first, box_head last): after
+# milestone m of TrainJob.backward the arena prefix [0, milestone_end[m]) is final, which is what lets the gradient
+# exchange of a data-parallel step run chunk by chunk behind the backward (skghoi_amd/trainer.py, ArenaExchange).
+_ORDER = (("clsW", "clsb"), ("W3_3",), ("nh_w", "nh_b", "no_w", "no_b"), ("W3_1", "W3_2"), ("W3_0", "adj_w", "adj_b"),
+          ("b1_0",), ("W2", "b2"), ("W1_0", "sp4_w", "sp4_b"), ("W1_2", "W1_1", "b1_2", "b1_1", "sp2_w", "sp2_b"),
+          ("fh_w", "fh_b", "ft_w", "ft_b", "sp0_w", "sp0_b", "W1_3", "b1_3"), ("bh3_w", "bh3_b"), ("bh1_w", "bh1_b", "b3"))
+
+
+def _resolve(gh, path):
+    o = gh
+    for k in path:
+        o = o[k] if isinstance(k, int) else getattr(o, k)
+    return o
+
+
+class Stacked:
+    """The PARAMETER ARENA of the head: one flat fp32 buffer holding all 408 parameters in the layout the kernels of the
+    training step read, and the live Parameters re-pointed into it (`p.data` = a view of the arena).  Nothing is copied
+    per step: the optimizer updates the arena in place, the GEMMs read it.  A gradient arena with the same layout gives
+    every `p.grad` as a view, so that the optimizer and the data-parallel gradient exchange work on two flat buffers.
+
+    Segments:  per MBF m (order attention_head, obj_to_sub, sub_to_obj, attention_head_g): W1_m [1024, in_m] (16 x
+    [64, in_m] row blocks = fc_1[b].weight), b1_m [1024], W3_m [16][1024][64] (branch-major: branch b is the contiguous
+    fc_3[b].weight); b3 [4][16][1024]; W2 [4 x 1024, 1024] and b2 [4 x 1024] of all four MBFs back to back (one GEMM
+    for their input gradient); clsW [K + 1, 2048] = predictor rows then the suppressor row, clsb [K + 1]; every other
+    parameter (box_head, spatial_head, fc_head / fc_tail, adjacency, LayerNorms) as a segment of its own shape.
+    Segment order: _ORDER (gradient readiness).
+
+    The aliasing is re-checked every step (408 data_ptr reads, ~40 us): `module.to()`, `p.data = t` or a replaced
+    Parameter re-point storage; the arena then takes the new values and the parameters are re-pointed into it."""
 
     def __init__(self, head, device):
         gh = head.box_pair_head
         self.device = device
-        self.K = head.num_classes
+        self.K = K = head.num_classes
         mbfs = [getattr(gh, n) for n in MBF_NAMES]
         self.in_dim = [m.fc_1[0].weight.shape[1] for m in mbfs]
-        seg = {}
-        off = 0
-
-        def add(name, *shape):
-            nonlocal off
-            n = int(np.prod(shape))
-            seg[name] = (off, shape)
-            off += (n + 3) // 4 * 4
+        shapes = {}
         for i in range(4):
-            add("W1_%d" % i, 1024, self.in_dim[i]); add("b1_%d" % i, 1024)
-            add("W3_%d" % i, 16, 1024, 64)
-        add("b3", 4, 16, 1024)
-        add("W2", 4096, 1024); add("b2", 4096)
-        add("clsW", self.K + 1, 2048); add("clsb", self.K + 1)
-        self.seg, self.total = seg, off
+            shapes["W1_%d" % i] = (1024, self.in_dim[i]); shapes["b1_%d" % i] = (1024,)
+            shapes["W3_%d" % i] = (16, 1024, 64)
+        shapes.update(b3=(4, 16, 1024), W2=(4096, 1024), b2=(4096,), clsW=(K + 1, 2048), clsb=(K + 1,))
+        plain = {}
+        for name, path in _PLAIN:
+            plain[name] = _resolve(gh, path)
+            shapes[name] = tuple(plain[name].shape)
+        seg, off, ends = {}, 0, []
+        for group in _ORDER:
+            for name in group:
+                n = int(np.prod(shapes[name]))
+                seg[name] = (off, shapes[name])
+                off += (n + 3) // 4 * 4                        # every segment 16-byte aligned
+            ends.append(off)
+        assert set(seg) == set(shapes)
+        self.seg, self.total, self.milestone_end = seg, off, ends
         self.numel = {k: int(np.prod(v[1])) for k, v in seg.items()}
-        self.buf = torch.empty(off, device=device, dtype=torch.float32)
+        self.buf = torch.zeros(off, device=device, dtype=torch.float32)
         # (live parameter, segment, selector inside the segment's view) in a fixed order
         self.entries = []
         for i, m in enumerate(mbfs):
@@ -79,22 +115,43 @@ class Stacked:
                 self.entries.append((m.fc_2[b].bias, "b2", (slice(1024 * i + 64 * b, 1024 * i + 64 * b + 64),)))
                 self.entries.append((m.fc_3[b].weight, "W3_%d" % i, (b,)))
                 self.entries.append((m.fc_3[b].bias, "b3", (i, b)))
-        K = self.K
         self.entries.append((head.box_pair_predictor.weight, "clsW", (slice(0, K),)))
         self.entries.append((head.box_pair_suppressor.weight, "clsW", (slice(K, K + 1),)))
         self.entries.append((head.box_pair_predictor.bias, "clsb", (slice(0, K),)))
         self.entries.append((head.box_pair_suppressor.bias, "clsb", (slice(K, K + 1),)))
-        self.src = [e[0] for e in self.entries]                       # the LIVE parameters (never cached aliases: a
-                                                                      # re-pointed p.data must be seen by the next step)
+        self.n_stacked = len(self.entries)
+        for name, _ in _PLAIN:
+            self.entries.append((plain[name], name, ()))
+        self.src = [e[0] for e in self.entries]                       # the LIVE parameters
         self.dst = [self.view(self.buf, e[1])[e[2]] for e in self.entries]
+        self.dst_ptrs = [t.data_ptr() for t in self.dst]
         self.ids = {id(p): k for k, p in enumerate(self.src)}
+        self.adoptions = 0
 
     def view(self, flat, name):
         off, shape = self.seg[name]
         return flat[off:off + self.numel[name]].view(shape)
 
+    def seg_off_array(self):
+        """int64 offsets (floats) of the arena segments in SKG_SEG_* order (include/skghoi.h)."""
+        a = getattr(self, "_seg_off", None)
+        if a is None:
+            a = self._seg_off = (C.c_int64 * len(_capi.TRAIN_SEGS))(*[self.seg[n][0] for n in _capi.TRAIN_SEGS])
+        return a
+
+    def aliased(self):
+        return [p.data_ptr() for p in self.src] == self.dst_ptrs
+
+    def adopt(self):
+        """Copies the live parameter values into the arena and re-points every Parameter into it."""
+        with torch.no_grad():
+            torch._foreach_copy_(self.dst, [p.detach() for p in self.src])
+            for p, d in zip(self.src, self.dst):
+                p.data = d
+        self.adoptions += 1
+
     def grad_arena(self):
-        """(arena, per-entry views) for one backward.  The arena of the previous step and its 392 view objects are reused
+        """(arena, per-entry views) for one backward.  The arena of the previous step and its 408 view objects are reused
         when nothing else holds them any more -- zero_grad(set_to_none=True) has dropped every p.grad (C++ side: the
         tensors' use counts) and no caller kept a gradient tensor (Python side: the reference counts of the cached view
         objects) -- which saves ~0.4 ms of view construction per step; otherwise (gradient accumulation, a caller
@@ -113,12 +170,12 @@ class Stacked:
         return sum(map(sys.getrefcount, views)) + sum(map(torch.Tensor._use_count, views))
 
     def refresh(self):
-        with torch.no_grad():
-            torch._foreach_copy_(self.dst, self.src)
+        if not self.aliased():
+            self.adopt()
         self.b3sum = self.view(self.buf, "b3").sum(dim=1)                 # [4, 1024]: fc_3 biases summed over branches
 
     def grad_views(self, garena):
-        """Views of a gradient arena (same layout) for the stacked parameters, in `entries` order.  Built with one unbind
+        """Views of a gradient arena (same layout) for all parameters, in `entries` order.  Built with one unbind
         per (MBF, kind) -- 16 branch slices per call -- instead of 388 separate slicing calls."""
         K = self.K
         W2 = self.view(garena, "W2").view(4, 16, 64, 1024); b2 = self.view(garena, "b2").view(4, 16, 64)
@@ -133,6 +190,7 @@ class Stacked:
                 out += [w1[b], c1[b], w2[b], c2[b], w3[b], c3[b]]
         cw, cb = self.view(garena, "clsW"), self.view(garena, "clsb")
         out += [cw[:K], cw[K:K + 1], cb[:K], cb[K:K + 1]]
+        out += [self.view(garena, name) for name, _ in _PLAIN]
         return out
 
 
@@ -454,7 +512,7 @@ class TrainJob:
         nh, no = gh.norm_h, gh.norm_o
         dHp = torch.empty(Mh, 1024, **f32); dHm = torch.empty(Mh, 1024, **f32)
         dOp = torch.empty(Mn, 1024, **f32); dOm = torch.empty(Mn, 1024, **f32)
-        g_nh = torch.empty(2, 1024, **f32); g_no = torch.empty(2, 1024, **f32)
+        g_nh = (gv("nh_w"), gv("nh_b")); g_no = (gv("no_w"), gv("no_b"))
         _check(lib.skg_layernorm_bwd_f32(dh_node.data_ptr(), 1024, S["Hp"].data_ptr(), S["st_h"].data_ptr(),
                                          nh.weight.data_ptr(), Mh, dHp.data_ptr(), S["M1"].data_ptr(), dHm.data_ptr(),
                                          g_nh[0].data_ptr(), g_nh[1].data_ptr(), stream), "skg_layernorm_bwd_f32")
@@ -478,7 +536,7 @@ class TrainJob:
         wadj = gh.adjacency.weight.detach().reshape(-1)
         _check(lib.skg_adjacency_bwd_f32(da[2].data_ptr(), da[3].data_ptr(), wadj.data_ptr(), S["Wt"].data_ptr(), Mg,
                                          dadj.data_ptr(), dWt.data_ptr(), stream), "skg_adjacency_bwd_f32")
-        g_adj_w = torch.empty(1, 1024, **f32); g_adj_b = torch.empty(1, **f32)
+        g_adj_w, g_adj_b = gv("adj_w"), gv("adj_b")
         dT = torch.empty(Mg, 1024, **f32)
         T = S["T"]
         self.gx([IG(dWt, W3[ATT], dT, mask=T, N_in=1024, w_blocks=blk),
@@ -514,7 +572,7 @@ class TrainJob:
         sp = gh.spatial_head
         s1, s2, sp48 = S["s1"], S["s2"], S["sp48"]
         ds2 = torch.empty(Mg, 256, **f32); ds1 = torch.empty(Mg, 128, **f32)
-        g_sp = [(torch.empty_like(sp[i].weight), torch.empty_like(sp[i].bias)) for i in (0, 2, 4)]
+        g_sp = [(gv("sp%d_w" % i), gv("sp%d_b" % i)) for i in (0, 2, 4)]
         self.gx([IG(dA1h, Wa1, dHp, accumulate=True, N_in=1024), IG(dA1o, Wa1[:, 1024:], dOp, accumulate=True, N_in=1024),
                  WG(dA1h, GH, dWa1, accumulate=True, k_in=1024), WG(dA1o, GO, dWa1[:, 1024:], accumulate=True, k_in=1024),
                  IG(dS, sp[4].weight, ds2, mask=s2), WG(dS, s2, g_sp[2][0], db=g_sp[2][1])])
@@ -525,8 +583,7 @@ class TrainJob:
         Xhn = S["Xhn"]
         fh, ft = gh.fc_head[0], gh.fc_tail[0]
         dXhn = torch.empty(Mh + Mn, 1088, **f32)
-        g_fh_w = torch.empty_like(fh.weight); g_fh_b = torch.empty_like(fh.bias)
-        g_ft_w = torch.empty_like(ft.weight); g_ft_b = torch.empty_like(ft.bias)
+        g_fh_w, g_fh_b, g_ft_w, g_ft_b = gv("fh_w"), gv("fh_b"), gv("ft_w"), gv("ft_b")
         gfeat = S["gfeat"]
         ops = [IG(dHp, fh.weight, dXhn[:Mh], N_in=1074), IG(dOp, ft.weight, dXhn[Mh:], N_in=1074),
                WG(dHp, Xhn[:Mh], g_fh_w, db=g_fh_b, k_in=1074), WG(dOp, Xhn[Mh:], g_ft_w, db=g_ft_b, k_in=1074),
@@ -543,8 +600,7 @@ class TrainJob:
         bh1, bh3 = gh.box_head[1], gh.box_head[3]
         E1, x0 = S["E1"], S["x0"]
         dE1 = torch.empty(NA, 1024, **f32)
-        g_bh3_w = torch.empty_like(bh3.weight); g_bh3_b = torch.empty_like(bh3.bias)
-        g_bh1_w = torch.empty_like(bh1.weight); g_bh1_b = torch.empty_like(bh1.bias)
+        g_bh3_w, g_bh3_b, g_bh1_w, g_bh1_b = gv("bh3_w"), gv("bh3_b"), gv("bh1_w"), gv("bh1_b")
         self.gx([IG(d_enc, bh3.weight, dE1, mask=E1), WG(d_enc, E1, g_bh3_w, db=g_bh3_b)])
         ops = [WG(dE1, x0, g_bh1_w, db=g_bh1_b)]
         dx0 = None
@@ -555,18 +611,117 @@ class TrainJob:
         # ---- the fc_3 bias of branch b is added once per row whatever b: every branch gets the MBF's bias gradient
         gv("b3").copy_(db3.unsqueeze(1).expand(4, 16, 1024))
         # ---- hand the gradients back in the order of the Function's parameter inputs
-        direct = {id(bh1.weight): g_bh1_w, id(bh1.bias): g_bh1_b, id(bh3.weight): g_bh3_w, id(bh3.bias): g_bh3_b,
-                  id(gh.adjacency.weight): g_adj_w, id(gh.adjacency.bias): g_adj_b,
-                  id(nh.weight): g_nh[0], id(nh.bias): g_nh[1], id(no.weight): g_no[0], id(no.bias): g_no[1],
-                  id(sp[0].weight): g_sp[0][0], id(sp[0].bias): g_sp[0][1], id(sp[2].weight): g_sp[1][0],
-                  id(sp[2].bias): g_sp[1][1], id(sp[4].weight): g_sp[2][0], id(sp[4].bias): g_sp[2][1],
-                  id(fh.weight): g_fh_w, id(fh.bias): g_fh_b, id(ft.weight): g_ft_w, id(ft.bias): g_ft_b}
         out = []
         for p in self.params:
             k = st.ids.get(id(p))
-            out.append(sviews[k] if k is not None else direct.get(id(p)))
+            out.append(sviews[k] if k is not None else None)
         self.S = None                                            # the saved activations die with the step
         return dx0, dgfeat, out
+
+
+class NativeJob(TrainJob):
+    """TrainJob whose dense forward / backward are ONE native call each (include/skghoi.h: skg_train_plan,
+    skghoi_amd/csrc/skg_train_plan.hip): the same launch sequence on the same operands, issued from C++ out of a plan
+    struct -- no per-launch Python, no per-activation tensor: every activation lives at a fixed offset of one workspace.
+    `on_stage` (optional): called after every backward stage s with the end of the gradient-arena prefix that is final
+    (Stacked.milestone_end[s]) -- the data-parallel exchange hooks in here."""
+
+    on_stage = None
+
+    def _plan(self, x0, gfeat):
+        st, lay, S = self.st, self.lay, self.S
+        pl = _capi.TrainPlan()
+        pl.NA, pl.Mg, pl.Mp, pl.Mh, pl.Mn, pl.A = lay.sum_all, lay.sum_g, lay.sum_p, lay.sum_h, lay.sum_n, lay.n_active
+        pl.K, pl.Bf, pl.Cf, pl.x0_k = self.K, gfeat.shape[0], gfeat.shape[1], x0.shape[1]
+        pl.bf16 = 1 if self.bf16 else 0
+        pl.ld_logits = (self.K + 1 + 3) // 4 * 4
+        pl.params = st.buf.data_ptr()
+        pl.seg_off = st.seg_off_array()
+        pl.x0, pl.gfeat, pl.sp48 = x0.data_ptr(), gfeat.data_ptr(), S["sp48"].data_ptr()
+        pl.meta = self.meta.data_ptr()
+        for k in ("enc_row_hn", "img_hn", "ent_row_hn", "hum_img", "node_img"):
+            setattr(pl, k, self.isl(k).data_ptr())
+        for k in ("grid_h", "grid_o", "grid_pair", "grid_img", "pair_grid", "pair_h", "pair_o"):
+            setattr(pl, k, S[k].data_ptr())
+        pl.pair_img, pl.hum_of, pl.node_of = self.pair_img.data_ptr(), self.hum_of.data_ptr(), self.node_of.data_ptr()
+        return pl
+
+    def forward_a(self, x0, gfeat):
+        lib = _capi.lib()
+        st, lay, dev, S = self.st, self.lay, self.dev, self.S
+        if not st.aliased():
+            st.adopt()
+        x0 = x0.detach().float().reshape(x0.shape[0], -1).contiguous()
+        gfeat = gfeat.detach().float().contiguous()
+        if x0.shape[1] != st.seg["bh1_w"][1][1]:
+            raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)" % (
+                x0.shape[0], x0.shape[1], st.seg["bh1_w"][1][1], 1024))
+        S["x0"], S["gfeat"] = x0, gfeat
+        pl = self.plan = self._plan(x0, gfeat)
+        n = int(lib.skg_train_ws_floats(C.byref(pl)))
+        if n < 0:
+            _check(n, "skg_train_ws_floats")
+        self.ws = torch.empty(n, device=dev, dtype=torch.float32)
+        pl.ws, pl.ws_floats = self.ws.data_ptr(), n
+        Mp1 = max(lay.sum_p, 1)
+        self.PF = torch.empty(Mp1, 2048, device=dev, dtype=torch.float32)
+        self.logits_full = torch.zeros(Mp1, pl.ld_logits, device=dev, dtype=torch.float32)
+        pl.pair_features, pl.logits = self.PF.data_ptr(), self.logits_full.data_ptr()
+        _check(lib.skg_train_forward_f32(C.byref(pl), 0, _stream()), "skg_train_forward_f32[0]")
+        self.part_a_done = True
+
+    def forward(self, x0, gfeat):
+        if not getattr(self, "part_a_done", False):
+            self.forward_a(x0, gfeat)
+        pl = self.plan
+        pl.ent = self.ent.data_ptr()
+        _check(_capi.lib().skg_train_forward_f32(C.byref(pl), 1, _stream()), "skg_train_forward_f32[1]")
+        self.S.update(PF=self.PF, logits=self.logits_full[:self.lay.sum_p])
+        return self.S
+
+    def saved(self, which):
+        """A saved activation out of the workspace (tests): 'enc', 'h_node', 'node', 'adjacency'."""
+        idx = dict(enc=0, h_node=1, node=2, adjacency=3)[which]
+        off = int(_capi.lib().skg_train_ws_offset(C.byref(self.plan), idx))
+        lay = self.lay
+        rows, cols = dict(enc=(lay.sum_all, 1024), h_node=(lay.sum_h, 1024), node=(lay.sum_n, 1024),
+                          adjacency=(lay.sum_g, 1))[which]
+        return self.ws[off:off + rows * cols].view(rows, cols)
+
+    def backward(self, dlogits, need_dx0, need_dgfeat):
+        lib = _capi.lib()
+        st, S, pl = self.st, self.S, self.plan
+        ga, sviews = st.grad_arena()
+        pl.grads = ga.data_ptr()
+        dlogits = dlogits.contiguous()
+        if dlogits.shape[1] != pl.ld_logits:
+            raise _capi.SkgError("dlogits has %d columns, the plan %d" % (dlogits.shape[1], pl.ld_logits))
+        pl.dlogits = dlogits.data_ptr()
+        dx0 = torch.empty_like(S["x0"]) if need_dx0 else None
+        dgfeat = torch.empty_like(S["gfeat"]) if need_dgfeat else None
+        pl.dx0, pl.dgfeat = _ptr(dx0), _ptr(dgfeat)
+        stream = _stream()
+        if self.on_stage is None:
+            _check(lib.skg_train_backward_f32(C.byref(pl), 0, _capi.TRAIN_BWD_STAGES, stream), "skg_train_backward_f32")
+        else:
+            for s_ in range(_capi.TRAIN_BWD_STAGES):
+                _check(lib.skg_train_backward_f32(C.byref(pl), s_, s_ + 1, stream), "skg_train_backward_f32[%d]" % s_)
+                self.on_stage(s_, ga, st.milestone_end[s_])
+        out = []
+        for p in self.params:
+            k = st.ids.get(id(p))
+            out.append(sviews[k] if k is not None else None)
+        self.S = None                                            # the saved activations die with the step
+        self.ws = None
+        return dx0, dgfeat, out
+
+
+def job_class(head):
+    """NativeJob (default) or the Python-issued TrainJob (`head.train_plan = "python"` / SKG_TRAIN_PLAN=python: the same
+    kernels launched one by one from Python -- kept as the readable statement of the sequence and as a cross-check)."""
+    import os
+    mode = os.environ.get("SKG_TRAIN_PLAN") or getattr(head, "train_plan", "native")
+    return TrainJob if mode == "python" else NativeJob
 
 
 # ---------------------------------------------------------------------------------------------------- step driver
@@ -603,7 +758,7 @@ def train_forward(head, eng, features, image_shapes, box_features, pre, targets)
     if box_features.shape[0] != lay.sum_all:
         raise _capi.SkgError("box_roi_pool returned %d rows for %d boxes" % (box_features.shape[0], lay.sum_all))
     st = getattr(head, "_stacked", None)
-    if st is None or st.device != dev or any(a is not b for a, b in zip(st.src[-4:], (
+    if st is None or st.device != dev or any(a is not b for a, b in zip(st.src[st.n_stacked - 4:st.n_stacked], (
             head.box_pair_predictor.weight, head.box_pair_suppressor.weight, head.box_pair_predictor.bias,
             head.box_pair_suppressor.bias))) or st.epoch != _reg_epoch():
         st = Stacked(head, dev)
@@ -659,7 +814,7 @@ def train_forward(head, eng, features, image_shapes, box_features, pre, targets)
            "skg_associate_f32")
     # ---- the dense part does not depend on the sampling below: enqueue it first, then pay the one host sync of the step
     params = _head_params(head)
-    job = TrainJob(head, eng, st, lay, pre, ibuf, offs, None, meta)
+    job = job_class(head)(head, eng, st, lay, pre, ibuf, offs, None, meta)
     job.params = params
     job.S.update(grid_h=grid_h, grid_o=grid_o, grid_pair=grid_pair, grid_img=grid_img, pair_grid=pair_grid,
                  pair_h=pair_h, pair_o=pair_o, x_keep=x_keep[:Mp], y_keep=y_keep[:Mp], sp48=sp48)

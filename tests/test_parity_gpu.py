@@ -370,12 +370,15 @@ def test_full_size_training_step_matches_reference(full_train_oracle, grad_mode)
     worst = 0.0
     for k, w in ograds.items():
         g = grads[k]
+        if k == "box_pair_head.adjacency.bias":
+            # shifts every logit of a softmax alike: the exact gradient is zero, every implementation returns the rounding
+            # noise of ~3200 cancelling terms (the reference's own autograd: 3e-9)
+            assert np.abs(g).max() < 1e-7 and np.abs(w).max() < 1e-7
+            continue
         scale = max(np.abs(w).max(), 1e-6)
         err = max(np.abs(g - w).max() - 1e-9, 0.0) / scale
         worst = max(worst, err)
         assert err <= 1e-4, "%s: rel err %.3e vs oracle autograd (|grad| max %.3e)" % (k, err, scale)
-        if k == "box_pair_head.adjacency.bias":
-            continue
         smp = want["grad.%s.sample" % k]; amax = max(float(want["grad.%s.absmax" % k]), 1e-9)
         got = cases.grad_sample(torch.from_numpy(g).reshape(-1)).numpy()
         assert np.abs(got - smp).max() <= 1e-4 * amax + 1e-9, "%s vs the reference's gradient sample" % k
@@ -439,3 +442,31 @@ def test_fused_step_sees_repointed_parameter_storage_and_refuses_a_second_backwa
     total.backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="second time"):
         total.backward()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["train_tiny", "train_skips", cases.FULL_TRAIN_CASE])
+def test_native_training_plan_equals_the_python_issued_sequence(name, precision):
+    """The native launch plan (skg_train_forward_f32 / skg_train_backward_f32: one C call per phase) against the same
+    kernel sequence issued launch by launch from Python (head.train_plan = "python"): identical logits, losses and
+    gradients up to the summation order of three tiny reductions the plan does in its own kernels (fc_3 bias sums,
+    attention fc_1 bias gradient), i.e. <= 2e-6 relative."""
+    case = cases.build_case(name)
+    out = {}
+    for plan in ("python", "native"):
+        head = gpu_run.build_head(case)
+        head.fused_training = True
+        head.precision = precision
+        head.train_plan = plan
+        from collections import OrderedDict
+        det = gpu_run.to_cuda(case["detections"]); tg = gpu_run.to_cuda(case["targets"])
+        feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
+        out[plan] = gpu_run._run_train(case, head, det, tg, feats, backward=True)
+    (fa, ga), (fb, gb) = out["python"], out["native"]
+    for k in ("hoi_loss", "interactiveness_loss", "transH_loss"):
+        assert abs(float(fa[k]) - float(fb[k])) <= 2e-6 * max(1.0, abs(float(fa[k]))), k
+    assert np.abs(fa["pair_features"] - fb["pair_features"]).max() <= 2e-6 * max(np.abs(fa["pair_features"]).max(), 1.0)
+    assert set(ga) == set(gb)
+    for k in ga:
+        scale = max(np.abs(ga[k]).max(), 1e-6)
+        assert np.abs(ga[k] - gb[k]).max() <= 5e-6 * scale + 1e-9, k
