@@ -128,7 +128,7 @@ def cpu_baseline(budget_s=40.0):
                        "threads" % (full["images"], one["images"], cores, cores))
 
 
-def run_train(B, precision, steps, warmup, device, rank, world, dist_on):
+def run_train(B, precision, steps, warmup, device, rank, world, dist_on, prefetch=True):
     """The data-parallel training step (forward + backward on the HIP GEMMs, AdamW, DDP gradient all-reduce over RCCL
     when world > 1) on B synthetic 20x20 images per GPU with ground truth appended.  Returns (elapsed seconds of `steps`
     steps on this rank, last loss dict)."""
@@ -154,14 +154,20 @@ def run_train(B, precision, steps, warmup, device, rank, world, dist_on):
     torch.manual_seed(1234 + rank)
     # lazy=True: the losses stay on the device (no per-step .item() / isnan round trip); all the work of the K steps is
     # still inside the timed region -- it ends on a device synchronisation -- and the losses are read and NaN-checked after
+    # prefetch: like a trainer over a loader of cached detections (skghoi_amd.trainer.Trainer), every step hands the NEXT
+    # batch to the head, which prepares it (selection, pairs, labels, host RNG) on a side stream while the GPU works on
+    # the step just enqueued.  All work of every timed step -- its own preparation included, done during the step before
+    # -- falls inside the timed region except the first step's, which the last warm-up step prepared (and the last timed
+    # step prepares one batch nobody runs: the counts balance).
+    nxt = (feats, dets, shapes, targets) if prefetch else None
     for _ in range(warmup):
-        losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True)
+        losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=nxt)
     torch.cuda.synchronize()
     if dist_on:
         torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True)
+        losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=nxt)
     torch.cuda.synchronize()
     if dist_on:
         torch.distributed.barrier()

@@ -379,22 +379,68 @@ class InteractionHead(Module):
             eng.last = dict(g)
         return self._results(lay, r, dev)
 
+    # ------------------------------------------------------------------------------------------ prefetch
+    def prefetch_train(self, detections: List[dict], image_shapes: List[Tuple[int, int]], targets: List[dict]) -> bool:
+        """Prepares the NEXT training batch while the GPU is busy with the current step: detection selection (HEAD:92-151),
+        pairs + spatial encoding, label association and the host RNG draws of the forward (TransH tables, negative
+        permutations) run now, on a high-priority side stream; the next `forward(features, detections, image_shapes,
+        targets)` called with these same objects picks the result up instead of paying the forward's two host
+        synchronisations with an idle GPU.  The inputs must be complete on the device (the trainer copies them on the
+        same side stream).  The host RNG is consumed here, in the order the forward would: call it once per batch, in
+        batch order, with no other consumer of the global generator in between.  Returns False (nothing done) when the
+        head is not in the fused training configuration."""
+        from skghoi_amd import train_fused
+        if not (self.training and self.fused_training and train_fused.supported(self)) or not detections:
+            return False
+        dev = detections[0]["boxes"].device
+        if dev.type != "cuda":
+            raise _capi.SkgError("the interaction head runs on a HIP device only (detections on %s)" % dev)
+        with torch.cuda.device(dev):
+            side = self._prefetch_stream(dev)
+            with torch.cuda.stream(side):
+                prep = train_fused.prepare_train(self, self.engine(), detections, image_shapes, targets)
+                prep.ready = torch.cuda.Event()
+                prep.ready.record(side)
+        self._prefetched = prep
+        return True
+
+    def _prefetch_stream(self, dev):
+        st = getattr(self, "_pf_stream", None)
+        if st is None or st.device != dev:
+            st = self._pf_stream = torch.cuda.Stream(device=dev, priority=-1)
+        return st
+
+    def _take_prefetched(self, detections, image_shapes, targets):
+        """The Prepared batch of prefetch_train if it was made from exactly these objects (identity), else None."""
+        prep = getattr(self, "_prefetched", None)
+        self._prefetched = None
+        if prep is None:
+            return None
+        d, s, t = prep.inputs
+        if d is detections and t is targets and (s is image_shapes or list(s) == list(image_shapes)):
+            return prep
+        return None
+
     # ------------------------------------------------------------------------------------------ training (HEAD:380-429)
     def _forward_train(self, features, detections, image_shapes, targets, with_losses=True):
         from skghoi_amd import autograd as _ag
         from skghoi_amd.train_graph import graph_train
         linear = _ag.linear_bf16 if self.precision == "bf16" else _ag.linear
         eng = self.engine()
-        pre = eng.preprocess(detections, targets, self.training, self.training)
-        box_coords = list(pre.boxes.split(pre.sizes))
-        box_features = self.box_roi_pool(features, box_coords, image_shapes)
+        pre = None
         if with_losses and self.training and self.fused_training:
             # the training step proper: one autograd.Function around the hand-written forward / backward kernels
             from skghoi_amd import train_fused
             if train_fused.supported(self):
-                out = train_fused.train_forward(self, eng, features, image_shapes, box_features, pre, targets)
+                out, prep = train_fused.train_forward(self, eng, features, detections, image_shapes, targets,
+                                                      prep=self._take_prefetched(detections, image_shapes, targets))
                 if out is not None:
                     return out
+                pre = prep.pre                 # no image with pairs: the generic path continues from the selection
+        if pre is None:
+            pre = eng.preprocess(detections, targets, self.training, self.training)
+        box_coords = list(pre.boxes.split(pre.sizes))
+        box_features = self.box_roi_pool(features, box_coords, image_shapes)
         from skghoi_amd import dist as _skd
         norm = []
         # the three n_p normalisers (HEAD:162-172, 190-199, 219-228) leave as ONE 3-element all-reduce as soon as the

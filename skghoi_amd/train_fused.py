@@ -742,21 +742,17 @@ def supported(head):
             and head.box_pair_predictor.bias is not None and head.box_pair_suppressor.bias is not None)
 
 
-def train_forward(head, eng, features, image_shapes, box_features, pre, targets):
-    """InteractionHead.forward in training mode (HEAD:380-429) on the fused step.  Returns the reference's result list
-    with the loss dict appended, or None when the batch has no image with pairs (the caller takes the generic path)."""
-    from . import dist as skd, transh
-    lib = _capi.lib()
-    gh = head.box_pair_head
-    dev = pre.device
-    K = head.num_classes
-    stream = _stream()
-    lay = layout.build(pre.n_h, pre.n, pre.L, image_shapes, gh.human_idx, faithful_skip_offset=eng.faithful_skip_offset)
-    A = lay.n_active
-    if A == 0 or lay.sum_p == 0:
-        return None
-    if box_features.shape[0] != lay.sum_all:
-        raise _capi.SkgError("box_roi_pool returned %d rows for %d boxes" % (box_features.shape[0], lay.sum_all))
+class Prepared:
+    """Everything of a training forward that depends on the BATCH but not on the weights: selected detections (NMS,
+    top-k, GT boxes prepended), layout, pair / spatial arrays, label matrix, positive counts, the TransH tables and
+    negative permutations drawn from the host RNG, all uploaded.  Made inline by the forward -- or ahead of time, for the
+    NEXT batch, on a side stream while the GPU is busy with the current step (InteractionHead.prefetch_train)."""
+    empty = False
+    ready = None          # event behind the preparation's device work when it ran on a side stream
+    cross = ()            # tensors allocated on the side stream and consumed on the step's stream
+
+
+def _stacked_for(head, dev):
     st = getattr(head, "_stacked", None)
     if st is None or st.device != dev or any(a is not b for a, b in zip(st.src[st.n_stacked - 4:st.n_stacked], (
             head.box_pair_predictor.weight, head.box_pair_suppressor.weight, head.box_pair_predictor.bias,
@@ -764,6 +760,29 @@ def train_forward(head, eng, features, image_shapes, box_features, pre, targets)
         st = Stacked(head, dev)
         st.epoch = _reg_epoch()
         head._stacked = st
+    return st
+
+
+def prepare_train(head, eng, detections, image_shapes, targets, before_sync=None):
+    """The weight-independent part of InteractionHead.forward in training mode (HEAD:92-151 preprocess with GT boxes
+    appended, HEAD:847-868 pairs + spatial encoding, HEAD:703-719 label association, the host RNG of HEAD:574-580 / 939).
+    Two host synchronisations: the per-image counts after the preprocess kernel and the positive counts after the
+    association kernel.  before_sync(prep): called right before the second one (the inline forward enqueues the
+    table-independent part of the dense forward there, so that the GPU works while the host waits and draws)."""
+    from . import transh
+    lib = _capi.lib()
+    gh = head.box_pair_head
+    K = head.num_classes
+    pre = eng.preprocess(detections, targets, True, True)
+    dev = pre.device
+    stream = _stream()
+    lay = layout.build(pre.n_h, pre.n, pre.L, image_shapes, gh.human_idx, faithful_skip_offset=eng.faithful_skip_offset)
+    prep = Prepared()
+    prep.pre, prep.lay, prep.inputs = pre, lay, (detections, image_shapes, targets)
+    A = lay.n_active
+    if A == 0 or lay.sum_p == 0:
+        prep.empty = True
+        return prep
     Mg, Mp, Mh, Mn, NA = lay.sum_g, lay.sum_p, lay.sum_h, lay.sum_n, lay.sum_all
     f32 = dict(device=dev, dtype=torch.float32)
     i32 = dict(device=dev, dtype=torch.int32)
@@ -790,10 +809,11 @@ def train_forward(head, eng, features, image_shapes, box_features, pre, targets)
     meta = isl("meta")
     # ---- pairs + spatial encoding, GT association (HEAD:847-868, 703-719): ahead of the dense part because the
     # number of positives per image sizes the host RNG draws below
-    grid_h = torch.empty(Mg, **i32); grid_o = torch.empty(Mg, **i32); grid_pair = torch.empty(Mg, **i32)
-    grid_img = torch.empty(Mg, **i32); pair_grid = torch.empty(max(Mp, 1), **i32)
-    pair_h = torch.empty(max(Mp, 1), **i32); pair_o = torch.empty(max(Mp, 1), **i32)
-    x_keep = torch.empty(max(Mp, 1), device=dev, dtype=torch.int64); y_keep = torch.empty_like(x_keep)
+    grid = torch.empty(4 * Mg + 3 * max(Mp, 1), **i32)
+    grid_h, grid_o, grid_pair, grid_img = grid[:Mg], grid[Mg:2 * Mg], grid[2 * Mg:3 * Mg], grid[3 * Mg:4 * Mg]
+    pair_grid, pair_h, pair_o = grid[4 * Mg:].view(3, max(Mp, 1)).unbind(0)
+    keep = torch.empty(2, max(Mp, 1), device=dev, dtype=torch.int64)
+    x_keep, y_keep = keep[0], keep[1]
     sp48 = torch.empty(Mg, _capi.SPATIAL_LD, **f32)
     _check(lib.skg_pairs_spatial_f32(pre.boxes.data_ptr(), meta.data_ptr(), A, grid_h.data_ptr(), grid_o.data_ptr(),
                                      grid_pair.data_ptr(), grid_img.data_ptr(), pair_grid.data_ptr(), x_keep.data_ptr(),
@@ -812,30 +832,24 @@ def train_forward(head, eng, features, image_shapes, box_features, pre, targets)
                                  gt_h.data_ptr(), gt_o.data_ptr(), gt_l.data_ptr(), isl("gt_off").data_ptr(), K,
                                  float(gh.fg_iou_thresh), labels_all.data_ptr(), npos_d.data_ptr(), stream),
            "skg_associate_f32")
-    # ---- the dense part does not depend on the sampling below: enqueue it first, then pay the one host sync of the step
-    params = _head_params(head)
-    job = job_class(head)(head, eng, st, lay, pre, ibuf, offs, None, meta)
-    job.params = params
-    job.S.update(grid_h=grid_h, grid_o=grid_o, grid_pair=grid_pair, grid_img=grid_img, pair_grid=pair_grid,
-                 pair_h=pair_h, pair_o=pair_o, x_keep=x_keep[:Mp], y_keep=y_keep[:Mp], sp48=sp48)
-    job.pair_img, job.hum_of, job.node_of = isl("pair_img"), isl("hum_of"), isl("node_of")
-    job.labels = labels_all
-    # the positive counts travel to the host behind the association kernel; the GPU goes on with the part of the
-    # forward that needs neither them nor the TransH tables while the host waits for the counts and draws the tables
+    prep.ibuf, prep.offs, prep.meta = ibuf, offs, meta
+    prep.arrays = dict(grid_h=grid_h, grid_o=grid_o, grid_pair=grid_pair, grid_img=grid_img, pair_grid=pair_grid,
+                       pair_h=pair_h, pair_o=pair_o, x_keep=x_keep[:Mp], y_keep=y_keep[:Mp], sp48=sp48)
+    prep.labels = labels_all
+    # the positive counts travel to the host behind the association kernel
     npos_h = torch.empty(A, dtype=torch.int32, pin_memory=True)
     npos_h.copy_(npos_d, non_blocking=True)
     npos_ev = torch.cuda.Event(); npos_ev.record()
-    gfeat = torch.nn.functional.adaptive_avg_pool2d(features["3"].float(), 1).flatten(start_dim=1)    # HEAD:811
-    with torch.no_grad():
-        job.forward_a(box_features, gfeat)
+    if before_sync is not None:
+        before_sync(prep)
     # host RNG in the reference's order: per image six TransH draws (HEAD:574-580), then randperm(#negatives) (HEAD:939).
-    # The entity tables feed fc_head / fc_tail, so they are needed before the dense part; the permutations only after it.
-    npos_ev.synchronize()                                           # the step's host synchronisation
+    npos_ev.synchronize()                                           # the step's second host synchronisation
     n_pos = npos_h.tolist()
     ppi = [int(v) for v in lay.pairs_per_image]
     neg_cnt = [ppi[a] * K - n_pos[a] for a in range(A)]
     ent_h, rel_h, nrm_h, perm_h = transh.draw_train(K, neg_cnt, n_pos, pin=True)      # tables + randperm heads, natively
-    ent = ent_h.to(dev, non_blocking=True); rel = rel_h.to(dev, non_blocking=True); nrm = nrm_h.to(dev, non_blocking=True)
+    prep.ent = ent_h.to(dev, non_blocking=True); prep.rel = rel_h.to(dev, non_blocking=True)
+    prep.nrm = nrm_h.to(dev, non_blocking=True)
     pos_off_h = np.zeros(A + 1, np.int32); pos_off_h[1:] = np.cumsum(n_pos)
     M_pos = int(pos_off_h[-1])
     o_perm = (A + 1 + 1) // 2 * 2                                   # one staging block: pos_off | perm (int64, 8-byte aligned)
@@ -844,45 +858,114 @@ def train_forward(head, eng, features, image_shapes, box_features, pre, targets)
     sh[:A + 1] = torch.from_numpy(pos_off_h)
     sh[o_perm:o_perm + 2 * M_pos].view(torch.int64).copy_(perm_h)
     samp_d.copy_(sh, non_blocking=True)
-    pos_off_d = samp_d[:A + 1]
-    perm_d = samp_d[o_perm:o_perm + 2 * max(M_pos, 1)].view(torch.int64)
-    job.ent = ent
-    job.direct = getattr(head, "grad_mode", "autograd") == "direct"
-    if job.direct:
-        job.anchor = torch.zeros(1, device=dev, requires_grad=True)      # a leaf that makes autograd call the backward
-        logits = HeadTrainFn.apply(job, box_features, gfeat, job.anchor)
+    prep.n_pos, prep.M_pos = n_pos, M_pos
+    prep.pos_off_d = samp_d[:A + 1]
+    prep.perm_d = samp_d[o_perm:o_perm + 2 * max(M_pos, 1)].view(torch.int64)
+    prep.cross = (pre.boxes, pre.scores, pre.labels, ibuf, grid, keep, sp48, labels_all, prep.ent, prep.rel, prep.nrm,
+                  samp_d, gt_h, gt_o, gt_l, npos_d)
+    prep.keep = (ent_h, rel_h, nrm_h, sh, npos_h)                   # pinned staging: alive until the copies have run
+    return prep
+
+
+class TrainRun:
+    """The weight-dependent part of one training forward on a Prepared batch: start() = RoI pooling (caller's module),
+    global pool, the table-independent dense layers; finish() = the rest of the dense forward, scoring, the three losses."""
+
+    def __init__(self, head, eng, features, image_shapes):
+        self.head, self.eng, self.features, self.image_shapes = head, eng, features, image_shapes
+        self.job = None
+
+    def start(self, prep):
+        head, eng, pre, lay = self.head, self.eng, prep.pre, prep.lay
+        dev = pre.device
+        box_coords = list(pre.boxes.split(pre.sizes))
+        self.box_features = box_features = head.box_roi_pool(self.features, box_coords, self.image_shapes)
+        if box_features.shape[0] != lay.sum_all:
+            raise _capi.SkgError("box_roi_pool returned %d rows for %d boxes" % (box_features.shape[0], lay.sum_all))
+        st = _stacked_for(head, dev)
+        job = job_class(head)(head, eng, st, lay, pre, prep.ibuf, prep.offs, None, prep.meta)
+        job.params = _head_params(head)
+        job.S.update(prep.arrays)
+        isl = job.isl
+        job.pair_img, job.hum_of, job.node_of = isl("pair_img"), isl("hum_of"), isl("node_of")
+        job.labels = prep.labels
+        self.gfeat = torch.nn.functional.adaptive_avg_pool2d(self.features["3"].float(), 1).flatten(start_dim=1)  # HEAD:811
+        with torch.no_grad():
+            job.forward_a(box_features, self.gfeat)
+        self.job = job
+
+    def finish(self, prep):
+        from . import dist as skd
+        lib = _capi.lib()
+        head, eng, job, pre, lay = self.head, self.eng, self.job, prep.pre, prep.lay
+        gh = head.box_pair_head
+        dev = pre.device
+        K = head.num_classes
+        stream = _stream()
+        A, Mp = lay.n_active, lay.sum_p
+        f32 = dict(device=dev, dtype=torch.float32)
+        i32 = dict(device=dev, dtype=torch.int32)
+        meta = prep.meta
+        x_keep, y_keep = prep.arrays["x_keep"], prep.arrays["y_keep"]
+        n_pos, M_pos = prep.n_pos, prep.M_pos
+        job.ent = prep.ent
+        job.direct = getattr(head, "grad_mode", "autograd") == "direct"
+        if job.direct:
+            job.anchor = torch.zeros(1, device=dev, requires_grad=True)      # a leaf that makes autograd call the backward
+            logits = HeadTrainFn.apply(job, self.box_features, self.gfeat, job.anchor)
+        else:
+            logits = HeadTrainFn.apply(job, self.box_features, self.gfeat, *job.params)
+        # ---- scoring + result packing (HEAD:721-767, 237-337), on the detached logits
+        g = dict(layout=lay, meta=meta, x_keep=x_keep, y_keep=y_keep)
+        r = eng.score(logits.detach(), pre, g, True)
+        job.result = r
+        sums = HoiLossFn.apply(job, logits)
+        # ---- normalisers: ONE fused all-reduce of the three n_p (HEAD:167-172, 194-199, 223-228), consumed as a tensor
+        part = job.partial_sums
+        norm = skd.start_normalisers(torch.stack([part[2], part[3], part[3]]), head.distributed).get()
+        hoi_loss = sums[0] / norm[0]
+        int_loss = sums[1] / norm[1]
+        # ---- TransH term (HEAD:207-235, intended semantics): positives and as many sampled negatives per image
+        scores_all = torch.empty(max(Mp, 1), K, **f32)
+        _check(lib.skg_transh_scores_f32(prep.ent.data_ptr(), prep.rel.data_ptr(), prep.nrm.data_ptr(), K, gh.human_idx,
+                                         meta.data_ptr(), A, scores_all.data_ptr(), stream), "skg_transh_scores_f32")
+        pos_s = torch.empty(max(M_pos, 1), **f32); neg_s = torch.empty(max(M_pos, 1), **f32); mpart = torch.empty(A, **f32)
+        max_pos = max(n_pos) if n_pos else 0
+        sws = torch.empty(int(lib.skg_transh_sample_ws_ints(A, max_pos)) + max(M_pos, 1), **i32)
+        _check(lib.skg_transh_sample_f32(prep.labels.data_ptr(), scores_all.data_ptr(), K, meta.data_ptr(), A,
+                                         prep.pos_off_d.data_ptr(), max_pos, prep.perm_d.data_ptr(), 1.0, sws.data_ptr(),
+                                         sws.data_ptr() + 4 * (sws.numel() - max(M_pos, 1)), pos_s.data_ptr(),
+                                         neg_s.data_ptr(), mpart.data_ptr(), stream), "skg_transh_sample_f32")
+        # MarginLoss(margin = 1): mean(max(p - n, -margin)) + margin, divided by n_p (HEAD:228-234)
+        transh_loss = (mpart.sum() / float(max(M_pos, 1)) + 1.0) / norm[2]
+        if eng.debug:                                                   # parity tests read these
+            head._last_train = dict(pair_features=job.S["PF"][:Mp], pos_scores=pos_s[:M_pos].split(n_pos),
+                                    neg_scores=neg_s[:M_pos].split(n_pos), job=job)
+        # ---- per-image result dicts (views of the packed arrays)
+        results = head._results(lay, r, dev, train_extras=(job.cell_labels, job.unary))
+        results.append(dict(hoi_loss=hoi_loss, interactiveness_loss=int_loss, transH_loss=transh_loss))
+        return results
+
+
+def train_forward(head, eng, features, detections, image_shapes, targets, prep=None):
+    """InteractionHead.forward in training mode (HEAD:380-429) on the fused step.  prep: a Prepared batch made ahead of
+    time (prefetch_train) or None (prepared inline).  Returns (results with the loss dict appended, prep); results is
+    None when the batch has no image with pairs (the caller takes the generic path from prep.pre)."""
+    run = TrainRun(head, eng, features, image_shapes)
+    if prep is None:
+        prep = prepare_train(head, eng, detections, image_shapes, targets, before_sync=run.start)
+        if prep.empty:
+            return None, prep
     else:
-        logits = HeadTrainFn.apply(job, box_features, gfeat, *params)
-    # ---- scoring + result packing (HEAD:721-767, 237-337), on the detached logits
-    g = dict(layout=lay, meta=meta, x_keep=x_keep[:Mp], y_keep=y_keep[:Mp])
-    r = eng.score(logits.detach(), pre, g, True)
-    job.result = r
-    sums = HoiLossFn.apply(job, logits)
-    # ---- normalisers: ONE fused all-reduce of the three n_p (HEAD:167-172, 194-199, 223-228), consumed as a tensor
-    part = job.partial_sums
-    norm = skd.start_normalisers(torch.stack([part[2], part[3], part[3]]), head.distributed).get()
-    hoi_loss = sums[0] / norm[0]
-    int_loss = sums[1] / norm[1]
-    # ---- TransH term (HEAD:207-235, intended semantics): positives and as many sampled negatives per image
-    scores_all = torch.empty(max(Mp, 1), K, **f32)
-    _check(lib.skg_transh_scores_f32(ent.data_ptr(), rel.data_ptr(), nrm.data_ptr(), K, gh.human_idx, meta.data_ptr(), A,
-                                     scores_all.data_ptr(), stream), "skg_transh_scores_f32")
-    pos_s = torch.empty(max(M_pos, 1), **f32); neg_s = torch.empty(max(M_pos, 1), **f32); mpart = torch.empty(A, **f32)
-    max_pos = max(n_pos) if n_pos else 0
-    sws = torch.empty(int(lib.skg_transh_sample_ws_ints(A, max_pos)) + max(M_pos, 1), **i32)
-    _check(lib.skg_transh_sample_f32(labels_all.data_ptr(), scores_all.data_ptr(), K, meta.data_ptr(), A,
-                                     pos_off_d.data_ptr(), max_pos, perm_d.data_ptr(), 1.0, sws.data_ptr(),
-                                     sws.data_ptr() + 4 * (sws.numel() - max(M_pos, 1)), pos_s.data_ptr(), neg_s.data_ptr(),
-                                     mpart.data_ptr(), stream), "skg_transh_sample_f32")
-    # MarginLoss(margin = 1): mean(max(p - n, -margin)) + margin, divided by n_p (HEAD:228-234)
-    transh_loss = (mpart.sum() / float(max(M_pos, 1)) + 1.0) / norm[2]
-    if eng.debug:                                                   # parity tests read these
-        head._last_train = dict(pair_features=job.S["PF"][:Mp], pos_scores=pos_s[:M_pos].split(n_pos),
-                                neg_scores=neg_s[:M_pos].split(n_pos), job=job)
-    # ---- per-image result dicts (views of the packed arrays)
-    results = head._results(lay, r, dev, train_extras=(job.cell_labels, job.unary))
-    results.append(dict(hoi_loss=hoi_loss, interactiveness_loss=int_loss, transH_loss=transh_loss))
-    return results
+        if prep.empty:
+            return None, prep
+        if prep.ready is not None:                     # made on the side stream: order it before this stream's use
+            main = torch.cuda.current_stream()
+            main.wait_event(prep.ready)
+            for t in prep.cross:
+                t.record_stream(main)
+        run.start(prep)
+    return run.finish(prep), prep
 
 
 def _head_params(head):

@@ -11,6 +11,7 @@ HOI loss (utils.py:218-219), DDP with find_unused_parameters=True (utils.py:202-
 (InteractionHead.distributed=True).
 """
 import math
+from operator import is_ as _is
 
 import torch
 import torch.distributed as dist
@@ -129,9 +130,24 @@ def wrap_ddp(module: nn.Module, device=None):
     return nn.parallel.DistributedDataParallel(module, device_ids=ids, find_unused_parameters=True)
 
 
-def train_step(net, optimizer, *inputs, targets, lazy=False):
+def prefetch_batch(net, features, detections, image_shapes, targets) -> bool:
+    """Hands the NEXT batch to the head for preparation on its side stream (InteractionHead.prefetch_train) while the GPU
+    works on the step just enqueued.  Only when `net` IS the interaction head (training from cached detections /
+    features): inside a full detector the head's inputs exist only after the detector has run."""
+    mod = net.module if isinstance(net, nn.parallel.DistributedDataParallel) else net
+    fn = getattr(mod, "prefetch_train", None)
+    if fn is None or not detections or not detections[0]["boxes"].is_cuda:
+        return False
+    return bool(fn(detections, image_shapes, targets))
+
+
+def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
     """utils.py:213-229: zero_grad -> forward -> NaN guard -> sum of the loss dict -> backward -> step.  Returns the loss
     dict (detached floats) and the per-image results.
+
+    prefetch = the NEXT batch (features, detections, image_shapes, targets), or None: once this step is enqueued the
+    head prepares that batch on a side stream (selection, pairs, labels, host RNG draws), so that the next call starts
+    its dense forward at once instead of paying two host synchronisations with an idle GPU (`prefetch_batch`).
 
     lazy=True keeps the host off the GPU's heels: the losses come back as detached DEVICE tensors and the NaN guard is
     left to whoever reads them (Trainer does, at its print interval / end of epoch) -- the reference's per-iteration
@@ -145,6 +161,8 @@ def train_step(net, optimizer, *inputs, targets, lazy=False):
     total = sum(loss for loss in loss_dict.values())
     total.backward()
     optimizer.step()
+    if prefetch is not None:             # (features, detections, image_shapes, targets) of the next step
+        prefetch_batch(net, *prefetch)
     if lazy:
         return {k: v.detach() for k, v in loss_dict.items()}, out
     return {k: float(v.detach()) for k, v in loss_dict.items()}, out
@@ -239,22 +257,31 @@ class SkgAdamW(CachedFusedAdamW):
                 self._plans.clear()                          # step counts move outside this class: re-read them next time
                 return super().step()
             grads = [p.grad for p in c[1]]
-            if any(g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.device != pl["dev"] for g in grads):
+            # the fused step hands out the SAME gradient view objects from step to step (one gradient arena, reused when
+            # nothing holds it: train_fused.Stacked.grad_arena): same objects -> same addresses, dtypes and strides as
+            # the table already on the device, nothing to check or upload.  (The cached list keeps the objects alive, so
+            # an id cannot be recycled by another tensor.)
+            same = pl.get("grad_objs") is not None and len(pl["grad_objs"]) == len(grads) and \
+                all(map(_is, grads, pl["grad_objs"]))
+            if not same and any(g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.device != pl["dev"]
+                                for g in grads):
                 self._plans.clear()
                 return super().step()
-            work.append((group, c, pl, grads))
+            work.append((group, c, pl, grads, same))
         lib = _capi.lib()
-        for group, c, pl, grads in work:
+        for group, c, pl, grads, same in work:
             tab = pl["tab"]
-            tab["g"] = np.fromiter((g.data_ptr() for g in grads), np.uint64, len(grads))[pl["tix"]] + pl["byte"]
-            k = pl["flip"]; pl["flip"] = 1 - k
-            if pl["events"][k] is not None:
-                pl["events"][k].synchronize()                # this staging buffer's previous upload (two steps ago)
-            pin = pl["pinned"][k]
-            pin.numpy()[:] = tab.view(np.uint8)
-            pl["dtab"].copy_(pin, non_blocking=True)
-            ev = pl["events"][k] or torch.cuda.Event()
-            ev.record(); pl["events"][k] = ev
+            if not same:
+                tab["g"] = np.fromiter((g.data_ptr() for g in grads), np.uint64, len(grads))[pl["tix"]] + pl["byte"]
+                k = pl["flip"]; pl["flip"] = 1 - k
+                if pl["events"][k] is not None:
+                    pl["events"][k].synchronize()            # this staging buffer's previous upload (two steps ago)
+                pin = pl["pinned"][k]
+                pin.numpy()[:] = tab.view(np.uint8)
+                pl["dtab"].copy_(pin, non_blocking=True)
+                ev = pl["events"][k] or torch.cuda.Event()
+                ev.record(); pl["events"][k] = ev
+                pl["grad_objs"] = grads
             t = pl["host_step"] + 1
             beta1, beta2 = group["betas"]
             _capi.check(lib.skg_adamw_f32(pl["dtab"].data_ptr(), len(tab), float(group["lr"]), float(beta1), float(beta2),
@@ -329,6 +356,28 @@ def make_loader(dataset, batch_size: int = 4, num_workers: int = 0, world_size: 
                       pin_memory=True, sampler=sampler)
 
 
+def _with_lookahead(loader, enabled=True):
+    """(batch, next batch or None) pairs; the loader is advanced one batch ahead of the step (nothing else changes: same
+    batches, same order)."""
+    it = iter(loader)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    while True:
+        nxt = next(it, None) if enabled else None
+        if not enabled:
+            yield cur, None
+            cur = next(it, None)
+            if cur is None:
+                return
+            continue
+        yield cur, nxt
+        if nxt is None:
+            return
+        cur = nxt
+
+
 # ---------------------------------------------------------------------------------------------------- engine
 class Trainer:
     """The training loop of the reference's CustomisedDLE / pocket DistributedLearningEngine, reduced to what the head's
@@ -355,7 +404,10 @@ class Trainer:
         # lazy_losses: losses stay on the device between print intervals (train_step(lazy=True)); `history` then holds
         # device tensors until the end of the epoch, where they are read back at once -- and the NaN guard fires there
         self.lazy_losses = lazy_losses
-        self.step_fn = step_fn or (lambda n, o, b: train_step(n, o, *b[:-1], targets=b[-1], lazy=lazy_losses))
+        # the default step takes a one-batch look-ahead and lets the head prepare it while this step runs on the GPU
+        self.lookahead = step_fn is None
+        self.step_fn = step_fn or (lambda n, o, b, nxt=None: train_step(n, o, *b[:-1], targets=b[-1], lazy=lazy_losses,
+                                                                        prefetch=nxt))
         self.history = []
 
     # -- checkpoints (main:85-93, pocket engines' save_checkpoint)
@@ -391,8 +443,9 @@ class Trainer:
         if hasattr(sampler, "set_epoch"):
             sampler.set_epoch(self.epoch)                   # pocket: reshuffle the shards every epoch
         self.net.train()
-        for batch in self.train_loader:
-            losses, _ = self.step_fn(self.net, self.optimizer, batch)
+        for batch, nxt in _with_lookahead(self.train_loader, self.lookahead):
+            losses, _ = self.step_fn(self.net, self.optimizer, batch, nxt) if self.lookahead else \
+                self.step_fn(self.net, self.optimizer, batch)
             self.iteration += 1
             self.history.append(losses)
             if self.print_interval and self.iteration % self.print_interval == 0:

@@ -463,10 +463,12 @@ def test_native_training_plan_equals_the_python_issued_sequence(name, precision)
         feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
         out[plan] = gpu_run._run_train(case, head, det, tg, feats, backward=True)
     (fa, ga), (fb, gb) = out["python"], out["native"]
+    # bf16: a last-bit difference of a summed bias can flip the bf16 rounding of an activation further down
+    tol_l, tol_g = (2e-6, 5e-6) if precision == "fp32" else (2e-3, 2e-2)
     for k in ("hoi_loss", "interactiveness_loss", "transH_loss"):
-        assert abs(float(fa[k]) - float(fb[k])) <= 2e-6 * max(1.0, abs(float(fa[k]))), k
-    assert np.abs(fa["pair_features"] - fb["pair_features"]).max() <= 2e-6 * max(np.abs(fa["pair_features"]).max(), 1.0)
+        assert abs(float(fa[k]) - float(fb[k])) <= tol_l * max(1.0, abs(float(fa[k]))), k
+    assert np.abs(fa["pair_features"] - fb["pair_features"]).max() <= tol_l * max(np.abs(fa["pair_features"]).max(), 1.0)
     assert set(ga) == set(gb)
     for k in ga:
         scale = max(np.abs(ga[k]).max(), 1e-6)
-        assert np.abs(ga[k] - gb[k]).max() <= 5e-6 * scale + 1e-9, k
+        assert np.abs(ga[k] - gb[k]).max() <= tol_g * scale + 1e-9, k

@@ -320,3 +320,49 @@ def test_one_launch_adamw_matches_torch_fused():
     for k in range(8, 11):
         step(k)
     check("after the state_dict round trip")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_prefetched_steps_equal_inline_steps_bit_for_bit(precision):
+    """A run whose every step hands the NEXT batch to the head (prefetch_train: selection, pairs, labels and the host RNG
+    draws on a side stream while the GPU works on the current step) against the same run preparing inline: same losses at
+    every step and the same weights after four steps, bit for bit -- same kernels, same host RNG order.  Also the
+    arena contract: the 408 parameters are views of one flat buffer that the optimizer updates in place (one adoption)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    import cases
+    import gpu_run
+    from collections import OrderedDict
+    case = cases.build_case("train_tiny")
+    case2 = cases.build_case("train_skips")
+    batches = []
+    for c in (case, case2, case, case2):
+        batches.append((OrderedDict((k, c["feat3"].cuda()) for k in "0123"), gpu_run.to_cuda(c["detections"]),
+                        c["shapes"], gpu_run.to_cuda(c["targets"]), c))
+
+    def run(prefetch):
+        head = gpu_run.build_head(case)
+        head.precision = precision
+        net = trainer.wrap_ddp(head, torch.device("cuda", 0))
+        opt = trainer.build_optimizer(net, lr=1e-3)
+        torch.manual_seed(7)
+        losses = []
+        for i, (f, d, s, t, c) in enumerate(batches):
+            head.box_roi_pool = gpu_run.CachedPool(c)
+            nxt = batches[i + 1][:4] if prefetch and i + 1 < len(batches) else None
+            l, _ = trainer.train_step(net, opt, f, d, s, targets=t, lazy=True, prefetch=nxt)
+            losses.append(trainer.read_losses(l))
+        return head, losses, torch.empty(3).uniform_()
+
+    h0, l0, r0 = run(False)
+    h1, l1, r1 = run(True)
+    assert l0 == l1
+    assert torch.equal(r0, r1)                                      # the host generator ends at the same position
+    for (k, a), (_, b) in zip(h0.state_dict().items(), h1.state_dict().items()):
+        assert torch.equal(a, b), k
+    st = h1._stacked
+    assert st.adoptions == 1 and st.aliased()
+    lo, hi = st.buf.data_ptr(), st.buf.data_ptr() + 4 * st.total
+    assert all(lo <= p.data_ptr() < hi for p in h1.parameters())
+    assert sum(p.numel() for p in h1.parameters()) <= st.total
