@@ -10,6 +10,7 @@ from skghoi_amd import synth, trainer
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 LAZY = not (len(sys.argv) > 3 and sys.argv[3] == "eager")
+PF = len(sys.argv) > 4 and sys.argv[4] == "prefetch"
 trainer.limit_host_threads()
 device = torch.device("cuda:0")
 head = bench.build_head(device).train()
@@ -30,13 +31,14 @@ class Pool(torch.nn.Module):
 head.box_roi_pool = Pool()
 net = trainer.wrap_ddp(head, device)
 opt = trainer.build_optimizer(net, lr=1e-4)
+NXT = (feats, dets, shapes, targets) if PF else None
 for _ in range(5):
-    trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=LAZY)
+    trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=LAZY, prefetch=NXT)
 torch.cuda.synchronize()
 N = 30
 t0 = time.perf_counter()
 for _ in range(N):
-    trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=LAZY)
+    trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=LAZY, prefetch=NXT)
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
@@ -55,7 +57,7 @@ train_fused.TrainJob.backward = _wrapped
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(N):
-    trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=LAZY)
+    trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=LAZY, prefetch=NXT)
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
