@@ -11,11 +11,12 @@ HOI loss (utils.py:218-219), DDP with find_unused_parameters=True (utils.py:202-
 (InteractionHead.distributed=True).
 """
 import math
-from operator import is_ as _is
 
 import torch
 import torch.distributed as dist
 from torch import nn
+
+_data_ptr = torch.Tensor.data_ptr
 
 
 def limit_host_threads(ranks_on_host: int = 1, cap: int = 4) -> int:
@@ -213,6 +214,13 @@ class SkgAdamW(CachedFusedAdamW):
         if len(set(st)) != 1:
             self._plans[gi] = dict(lists=c, ok=False)
             return self._plans[gi]
+        # the per-parameter `step` tensors become views of ONE flat tensor: counting a step is then one tiny kernel instead
+        # of a multi-tensor launch over 408 pointers (same state_dict: 0-dim tensors with the same values)
+        flat_step = torch.stack([s.reshape(()) for s in steps]).contiguous()
+        views = list(flat_step.unbind(0))
+        for p_, v_ in zip(params, views):
+            self.state[p_]["step"] = v_
+        steps[:] = views
         if SkgAdamW._DT is None:
             SkgAdamW._DT = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("count", "u4"), ("res", "u4")])
         numel = np.array([p.numel() for p in params], np.int64)
@@ -233,6 +241,7 @@ class SkgAdamW(CachedFusedAdamW):
         nb = tab.nbytes
         pl = dict(lists=c, ok=True, tab=tab, tix=tix, byte=byte, host_step=int(st[0]), dev=dev, numel=numel,
                   pbase=[p.data_ptr() for p in params],
+                  flat_step=flat_step,
                   pinned=[torch.empty(nb, dtype=torch.uint8, pin_memory=True) for _ in range(2)],
                   events=[None, None], dtab=torch.empty(nb, dtype=torch.uint8, device=dev), flip=0)
         self._plans[gi] = pl
@@ -257,12 +266,16 @@ class SkgAdamW(CachedFusedAdamW):
                 self._plans.clear()                          # step counts move outside this class: re-read them next time
                 return super().step()
             grads = [p.grad for p in c[1]]
-            # the fused step hands out the SAME gradient view objects from step to step (one gradient arena, reused when
-            # nothing holds it: train_fused.Stacked.grad_arena): same objects -> same addresses, dtypes and strides as
-            # the table already on the device, nothing to check or upload.  (The cached list keeps the objects alive, so
-            # an id cannot be recycled by another tensor.)
-            same = pl.get("grad_objs") is not None and len(pl["grad_objs"]) == len(grads) and \
-                all(map(_is, grads, pl["grad_objs"]))
+            # the fused step hands out the SAME gradient views from step to step (one gradient arena, reused when nothing
+            # holds it: train_fused.Stacked.grad_arena): same addresses as in the table already on the device -> nothing
+            # to rebuild or upload.  Only the addresses are kept here: a reference to the view objects would count as a
+            # holder and make the step allocate a fresh arena every time.
+            try:
+                ptrs = list(map(_data_ptr, grads))
+            except TypeError:                                # a parameter without gradient
+                self._plans.clear()
+                return super().step()
+            same = pl.get("grad_ptrs") == ptrs
             if not same and any(g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.device != pl["dev"]
                                 for g in grads):
                 self._plans.clear()
@@ -281,13 +294,13 @@ class SkgAdamW(CachedFusedAdamW):
                 pl["dtab"].copy_(pin, non_blocking=True)
                 ev = pl["events"][k] or torch.cuda.Event()
                 ev.record(); pl["events"][k] = ev
-                pl["grad_objs"] = grads
+                pl["grad_ptrs"] = ptrs
             t = pl["host_step"] + 1
             beta1, beta2 = group["betas"]
             _capi.check(lib.skg_adamw_f32(pl["dtab"].data_ptr(), len(tab), float(group["lr"]), float(beta1), float(beta2),
                                           float(group["eps"]), float(group["weight_decay"]), 1.0 - beta1 ** t,
                                           1.0 - beta2 ** t, _stream()), "skg_adamw_f32")
-            torch._foreach_add_(c[4], 1)
+            pl["flat_step"].add_(1)
             pl["host_step"] = t
         return None
 
