@@ -280,6 +280,7 @@ class InteractionHead(Module):
         self.precision = precision
         self.fused_training = True      # False: training through autograd over per-layer Functions (skghoi_amd/train_graph.py)
         self.grad_mode = "autograd"     # "direct": the fused step writes p.grad itself (skghoi_amd/train_fused.py, HeadTrainFn)
+        self.prefetch_thread = True     # prefetch_train prepares the next batch on a helper thread (False: on the caller's)
         self._engine = None
 
     def engine(self) -> HeadEngine:
@@ -395,13 +396,25 @@ class InteractionHead(Module):
         dev = detections[0]["boxes"].device
         if dev.type != "cuda":
             raise _capi.SkgError("the interaction head runs on a HIP device only (detections on %s)" % dev)
-        with torch.cuda.device(dev):
-            side = self._prefetch_stream(dev)
-            with torch.cuda.stream(side):
-                prep = train_fused.prepare_train(self, self.engine(), detections, image_shapes, targets)
+        eng = self.engine()
+        side = self._prefetch_stream(dev)
+
+        def work():
+            with torch.cuda.device(dev), torch.cuda.stream(side):
+                prep = train_fused.prepare_train(self, eng, detections, image_shapes, targets)
                 prep.ready = torch.cuda.Event()
                 prep.ready.record(side)
-        self._prefetched = prep
+            return prep
+
+        if self.prefetch_thread:
+            # on a helper thread: its waits (two device round trips) and its native calls (detection kernels, the host RNG
+            # draws) release the GIL, so the caller goes on enqueuing the current step's backward and optimizer meanwhile
+            if getattr(self, "_pf_pool", None) is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pf_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="skg-prefetch")
+            self._prefetched = self._pf_pool.submit(work)
+        else:
+            self._prefetched = work()
         return True
 
     def _prefetch_stream(self, dev):
@@ -416,6 +429,8 @@ class InteractionHead(Module):
         self._prefetched = None
         if prep is None:
             return None
+        if hasattr(prep, "result"):
+            prep = prep.result()               # the helper thread's preparation (re-raises what it raised)
         d, s, t = prep.inputs
         if d is detections and t is targets and (s is image_shapes or list(s) == list(image_shapes)):
             return prep

@@ -16,6 +16,7 @@ fixed sequence of batched launches over concatenated row spaces (skghoi_amd/layo
 There is no CPU fallback: the library must be built and tensors must live on a HIP device.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -582,8 +583,11 @@ class HeadEngine:
         host.copy_(countx, non_blocking=True)
         ev = self._cnt_event
         ev.record()
-        while not ev.query():
-            pass
+        if threading.current_thread() is threading.main_thread():
+            while not ev.query():
+                pass
+        else:
+            ev.synchronize()               # a helper thread must not spin: the poll holds the GIL, the wait releases it
         return host.numpy().copy()
 
     def pre_launch(self, detections, targets, append_gt, training, check_weights=False):

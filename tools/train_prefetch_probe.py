@@ -29,8 +29,9 @@ head.box_roi_pool = Pool()
 net = trainer.wrap_ddp(head, device)
 opt = trainer.build_optimizer(net, lr=1e-4)
 pc = time.perf_counter
-for mode in ("inline", "prefetch", "inline", "prefetch"):
-    nxt = (feats, dets, shapes, targets) if mode == "prefetch" else None
+for mode in ("inline", "prefetch", "thread", "inline", "prefetch", "thread"):
+    nxt = (feats, dets, shapes, targets) if mode != "inline" else None
+    head.prefetch_thread = mode == "thread"
     for _ in range(6):
         trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=nxt)
     torch.cuda.synchronize()
@@ -52,5 +53,5 @@ for mode in ("inline", "prefetch", "inline", "prefetch"):
     t2 = pc()
     print("%-8s host %.3f ms/step (with final sync %.3f)  " % (mode, (t1 - t0) / N * 1e3, (t2 - t0) / N * 1e3) +
           "  ".join("%s %.3f" % (k, v / N * 1e3) for k, v in acc.items()), flush=True)
-    if mode == "prefetch":
-        head._prefetched = None
+    if mode != "inline":
+        head._take_prefetched(None, None, None)
