@@ -403,6 +403,18 @@ int skg_hoi_loss_f32(const float* logits, int64_t ldl, int K, const skg_image_me
                      const float* labels, float* cell_labels, float* unary, float* partial, float* dlogits,
                      void* stream);
 
+/* The three loss scalars from the partial sums the loss and sampling kernels leave (HEAD:162-177, 190-205, 228-234):
+ * sums = column sums of partial [rows, 4]; n_p = norm_in [3] (data parallel: all_reduce_sum(counts) / world, HEAD:167-172)
+ * or, when NULL, {sums[2], sums[3], sums[3]};  losses = {sums[0] / n_p[0], sums[1] / n_p[1], (sum(mpart[0..n_img)) /
+ * max(m_pos, 1) + margin) / n_p[2]};  scale = {1 / n_p[0], 1 / n_p[1]};  counts_out (optional) = {sums[2], sums[3],
+ * sums[3]} -- a data-parallel caller asks for the counts first (losses = NULL), all-reduces them and calls again.       */
+int skg_loss_finish_f32(const float* partial, int rows, const float* mpart, int n_img, int64_t m_pos, float margin,
+                        const float* norm_in, float* losses, float* scale, float* counts_out, void* stream);
+/* out[r, c] = dl[r, c] * (c < K ? scale[0] * g0[0] : scale[1] * g1[0]): the gradient of the summed losses w.r.t. the
+ * logits from skg_hoi_loss_f32's d(sum)/d(logits), the normalisers and the upstream gradients of the two focal terms.  */
+int skg_scale_dlogits_f32(const float* dl, int64_t ld, int rows, int K, const float* scale, const float* g0,
+                          const float* g1, float* out, void* stream);
+
 /* TransH positive / negative sampling of the training step (HEAD:936-963) and the margin term (HEAD:207-235 as intended;
  * heads/MarginLoss.py:28-36): labels, scores [sumP, K]; pos_off [n_active + 1] = prefix of the positives per image and
  * max_pos_per_image their maximum (the host knows them from skg_associate_f32's npos); perm [sum m] = per image the first

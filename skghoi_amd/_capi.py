@@ -138,6 +138,8 @@ PROTOTYPES = {
     "skg_transh_sample_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _f32, _vp, _vp, _vp, _vp, _vp,
                                         _vp]),
     "skg_hoi_loss_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "skg_loss_finish_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "skg_scale_dlogits_f32": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "skg_train_ws_floats": (C.c_int64, [C.POINTER(TrainPlan)]),
     "skg_train_forward_f32": (C.c_int, [C.POINTER(TrainPlan), C.c_int, _vp]),
     "skg_train_backward_f32": (C.c_int, [C.POINTER(TrainPlan), C.c_int, C.c_int, _vp]),

@@ -606,3 +606,72 @@ extern "C" int skg_transh_sample_f32(const float* labels, const float* scores, i
                        ws, counts, pos_off, perm, margin, pos_cells, pos_scores, neg_scores, partial);
     return skg_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------ loss tail
+// The scalars of the three loss terms from what the loss / sampling kernels left behind (HEAD:162-177, 190-205, 228-234):
+//   sums = sum over rows of partial [rows, 4] = {cell loss, pair loss, #positive cells, #positive pairs}
+//   n_p  = norm_in (the data-parallel normalisers all_reduce_sum(counts) / world, HEAD:167-172) or {sums[2], sums[3], sums[3]}
+//   losses = {sums[0] / n_p[0], sums[1] / n_p[1], (sum(mpart) / max(M_pos, 1) + margin) / n_p[2]}
+//   scale  = {1 / n_p[0], 1 / n_p[1]}: what d(loss)/d(logit) of the loss kernel has to be multiplied with
+//   counts_out (optional) = {sums[2], sums[3], sums[3]}: the per-rank counts a data-parallel caller all-reduces first
+// One wavefront; fixed summation order (deterministic).
+__global__ __launch_bounds__(64) void skg_loss_finish_kernel(const float* __restrict__ partial, int rows,
+                                                             const float* __restrict__ mpart, int n_img, float m_pos,
+                                                             float margin, const float* __restrict__ norm_in,
+                                                             float* __restrict__ losses, float* __restrict__ scale,
+                                                             float* __restrict__ counts_out) {
+    const int lane = threadIdx.x;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, sm = 0.f;
+    for (int r = lane; r < rows; r += 64) {
+        s0 += partial[4 * r]; s1 += partial[4 * r + 1]; s2 += partial[4 * r + 2]; s3 += partial[4 * r + 3];
+    }
+    for (int a = lane; a < n_img; a += 64) sm += mpart[a];
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); s3 += __shfl_xor(s3, o);
+        sm += __shfl_xor(sm, o);
+    }
+    if (lane == 0) {
+        if (counts_out) { counts_out[0] = s2; counts_out[1] = s3; counts_out[2] = s3; }
+        if (losses) {
+            const float n0 = norm_in ? norm_in[0] : s2, n1 = norm_in ? norm_in[1] : s3, n2 = norm_in ? norm_in[2] : s3;
+            losses[0] = s0 / n0; losses[1] = s1 / n1;
+            losses[2] = (sm / (m_pos > 1.f ? m_pos : 1.f) + margin) / n2;
+            scale[0] = 1.f / n0; scale[1] = 1.f / n1;
+        }
+    }
+}
+
+extern "C" int skg_loss_finish_f32(const float* partial, int rows, const float* mpart, int n_img, int64_t m_pos,
+                                   float margin, const float* norm_in, float* losses, float* scale, float* counts_out,
+                                   void* stream) {
+    if (rows < 0 || n_img < 0 || !partial || !mpart || (!losses && !counts_out) || (losses && !scale)) return SKG_E_ARG;
+    hipLaunchKernelGGL(skg_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, rows, mpart, n_img,
+                       (float)m_pos, margin, norm_in, losses, scale, counts_out);
+    return skg_launch_status();
+}
+
+// dl[r, c] *= (c < K ? scale[0] * g[0] : scale[1] * g[1])  -- d(total)/d(logits) from the loss kernel's d(sum)/d(logits):
+// scale = 1 / n_p of the two focal terms (skg_loss_finish_f32), g = the upstream gradients of the two loss scalars.
+__global__ __launch_bounds__(256) void skg_scale_dlogits_kernel(float* __restrict__ dl, int64_t ld, int rows, int K,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ g0,
+                                                                const float* __restrict__ g1,
+                                                                float* __restrict__ out) {
+    const float a = scale[0] * g0[0], b = scale[1] * g1[0];
+    const int64_t n = (int64_t)rows * ld;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % ld);
+        out[i] = dl[i] * (c < K ? a : b);
+    }
+}
+
+extern "C" int skg_scale_dlogits_f32(const float* dl, int64_t ld, int rows, int K, const float* scale, const float* g0,
+                                     const float* g1, float* out, void* stream) {
+    if (rows < 0 || K <= 0 || ld <= K || !dl || !scale || !g0 || !g1 || !out) return SKG_E_ARG;
+    if (rows == 0) return 0;
+    int64_t n = (int64_t)rows * ld;
+    int blocks = (int)((n + 256 * 4 - 1) / (256 * 4)); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(skg_scale_dlogits_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, const_cast<float*>(dl), ld,
+                       rows, K, scale, g0, g1, out);
+    return skg_launch_status();
+}

@@ -198,30 +198,49 @@ def _lin(x, W, out, bias=None, relu=False, **kw):
     return gemmx.forward(x, W, out, bias=bias, relu=relu, **kw)
 
 
-class HeadTrainFn(torch.autograd.Function):
-    """(pooled box features, global features, 408 parameters) -> classifier logits [sumP, ld] of the kept pairs.
+class StepFn(torch.autograd.Function):
+    """The whole differentiable part of the training step as ONE autograd node:
+    (pooled box features, global features, parameters) -> the three loss scalars (HEAD:419-427).
+
+    forward: dense forward (job.forward) -> scoring (HEAD:721-767, 237-337) -> both focal terms + d(sum)/d(logits) in one
+    kernel -> TransH scores, sampling, margin term -> normalisers (one fused all-reduce when data parallel) -> the three
+    scalars.  backward: d(total)/d(logits) = d(sum)/d(logits) * (upstream gradient / n_p) per loss column (one kernel),
+    then the hand-written backward (job.backward).  The TransH term reaches only the step's throw-away embeddings
+    (SURVEY 8a-17): it has no gradient towards the inputs.
 
     grad_mode "autograd" (default): the parameters are inputs of the Function and their gradients are returned to the
     autograd engine (hooks, DDP and torch.autograd.grad see them).  grad_mode "direct": the Function's only parameter-side
-    input is a one-element anchor; the backward writes `p.grad` itself (assign, or add to an existing gradient).  The
-    engine's per-leaf bookkeeping for 408 parameters costs ~1.2 ms of host time per step at which the GPU has nothing
-    queued -- a fifth of a batch-4 step; the single-process trainer (skghoi_amd/trainer.py) switches it on."""
+    input is a one-element anchor; the backward writes `p.grad` itself (assign, or add to an existing gradient) -- the
+    engine's per-leaf bookkeeping for 408 parameters costs ~1 ms of host time per step; the single-process trainer
+    (skghoi_amd/trainer.py) switches it on."""
 
     @staticmethod
-    def forward(ctx, job, x0, gfeat, *params):
+    def forward(ctx, run, prep, x0, gfeat, *params):
+        job = run.job
         S = job.forward(x0, gfeat)
+        losses = run.tail(prep, S["logits"])
         ctx.job = job
         ctx.in_meta = ((x0.shape, x0.dtype), (gfeat.shape, gfeat.dtype))
-        return S["logits"]
+        return losses[0], losses[1], losses[2]
 
     @staticmethod
-    def backward(ctx, dlogits):
+    def backward(ctx, g0, g1, g2):
         job = ctx.job
         if job.S is None:
             raise RuntimeError("Trying to backward through the fused interaction-head step a second time: its saved "
                                "activations are freed by the first backward (retain_graph is not supported by the "
                                "fused step; use head.fused_training = False for repeated backward passes)")
-        dx0, dgfeat, pgrads = job.backward(dlogits, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        src = job.dlogits                                  # d(sum of the focal terms)/d(logits): stays as the kernel left it
+        d = torch.empty_like(src)
+        z = None
+        if g0 is None or g1 is None:
+            z = torch.zeros(1, device=src.device, dtype=torch.float32)
+        g0 = z if g0 is None else g0.reshape(-1)[:1].float()
+        g1 = z if g1 is None else g1.reshape(-1)[:1].float()
+        _check(_capi.lib().skg_scale_dlogits_f32(src.data_ptr(), src.stride(0), src.shape[0], job.K,
+                                                 job.loss_scale.data_ptr(), g0.data_ptr(), g1.data_ptr(), d.data_ptr(),
+                                                 _stream()), "skg_scale_dlogits_f32")
+        dx0, dgfeat, pgrads = job.backward(d, ctx.needs_input_grad[2], ctx.needs_input_grad[3])
         # the step works on flattened fp32 copies of its inputs: hand the gradients back in the inputs' own shape / dtype
         # (pooled box features arrive as [N, 256, 7, 7] when the RoI pooling in front is differentiable)
         (s0, t0), (s1, t1) = ctx.in_meta
@@ -237,32 +256,8 @@ class HeadTrainFn(torch.autograd.Function):
                     p.grad = g
                 else:
                     p.grad.add_(g)
-            return None, dx0, dgfeat, torch.zeros_like(job.anchor)
-        return (None, dx0, dgfeat) + tuple(pgrads)
-
-
-class HoiLossFn(torch.autograd.Function):
-    """logits -> (sum of the focal losses over the scored cells, over the pairs); backward scales the gradient the loss
-    kernel produced in the same pass."""
-
-    @staticmethod
-    def forward(ctx, job, logits):
-        sums = job.loss_forward(logits)
-        ctx.job = job
-        return sums[0], sums[1]
-
-    @staticmethod
-    def backward(ctx, g1, g2):
-        job = ctx.job
-        K = job.K
-        # columns < K belong to the cell loss, column K to the pair loss (the pair weight is detached in the scores).
-        # Out of place: job.dlogits stays the unscaled d(sum)/dlogits, so a second backward through this node (e.g.
-        # autograd.grad followed by .backward()) scales it once again from the same values, not twice.
-        src = job.dlogits
-        d = torch.empty_like(src)
-        torch.mul(src[:, :K], g1, out=d[:, :K])
-        torch.mul(src[:, K:], g2, out=d[:, K:])          # suppressor column + zero padding
-        return None, d
+            return None, None, dx0, dgfeat, torch.zeros_like(job.anchor)
+        return (None, None, dx0, dgfeat) + tuple(pgrads)
 
 
 class TrainJob:
@@ -447,8 +442,8 @@ class TrainJob:
                                     r["index"].data_ptr(), r["prediction"].data_ptr(), r["scores"].data_ptr(),
                                     self.labels.data_ptr(), self.cell_labels.data_ptr(), self.unary.data_ptr(),
                                     partial.data_ptr(), self.dlogits.data_ptr(), _stream()), "skg_hoi_loss_f32")
-        self.partial_sums = partial.sum(dim=0)            # {cell loss, pair loss, #positive cells, #positive pairs}
-        return self.partial_sums
+        self.partial = partial                            # rows of {cell loss, pair loss, #positive cells, #positive pairs}
+        return partial
 
     # ------------------------------------------------------------------------------------------------ backward
     def backward(self, dlogits, need_dx0, need_dgfeat):
@@ -894,7 +889,10 @@ class TrainRun:
             job.forward_a(box_features, self.gfeat)
         self.job = job
 
-    def finish(self, prep):
+    def tail(self, prep, logits):
+        """Everything between the logits and the three loss scalars (runs inside StepFn.forward: no autograd): scoring +
+        result packing, both focal terms with d(sum)/d(logits), TransH scores / sampling / margin term, normalisers.
+        Returns losses [3] = (hoi, interactiveness, transH)."""
         from . import dist as skd
         lib = _capi.lib()
         head, eng, job, pre, lay = self.head, self.eng, self.job, prep.pre, prep.lay
@@ -906,44 +904,56 @@ class TrainRun:
         f32 = dict(device=dev, dtype=torch.float32)
         i32 = dict(device=dev, dtype=torch.int32)
         meta = prep.meta
-        x_keep, y_keep = prep.arrays["x_keep"], prep.arrays["y_keep"]
         n_pos, M_pos = prep.n_pos, prep.M_pos
-        job.ent = prep.ent
-        job.direct = getattr(head, "grad_mode", "autograd") == "direct"
-        if job.direct:
-            job.anchor = torch.zeros(1, device=dev, requires_grad=True)      # a leaf that makes autograd call the backward
-            logits = HeadTrainFn.apply(job, self.box_features, self.gfeat, job.anchor)
-        else:
-            logits = HeadTrainFn.apply(job, self.box_features, self.gfeat, *job.params)
-        # ---- scoring + result packing (HEAD:721-767, 237-337), on the detached logits
-        g = dict(layout=lay, meta=meta, x_keep=x_keep, y_keep=y_keep)
-        r = eng.score(logits.detach(), pre, g, True)
-        job.result = r
-        sums = HoiLossFn.apply(job, logits)
-        # ---- normalisers: ONE fused all-reduce of the three n_p (HEAD:167-172, 194-199, 223-228), consumed as a tensor
-        part = job.partial_sums
-        norm = skd.start_normalisers(torch.stack([part[2], part[3], part[3]]), head.distributed).get()
-        hoi_loss = sums[0] / norm[0]
-        int_loss = sums[1] / norm[1]
+        # ---- scoring + result packing (HEAD:721-767, 237-337)
+        g = dict(layout=lay, meta=meta, x_keep=prep.arrays["x_keep"], y_keep=prep.arrays["y_keep"])
+        self.r = job.result = eng.score(logits, pre, g, True)
+        partial = job.loss_forward(logits)
         # ---- TransH term (HEAD:207-235, intended semantics): positives and as many sampled negatives per image
         scores_all = torch.empty(max(Mp, 1), K, **f32)
         _check(lib.skg_transh_scores_f32(prep.ent.data_ptr(), prep.rel.data_ptr(), prep.nrm.data_ptr(), K, gh.human_idx,
                                          meta.data_ptr(), A, scores_all.data_ptr(), stream), "skg_transh_scores_f32")
-        pos_s = torch.empty(max(M_pos, 1), **f32); neg_s = torch.empty(max(M_pos, 1), **f32); mpart = torch.empty(A, **f32)
+        out = torch.empty(2 * max(M_pos, 1) + A + 8, **f32)              # pos scores | neg scores | margin partials | losses, scale
+        pos_s, neg_s = out[:max(M_pos, 1)], out[max(M_pos, 1):2 * max(M_pos, 1)]
+        mpart = out[2 * max(M_pos, 1):2 * max(M_pos, 1) + A]
+        tail = out[2 * max(M_pos, 1) + A:]
+        losses, job.loss_scale = tail[:3], tail[4:6]
         max_pos = max(n_pos) if n_pos else 0
         sws = torch.empty(int(lib.skg_transh_sample_ws_ints(A, max_pos)) + max(M_pos, 1), **i32)
         _check(lib.skg_transh_sample_f32(prep.labels.data_ptr(), scores_all.data_ptr(), K, meta.data_ptr(), A,
                                          prep.pos_off_d.data_ptr(), max_pos, prep.perm_d.data_ptr(), 1.0, sws.data_ptr(),
                                          sws.data_ptr() + 4 * (sws.numel() - max(M_pos, 1)), pos_s.data_ptr(),
                                          neg_s.data_ptr(), mpart.data_ptr(), stream), "skg_transh_sample_f32")
-        # MarginLoss(margin = 1): mean(max(p - n, -margin)) + margin, divided by n_p (HEAD:228-234)
-        transh_loss = (mpart.sum() / float(max(M_pos, 1)) + 1.0) / norm[2]
+        # ---- normalisers (HEAD:167-172, 194-199, 223-228) and the scalars: MarginLoss(margin = 1) is
+        #      mean(max(p - n, -margin)) + margin, divided by n_p (HEAD:228-234)
+        rows = partial.shape[0]
+        norm = None
+        if head.distributed and skd.dist.is_available() and skd.dist.is_initialized() and skd.dist.get_world_size() > 1:
+            counts = torch.empty(3, **f32)
+            _check(lib.skg_loss_finish_f32(partial.data_ptr(), rows, mpart.data_ptr(), A, M_pos, 1.0, None, None, None,
+                                           counts.data_ptr(), stream), "skg_loss_finish_f32")
+            norm = skd.start_normalisers(counts, True).get().contiguous()     # ONE fused 3-element all-reduce
+        _check(lib.skg_loss_finish_f32(partial.data_ptr(), rows, mpart.data_ptr(), A, M_pos, 1.0, _ptr(norm),
+                                       losses.data_ptr(), job.loss_scale.data_ptr(), None, stream), "skg_loss_finish_f32")
+        self.pos_s, self.neg_s = pos_s[:M_pos], neg_s[:M_pos]
+        return losses
+
+    def finish(self, prep):
+        head, eng, job, pre, lay = self.head, self.eng, self.job, prep.pre, prep.lay
+        dev = pre.device
+        job.ent = prep.ent
+        job.direct = getattr(head, "grad_mode", "autograd") == "direct"
+        if job.direct:
+            job.anchor = torch.zeros(1, device=dev, requires_grad=True)      # a leaf that makes autograd call the backward
+            hoi, inter, transh = StepFn.apply(self, prep, self.box_features, self.gfeat, job.anchor)
+        else:
+            hoi, inter, transh = StepFn.apply(self, prep, self.box_features, self.gfeat, *job.params)
         if eng.debug:                                                   # parity tests read these
-            head._last_train = dict(pair_features=job.S["PF"][:Mp], pos_scores=pos_s[:M_pos].split(n_pos),
-                                    neg_scores=neg_s[:M_pos].split(n_pos), job=job)
+            head._last_train = dict(pair_features=job.S["PF"][:lay.sum_p], pos_scores=self.pos_s.split(prep.n_pos),
+                                    neg_scores=self.neg_s.split(prep.n_pos), job=job)
         # ---- per-image result dicts (views of the packed arrays)
-        results = head._results(lay, r, dev, train_extras=(job.cell_labels, job.unary))
-        results.append(dict(hoi_loss=hoi_loss, interactiveness_loss=int_loss, transH_loss=transh_loss))
+        results = head._results(lay, self.r, dev, train_extras=(job.cell_labels, job.unary))
+        results.append(dict(hoi_loss=hoi, interactiveness_loss=inter, transH_loss=transh.detach()))
         return results
 
 
