@@ -479,7 +479,7 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
                                WG(ds1, sp48, g_sp0, G.at(SKG_SEG_SP0_B), false, -1, -1, 46),
                                WG(dG1, gfeat, dW1[GL], db1[GL], false), skg_gemmx_desc()};
         int n = 6;
-        if (P->dgfeat) l[n++] = IG(dG1, W1[GL], Mat(P->dgfeat, Bf, Cf), nullptr, false);
+        if (P->dgfeat || c.dry) l[n++] = IG(dG1, W1[GL], Mat(P->dgfeat, Bf, Cf), nullptr, false);   // (sizing: assume it)
         launch(c, l, n);
         CK(skg_entity_rows_bwd_f32(w.dXhn, 1088, P->hum_of, P->node_of, Mh, NA, w.enc, w.d_enc, c.stream));
     } break;
@@ -492,7 +492,7 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
         // ---- box_head layer 1; every fc_3 branch gets its MBF's bias gradient (the bias is added once per row)
         skg_gemmx_desc l[2] = {WG(dE1, x0, g_bh1, G.at(SKG_SEG_BH1_B), false), skg_gemmx_desc()};
         int n = 1;
-        if (P->dx0) l[n++] = IG(dE1, bh1_w, Mat(P->dx0, NA, kx), nullptr, false);
+        if (P->dx0 || c.dry) l[n++] = IG(dE1, bh1_w, Mat(P->dx0, NA, kx), nullptr, false);
         launch(c, l, n);
         if (!c.dry)
             hipLaunchKernelGGL(b3bcast_kernel, dim3(256), dim3(256), 0, c.stream, w.db3, G.at(SKG_SEG_B3));

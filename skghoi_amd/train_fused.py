@@ -618,10 +618,8 @@ class NativeJob(TrainJob):
     """TrainJob whose dense forward / backward are ONE native call each (include/skghoi.h: skg_train_plan,
     skghoi_amd/csrc/skg_train_plan.hip): the same launch sequence on the same operands, issued from C++ out of a plan
     struct -- no per-launch Python, no per-activation tensor: every activation lives at a fixed offset of one workspace.
-    `on_stage` (optional): called after every backward stage s with the end of the gradient-arena prefix that is final
-    (Stacked.milestone_end[s]) -- the data-parallel exchange hooks in here."""
-
-    on_stage = None
+    Data parallel (`head.grad_exchange`, skghoi_amd/trainer.py ArenaExchange): the backward runs stage by stage and after
+    every stage the gradient-arena prefix that is final (Stacked.milestone_end[s]) is handed to the exchange."""
 
     def _plan(self, x0, gfeat):
         st, lay, S = self.st, self.lay, self.S
@@ -696,12 +694,18 @@ class NativeJob(TrainJob):
         dgfeat = torch.empty_like(S["gfeat"]) if need_dgfeat else None
         pl.dx0, pl.dgfeat = _ptr(dx0), _ptr(dgfeat)
         stream = _stream()
-        if self.on_stage is None:
+        ex = getattr(self.head, "grad_exchange", None)
+        if ex is None:
             _check(lib.skg_train_backward_f32(C.byref(pl), 0, _capi.TRAIN_BWD_STAGES, stream), "skg_train_backward_f32")
         else:
-            for s_ in range(_capi.TRAIN_BWD_STAGES):
+            # data parallel: after every stage the gradient-arena prefix that stage completed goes out to the peers
+            # (skghoi_amd/trainer.py, ArenaExchange), concurrent with the stages still to run
+            ex.begin(ga)
+            n = _capi.TRAIN_BWD_STAGES
+            for s_ in range(n):
                 _check(lib.skg_train_backward_f32(C.byref(pl), s_, s_ + 1, stream), "skg_train_backward_f32[%d]" % s_)
-                self.on_stage(s_, ga, st.milestone_end[s_])
+                ex.on_stage(s_, ga, st.milestone_end[s_], last=(s_ == n - 1))
+            ex.finish()
         out = []
         for p in self.params:
             k = st.ids.get(id(p))

@@ -117,6 +117,101 @@ def _interaction_heads(module: nn.Module):
     return [m for m in module.modules() if isinstance(m, InteractionHead)]
 
 
+class ArenaExchange:
+    """Gradient exchange of the fused training step over its flat gradient ARENA (skghoi_amd/train_fused.py, Stacked).
+
+    The reference wraps the net in DistributedDataParallel(find_unused_parameters=True) (utils.py:202-205): per-parameter
+    hooks fill buckets while autograd walks the graph.  The fused step is ONE autograd node -- all 408 gradients would
+    become ready at the same instant and every bucket's all-reduce would queue up behind the whole backward.  Here the
+    backward itself drives the exchange: the arena is laid out in the order in which the backward FINISHES gradients
+    (read-out layers first, box_head last), and after every stage the newly final prefix goes out as an all-reduce on the
+    process group's own stream (RCCL over xGMI), concurrent with the stages still to run; the optimizer waits for the
+    last one.  Collectives per step: the fused 3-element normaliser all-reduce + one per chunk (prefixes are coalesced to
+    at least `min_chunk` floats; the 12.8 M-float box_head.1 gradient closes the backward and is the tail that cannot
+    overlap).  Gradients are averaged (sum, then 1 / world folded into ONE scaling pass: gloo has no AVG).
+
+    Ranks whose batch took the generic path (no image with pairs: nothing ran through the fused node) still have to
+    meet their peers in the same collectives: `after_backward` sends their parameter gradients (zeros where a parameter
+    has none -- DDP's find_unused_parameters semantics) through the same chunk sequence."""
+
+    def __init__(self, head, group=None, min_chunk=1 << 21):
+        self.head, self.group, self.min_chunk = head, group, int(min_chunk)
+        self.world = dist.get_world_size(group)
+        self.works, self.done, self.ga = [], 0, None
+        self.ran = False
+        self.collectives = 0                  # arena collectives of the last step
+        self.timing = False
+        self.last_ms = None                   # with timing: (device time the step's stream waited for the exchange, ms)
+
+    # -- driven by NativeJob.backward
+    def begin(self, ga):
+        self.works, self.done, self.ga, self.collectives = [], 0, ga, 0
+        self.ran = True
+
+    def on_stage(self, s, ga, end, last=False):
+        if end - self.done >= self.min_chunk or (last and end > self.done):
+            self.works.append(dist.all_reduce(ga[self.done:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.done = end
+            self.collectives += 1
+
+    def finish(self):
+        """Orders the step's stream behind every chunk and forms the average."""
+        ga = self.ga
+        if self.done < ga.numel():                              # (arena padding at the very end)
+            self.on_stage(-1, ga, ga.numel(), last=True)
+        ev0 = ev1 = None
+        if self.timing and ga.is_cuda:
+            ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        for w in self.works:
+            w.wait()
+        ga.mul_(1.0 / self.world)
+        if ev0 is not None:
+            ev1.record()
+            self._events = (ev0, ev1)
+        self.works = []
+
+    def read_timing(self):
+        ev = getattr(self, "_events", None)
+        if ev is None:
+            return None
+        ev[1].synchronize()
+        self.last_ms = ev[0].elapsed_time(ev[1])
+        return self.last_ms
+
+    # -- driven by train_step
+    def after_backward(self):
+        """Call between backward and optimizer.step().  No-op when the fused node ran; otherwise this rank joins its peers'
+        collectives with whatever gradients its parameters hold."""
+        if self.ran:
+            self.ran = False
+            return
+        from . import train_fused
+        head = self.head
+        dev = next(head.parameters()).device
+        st = train_fused._stacked_for(head, dev)
+        if not st.aliased():
+            st.adopt()
+        ga = torch.zeros(st.total, device=dev, dtype=torch.float32)
+        views = st.grad_views(ga)
+        with torch.no_grad():
+            for p, v in zip(st.src, views):
+                if p.grad is not None:
+                    v.copy_(p.grad)
+        self.begin(ga)
+        for s_, end in enumerate(st.milestone_end):
+            self.on_stage(s_, ga, end, last=(s_ == len(st.milestone_end) - 1))
+        self.finish()
+        for p, v in zip(st.src, views):
+            if p.requires_grad:
+                p.grad = v
+        self.ran = False
+
+
+def exchanges(module: nn.Module):
+    return [h.grad_exchange for h in _interaction_heads(module) if getattr(h, "grad_exchange", None) is not None]
+
+
 def wrap_ddp(module: nn.Module, device=None):
     """utils.py:202-205 (pocket's engine wraps the net in DDP with find_unused_parameters=True).  A single process needs
     no gradient hooks: the head's fused step then writes p.grad directly (grad_mode "direct", ~1 ms of autograd
@@ -125,8 +220,30 @@ def wrap_ddp(module: nn.Module, device=None):
         for h in _interaction_heads(module):
             h.grad_mode = "direct"
         return module
-    for h in _interaction_heads(module):
-        h.grad_mode = "autograd"
+    # data parallel: every interaction head exchanges its own gradients over its arena, behind its backward
+    # (ArenaExchange); whatever else the module trains (a detector backbone) stays with DistributedDataParallel
+    from . import train_fused
+    ignore = []
+    heads = _interaction_heads(module)
+    names = {id(m): n for n, m in module.named_modules()}
+    for h in heads:
+        dev = next(h.parameters()).device
+        if train_fused.supported(h) and h.fused_training and dev.type == "cuda":
+            h.grad_mode = "direct"
+            st = train_fused._stacked_for(h, dev)
+            if not st.aliased():
+                st.adopt()
+            dist.broadcast(st.buf, 0)                       # DDP's constructor broadcast: rank 0's parameters everywhere
+            h.grad_exchange = ArenaExchange(h)
+            prefix = names[id(h)]
+            ignore += [(prefix + "." if prefix else "") + n for n, _ in h.named_parameters()]
+        else:
+            h.grad_mode = "autograd"
+    rest = [n for n, p in module.named_parameters() if p.requires_grad and n not in set(ignore)]
+    if not rest:
+        return module
+    if ignore:
+        nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(module, ignore)
     ids = [device.index] if device is not None and device.type == "cuda" else None
     return nn.parallel.DistributedDataParallel(module, device_ids=ids, find_unused_parameters=True)
 
@@ -161,6 +278,8 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
         raise ValueError(f"The HOI loss is NaN")
     total = sum(loss for loss in loss_dict.values())
     total.backward()
+    for ex in exchanges(net):            # data parallel: a rank whose batch bypassed the fused node joins its peers here
+        ex.after_backward()
     optimizer.step()
     if prefetch is not None:             # (features, detections, image_shapes, targets) of the next step
         prefetch_batch(net, *prefetch)

@@ -134,3 +134,117 @@ def test_bench_launcher_propagates_a_rank_failure():
     r = _run_bench(["--gpus", "2", "--dry-run", "--steps", "2"], {"SKG_BENCH_BACKEND": "gloo", "SKG_BENCH_FAIL_RANK": "1"})
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def _exchange_worker(rank, world, port, q):
+    """One rank of the data-parallel gradient-exchange test (CPU, gloo): oracle gradients of THIS rank's image under the
+    reference's data-parallel loss (sum / (all_reduce_sum(n_p) / world), HEAD:167-172), laid out in the gradient arena,
+    exchanged chunk by chunk as the fused backward would (stage prefixes), then compared with the single-process oracle
+    gradients of the whole two-image batch."""
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import cases
+    import helpers
+    from oracle import skg_oracle as O
+    from skghoi_amd import GraphHead, InteractionHead, synth, train_fused, trainer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    case = cases.build_case("train_tiny")
+    cfg = case["cfg"]
+    tables = helpers.golden_tables(helpers.load_golden("train_tiny"))
+
+    def oracle(lo, hi):
+        sd = synth.make_state_dict(cfg["K"], case["C"], case["p"], seed=case["weight_seed"])
+        sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        torch.manual_seed(case["rng_seed"])
+        off = [0]
+
+        def pool(coords):                       # the cached pooled features are indexed by global box row
+            n = sum(len(c) for c in coords)
+            return cases.pooled_for(case, 64)[off[0]:off[0] + n]
+        results, extras = O.interaction_head_forward(
+            sd, case["feat3"][lo:hi], case["detections"][lo:hi], case["shapes"][lo:hi], pool, cfg["K"], cfg["human_idx"],
+            case["o2v"], targets=case["targets"][lo:hi], training=True, max_human=case["max_human"],
+            max_object=case["max_object"], num_iter=case["num_iter"], tables=tables[lo:hi])
+        return sd, results, extras
+
+    # rows of the first image in the pooled cache (the second rank's boxes start after them)
+    sd_all, res_all, ex_all = oracle(0, 2)
+    n0 = len(ex_all["preprocessed"][0]["boxes"])
+    lo, hi = rank, rank + 1
+    sd = synth.make_state_dict(cfg["K"], case["C"], case["p"], seed=case["weight_seed"])
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    torch.manual_seed(case["rng_seed"])
+    results, extras = O.interaction_head_forward(
+        sd, case["feat3"][lo:hi], case["detections"][lo:hi], case["shapes"][lo:hi],
+        lambda coords: cases.pooled_for(case, 64)[n0 * rank:n0 * rank + sum(len(c) for c in coords)], cfg["K"],
+        cfg["human_idx"], case["o2v"], targets=case["targets"][lo:hi], training=True, max_human=case["max_human"],
+        max_object=case["max_object"], num_iter=case["num_iter"], tables=tables[lo:hi])
+    n_cells = float(sum(int(torch.count_nonzero(r["labels"])) for r in results))
+    n_pairs = float(sum(int(torch.count_nonzero(r["unary_labels"])) for r in results))
+    # ---- the step's ONE fused normaliser all-reduce, then the arena chunks: census of the python-level collectives
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda t_, *a_, **k_: (calls.append(t_.numel()), orig(t_, *a_, **k_))[1]
+    try:
+        norm = skd.start_normalisers(torch.tensor([n_cells, n_pairs, n_pairs])).get()      # all_reduce_sum / world
+        params = list(sd.values())
+        g_hoi = torch.autograd.grad(extras["losses"]["hoi_loss"], params, retain_graph=True, allow_unused=True)
+        g_int = torch.autograd.grad(extras["losses"]["interactiveness_loss"], params, allow_unused=True)
+        # local loss = sum / n_local  ->  data-parallel loss = sum / n_p  (n_p = norm): rescale the local gradients
+        a, b = n_cells / float(norm[0]), n_pairs / float(norm[1])
+        mine = {k: (0 if gh is None else a * gh) + (0 if gi is None else b * gi) for k, gh, gi in zip(sd, g_hoi, g_int)}
+        gh_ = GraphHead(case["C"], case["p"], 1024, 1024, cfg["K"], cfg["human_idx"], case["o2v"])
+        head = InteractionHead(torch.nn.Identity(), gh_, torch.nn.Linear(2048, 1), torch.nn.Linear(2048, cfg["K"]),
+                               human_idx=cfg["human_idx"], num_classes=cfg["K"])
+        st = train_fused.Stacked(head, torch.device("cpu"))
+        ga = torch.zeros(st.total)
+        views = st.grad_views(ga)
+        names = {id(p): n for n, p in head.named_parameters()}
+        for p, v in zip(st.src, views):
+            g = mine[names[id(p)]]
+            if torch.is_tensor(g):
+                v.copy_(g)
+        ex = trainer.ArenaExchange(head, min_chunk=1 << 18)
+        ex.begin(ga)
+        for s_, end in enumerate(st.milestone_end):
+            ex.on_stage(s_, ga, end, last=(s_ == len(st.milestone_end) - 1))
+        ex.finish()
+    finally:
+        dist.all_reduce = orig
+    # ---- against the single-process gradients of the two-image batch
+    total = ex_all["losses"]["hoi_loss"] + ex_all["losses"]["interactiveness_loss"]
+    want = torch.autograd.grad(total, list(sd_all.values()), allow_unused=True)
+    worst = 0.0
+    byname = {names[id(p)]: v for p, v in zip(st.src, views)}
+    for k, w in zip(sd_all, want):
+        if w is None:
+            continue
+        scale = max(float(w.abs().max()), 1e-6)
+        worst = max(worst, float((byname[k] - w).abs().max()) / scale)
+    q.put((rank, calls, ex.collectives, st.total, worst))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_arena_gradient_exchange_equals_single_process_batch_gradients():
+    """Two gloo ranks, one image each: the arena exchange (chunked all-reduce of the stage prefixes, averaged) of the
+    per-rank oracle gradients under the reference's data-parallel normaliser equals the oracle gradients of the two-image
+    batch in one process (HEAD:167-172 + DDP's gradient mean); exactly {1 normaliser, k arena} collectives per step."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, calls, k, total, worst in res:
+        assert calls[0] == 3 and len(calls) == 1 + k and 2 <= k <= 12, calls
+        assert sum(calls[1:]) == total
+        assert worst <= 1e-4, worst               # fp32 summation order, like the other gradient tests
