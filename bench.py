@@ -172,7 +172,20 @@ def run_train(B, precision, steps, warmup, device, rank, world, dist_on, prefetc
     if dist_on:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
-    return elapsed, trainer.read_losses(losses)
+    info = {}
+    exs = trainer.exchanges(net)
+    if exs:
+        # one more step, untimed, with HIP events around the point where the step's stream waits for the gradient exchange:
+        # the part of the all-reduce that the backward did not cover
+        exs[0].timing = True
+        trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=None)
+        info["grad_exchange"] = dict(collectives_per_step=exs[0].collectives + 1,
+                                     exposed_wait_ms=round(exs[0].read_timing(), 4),
+                                     note="1 fused normaliser all-reduce + the gradient arena in chunks issued from inside "
+                                          "the backward (skghoi_amd.trainer.ArenaExchange); exposed_wait = device time the "
+                                          "step's stream waited for the chunks after its last backward kernel")
+        exs[0].timing = False
+    return elapsed, trainer.read_losses(losses), info
 
 
 def train_mode(args, device, rank, world, dist_on):
@@ -181,7 +194,7 @@ def train_mode(args, device, rank, world, dist_on):
     from skghoi_amd import dist as skd
     B = args.batch if args.batch != 256 else 4
     args.precision = args.precision or "fp32"
-    elapsed, losses = run_train(B, args.precision, args.steps, args.warmup, device, rank, world, dist_on)
+    elapsed, losses, info = run_train(B, args.precision, args.steps, args.warmup, device, rank, world, dist_on)
     elapsed = skd.max_over_ranks(elapsed, device=device)
     if rank == 0:
         print(json.dumps(dict(metric="images/sec through the interaction-head TRAINING step (20x20 pairs)",
@@ -192,7 +205,7 @@ def train_mode(args, device, rank, world, dist_on):
                               config=dict(workload="train step: fwd + bwd + AdamW, NegativeSampling + MarginLoss + "
                                                    "two focal terms, 20x20 synthetic images with GT appended",
                                           batch_per_gpu=B, parallelism="dp%d" % world),
-                              losses=losses, dist=dist_info(world))))
+                              losses=losses, dist=dist_info(world), **info)))
     if dist_on:
         dist.destroy_process_group()
 
@@ -540,7 +553,7 @@ def main():
         _trainer.limit_host_threads(world)
         train = {}
         for prec in ("fp32", "bf16"):
-            el_t, losses = run_train(4, prec, 10, 4, device, rank, world, False)
+            el_t, losses, _ = run_train(4, prec, 10, 4, device, rank, world, False)
             train[prec] = dict(ms_per_step=round(el_t / 10 * 1e3, 3), images_per_s=round(40 / el_t, 2), batch=4,
                                steps=10, losses={k: round(v, 6) for k, v in losses.items()})
         train["note"] = ("NegativeSampling + MarginLoss + two focal terms, forward + backward + AdamW, 4 synthetic 20x20 "

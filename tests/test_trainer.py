@@ -104,7 +104,7 @@ def test_two_rank_ddp_train_step_on_one_gpu():
     # by the gradient arena in a few chunks issued from inside the backward (trainer.ArenaExchange) -- no barrier anywhere
     assert c0 == c1 and c0[0] == ("all_reduce", 3) and all(k == "all_reduce" for k, _ in c0), (c0, c1)
     chunks = [n for _, n in c0[1:]]
-    assert 2 <= len(chunks) <= 12 and sum(chunks) >= 29_000_000 and min(chunks[:-1]) >= 1 << 21
+    assert 2 <= len(chunks) <= 12 and sum(chunks) >= 16_000_000 and min(chunks[:-1]) >= 1 << 21      # (C = 8, p = 2 head)
     for l in (l0, l1):
         assert all(np.isfinite(v) for v in l.values()) and set(l) == {"hoi_loss", "interactiveness_loss", "transH_loss"}
     assert np.array_equal(v0, v1)            # gradients were averaged: both replicas took the same step

@@ -11,5 +11,5 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 from skghoi_amd import trainer
 trainer.limit_host_threads()
 dev = torch.device("cuda", 0)
-el, losses = bench.run_train(4, prec, steps, 8, dev, 0, 1, False, prefetch=pf)
+el, losses, _ = bench.run_train(4, prec, steps, 8, dev, 0, 1, False, prefetch=pf)
 print("%s prefetch=%s: %.3f ms/step" % (prec, pf, el / steps * 1e3), losses)
