@@ -65,12 +65,12 @@ def make_inputs(B, rank, device):
     return dets, pooled, OrderedDict((k, feat3) for k in "0123"), shapes
 
 
-def build_head(device):
+def build_head(device, max_human=N_H, max_object=N_O):
     from skghoi_amd import GraphHead, InteractionHead, synth
     o2v = synth.hico_object_to_verb()
     gh = GraphHead(C_FEAT, POOL, 1024, 1024, 117, 49, o2v, num_iter=2)
     head = InteractionHead(torch.nn.Identity(), gh, torch.nn.Linear(2048, 1), torch.nn.Linear(2048, 117),
-                           human_idx=49, num_classes=117, max_human=N_H, max_object=N_O)
+                           human_idx=49, num_classes=117, max_human=max_human, max_object=max_object)
     head.load_state_dict(synth.make_state_dict(117, C_FEAT, POOL, seed=0))
     return head.to(device).eval()
 
@@ -363,6 +363,60 @@ def dist_info(world):
     return dict(world_size=1, backend=None, launcher=None)
 
 
+def b1_stream(device, n_forwards=2048, n_images=256, seed=2024):
+    """The reference's evaluation loop (utils.py:160-167: one image per forward over the 9 658 test images) on a stream of
+    single images whose (humans, nodes) follow a HICO-DET-like spread at the reference's default caps (max_human =
+    max_object = 15): n_h in 1..15 with P ~ 1 / k^1.2, objects in 1..15 with P ~ 1 / k^0.8 (many small graphs, a tail of
+    large ones), ~150 distinct shapes.  Two passes over the same stream: the first pays the plan captures (one per shape
+    BUCKET, skghoi_amd/small.py), the second is the steady state.  Per-forward latency = call to results complete on
+    the device (synchronised per forward, like a loop that consumes each result)."""
+    from skghoi_amd import synth
+    head = build_head(device, max_human=15, max_object=15)
+    rs = np.random.RandomState(seed)
+    kh = np.arange(1, 16); ph = kh ** -1.2; ph /= ph.sum()
+    ko = np.arange(1, 16); po = ko ** -0.8; po /= po.sum()
+    imgs, shapes_seen = [], set()
+    for i in range(n_images):
+        nh, no = int(rs.choice(kh, p=ph)), int(rs.choice(ko, p=po))
+        im = synth.make_image(50000 + i, n_h=nh, n_o=no, out_channels=C_FEAT, pool=POOL)
+        det = [dict(boxes=im["boxes"].to(device), labels=im["labels"].to(device), scores=im["scores"].to(device))]
+        f3 = im["feat3"].to(device)
+        imgs.append((det, im["pooled"].to(device), OrderedDict((k, f3) for k in "0123"), [im["hw"]]))
+        shapes_seen.add((nh, nh + no))
+    pool = ResidentPool(None)
+    head.box_roi_pool = pool
+    order = rs.randint(0, n_images, n_forwards)
+    runner = None
+    out = {}
+    with torch.no_grad():
+        for name in ("first_pass", "steady_state"):
+            lat = np.zeros(n_forwards)
+            torch.cuda.synchronize()
+            t_all = time.perf_counter()
+            for k, i in enumerate(order):
+                det, pooled, feats, shp = imgs[int(i)]
+                pool.pooled = pooled
+                t0 = time.perf_counter()
+                head(feats, det, shp)
+                torch.cuda.synchronize()
+                lat[k] = time.perf_counter() - t0
+            wall = time.perf_counter() - t_all
+            st = head.engine()._small.stats()
+            prev = runner or dict(hits=0, misses=0, captures=0, evictions=0)
+            calls = st["hits"] + st["misses"] - prev["hits"] - prev["misses"]
+            out[name] = dict(forwards=n_forwards, mean_ms=round(float(lat.mean()) * 1e3, 4),
+                             p50_ms=round(float(np.percentile(lat, 50)) * 1e3, 4),
+                             p95_ms=round(float(np.percentile(lat, 95)) * 1e3, 4),
+                             max_ms=round(float(lat.max()) * 1e3, 3), images_per_s=round(n_forwards / wall, 1),
+                             plan_hit_rate=round((st["hits"] - prev["hits"]) / max(calls, 1), 4),
+                             captures=st["captures"] - prev["captures"], evictions=st["evictions"] - prev["evictions"])
+            runner = st
+    out.update(distinct_shapes=len(shapes_seen), plans=runner["plans"], max_human=15, max_object=15, precision=head.precision,
+               note="single-image eval forwards over %d synthetic images with a HICO-like spread of graph sizes; one "
+                    "captured launch plan per bucket of (humans, nodes), true sizes in the device-side meta record" % n_images)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -379,6 +433,7 @@ def main():
                          "arithmetic) or fp16x2 (opt-in split operands on the fp16 MFMA).  train: fp32 (default) or bf16")
     ap.add_argument("--no-legs", action="store_true",
                     help="headline only: skip the extra legs (fp16x2, small-batch latency, training step)")
+    ap.add_argument("--b1-stream", action="store_true", help="only the single-image shape-stream leg (prints its record)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="train: NegativeSampling+MarginLoss training step (fwd+bwd+AdamW) as the headline instead")
     ap.add_argument("--dry-run", action="store_true",
@@ -420,6 +475,9 @@ def main():
 
     if args.mode == "train":
         return train_mode(args, device, rank, world, dist_on)
+    if args.b1_stream:
+        print(json.dumps(b1_stream(device)))
+        return
 
     from skghoi_amd import engine
     head = build_head(device)
@@ -546,6 +604,7 @@ def main():
         # (b) small batches: the reference's own evaluation runs one image per forward (utils.py:166-167)
         out["b1_latency_ms"] = round(small_batch_latency(head, dets, pooled, feats, shapes, 1), 4)
         out["b4_latency_ms"] = round(small_batch_latency(head, dets, pooled, feats, shapes, min(4, args.batch)), 4)
+        out["b1_stream"] = b1_stream(device)
         out["small_batch"] = dict(precision=head.precision, b1_images_per_s=round(1e3 / out["b1_latency_ms"], 1),
                                   b4_images_per_s=round(4e3 / out["b4_latency_ms"], 1),
                                   note="mean wall time per eval forward, 200 back-to-back forwards after 30 warm-ups")

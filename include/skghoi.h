@@ -87,6 +87,14 @@ int skg_pairs_spatial_f32(const float* boxes, const skg_image_meta* meta, int n_
                           int32_t* grid_h, int32_t* grid_o, int32_t* grid_pair, int32_t* grid_img,
                           int32_t* pair_grid, int64_t* x_keep, int64_t* y_keep, int32_t* pair_h, int32_t* pair_o,
                           float* spatial, int scrub_nan, void* stream);
+/* The same with CAPACITY PADDING for launch plans captured once per bucket of shapes (skghoi_amd/small.py): every image owns
+ * grid_cap grid rows and pair_cap pair rows (its meta offsets are strided accordingly) of which it uses n_h * n and
+ * n_h * (n - 1).  The unused tails receive index entries that are safe to gather / scatter through (a valid row to read,
+ * -1 = "not stored" in grid_pair) and zero spatial features.  grid_cap = pair_cap = 0: no padding (= skg_pairs_spatial_f32). */
+int skg_pairs_spatial_padded_f32(const float* boxes, const skg_image_meta* meta, int n_active, int32_t* grid_h,
+                                 int32_t* grid_o, int32_t* grid_pair, int32_t* grid_img, int32_t* pair_grid,
+                                 int64_t* x_keep, int64_t* y_keep, int32_t* pair_h, int32_t* pair_o, float* spatial,
+                                 int scrub_nan, int grid_cap, int pair_cap, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * MultiScaleRoIAlign (models/adamixer_transH_spatial_r50_models.py:158-162, called at HEAD:387): the producer of the

@@ -84,6 +84,8 @@ PROTOTYPES = {
     "skg_pack_detections_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "skg_pairs_spatial_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int,
                                         _vp]),
+    "skg_pairs_spatial_padded_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                               C.c_int, C.c_int, C.c_int, _vp]),
     "skg_roi_align_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp,
                                     C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "skg_roi_align_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp,

@@ -291,9 +291,17 @@ class InteractionHead(Module):
                 or e.suppressor is not self.box_pair_suppressor \
                 or e.max_human != self.max_human or e.max_object != self.max_object \
                 or e.box_nms_thresh != float(self.box_nms_thresh) or e.box_score_thresh != float(self.box_score_thresh):
+            old = e
             e = HeadEngine(self.box_pair_head, self.box_pair_predictor, self.box_pair_suppressor, self.human_idx,
                            self.num_classes, self.box_nms_thresh, self.box_score_thresh, self.max_human,
                            self.max_object, faithful_skip_offset=self.reference_quirks)
+            if old is not None:
+                # the engine being replaced owns captured launch plans (hipGraphs): they go through the one teardown path
+                # -- idle device, before anything of a new capture exists (skghoi_amd/small.py) -- not by refcount
+                e.small_batch_max, e.small_batch_buckets = old.small_batch_max, old.small_batch_buckets
+                if old._small is not None:
+                    old._small.close()
+                    old._small = None
             self._engine = e
         e.faithful_skip_offset = self.reference_quirks
         e.precision = self.precision

@@ -26,6 +26,8 @@ __global__ __launch_bounds__(256) void skg_graph_aggregate_kernel(
     const int a = to_human ? hum_img[dst] : node_img[dst];
     const skg_image_meta mt = meta[a];
     const int local = to_human ? dst - mt.hum_off : dst - mt.node_off;
+    // capacity padding (plans sized for a bucket of shapes): rows past the image's humans / nodes are nobody's destination
+    if (local >= (to_human ? mt.n_h : mt.n)) return;
     const int cnt = to_human ? mt.n : mt.n_h;                 // number of senders
     const int64_t row0 = to_human ? (int64_t)mt.grid_off + (int64_t)local * mt.n : (int64_t)mt.grid_off + local;
     const int64_t rstep = to_human ? 1 : mt.n;

@@ -14,7 +14,8 @@ __global__ __launch_bounds__(PS_THREADS) void skg_pairs_spatial_kernel(
     const float* __restrict__ boxes, const skg_image_meta* __restrict__ meta, int32_t* __restrict__ grid_h,
     int32_t* __restrict__ grid_o, int32_t* __restrict__ grid_pair, int32_t* __restrict__ grid_img,
     int32_t* __restrict__ pair_grid, int64_t* __restrict__ x_keep, int64_t* __restrict__ y_keep,
-    int32_t* __restrict__ pair_h, int32_t* __restrict__ pair_o, float* __restrict__ spatial, int scrub_nan) {
+    int32_t* __restrict__ pair_h, int32_t* __restrict__ pair_o, float* __restrict__ spatial, int scrub_nan,
+    int grid_cap, int pair_cap) {
     __shared__ float4 sbox[SKG_MAX_NODES];
     const int a = blockIdx.x;
     const skg_image_meta mt = meta[a];
@@ -86,6 +87,26 @@ __global__ __launch_bounds__(PS_THREADS) void skg_pairs_spatial_kernel(
 #pragma unroll
         for (int k = 0; k < SKG_SPATIAL_LD / 4; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
     }
+    // Capacity padding (captured small-batch plans sized for a BUCKET of shapes, skghoi_amd/small.py): the image owns
+    // grid_cap grid rows and pair_cap pair rows of which it uses G and n_h (n - 1).  The unused tail gets index entries that
+    // are safe to gather / scatter through -- a valid human / node / grid row to read, -1 (= not stored) to scatter to -- and
+    // zero spatial features, so that the launches that walk all capacity rows compute finite garbage nobody reads.
+    if (grid_cap > G) {
+        for (int r = G + lane; r < grid_cap; r += PS_THREADS) {
+            const int gr = mt.grid_off + r;
+            grid_h[gr] = mt.hum_off; grid_o[gr] = mt.node_off; grid_img[gr] = mt.image; grid_pair[gr] = -1;
+            float4* dst = reinterpret_cast<float4*>(spatial + (int64_t)gr * SKG_SPATIAL_LD);
+#pragma unroll
+            for (int k = 0; k < SKG_SPATIAL_LD / 4; ++k) dst[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const int P = n_h * (n - 1);
+    if (pair_cap > P) {
+        for (int q = P + lane; q < pair_cap; q += PS_THREADS) {
+            const int p = mt.pair_off + q;
+            pair_grid[p] = mt.grid_off; x_keep[p] = 0; y_keep[p] = 0; pair_h[p] = mt.hum_off; pair_o[p] = mt.node_off;
+        }
+    }
     // torch.nan_to_num over the whole image tensor if it holds any NaN (HEAD:866-868): NaN -> 0, +-inf -> +-FLT_MAX
     if (__syncthreads_or(scrub_nan && any_nan)) {
         for (int r = lane; r < G; r += PS_THREADS) {
@@ -104,14 +125,22 @@ extern "C" int skg_pairs_spatial_f32(const float* boxes, const skg_image_meta* m
                                      int32_t* grid_o, int32_t* grid_pair, int32_t* grid_img, int32_t* pair_grid,
                                      int64_t* x_keep, int64_t* y_keep, int32_t* pair_h, int32_t* pair_o,
                                      float* spatial, int scrub_nan, void* stream) {
-    if (n_active < 0) return SKG_E_ARG;
+    return skg_pairs_spatial_padded_f32(boxes, meta, n_active, grid_h, grid_o, grid_pair, grid_img, pair_grid, x_keep,
+                                        y_keep, pair_h, pair_o, spatial, scrub_nan, 0, 0, stream);
+}
+
+extern "C" int skg_pairs_spatial_padded_f32(const float* boxes, const skg_image_meta* meta, int n_active, int32_t* grid_h,
+                                            int32_t* grid_o, int32_t* grid_pair, int32_t* grid_img, int32_t* pair_grid,
+                                            int64_t* x_keep, int64_t* y_keep, int32_t* pair_h, int32_t* pair_o,
+                                            float* spatial, int scrub_nan, int grid_cap, int pair_cap, void* stream) {
+    if (n_active < 0 || grid_cap < 0 || pair_cap < 0) return SKG_E_ARG;
     if (n_active == 0) return 0;
     if (!boxes || !meta || !grid_h || !grid_o || !grid_pair || !grid_img || !pair_grid || !x_keep || !y_keep ||
         !pair_h || !pair_o || !spatial)
         return SKG_E_ARG;
     if (!skg_aligned16(boxes) || !skg_aligned16(spatial)) return SKG_E_ALIGN;
     hipLaunchKernelGGL(skg_pairs_spatial_kernel, dim3(n_active), dim3(PS_THREADS), 0, (hipStream_t)stream, boxes, meta, grid_h,
-                       grid_o, grid_pair, grid_img, pair_grid, x_keep, y_keep, pair_h, pair_o, spatial, scrub_nan);
+                       grid_o, grid_pair, grid_img, pair_grid, x_keep, y_keep, pair_h, pair_o, spatial, scrub_nan, grid_cap, pair_cap);
     return skg_launch_status();
 }
 

@@ -496,6 +496,7 @@ class HeadEngine:
         self._cnt_host_dev = None
         self.plan_epoch = 0
         self.small_batch_max = 8    # eval batches of up to this many images replay a captured hipGraph (skghoi_amd/small.py); 0: off
+        self.small_batch_buckets = True   # single images share one plan per BUCKET of (humans, nodes) instead of one per shape
         self._small = None
         self.last = None          # intermediates of the last graph pass (parity tests read them)
 
@@ -829,7 +830,7 @@ class HeadEngine:
                 out[k] = torch.cat(v)
         return out
 
-    def _chunk_phase_a(self, ch, pw, pre, G1, x_keep, y_keep, PF, ibuf=None, offs=None, meta=None):
+    def _chunk_phase_a(self, ch, pw, pre, G1, x_keep, y_keep, PF, ibuf=None, offs=None, meta=None, caps=None):
         """Pairs, spatial encoding, spatial head and the global read-out branch of one chunk: everything that does not
         depend on the TransH tables.  ibuf / offs / meta: index arrays already on the device (captured-graph path:
         they are part of the launch plan, `meta` is its per-call record array)."""
@@ -856,11 +857,13 @@ class HeadEngine:
         grid_img = torch.empty(Mg, **i32); pair_grid = torch.empty(max(Mp, 1), **i32)
         pair_h = torch.empty(max(Mp, 1), **i32); pair_o = torch.empty(max(Mp, 1), **i32)
         sp48 = torch.empty(Mg, _capi.SPATIAL_LD, **f32)
-        _capi.check(lib.skg_pairs_spatial_f32(pre.boxes.data_ptr(), meta.data_ptr(), A, grid_h.data_ptr(),
-                                              grid_o.data_ptr(), grid_pair.data_ptr(), grid_img.data_ptr(),
-                                              pair_grid.data_ptr(), xk.data_ptr(), yk.data_ptr(),
-                                              pair_h.data_ptr(), pair_o.data_ptr(), sp48.data_ptr(), 1, st),
-                    "skg_pairs_spatial_f32")
+        # caps = (grid rows, pair rows) every image OWNS when the launch plan is sized for a bucket of shapes (small.py)
+        gcap, pcap = caps if caps is not None else (0, 0)
+        _capi.check(lib.skg_pairs_spatial_padded_f32(pre.boxes.data_ptr(), meta.data_ptr(), A, grid_h.data_ptr(),
+                                                     grid_o.data_ptr(), grid_pair.data_ptr(), grid_img.data_ptr(),
+                                                     pair_grid.data_ptr(), xk.data_ptr(), yk.data_ptr(),
+                                                     pair_h.data_ptr(), pair_o.data_ptr(), sp48.data_ptr(), 1, gcap, pcap,
+                                                     st), "skg_pairs_spatial_padded_f32")
         # ---- spatial_head (HEAD:662-669, 888)
         s1 = torch.empty(Mg, 128, **f32); s2 = torch.empty(Mg, 256, **f32); S = torch.empty(Mg, 1024, **f32)
         gemm(sp48, pw.sp0_w, pw.sp0_b, s1, Mg, 128, _capi.SPATIAL_LD, _capi.EPI_BIAS_RELU)

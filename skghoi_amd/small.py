@@ -19,6 +19,19 @@ _chunk_phase_a / _chunk_phase_b / _classify / score), so results are bit-identic
 the same shape never enters a launch argument: image sizes and result offsets travel in the device-side meta records,
 the number of scored cells in a device word (skg_postprocess_f32's L_total_dev).
 
+SHAPE BUCKETS (single images, the reference's evaluation mode): a dataset walks hundreds of distinct (humans, nodes)
+shapes -- up to 15 x 30 at the default caps -- and a plan per exact shape means a capture (eager pass + capture + teardown
+of an evicted plan, ~10-20 ms) on most images of the first epoch.  A single image therefore takes the plan of its BUCKET
+(ch, cn) = the next capacities >= (n_h, n) out of a geometric ladder (1, 2, 3, 4, 6, 8, 11, 15, 21, 30, ...): every row
+space of the plan is sized for (ch, cn), the launches walk all capacity rows, and the image's true (n_h, n) travel in the
+device-side meta record like everything else that varies per call.  The kernels that work per graph (pair enumeration,
+softmax aggregation, scoring) read (n_h, n) from the record; the row-wise ones (GEMMs, LayerNorm, products) compute finite
+garbage in the unused rows, which nothing reads: the pair kernel fills the index arrays of the unused tail with safe
+entries and zero features (skg_pairs_spatial_padded_f32).  A few dozen plans cover every shape; padded work costs
+at most (1.4)^2 of the rows.  Results equal the eager path's up to the summation order of split-K reductions (their
+factors follow the capacity), i.e. ~1e-7 relative; integer outputs are identical.  Batches of 2..8 images keep one plan per
+exact shape tuple.
+
 Reference path replaced: heads/adamixer_transH_spatial_r50_head.py:341-429 (InteractionHead.forward, eval mode).
 """
 import copy
@@ -35,7 +48,17 @@ META_WORDS = layout.META_DTYPE.itemsize // 4
 
 
 class _Plan:
-    pass
+    caps = None            # (grid rows, pair rows) the image owns when the plan serves a bucket of shapes
+
+
+def capacity(v, limit):
+    """Smallest rung >= v of the ladder 1, 2, 3, 4, 6, 8, 11, 15, 21, 30, 42, ... (ratio ~1.4), capped at `limit`."""
+    c, step = 1, 0
+    ladder = (1, 2, 3, 4, 6, 8, 11, 15, 21, 30, 42, 60, 80, 112, 160)
+    for c in ladder:
+        if c >= v:
+            break
+    return max(min(c, limit), v)
 
 
 class SmallBatchRunner:
@@ -50,9 +73,21 @@ class SmallBatchRunner:
         self.side = None                   # second stream of the plan bodies (second branch of the captured graphs)
         self.epoch = engine.plan_epoch
         self.retired = []                  # dropped plans: destroyed only on an idle device, never next to a capture
+        self.captures = self.evictions = 0
 
     def _retire(self, plans):
         self.retired.extend(plans)
+
+    def stats(self):
+        n = self.hits + self.misses
+        return dict(calls=n, hits=self.hits, misses=self.misses, hit_rate=(self.hits / n if n else None),
+                    captures=self.captures, evictions=self.evictions, plans=len(self.plans))
+
+    def close(self):
+        """Drops every plan through the idle-device path (engine replaced, head torn down, tests)."""
+        self._retire(self.plans.values())
+        self.plans.clear()
+        self._bury_retired()
 
     def _bury_retired(self):
         """Destroys dropped plans (their hipGraphExec, pool blocks, events, pinned staging) -- with the device idle and
@@ -151,7 +186,7 @@ class SmallBatchRunner:
             with torch.cuda.stream(side):
                 side.wait_event(fork)
                 cx = eng._chunk_phase_a(p.ch, pw, p.pre, None, x_keep, y_keep, PF, ibuf=p.ibuf, offs=p.offs,
-                                        meta=p.meta_dev)
+                                        meta=p.meta_dev, caps=p.caps)
                 s_ready = torch.cuda.Event(); s_ready.record(side)
             # box_head layer 2 (HEAD:812) and attention_head_g's fc_1 on the global features (HEAD:971): independent
             gemm_group([((p.enc1, pw.bh3_w, pw.bh3_b, enc, NA, 1024, 1024, _capi.EPI_BIAS_RELU), {}),
@@ -196,6 +231,7 @@ class SmallBatchRunner:
             if gc_on:
                 gc.enable()
         p.graph = g
+        self.captures += 1
 
     # ------------------------------------------------------------------------------------------------ forward
     def eligible(self, head, detections, targets):
@@ -216,16 +252,35 @@ class SmallBatchRunner:
             self.plans.clear()
             self.epoch = eng.plan_epoch
         feat3 = features["3"]
-        key = (tuple(pre.n_h.tolist()), tuple(pre.n.tolist()), tuple(feat3.shape[:2]), eng.precision,
-               eng.gh.num_iter, eng.faithful_skip_offset, eng.plan_epoch, dev.index)
+        # single images: one plan per BUCKET of shapes (module docstring); the true (n_h, n) go into the per-call record
+        bucket = None
+        if pre.B == 1 and eng.small_batch_buckets:
+            nh1, n1 = int(pre.n_h[0]), int(pre.n[0])
+            if nh1 >= 1 and 2 <= n1 <= _capi.TRANSH_ENT:
+                bucket = (capacity(nh1, max(eng.max_human, nh1)),
+                          capacity(n1, min(max(eng.max_human + eng.max_object, n1), _capi.TRANSH_ENT)))
+        shape_key = ("bucket",) + bucket if bucket else (tuple(pre.n_h.tolist()), tuple(pre.n.tolist()))
+        key = shape_key + (tuple(feat3.shape[:2]), eng.precision, eng.gh.num_iter, eng.faithful_skip_offset,
+                           eng.plan_epoch, dev.index)
         p = self.plans.get(key)
-        if p is None:
-            lay = layout.build(pre.n_h, pre.n, pre.L, image_shapes, eng.human_idx,
-                               faithful_skip_offset=eng.faithful_skip_offset)
-            if lay.n_active == 0 or lay.n_visit == 0 or lay.sum_p == 0:
+        call_lay = None
+        if bucket:
+            call_lay = layout.single(nh1, n1, int(pre.L[0]), image_shapes[0])
+            if call_lay.sum_p == 0:
                 return self._fallback(head, pre, features, image_shapes)
-        else:
+        elif p is None:
+            call_lay = layout.build(pre.n_h, pre.n, pre.L, image_shapes, eng.human_idx,
+                                    faithful_skip_offset=eng.faithful_skip_offset)
+            if call_lay.n_active == 0 or call_lay.n_visit == 0 or call_lay.sum_p == 0:
+                return self._fallback(head, pre, features, image_shapes)
+        if p is not None:
             lay = p.lay
+        elif bucket:                                # the plan's layout: one image of exactly the bucket's capacity
+            lay = layout.build([bucket[0]], [bucket[1]], None, image_shapes, eng.human_idx,
+                               faithful_skip_offset=eng.faithful_skip_offset)
+        else:
+            lay = call_lay
+        n_act = int(sum(pre.sizes))                 # selected boxes of this call (<= lay.sum_all for a bucket plan)
         # ---- static inputs of this call
         new = p is None
         if new:
@@ -233,23 +288,27 @@ class SmallBatchRunner:
             eng.pre_pack(pre)
             box_coords = list(pre.boxes.split(pre.sizes))
             pooled = head.box_roi_pool(features, box_coords, image_shapes)
-            if pooled.shape[0] != lay.sum_all:
-                raise _capi.SkgError("box_roi_pool returned %d rows for %d boxes" % (pooled.shape[0], lay.sum_all))
+            if pooled.shape[0] != n_act:
+                raise _capi.SkgError("box_roi_pool returned %d rows for %d boxes" % (pooled.shape[0], n_act))
             if pooled[0].numel() != pw.bh1_k:
                 raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)" % (
                     pooled.shape[0], pooled[0].numel(), pw.bh1_k, 1024))
             p = self._build_plan(key, pre, lay, pw, feat3, pooled)
-            p.boxes.copy_(pre.boxes); p.scores.copy_(pre.scores); p.labels.copy_(pre.labels)
+            if bucket:
+                p.caps = (bucket[0] * bucket[1], bucket[0] * (bucket[1] - 1))
+            p.boxes[:n_act].copy_(pre.boxes); p.scores[:n_act].copy_(pre.scores); p.labels[:n_act].copy_(pre.labels)
             while len(self.plans) >= self.max_plans:
                 self._retire([self.plans.popitem(last=False)[1]])
+                self.evictions += 1
             self.plans[key] = p
         else:
             self.hits += 1
             self.plans.move_to_end(key)
-            eng.pre_pack(pre, out=(p.boxes, p.scores, p.labels), sel_off=p.sel_off)
-            pooled = head.box_roi_pool(features, list(p.boxes.split(pre.sizes)), image_shapes)
-            if pooled.shape[0] != lay.sum_all:
-                raise _capi.SkgError("box_roi_pool returned %d rows for %d boxes" % (pooled.shape[0], lay.sum_all))
+            sel_off = p.sel_off if not bucket else eng._det_offsets(pre.sizes, dev)
+            eng.pre_pack(pre, out=(p.boxes[:n_act], p.scores[:n_act], p.labels[:n_act]), sel_off=sel_off)
+            pooled = head.box_roi_pool(features, list(p.boxes[:n_act].split(pre.sizes)), image_shapes)
+            if pooled.shape[0] != n_act:
+                raise _capi.SkgError("box_roi_pool returned %d rows for %d boxes" % (pooled.shape[0], n_act))
         # the two launches that read caller-owned tensors go first: global average pool (HEAD:811), box_head layer 1
         # (HEAD:812, 51 MB of weights) -- the GPU works on them while the host fills in the per-call records below
         lib = _capi.lib()
@@ -260,7 +319,7 @@ class SmallBatchRunner:
         if x0.dtype != torch.float32:
             x0 = x0.float()
         if p.x0_pad is not None:
-            p.x0_pad[:, :x0.shape[1]] = x0
+            p.x0_pad[:n_act, :x0.shape[1]] = x0
             x0 = p.x0_pad
         elif not x0.is_contiguous():
             x0 = x0.contiguous()
@@ -268,7 +327,8 @@ class SmallBatchRunner:
             with eng._split_ctx(pw):
                 p.bh1_desc = gemm_desc(x0, pw.bh1_w, pw.bh1_b, p.enc1, lay.sum_all, 1024, x0.shape[1],
                                        _capi.EPI_BIAS_RELU, split_k=p.sk, split_ws=p.ws)
-        p.bh1_desc.A = x0.data_ptr()               # the one field that changes from call to call
+        p.bh1_desc.A = x0.data_ptr()               # the fields that change from call to call: the caller's tensor and (bucket
+        p.bh1_desc.M = n_act                       # plans) its row count
         if p.bh1_desc.w_split:
             p.bh1_exp = enqueue_row_exponents(p.bh1_desc, x0.device)
         _capi.check(lib.skg_gemm_f32(C.byref(p.bh1_desc), _stream()), "skg_gemm_f32[box_head 1]")
@@ -282,6 +342,8 @@ class SmallBatchRunner:
             p.meta_i32[0, 9] = 0
             p.meta_f32[0, 10] = float(image_shapes[b0][0]); p.meta_f32[0, 11] = float(image_shapes[b0][1])
             Lt = int(L[0])
+            if bucket:                             # the image's true graph inside the bucket's capacity
+                p.meta_i32[0, 1] = nh1; p.meta_i32[0, 2] = n1
         else:
             p.meta_i32[:, 9] = np.cumsum(L) - L
             p.meta_f32[:, 10] = [float(image_shapes[int(b)][0]) for b in act]
@@ -298,13 +360,19 @@ class SmallBatchRunner:
         p.graph.replay()
         out = p.arena.clone()                      # the plan's output buffer is overwritten by the next replay
         # ---- per-call views of the copied arena
-        Mp, Lmax, Mq = p.Mp, p.Lmax, p.Mq
+        Lmax, Mq = p.Lmax, p.Mq
+        Mp = call_lay.sum_p if bucket else p.Mp    # kept pairs of THIS image (a prefix of the plan's pair rows)
         i64 = out[:8 * p.n_i64].view(torch.int64)
         f = out[8 * p.n_i64:].view(torch.float32)
         r = dict(index=i64[:Lt], prediction=i64[Lmax:Lmax + Lt], object=i64[2 * Lmax:2 * Lmax + Mp],
                  scores=f[:Lt], prior=f[Lmax:Lmax + 2 * max(Lt, 1)].view(2, max(Lt, 1))[:, :Lt],
                  weights=f[3 * Lmax:3 * Lmax + Mp], boxes_h=f[3 * Lmax + Mq:3 * Lmax + Mq + 4 * Mp].view(Mp, 4),
                  boxes_o=f[3 * Lmax + 5 * Mq:3 * Lmax + 5 * Mq + 4 * Mp].view(Mp, 4))
+        if bucket:
+            eng.last = dict(p.out, layout=call_lay, plan=p, logits=p.out["logits"][:Mp],
+                            pair_features=p.out["pair_features"][:Mp], x_keep=p.out["x_keep"][:Mp],
+                            y_keep=p.out["y_keep"][:Mp], enc=p.out["enc"][:n_act])
+            return head._results(call_lay, r, dev)
         call_lay = copy.copy(lay)
         cells = np.zeros(lay.n_active, np.int64); cells[:] = L
         call_lay.cells_per_image = cells

@@ -18,10 +18,11 @@ pytestmark = pytest.mark.gpu
 SMALL_CASES = [c for c in cases.EVAL_CASES if c not in ("eval_targets", "many12")]
 
 
-def _run(head, case, seed, small, det=None, shapes=None, feat3=None):
+def _run(head, case, seed, small, det=None, shapes=None, feat3=None, buckets=False):
     eng = head.engine()
     eng.debug = False
     eng.small_batch_max = 8 if small else 0
+    eng.small_batch_buckets = buckets            # exact-shape plans are bit-identical to eager; bucket plans: see below
     det = gpu_run.to_cuda(case["detections"]) if det is None else det
     feat3 = case["feat3"].cuda() if feat3 is None else feat3
     feats = OrderedDict((k, feat3) for k in "0123")
@@ -160,3 +161,112 @@ def test_graph_path_with_exact_row_exponent_passes(monkeypatch):
             assert torch.equal(gl, wl)
     plans = list(head.engine()._small.plans.values())
     assert plans and all(len(p.amax_keep) > 0 for p in plans)
+
+
+def _close(a, b, atol=2e-6, rtol=2e-5):
+    """Bucket plans: integer outputs identical, floats up to the summation order of split-K reductions."""
+    assert len(a) == len(b)
+    for ra, rb in zip(a, b):
+        assert set(ra) == set(rb)
+        for k in ra:
+            assert ra[k].shape == rb[k].shape and ra[k].dtype == rb[k].dtype, k
+            if ra[k].dtype.is_floating_point:
+                assert torch.allclose(ra[k], rb[k], atol=atol, rtol=rtol), (k, (ra[k] - rb[k]).abs().max().item())
+            else:
+                assert torch.equal(ra[k], rb[k]), k
+
+
+def _single_image(i, n_h, n_o, C, p, hw=(800, 1200)):
+    im = synth.make_image(7000 + i, n_h=n_h, n_o=n_o, out_channels=C, pool=p)
+    det = [dict(boxes=im["boxes"].cuda(), labels=im["labels"].cuda(), scores=im["scores"].cuda())]
+    return det, im["pooled"].cuda(), im["feat3"].cuda()
+
+
+def test_bucket_plans_serve_every_shape_of_the_bucket(precision):
+    """One captured plan per BUCKET of (humans, nodes): images of different shapes inside a bucket replay the same plan --
+    larger after smaller, smaller after larger (stale rows of the earlier image stay in the unused tail) -- and every
+    result equals the eager path's: indices / predictions / objects identical, scores and boxes to rounding."""
+    case = cases.build_case("tiny")
+    head = gpu_run.build_head(case).eval()
+
+    class Pool(torch.nn.Module):
+        pooled = None
+
+        def forward(self, features, boxes, image_shapes):
+            assert sum(len(b) for b in boxes) == self.pooled.shape[0]
+            return self.pooled
+
+    head.box_roi_pool = Pool()
+    shapes = [(5, 8), (6, 9), (5, 7), (6, 6), (5, 9), (6, 9)]            # (humans, objects): all in the bucket (6, 15)
+    from skghoi_amd.small import capacity
+    assert len({(capacity(h, 15), capacity(h + o, 30)) for h, o in shapes}) == 1
+    for i, (nh, no) in enumerate(shapes):
+        det, pooled, feat3 = _single_image(i, nh, no, case["C"], case["p"])
+        Pool.pooled = pooled
+        want, wl, wa = _run(head, case, 90 + i, small=False, det=det, shapes=[(800, 1200)], feat3=feat3)
+        got, gl, ga = _run(head, case, 90 + i, small=True, det=det, shapes=[(800, 1200)], feat3=feat3, buckets=True)
+        _close(got, want)
+        assert torch.equal(ga, wa)
+        assert gl.shape == wl.shape and torch.allclose(gl, wl, atol=2e-6, rtol=2e-5)
+        assert got[0]["boxes_h"].shape == (nh * (nh + no - 1), 4)
+    st = head.engine()._small.stats()
+    assert st["captures"] == 1 and st["misses"] == 1 and st["hits"] == len(shapes) - 1, st
+    # and the golden of the reference still holds through a bucket plan
+    g = helpers.load_golden("tiny")
+    head2 = gpu_run.build_head(case).eval()
+    res, _, _ = _run(head2, case, case["rng_seed"], small=True, buckets=True)
+    for k in ("index", "prediction", "object"):
+        assert np.array_equal(res[0][k].cpu().numpy(), g["res0.%s" % k]), k
+    assert np.abs(res[0]["scores"].cpu().numpy() - g["res0.scores"]).max() <= 1e-5
+
+
+def test_plan_eviction_retire_and_recapture_give_eager_results():
+    """max_plans = 2 with three shapes in turn: every call beyond the second evicts the least recently used plan, the
+    evicted plan is destroyed on the next capture's idle-device teardown, and a shape that comes back is captured again.
+    Every result -- first capture, replay of a survivor, re-capture after eviction -- is bit-identical to the eager path
+    (exact-shape plans)."""
+    case = cases.build_case("tiny")
+    head = gpu_run.build_head(case).eval()
+
+    class Pool(torch.nn.Module):
+        pooled = None
+
+        def forward(self, features, boxes, image_shapes):
+            return self.pooled
+
+    head.box_roi_pool = Pool()
+    eng = head.engine()
+    from skghoi_amd.small import SmallBatchRunner
+    eng._small = SmallBatchRunner(eng, max_plans=2)
+    order = [(2, 3), (3, 2), (2, 3), (4, 4), (3, 2), (2, 3), (4, 4)]
+    imgs = {}
+    for i, shp in enumerate(sorted(set(order))):
+        imgs[shp] = _single_image(40 + i, shp[0], shp[1], case["C"], case["p"])
+    for i, shp in enumerate(order):
+        det, pooled, feat3 = imgs[shp]
+        Pool.pooled = pooled
+        want, wl, _ = _run(head, case, 300 + i, small=False, det=det, shapes=[(800, 1200)], feat3=feat3)
+        got, gl, _ = _run(head, case, 300 + i, small=True, det=det, shapes=[(800, 1200)], feat3=feat3)
+        _same(got, want)
+        assert torch.equal(gl, wl)
+        assert head.engine()._small is eng._small and len(eng._small.plans) <= 2
+    st = eng._small.stats()
+    # (2,3) (3,2) miss; (2,3) hit; (4,4) miss, evicts (3,2); (3,2) miss, evicts (2,3); (2,3) miss, evicts (4,4); (4,4) miss
+    assert st["misses"] == 6 and st["hits"] == 1 and st["evictions"] == 4 and st["captures"] == 6, st
+    assert len(eng._small.retired) <= 1                     # everything but the last eviction has been buried
+
+
+def test_engine_rebuild_tears_plans_down_through_the_idle_path():
+    """capture -> a threshold change rebuilds the HeadEngine -> capture again: the old runner's plans are closed by the
+    head (idle-device teardown), not dropped by refcount next to the new capture; results stay equal to eager."""
+    case = cases.build_case("tiny")
+    head = gpu_run.build_head(case).eval()
+    a, _, _ = _run(head, case, 5, small=True)
+    old = head.engine()._small
+    assert old is not None and len(old.plans) == 1
+    head.box_score_thresh = 0.21                            # engine() builds a new HeadEngine on the next call
+    b, lb, _ = _run(head, case, 5, small=True)
+    new = head.engine()._small
+    assert new is not old and len(old.plans) == 0 and not old.retired and len(new.plans) == 1
+    want, lw, _ = _run(head, case, 5, small=False)
+    _same(b, want)
