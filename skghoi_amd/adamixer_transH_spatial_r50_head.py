@@ -239,6 +239,41 @@ def _graph_lists(gh, eng, pre, g):
     return feats, bh, bo, oc, labels, prior, [], []
 
 
+class _Prefetch:
+    """A training batch being prepared ahead of its forward (InteractionHead.prefetch_train): the steps of
+    train_fused.prepare_steps, each resumed on the head's side stream.  advance() runs up to the next host
+    synchronisation point (the caller does other host work meanwhile: the kernel whose result that point reads is
+    running); finish() runs the rest and returns the Prepared batch."""
+
+    def __init__(self, head, gen, dev, stream, inputs):
+        self.head, self.gen, self.dev, self.stream, self.inputs = head, gen, dev, stream, inputs
+        self.prep = None
+        self.done = False
+
+    def advance(self):
+        if self.done:
+            return False
+        with torch.cuda.device(self.dev), torch.cuda.stream(self.stream):
+            try:
+                next(self.gen)
+                return True
+            except StopIteration as end:
+                self.prep = end.value
+                self.prep.ready = torch.cuda.Event()
+                self.prep.ready.record(self.stream)
+                self.done = True
+                return False
+
+    def finish(self):
+        while self.advance():
+            pass
+        return self.prep
+
+    def abandon(self):
+        self.gen.close()
+        self.done = True
+
+
 class InteractionHead(Module):
     """Interaction head that constructs and classifies box pairs (HEAD:29-429): same constructor keywords, forward
     signature and result dictionaries.
@@ -280,9 +315,6 @@ class InteractionHead(Module):
         self.precision = precision
         self.fused_training = True      # False: training through autograd over per-layer Functions (skghoi_amd/train_graph.py)
         self.grad_mode = "autograd"     # "direct": the fused step writes p.grad itself (skghoi_amd/train_fused.py, StepFn)
-        # prefetch_train on a helper thread: measured and left off -- the preparation is mostly Python under the GIL, so
-        # the caller ends up waiting for it (batch-4 bf16 step 2.53 ms against 2.2-2.4 on the caller's thread)
-        self.prefetch_thread = False
         self._engine = None
 
     def engine(self) -> HeadEngine:
@@ -407,25 +439,11 @@ class InteractionHead(Module):
         if dev.type != "cuda":
             raise _capi.SkgError("the interaction head runs on a HIP device only (detections on %s)" % dev)
         eng = self.engine()
-        side = self._prefetch_stream(dev)
-
-        def work():
-            with torch.cuda.device(dev), torch.cuda.stream(side):
-                prep = train_fused.prepare_train(self, eng, detections, image_shapes, targets)
-                prep.ready = torch.cuda.Event()
-                prep.ready.record(side)
-            return prep
-
-        if self.prefetch_thread:
-            # on a helper thread: its waits (two device round trips) and its native calls (detection kernels, the host RNG
-            # draws) release the GIL, so the caller goes on enqueuing the current step's backward and optimizer meanwhile
-            if getattr(self, "_pf_pool", None) is None:
-                from concurrent.futures import ThreadPoolExecutor
-                self._pf_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="skg-prefetch")
-            self._prefetched = self._pf_pool.submit(work)
-        else:
-            self._prefetched = work()
-        return True
+        h = _Prefetch(self, train_fused.prepare_steps(self, eng, detections, image_shapes, targets), dev,
+                      self._prefetch_stream(dev), (detections, image_shapes, targets))
+        h.advance()                            # launches the detection-selection kernel; its counts are read later
+        self._prefetched = h
+        return h
 
     def _prefetch_stream(self, dev):
         st = getattr(self, "_pf_stream", None)
@@ -439,8 +457,11 @@ class InteractionHead(Module):
         self._prefetched = None
         if prep is None:
             return None
-        if hasattr(prep, "result"):
-            prep = prep.result()               # the helper thread's preparation (re-raises what it raised)
+        d, s, t = prep.inputs
+        if not (d is detections and t is targets):
+            prep.abandon()
+            return None
+        prep = prep.finish()
         d, s, t = prep.inputs
         if d is detections and t is targets and (s is image_shapes or list(s) == list(image_shapes)):
             return prep

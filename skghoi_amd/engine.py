@@ -569,21 +569,32 @@ class HeadEngine:
             self._det_off_cache[key] = t
         return t
 
-    def _read_counts(self, countx):
+    def _read_counts(self, countx, defer=False):
         """The forward's one device -> host read.  Small batches poll a HIP event behind an asynchronous copy into pinned
         memory: a blocking copy parks the thread and the wake-up costs tens of microseconds, which at one image per
         forward is a tenth of the whole latency.  Returns a numpy int32 array (a private copy)."""
         n = countx.numel()
-        if n > 4 * 16 + 2 * _capi.CHECKSUM_PARTIALS or _NO_SPIN:   # larger batches: the plain blocking copy
-            return countx.cpu().numpy()
+        if n > 4 * 16 + 2 * _capi.CHECKSUM_PARTIALS or (_NO_SPIN and not defer):   # larger batches: the plain blocking copy
+            return ("blocking", countx, None) if defer else countx.cpu().numpy()
         if self._cnt_host is None or self._cnt_host.numel() < n or self._cnt_host_dev != countx.device:
             self._cnt_host = torch.empty(max(n, 4 * 16 + 2 * _capi.CHECKSUM_PARTIALS), dtype=torch.int32, pin_memory=True)
             self._cnt_event = torch.cuda.Event()
             self._cnt_host_dev = countx.device
+        if defer:                          # read back later: a staging buffer and event of its own (other forwards of
+            host = torch.empty(n, dtype=torch.int32, pin_memory=True)       # this engine may run in between)
+            host.copy_(countx, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record()
+            return ("pinned", host, ev)
         host = self._cnt_host[:n]
         host.copy_(countx, non_blocking=True)
         ev = self._cnt_event
         ev.record()
+        return self._read_counts_end(("pinned", host, ev))
+
+    def _read_counts_end(self, pending):
+        kind, host, ev = pending
+        if kind == "blocking":
+            return host.cpu().numpy()
         if threading.current_thread() is threading.main_thread():
             while not ev.query():
                 pass
@@ -591,7 +602,7 @@ class HeadEngine:
             ev.synchronize()               # a helper thread must not spin: the poll holds the GIL, the wait releases it
         return host.numpy().copy()
 
-    def pre_launch(self, detections, targets, append_gt, training, check_weights=False):
+    def pre_launch(self, detections, targets, append_gt, training, check_weights=False, defer=False):
         """First half of preprocess: score filter + class-wise NMS + top-k on the device and the ONE host
         synchronisation of a forward (per-image counts, plus the parameter checksum riding on the same copy).
         Returns a Preprocessed holding the raw inputs, the selection and the counts; pre_pack() gathers."""
@@ -655,7 +666,18 @@ class HeadEngine:
                                            self.max_human, self.max_object, vt.nverbs.data_ptr(), vt.num_obj,
                                            prior_pow, index.data_ptr(), countx.data_ptr(), _stream()),
                     "skg_preprocess_f32")
-        cntx = self._read_counts(countx)                                        # the one synchronisation point
+        if defer:
+            # the caller goes on with other host work while the kernel runs and comes back with pre_launch_end()
+            return dict(pending=self._read_counts(countx, defer=True), countx=countx, watch=watch, B=B, dev=dev,
+                        index=index, raw=(boxes, scores, labels, det_off))
+        return self.pre_launch_end(dict(pending=None, cntx=self._read_counts(countx), countx=countx, watch=watch, B=B,
+                                        dev=dev, index=index, raw=(boxes, scores, labels, det_off)))
+
+    def pre_launch_end(self, st):
+        """Second half of pre_launch(defer=True): waits for the counts and builds the Preprocessed record."""
+        B, dev, watch, index = st["B"], st["dev"], st["watch"], st["index"]
+        boxes, scores, labels, det_off = st["raw"]
+        cntx = st["cntx"] if st.get("pending") is None else self._read_counts_end(st["pending"])   # the synchronisation point
         cnt = cntx[:4 * B].reshape(B, 4)
         if B and cnt[:, 0].min() < 0:
             bad = int(np.argmax(cnt[:, 0] < 0))

@@ -763,16 +763,31 @@ def _stacked_for(head, dev):
 
 
 def prepare_train(head, eng, detections, image_shapes, targets, before_sync=None):
+    """prepare_steps() run to the end in one go (the inline forward)."""
+    gen = prepare_steps(head, eng, detections, image_shapes, targets, before_sync)
+    try:
+        while True:
+            next(gen)
+    except StopIteration as done:
+        return done.value
+
+
+def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None):
     """The weight-independent part of InteractionHead.forward in training mode (HEAD:92-151 preprocess with GT boxes
-    appended, HEAD:847-868 pairs + spatial encoding, HEAD:703-719 label association, the host RNG of HEAD:574-580 / 939).
+    appended, HEAD:847-868 pairs + spatial encoding, HEAD:703-719 label association, the host RNG of HEAD:574-580 / 939,
+    and the whole TransH term HEAD:207-235 / 936-963: its scores depend only on the step's throw-away embeddings).
     Two host synchronisations: the per-image counts after the preprocess kernel and the positive counts after the
-    association kernel.  before_sync(prep): called right before the second one (the inline forward enqueues the
-    table-independent part of the dense forward there, so that the GPU works while the host waits and draws)."""
+    association kernel.  A GENERATOR that yields right before each of them, so that a prefetching caller can do other host
+    work (enqueue the current step's backward, then its optimizer) while the kernels run, and returns the Prepared batch.
+    before_sync(prep): called right before the second one (the inline forward enqueues the table-independent part of the
+    dense forward there, so that the GPU works while the host waits and draws)."""
     from . import transh
     lib = _capi.lib()
     gh = head.box_pair_head
     K = head.num_classes
-    pre = eng.preprocess(detections, targets, True, True)
+    launched = eng.pre_launch(detections, targets, True, True, defer=True)
+    yield 1
+    pre = eng.pre_pack(eng.pre_launch_end(launched))
     dev = pre.device
     stream = _stream()
     lay = layout.build(pre.n_h, pre.n, pre.L, image_shapes, gh.human_idx, faithful_skip_offset=eng.faithful_skip_offset)
@@ -841,6 +856,7 @@ def prepare_train(head, eng, detections, image_shapes, targets, before_sync=None
     npos_ev = torch.cuda.Event(); npos_ev.record()
     if before_sync is not None:
         before_sync(prep)
+    yield 2
     # host RNG in the reference's order: per image six TransH draws (HEAD:574-580), then randperm(#negatives) (HEAD:939).
     npos_ev.synchronize()                                           # the step's second host synchronisation
     n_pos = npos_h.tolist()
@@ -860,8 +876,23 @@ def prepare_train(head, eng, detections, image_shapes, targets, before_sync=None
     prep.n_pos, prep.M_pos = n_pos, M_pos
     prep.pos_off_d = samp_d[:A + 1]
     prep.perm_d = samp_d[o_perm:o_perm + 2 * max(M_pos, 1)].view(torch.int64)
+    # ---- TransH term (HEAD:207-235, intended semantics): the scores of the positives and of as many sampled negatives per
+    # image, and per image sum_i max(p_i - n_i, -margin).  Nothing here depends on the head's weights (the embeddings are
+    # drawn fresh per image), so it belongs to the preparation -- off the step's critical path when prefetched.
+    scores_all = torch.empty(max(Mp, 1), K, **f32)
+    _check(lib.skg_transh_scores_f32(prep.ent.data_ptr(), prep.rel.data_ptr(), prep.nrm.data_ptr(), K, gh.human_idx,
+                                     meta.data_ptr(), A, scores_all.data_ptr(), stream), "skg_transh_scores_f32")
+    tr = torch.empty(2 * max(M_pos, 1) + A, **f32)                   # pos scores | neg scores | margin partials
+    pos_s, neg_s, mpart = tr[:max(M_pos, 1)], tr[max(M_pos, 1):2 * max(M_pos, 1)], tr[2 * max(M_pos, 1):]
+    max_pos = max(n_pos) if n_pos else 0
+    sws = torch.empty(int(lib.skg_transh_sample_ws_ints(A, max_pos)) + max(M_pos, 1), **i32)
+    _check(lib.skg_transh_sample_f32(labels_all.data_ptr(), scores_all.data_ptr(), K, meta.data_ptr(), A,
+                                     prep.pos_off_d.data_ptr(), max_pos, prep.perm_d.data_ptr(), 1.0, sws.data_ptr(),
+                                     sws.data_ptr() + 4 * (sws.numel() - max(M_pos, 1)), pos_s.data_ptr(),
+                                     neg_s.data_ptr(), mpart.data_ptr(), stream), "skg_transh_sample_f32")
+    prep.pos_s, prep.neg_s, prep.mpart = pos_s[:M_pos], neg_s[:M_pos], mpart
     prep.cross = (pre.boxes, pre.scores, pre.labels, ibuf, grid, keep, sp48, labels_all, prep.ent, prep.rel, prep.nrm,
-                  samp_d, gt_h, gt_o, gt_l, npos_d)
+                  samp_d, gt_h, gt_o, gt_l, npos_d, scores_all, tr, sws)
     prep.keep = (ent_h, rel_h, nrm_h, sh, npos_h)                   # pinned staging: alive until the copies have run
     return prep
 
@@ -913,21 +944,9 @@ class TrainRun:
         g = dict(layout=lay, meta=meta, x_keep=prep.arrays["x_keep"], y_keep=prep.arrays["y_keep"])
         self.r = job.result = eng.score(logits, pre, g, True)
         partial = job.loss_forward(logits)
-        # ---- TransH term (HEAD:207-235, intended semantics): positives and as many sampled negatives per image
-        scores_all = torch.empty(max(Mp, 1), K, **f32)
-        _check(lib.skg_transh_scores_f32(prep.ent.data_ptr(), prep.rel.data_ptr(), prep.nrm.data_ptr(), K, gh.human_idx,
-                                         meta.data_ptr(), A, scores_all.data_ptr(), stream), "skg_transh_scores_f32")
-        out = torch.empty(2 * max(M_pos, 1) + A + 8, **f32)              # pos scores | neg scores | margin partials | losses, scale
-        pos_s, neg_s = out[:max(M_pos, 1)], out[max(M_pos, 1):2 * max(M_pos, 1)]
-        mpart = out[2 * max(M_pos, 1):2 * max(M_pos, 1) + A]
-        tail = out[2 * max(M_pos, 1) + A:]
+        mpart = prep.mpart                                              # TransH margin partials: made by the preparation
+        tail = torch.empty(8, **f32)
         losses, job.loss_scale = tail[:3], tail[4:6]
-        max_pos = max(n_pos) if n_pos else 0
-        sws = torch.empty(int(lib.skg_transh_sample_ws_ints(A, max_pos)) + max(M_pos, 1), **i32)
-        _check(lib.skg_transh_sample_f32(prep.labels.data_ptr(), scores_all.data_ptr(), K, meta.data_ptr(), A,
-                                         prep.pos_off_d.data_ptr(), max_pos, prep.perm_d.data_ptr(), 1.0, sws.data_ptr(),
-                                         sws.data_ptr() + 4 * (sws.numel() - max(M_pos, 1)), pos_s.data_ptr(),
-                                         neg_s.data_ptr(), mpart.data_ptr(), stream), "skg_transh_sample_f32")
         # ---- normalisers (HEAD:167-172, 194-199, 223-228) and the scalars: MarginLoss(margin = 1) is
         #      mean(max(p - n, -margin)) + margin, divided by n_p (HEAD:228-234)
         rows = partial.shape[0]
@@ -939,7 +958,7 @@ class TrainRun:
             norm = skd.start_normalisers(counts, True).get().contiguous()     # ONE fused 3-element all-reduce
         _check(lib.skg_loss_finish_f32(partial.data_ptr(), rows, mpart.data_ptr(), A, M_pos, 1.0, _ptr(norm),
                                        losses.data_ptr(), job.loss_scale.data_ptr(), None, stream), "skg_loss_finish_f32")
-        self.pos_s, self.neg_s = pos_s[:M_pos], neg_s[:M_pos]
+        self.pos_s, self.neg_s = prep.pos_s, prep.neg_s
         return losses
 
     def finish(self, prep):

@@ -248,15 +248,15 @@ def wrap_ddp(module: nn.Module, device=None):
     return nn.parallel.DistributedDataParallel(module, device_ids=ids, find_unused_parameters=True)
 
 
-def prefetch_batch(net, features, detections, image_shapes, targets) -> bool:
+def prefetch_batch(net, features, detections, image_shapes, targets):
     """Hands the NEXT batch to the head for preparation on its side stream (InteractionHead.prefetch_train) while the GPU
-    works on the step just enqueued.  Only when `net` IS the interaction head (training from cached detections /
+    works on the step just enqueued; returns the handle of the preparation in progress (advance() / finish()) or None.  Only when `net` IS the interaction head (training from cached detections /
     features): inside a full detector the head's inputs exist only after the detector has run."""
     mod = net.module if isinstance(net, nn.parallel.DistributedDataParallel) else net
     fn = getattr(mod, "prefetch_train", None)
     if fn is None or not detections or not detections[0]["boxes"].is_cuda:
-        return False
-    return bool(fn(detections, image_shapes, targets))
+        return None
+    return fn(detections, image_shapes, targets) or None
 
 
 def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
@@ -277,12 +277,17 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
     if not lazy and torch.isnan(loss_dict["hoi_loss"]):
         raise ValueError(f"The HOI loss is NaN")
     total = sum(loss for loss in loss_dict.values())
+    # the next batch's preparation is interleaved with this step's host work: each of its two device round trips (selection
+    # counts, positive counts) runs on the side stream while this thread enqueues the backward resp. the optimizer
+    ahead = prefetch_batch(net, *prefetch) if prefetch is not None else None       # selection kernel launched
     total.backward()
+    if ahead is not None:
+        ahead.advance()                  # counts read (ready by now), pairs + association launched
     for ex in exchanges(net):            # data parallel: a rank whose batch bypassed the fused node joins its peers here
         ex.after_backward()
     optimizer.step()
-    if prefetch is not None:             # (features, detections, image_shapes, targets) of the next step
-        prefetch_batch(net, *prefetch)
+    if ahead is not None:
+        ahead.finish()                   # positive counts read, host RNG draws, uploads, TransH term
     if lazy:
         return {k: v.detach() for k, v in loss_dict.items()}, out
     return {k: float(v.detach()) for k, v in loss_dict.items()}, out

@@ -29,9 +29,8 @@ head.box_roi_pool = Pool()
 net = trainer.wrap_ddp(head, device)
 opt = trainer.build_optimizer(net, lr=1e-4)
 pc = time.perf_counter
-for mode in ("inline", "prefetch", "thread", "inline", "prefetch", "thread"):
+for mode in ("inline", "prefetch", "inline", "prefetch"):
     nxt = (feats, dets, shapes, targets) if mode != "inline" else None
-    head.prefetch_thread = mode == "thread"
     for _ in range(6):
         trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=nxt)
     torch.cuda.synchronize()
@@ -41,13 +40,18 @@ for mode in ("inline", "prefetch", "thread", "inline", "prefetch", "thread"):
     for _ in range(N):
         a = pc(); opt.zero_grad(set_to_none=True)
         b = pc(); out = net(feats, dets, shapes, targets); ld = out.pop(); total = sum(ld.values())
+        c0 = pc(); ahead = trainer.prefetch_batch(net, *nxt) if nxt is not None else None
         c = pc(); total.backward()
+        d0 = pc()
+        if ahead is not None:
+            ahead.advance()
         d = pc(); opt.step()
         e = pc()
-        if nxt is not None:
-            trainer.prefetch_batch(net, *nxt)
+        if ahead is not None:
+            ahead.finish()
         f = pc()
-        acc["zero"] += b - a; acc["fwd"] += c - b; acc["bwd"] += d - c; acc["opt"] += e - d; acc["pre"] += f - e
+        acc["zero"] += b - a; acc["fwd"] += c0 - b; acc["bwd"] += d0 - c; acc["opt"] += e - d
+        acc["pre"] += (c - c0) + (d - d0) + (f - e)
     t1 = pc()
     torch.cuda.synchronize()
     t2 = pc()
