@@ -173,6 +173,11 @@ def run_train(B, precision, steps, warmup, device, rank, world, dist_on, prefetc
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
     info = {}
+    pl = getattr(head, "_last_train_plan", None)
+    if pl is not None:
+        import ctypes
+        from skghoi_amd import _capi
+        info["gflop_per_step"] = round(float(_capi.lib().skg_train_flops(ctypes.byref(pl), 2)) / 1e9, 3)
     exs = trainer.exchanges(net)
     if exs:
         # one more step, untimed, with HIP events around the point where the step's stream waits for the gradient exchange:
@@ -611,12 +616,40 @@ def main():
         # (c) the training step at the reference's batch 4 per GPU (main:158): fwd + bwd + AdamW
         _trainer.limit_host_threads(world)
         train = {}
+        busy = {}
+        bpath = os.path.join(ROOT, "profiles", "train_gpu_busy.json")    # kernel time per step from the rocprofv3 run
+        if os.path.isfile(bpath):
+            try:
+                busy = json.load(open(bpath))
+            except Exception:
+                busy = {}
         for prec in ("fp32", "bf16"):
-            el_t, losses, _ = run_train(4, prec, 10, 4, device, rank, world, False)
-            train[prec] = dict(ms_per_step=round(el_t / 10 * 1e3, 3), images_per_s=round(40 / el_t, 2), batch=4,
-                               steps=10, losses={k: round(v, 6) for k, v in losses.items()})
+            ks = 30
+            el_t, losses, inf = run_train(4, prec, ks, 8, device, rank, world, False)
+            ms = el_t / ks * 1e3
+            rec = dict(ms_per_step=round(ms, 3), images_per_s=round(4 * ks / el_t, 2), batch=4, steps=ks,
+                       losses={k: round(v, 6) for k, v in losses.items()})
+            el_i, _, _ = run_train(4, prec, 10, 4, device, rank, world, False, prefetch=False)
+            rec["inline_ms_per_step"] = round(el_i / 10 * 1e3, 3)           # the same step without the look-ahead
+            gf = inf.get("gflop_per_step")
+            if gf:
+                peak = PEAK_F16_MFMA_TFLOPS if prec == "bf16" else PEAK_F32_MFMA_TFLOPS
+                ach = gf / ms                                                # GFLOP / ms = TFLOP/s
+                b = busy.get(prec)
+                rec["roofline"] = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
+                                       frac=round(ach / peak, 4), gflop_per_step=gf,
+                                       gpu_busy_ms=(b or {}).get("ms_per_step"),
+                                       gpu_busy_share=(round(b["ms_per_step"] / ms, 3) if b else None),
+                                       gpu_busy_source=(b or {}).get("source"),
+                                       note="2MNK of every dense product of the step (forward + backward, from the launch "
+                                            "plan: skg_train_flops) / step time / dense MFMA peak of the operand type; "
+                                            "a batch-4 step is ~110 dependent launches of 2-120 us: launch- and "
+                                            "latency-bound, not MFMA-bound")
+            train[prec] = rec
         train["note"] = ("NegativeSampling + MarginLoss + two focal terms, forward + backward + AdamW, 4 synthetic 20x20 "
-                         "images with ground truth appended; bf16 = bf16 GEMM operands, fp32 accumulation / master weights")
+                         "images with ground truth appended; bf16 = bf16 GEMM operands, fp32 accumulation / master weights; "
+                         "every step hands the next batch to the head for preparation (prefetch), as a trainer over a "
+                         "loader of cached detections does")
         out["train"] = train
         torch.set_num_threads(max(1, host_cpu_share() // world))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

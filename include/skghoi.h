@@ -543,6 +543,9 @@ int skg_train_forward_f32(const skg_train_plan* plan_host, int part, void* strea
  * the segments in the arena follows the stages: read-out layers first, box_head last), so a data-parallel caller can
  * exchange the arena chunk by chunk between calls.                                                                      */
 int skg_train_backward_f32(const skg_train_plan* plan_host, int first_stage, int last_stage, void* stream);
+/* Arithmetic of the plan: 2 M N K summed over every dense product it issues (which = 0 forward, 1 backward, 2 both; the
+ * backward is counted with dx0 / dgfeat requested).  For roofline records.                                              */
+double skg_train_flops(const skg_train_plan* plan_host, int which);
 /* Offset (floats) of a saved activation inside ws, for tests: 0 enc, 1 h_node, 2 node, 3 adjacency logits, 4 raw fc_2.   */
 int64_t skg_train_ws_offset(const skg_train_plan* plan_host, int which);
 

@@ -146,6 +146,7 @@ PROTOTYPES = {
     "skg_train_forward_f32": (C.c_int, [C.POINTER(TrainPlan), C.c_int, _vp]),
     "skg_train_backward_f32": (C.c_int, [C.POINTER(TrainPlan), C.c_int, C.c_int, _vp]),
     "skg_train_ws_offset": (C.c_int64, [C.POINTER(TrainPlan), C.c_int]),
+    "skg_train_flops": (C.c_double, [C.POINTER(TrainPlan), C.c_int]),
 }
 
 _LIB = None

@@ -34,6 +34,7 @@ struct Ctx {
     int64_t scratch_need;        // floats
     float* scratch;              // split-K partials (one region, reused by consecutive launches of the stream)
     int rc;
+    double flops;                // 2 M N K over every dense product issued (sizing pass: what the plan WILL issue)
 };
 
 // ---- skg_gemmx descriptor builders (skghoi_amd/gemmx.py: forward / input_grad / weight_grad)
@@ -113,6 +114,7 @@ static void launch(Ctx& c, skg_gemmx_desc* ops, int n) {
             }
         }
         if (used > c.scratch_need) c.scratch_need = used;
+        for (int i = 0; i < cnt; ++i) c.flops += 2.0 * live[i0 + i].M * (double)live[i0 + i].N * live[i0 + i].K;
         if (c.dry) continue;
         int rc = bf16 ? skg_gemmx_bf16(live + i0, cnt, c.stream) : skg_gemmx_f32(live + i0, cnt, c.stream);
         if (rc) { c.rc = rc; return; }
@@ -284,6 +286,7 @@ static void forward(Ctx& c, const Ws& w, int part) {
             else if (i == OS) { d.C = w.Tos; d.P = w.C1o; d.p_idx = P->grid_o; d.ldp = 1024; }
             else if (i == SO) { d.C = w.Tso; d.P = w.C1h; d.p_idx = P->grid_h; d.ldp = 1024; }
             else { d.C = w.Tg; d.P = w.G1; d.p_idx = P->grid_img; d.ldp = 1024; d.out_rows = P->grid_pair; }
+            c.flops += 2.0 * Mg * 1024.0 * 1024.0;
             CK(skg_gemm_f32(&d, c.stream));
         }
     }
@@ -509,7 +512,7 @@ int64_t skg_train_ws_floats(const skg_train_plan* P) {
     int rc = check_plan(P);
     if (rc) return rc;
     Ws w; layout_ws(P, nullptr, w);
-    Ctx c{P, nullptr, true, 0, nullptr, 0};
+    Ctx c{P, nullptr, true, 0, nullptr, 0, 0.0};
     forward(c, w, 0); forward(c, w, 1); backward(c, w, 0, SKG_TRAIN_BWD_STAGES);
     return w.total + c.scratch_need + 4;
 }
@@ -521,9 +524,9 @@ int skg_train_forward_f32(const skg_train_plan* P, int part, void* stream) {
     if (part == 1 && (!P->ent || !P->logits || !P->pair_features)) return SKG_E_ARG;
     Ws w; layout_ws(P, P->ws, w);
     if (w.total > P->ws_floats) return SKG_E_LIMIT;
-    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0};
+    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0, 0.0};
     // bound the scratch: the sizing pass told the caller how much the largest launch needs
-    Ctx d{P, nullptr, true, 0, nullptr, 0};
+    Ctx d{P, nullptr, true, 0, nullptr, 0, 0.0};
     forward(d, w, part);
     if (w.total + d.scratch_need > P->ws_floats) return SKG_E_LIMIT;
     forward(c, w, part);
@@ -538,13 +541,23 @@ int skg_train_backward_f32(const skg_train_plan* P, int first_stage, int last_st
         first_stage > last_stage)
         return SKG_E_ARG;
     Ws w; layout_ws(P, P->ws, w);
-    Ctx d{P, nullptr, true, 0, nullptr, 0};
+    Ctx d{P, nullptr, true, 0, nullptr, 0, 0.0};
     backward(d, w, first_stage, last_stage);
     if (w.total + d.scratch_need > P->ws_floats) return SKG_E_LIMIT;
-    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0};
+    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0, 0.0};
     backward(c, w, first_stage, last_stage);
     if (!c.rc) { hipError_t e = hipGetLastError(); if (e != hipSuccess) c.rc = (int)e; }
     return c.rc;
+}
+
+/* 2 M N K summed over every dense product of the step: which = 0 forward (both parts), 1 backward, 2 both */
+double skg_train_flops(const skg_train_plan* P, int which) {
+    if (check_plan(P)) return -1.0;
+    Ws w; layout_ws(P, nullptr, w);
+    Ctx c{P, nullptr, true, 0, nullptr, 0, 0.0};
+    if (which == 0 || which == 2) { forward(c, w, 0); forward(c, w, 1); }
+    if (which == 1 || which == 2) backward(c, w, 0, SKG_TRAIN_BWD_STAGES);
+    return c.flops;
 }
 
 /* offset (floats) of a saved activation inside the workspace: 0 = pair-independent debug reads (tests) */

@@ -651,6 +651,7 @@ class NativeJob(TrainJob):
                 x0.shape[0], x0.shape[1], st.seg["bh1_w"][1][1], 1024))
         S["x0"], S["gfeat"] = x0, gfeat
         pl = self.plan = self._plan(x0, gfeat)
+        self.head._last_train_plan = pl            # (bench.py reads the step's arithmetic off it: skg_train_flops)
         n = int(lib.skg_train_ws_floats(C.byref(pl)))
         if n < 0:
             _check(n, "skg_train_ws_floats")
@@ -671,6 +672,10 @@ class NativeJob(TrainJob):
         _check(_capi.lib().skg_train_forward_f32(C.byref(pl), 1, _stream()), "skg_train_forward_f32[1]")
         self.S.update(PF=self.PF, logits=self.logits_full[:self.lay.sum_p])
         return self.S
+
+    def flops(self):
+        """2 M N K over every dense product of this step (forward + backward), from the plan itself."""
+        return float(_capi.lib().skg_train_flops(C.byref(self.plan), 2))
 
     def saved(self, which):
         """A saved activation out of the workspace (tests): 'enc', 'h_node', 'node', 'adjacency'."""
