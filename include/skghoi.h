@@ -153,7 +153,7 @@ typedef struct {
     const float* res; int64_t ldres;   /* [M, N]                                                                    */
     /* split-K (BIAS / BIAS_RELU / BIAS_RES_RELU): K is cut in split_k slices computed by separate workgroups; raw partial sums
      * go to split_ws [split_k, M, N] and a second kernel adds them in slice order and applies the epilogue.          */
-    int32_t split_k;                   /* 0 or 1 = off; < 0: STREAM-K with -split_k workgroups (see skg_gemm_sk_ws_floats) */
+    int32_t split_k;                   /* 0 or 1 = off                                                              */
     float   w_scale;                   /* with w_split: 1 / scale given to skg_split_weights_f16x2 (a power of two)  */
     float*  split_ws;
     /* optional: W as two fp16 planes per element (h + m, 22 significant bits) in MFMA-fragment order, made by
@@ -174,13 +174,6 @@ typedef struct {
 int skg_row_exponents_f32(const float* A, int64_t lda, const int32_t* a_rows, int M, int K, int32_t* exp_out, void* stream);
 
 int skg_gemm_f32(const skg_gemm_desc* desc_host, void* stream);
-/* Stream-K form of skg_gemm_f32 for mid-size problems (a few hundred 128 x 128 tiles: eval batches of 2..16 images, the grid
- * GEMMs of a batch-4 training step): split_k = -G launches exactly G workgroups that share the tiles x k-tiles iteration
- * space evenly; tiles cut by a workgroup boundary are completed by their last arriver (deterministic: partials are always
- * added in workgroup order), with ANY epilogue.  Needs K % 16 == 0, no a_rows, no w_split.  split_ws = this many floats
- * (16-byte aligned, independent of M and N but for the limit of 16384 tiles), of which the first 16384 words must be ZERO
- * before the first launch (the kernel leaves them zero); launches sharing a workspace must be ordered on one stream.                                                   */
-int64_t skg_gemm_sk_ws_floats(int M, int N, int G);
 
 /* Re-encodes an nn.Linear weight W [N, K] (fp32, leading dimension ldw) for skg_gemm_desc.w_split: every value of
  * scale * W becomes h + m (two fp16), stored as 1 KiB planes [ceil(N/32)][ceil(K/16)][h|m][k half][32 rows][8 k],

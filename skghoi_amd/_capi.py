@@ -95,7 +95,6 @@ PROTOTYPES = {
     "skg_transh_draw_f32": (C.c_int, [_vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "skg_transh_draw_train_f32": (C.c_int, [_vp, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "skg_gemm_dot_partials": (C.c_int, [C.POINTER(GemmDesc)]),
-    "skg_gemm_sk_ws_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "skg_split_weights_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "skg_split_weights_f16x2": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _f32, _vp, _vp]),
     "skg_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),

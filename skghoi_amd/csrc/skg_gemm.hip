@@ -87,28 +87,12 @@ __device__ __forceinline__ const char* skg_uniform_ptr(const char* p) {
     return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
 }
 
-// ---- stream-K (mid-size problems: a few hundred 128 x 128 tiles, skg_gemm_sk_kernel below).  One segment = the k-tiles
-// [k0, k1) of output tile `tile` that a workgroup owns; a tile whose k range is shared by n_contrib > 1 workgroups is
-// finished by whichever of them arrives LAST (no workgroup ever waits for another one).
-struct skg_sk_seg {
-    int tile, k0, k1;            // linear tile index (N fastest), k-tile range
-    int n_contrib, w_lo;         // workgroups sharing the tile, the first of them
-    int64_t tile_it0;            // first iteration (tile * k-tiles) of the tile
-    int64_t I; int G;            // total iterations, workgroups: workgroup x owns iterations [x I / G, (x + 1) I / G)
-    float* slots;                // [G][2][64][256] partial accumulators in register order
-    uint32_t* tickets;           // [tiles], zero between launches
-};
-#define SKG_SK_SLOT 16384        // floats per partial tile (128 x 128)
-#define SKG_SK_TICKETS 16384     // words reserved for the tickets at the head of the workspace (fixed: a workspace can be
-                                 // reused by launches of any shape without slot data ever landing on a ticket)
-
 // EPI >= 0: epilogue fixed at compile time; EPI < 0: taken from the descriptor (grouped launches of small GEMMs).
 // T = tile scale: block tile 64T x 64T, wave tile 32T x 32T = T x T MFMA tiles (T = 2: 128 x 128, the throughput
 // shape; T = 1: 64 x 64 for small M, four times the workgroups for the same problem).
 // MODE = main loop: 0 register-staged fp32 MFMA, 1 DMA-staged fp32 MFMA, 2 fp16x2-split operands on the fp16 MFMA.
 template <int EPI_T, int MODE, int T>
-__device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_id, float* smem,
-                                              const skg_sk_seg* sk = nullptr) {
+__device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_id, float* smem) {
     static_assert(MODE == 1 || MODE == 3 || T == 2, "only the DMA-staged and the latency loop have a 64 x 64 variant");
     static_assert(MODE != 3 || T == 1, "the latency loop is a 64 x 64 tile");
     constexpr bool GLDS = MODE == 1;
@@ -119,7 +103,6 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
     // [s * tiles, (s + 1) * tiles); raw partial sums land in d.split_ws[s] and skg_splitk_reduce_kernel applies the
     // bias / ReLU epilogue in a fixed slice order (deterministic).
     int kt_begin = 0, kt_end = (d.K + BK - 1) / BK, split_slice = 0;
-    if (sk) { kt_begin = sk->k0; kt_end = sk->k1; }
     if (d.split_k > 1) {
         const int tiles = (int)skg_gemm_blocks(d.M, d.N, Kmap, T);
         split_slice = block_id / tiles;
@@ -145,10 +128,7 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
     {
         int g, NG;
         skg_gemm_map(nbn, Kmap, T, g, NG);
-        if (sk) {
-            bn = sk->tile % nbn;
-            bm = sk->tile / nbn;
-        } else if (NG >= 8 || (int64_t)nbm * nbn <= SKG_DIRECT_MAP_TILES) {
+        if (NG >= 8 || (int64_t)nbm * nbn <= SKG_DIRECT_MAP_TILES) {
             bn = block_id % nbn;
             bm = block_id / nbn;
         } else {
@@ -643,63 +623,6 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
         }
     }
 
-    // ---- stream-K: a tile shared by several workgroups.  Every contributor publishes its partial accumulators (register
-    // order: 64 coalesced dword stores per lane) and takes a ticket; the LAST arriver adds all partials in contributor order
-    // -- the same order whoever is last: the result is deterministic -- and goes on to the epilogue; the others are done.
-    // Publish: plain stores -> every wave's vmcnt(0) -> barrier -> one lane: agent-scope release, vmcnt(0), ticket add.
-    // Last arriver: agent-scope acquire -> vmcnt(0) -> barrier -> plain loads (MI355X_MICROARCH.md, inter-workgroup forms).
-    if constexpr (MODE == 1 && T == 2) {
-        if (sk && sk->n_contrib > 1) {
-            const int w = blockIdx.x;
-            auto slot_of = [&](int x) {
-                const int64_t x0 = (int64_t)x * sk->I / sk->G;             // first iteration of workgroup x
-                return sk->slots + ((int64_t)2 * x + (x0 < sk->tile_it0 ? 1 : 0)) * SKG_SK_SLOT;
-            };
-            float* mine = slot_of(w);
-#pragma unroll
-            for (int mi = 0; mi < T; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < T; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mine[((mi * T + ni) * 16 + r) * 256 + tid] = acc[mi][ni][r];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            int* flag = reinterpret_cast<int*>(smem);                      // the staging tiles are dead
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const uint32_t old = __hip_atomic_fetch_add(sk->tickets + sk->tile, 1u, __ATOMIC_RELAXED,
-                                                            __HIP_MEMORY_SCOPE_AGENT);
-                const int last = old == (uint32_t)(sk->n_contrib - 1);
-                if (last) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(sk->tickets + sk->tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
-                }
-                *flag = last;
-            }
-            __syncthreads();
-            const int last = *flag;
-            __syncthreads();                                               // (smem is reused by the epilogue)
-            if (!last) return;
-#pragma unroll
-            for (int mi = 0; mi < T; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < T; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-            for (int j = 0; j < sk->n_contrib; ++j) {
-                const float* src = slot_of(sk->w_lo + j);
-#pragma unroll
-                for (int mi = 0; mi < T; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < T; ++ni)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] += src[((mi * T + ni) * 16 + r) * 256 + tid];
-            }
-        }
-    }
-
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5),
     // i.e. a lane owns ONE column of 16 rows: stored directly that is 4-byte accesses.  Instead each wave transposes
     // its accumulators through LDS (the staging tiles are dead now; 32 rows x 64 columns per pass, rows padded to 68
@@ -913,44 +836,6 @@ __global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_kernel(const skg_gemm_
     skg_gemm_tile<EPI, MODE, T>(d, blockIdx.x, smem);
 }
 
-// ---- stream-K launch for MID-SIZE problems (a few hundred 128 x 128 tiles: 2..16 images of eval, the grid GEMMs of a
-// batch-4 training step).  With one workgroup per tile such a problem fills 78 % of the CUs with one wave per SIMD (M = 3200,
-// N = 1024: 200 tiles, 58-62 % MFMA duty, 83 us for work that takes 43 us at peak), 64 x 64 tiles are LDS-read bound, and
-// split-K 5 moves 65 MB of partials through a second launch.  Here exactly G workgroups (two per CU) share the
-// tiles x k-tiles iteration space evenly: workgroup w owns iterations [w I / G, (w + 1) I / G) -- every SIMD gets the same
-// number of MFMAs -- walks them tile by tile on the direct-to-LDS loop, and tiles cut by a workgroup boundary are
-// finished by their last arriver (skg_gemm_tile).  d.split_k = -G, d.split_ws = skg_gemm_sk_ws_floats() floats whose
-// first `tiles` words are zero.
-template <int EPI>
-__global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_sk_kernel(const skg_gemm_desc d) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
-    const int G = -d.split_k;
-    const int nbm = (d.M + BM - 1) / BM, nbn = (d.N + BN - 1) / BN;
-    const int kt = d.K / BK;
-    const int tiles = nbm * nbn;
-    skg_sk_seg sk;
-    sk.I = (int64_t)tiles * kt; sk.G = G;
-    sk.tickets = reinterpret_cast<uint32_t*>(d.split_ws);
-    sk.slots = d.split_ws + SKG_SK_TICKETS;
-    const int w = blockIdx.x;
-    int64_t it = (int64_t)w * sk.I / G;
-    const int64_t it_end = (int64_t)(w + 1) * sk.I / G;
-    while (it < it_end) {
-        sk.tile = (int)(it / kt);
-        sk.tile_it0 = (int64_t)sk.tile * kt;
-        sk.k0 = (int)(it - sk.tile_it0);
-        const int64_t left = it_end - it;
-        sk.k1 = left < kt - sk.k0 ? sk.k0 + (int)left : kt;
-        // workgroup that owns iteration i: ((i + 1) G - 1) / I
-        sk.w_lo = (int)(((sk.tile_it0 + 1) * G - 1) / sk.I);
-        const int w_hi = (int)(((sk.tile_it0 + kt) * G - 1) / sk.I);
-        sk.n_contrib = w_hi - sk.w_lo + 1;
-        skg_gemm_tile<EPI, 1, 2>(d, 0, smem, &sk);
-        it += sk.k1 - sk.k0;
-        __syncthreads();                                   // the next segment restages the LDS tiles
-    }
-}
-
 // Several independent small GEMMs in ONE launch (node-row GEMMs with M = sum n_h or sum n fill a fraction of the 256
 // CUs each; grouped they run side by side).  Block ranges: [start[g], start[g+1]).
 struct skg_gemm_group_args {
@@ -1137,20 +1022,12 @@ extern "C" int skg_gemm_small_tiles(int tiles) {
 
 // 64 x 64 tiles when the 128 x 128 grid would leave most CUs idle (small M: low-batch inference); needs the DMA path.
 static int skg_gemm_tile_scale(const skg_gemm_desc* d) {
-    if (d->split_k < 0) return 2;                         // stream-K runs on the 128 x 128 direct-to-LDS loop
     const bool glds = SKG_USE_GLDS && BK == 16 && (d->K % BK) == 0 && !d->a_rows &&
                       (int64_t)BM * d->lda * 4 < 0xffffffffLL && (int64_t)BN * d->ldw * 4 < 0xffffffffLL;
     const int64_t tiles128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * (d->split_k > 1 ? d->split_k : 1);
     if (d->w_split && (d->K % 16) == 0 && d->w_scale > 0.f) return 2;
     // M <= 64: a 128-row tile would spend half of its MFMAs on padding rows whatever the grid size (box_head at one image)
     return (glds && (tiles128 < g_small_tiles || d->M <= 64)) ? 1 : 2;
-}
-
-extern "C" int64_t skg_gemm_sk_ws_floats(int M, int N, int G) {
-    if (M <= 0 || N <= 0 || G <= 0) return SKG_E_ARG;
-    const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    if (tiles > SKG_SK_TICKETS) return SKG_E_LIMIT;
-    return SKG_SK_TICKETS + (int64_t)G * 2 * SKG_SK_SLOT;
 }
 
 extern "C" int skg_gemm_dot_partials(const skg_gemm_desc* dh) {
@@ -1164,12 +1041,6 @@ static int skg_gemm_validate(const skg_gemm_desc& d) {
                                           d.epilogue != SKG_EPI_BIAS_RES_RELU) || d.split_k > 64))
         return SKG_E_ARG;
     if (d.M < 0 || d.N <= 0 || d.K <= 0 || !d.A || !d.W) return SKG_E_ARG;
-    if (d.split_k < 0) {                                  // stream-K: the direct-to-LDS loop's requirements, a workspace
-        const bool glds = SKG_USE_GLDS && BK == 16 && (d.K % BK) == 0 && !d.a_rows &&
-                          (int64_t)BM * d.lda * 4 < 0xffffffffLL && (int64_t)BN * d.ldw * 4 < 0xffffffffLL;
-        if (!glds || !d.split_ws || d.split_k < -4096 || d.w_split || !skg_aligned16(d.split_ws)) return SKG_E_ARG;
-        if ((int64_t)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) > SKG_SK_TICKETS) return SKG_E_LIMIT;
-    }
     if ((d.K & 3) || (d.lda & 3) || (d.ldw & 3)) return SKG_E_ALIGN;
     if (!skg_aligned16(d.A) || !skg_aligned16(d.W)) return SKG_E_ALIGN;
     if (d.lda < d.K && !d.a_rows && d.M > 1) return SKG_E_ARG;
@@ -1257,18 +1128,6 @@ extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
     if (d.M == 0) return 0;
     const bool glds = SKG_USE_GLDS && BK == 16 && (d.K % BK) == 0 && !d.a_rows &&
                       (int64_t)BM * d.lda * 4 < 0xffffffffLL && (int64_t)BN * d.ldw * 4 < 0xffffffffLL;
-    if (d.split_k < 0) {
-        dim3 grid((unsigned)(-d.split_k)), block(256);
-        hipStream_t s = (hipStream_t)stream;
-        switch (d.epilogue) {
-            case SKG_EPI_BIAS:          hipLaunchKernelGGL((skg_gemm_sk_kernel<SKG_EPI_BIAS>), grid, block, 0, s, d); break;
-            case SKG_EPI_BIAS_RELU:     hipLaunchKernelGGL((skg_gemm_sk_kernel<SKG_EPI_BIAS_RELU>), grid, block, 0, s, d); break;
-            case SKG_EPI_MUL_RELU:      hipLaunchKernelGGL((skg_gemm_sk_kernel<SKG_EPI_MUL_RELU>), grid, block, 0, s, d); break;
-            case SKG_EPI_RELU_DOT:      hipLaunchKernelGGL((skg_gemm_sk_kernel<SKG_EPI_RELU_DOT>), grid, block, 0, s, d); break;
-            case SKG_EPI_BIAS_RES_RELU: hipLaunchKernelGGL((skg_gemm_sk_kernel<SKG_EPI_BIAS_RES_RELU>), grid, block, 0, s, d); break;
-        }
-        return skg_launch_status();
-    }
     const bool split = d.w_split && (d.K % 16) == 0 && d.w_scale > 0.f;
     const int T = split ? 2 : skg_gemm_tile_scale(&d);
     const int64_t nblk = skg_gemm_blocks(d.M, d.N, d.K, T) * (d.split_k > 1 ? d.split_k : 1);

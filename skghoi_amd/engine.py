@@ -296,39 +296,10 @@ def pick_split_k(M, N, K, target_blocks=1024):
     return int(max(1, min(-(-target_blocks // blocks), K // 256, 64)))
 
 
-# ---- stream-K for mid-size GEMMs (csrc/skg_gemm.hip, skg_gemm_sk_kernel): G workgroups share tiles x k-tiles evenly.
-STREAM_K = _os.environ.get("SKG_STREAM_K", "1") == "1"     # developer switch
-STREAM_K_MIN_TILES, STREAM_K_MAX_TILES = 96, 1536       # 128 x 128 tiles of the problem (measured window)
-_SK_WS = {}
-
-
-def pick_stream_k(M, N, K, a_rows=None):
-    """Workgroups of a stream-K launch for this problem, or 0 for the ordinary tile-per-workgroup launch."""
-    if not STREAM_K or a_rows is not None or K % 16 or K < 256 or _active_splits() is not None:
-        return 0
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if not (STREAM_K_MIN_TILES <= tiles <= STREAM_K_MAX_TILES):
-        return 0
-    return 512
-
-
-def stream_k_workspace(device, G, M, N):
-    """The partial-tile workspace of stream-K launches on the CURRENT stream of `device` (launches that share it are
-    ordered on that stream; a captured plan's two branches run on two streams and get one each).  Tickets zeroed once."""
-    key = (device.index, _stream())
-    need = int(_capi.lib().skg_gemm_sk_ws_floats(M, N, G))
-    ws = _SK_WS.get(key)
-    if ws is None or ws.numel() < need:
-        ws = torch.zeros(need, device=device, dtype=torch.float32)
-        _SK_WS[key] = ws
-    return ws
-
-
-def dot_partials(M, N, K, lda, ldw, stream_k=0):
+def dot_partials(M, N, K, lda, ldw):
     """Slab count of the dot_partial output of an EPI_RELU_DOT launch (depends on the tile shape the launcher picks)."""
     d = _capi.GemmDesc()
     d.M, d.N, d.K, d.lda, d.ldw, d.epilogue = M, N, K, lda, ldw, _capi.EPI_RELU_DOT
-    d.split_k = -stream_k if stream_k else 0
     d.w_split = 1 if (_active_splits() is not None and K % 16 == 0) else 0       # only null / non-null matters here
     d.w_scale = 1.0
     n = _capi.lib().skg_gemm_dot_partials(C.byref(d))
@@ -337,14 +308,8 @@ def dot_partials(M, N, K, lda, ldw, stream_k=0):
     return n
 
 
-def gemm(A, W, bias, C_out, M, N, K, epilogue, stream_k=None, **kw):
-    """One skg_gemm_f32 launch (see gemm_desc for the keywords).  stream_k: None = decide by shape (pick_stream_k), 0 = off,
-    G = that many workgroups."""
-    if stream_k is None:
-        stream_k = pick_stream_k(M, N, K, kw.get("a_rows")) if not kw.get("split_k") else 0
-    if stream_k:
-        kw["split_k"] = -int(stream_k)
-        kw["split_ws"] = stream_k_workspace(A.device, int(stream_k), M, N)
+def gemm(A, W, bias, C_out, M, N, K, epilogue, **kw):
+    """One skg_gemm_f32 launch (see gemm_desc for the keywords)."""
     d = gemm_desc(A, W, bias, C_out, M, N, K, epilogue, **kw)
     keep_exp = enqueue_row_exponents(d, A.device) if d.w_split else None
     timed = GEMM_TIMER is not None and (GEMM_TIMER_EPI is None or epilogue in GEMM_TIMER_EPI)
@@ -992,20 +957,16 @@ class HeadEngine:
                     dict(P=C1h, p_idx=grid_h, ldp=1024))]
             if need_S is not None:
                 need_S()
-            if pick_stream_k(Mg, 1024, 1024):   # mid-size grids: each GEMM alone fills every SIMD evenly (stream-K)
-                for a, kw in fc2:
-                    gemm(*a, **kw)
-            elif Mg < self.GROUP_FC2_BELOW:     # small grids: one launch fills the CUs better than three (+17 % at 4 images)
+            if Mg < self.GROUP_FC2_BELOW:       # small grids: one launch fills the CUs better than three (+17 % at 4 images)
                 gemm_group(fc2)
             else:
                 for a, kw in fc2:
                     gemm(*a, **kw)
             # ---- attention fc_3 + ReLU + adjacency dot (HEAD:896-897)
-            sk = pick_stream_k(Mg, 1024, 1024)
-            n_part = dot_partials(Mg, 1024, 1024, T.stride(0), pw.att["w3"].stride(0), stream_k=sk)
+            n_part = dot_partials(Mg, 1024, 1024, T.stride(0), pw.att["w3"].stride(0))
             part = torch.empty(n_part, Mg, **f32)
             gemm(T, pw.att["w3"], pw.att["b3"], None, Mg, 1024, 1024, _capi.EPI_RELU_DOT, dot_w=pw.adj_w,
-                 dot_partial=part, stream_k=sk)
+                 dot_partial=part)
             # ---- softmax-weighted aggregation before fc_3 (HEAD:907-922)
             U = torch.empty(Mh, 1024, **f32); V = torch.empty(Mn, 1024, **f32); adj = torch.empty(Mg, **f32)
             _capi.check(lib.skg_graph_aggregate_f32(part.data_ptr(), n_part, Mg, pw.adj_b, meta.data_ptr(), A,

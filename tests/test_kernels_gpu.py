@@ -574,53 +574,3 @@ def test_gemm_bf16_random():
         tol = 2e-2 if out_bf16 else 2e-5
         assert (out[:, :N].double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), it
         assert torch.all(out[:, N:].float() == -7.0), it
-
-
-@pytest.mark.parametrize("epi", ["bias", "bias_relu", "mul_relu", "relu_dot", "res_relu"])
-@pytest.mark.parametrize("M,N,K,G", [(3120, 1024, 1024, 512), (1000, 1024, 512, 256), (3200, 118, 2048, 512),
-                                     (700, 300, 256, 300), (130, 1024, 1024, 96)])
-def test_stream_k_launch_equals_the_tile_per_workgroup_launch(M, N, K, G, epi):
-    """skg_gemm_f32 with split_k = -G (stream-K: G workgroups share tiles x k-tiles evenly, cut tiles are completed by
-    their last arriver) against the ordinary launch, every epilogue, ragged M / N, more and fewer workgroups than tiles:
-    equal to fp32 summation order (the k range of a cut tile is summed in 2-4 pieces), deterministic run to run, and the
-    ticket words are back at zero afterwards (the next launch and every graph replay start clean)."""
-    from skghoi_amd import engine as E
-    g = torch.Generator().manual_seed(M + N + K)
-    A = (torch.rand(M, K, generator=g) * 2 - 1).cuda(); W = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).cuda()
-    b = torch.rand(N, generator=g).cuda()
-    kw = {}
-    code = dict(bias=_capi.EPI_BIAS, bias_relu=_capi.EPI_BIAS_RELU, mul_relu=_capi.EPI_MUL_RELU,
-                relu_dot=_capi.EPI_RELU_DOT, res_relu=_capi.EPI_BIAS_RES_RELU)[epi]
-
-    def run(sk):
-        C = torch.zeros(M, N, device="cuda")
-        kw = {}
-        extra = {}
-        if epi == "mul_relu":
-            P = torch.rand(37, N, generator=g).cuda(); Q = torch.rand(53, N, generator=g).cuda()
-            kw = dict(P=P, p_idx=(torch.arange(M) % 37).int().cuda(), ldp=N, Q=Q, q_idx=(torch.arange(M) % 53).int().cuda(),
-                      ldq=N, mbias=b, C_raw=torch.zeros(M, N, device="cuda"), ldc_raw=N,
-                      out_rows=torch.where(torch.arange(M) % 7 == 0, -1, torch.arange(M)).int().cuda())
-            extra["raw"] = kw["C_raw"]
-        if epi == "relu_dot":
-            n_part = E.dot_partials(M, N, K, K, K, stream_k=sk)
-            kw = dict(dot_w=b, dot_partial=torch.zeros(n_part, M, device="cuda"))
-            extra["dot"] = kw["dot_partial"]
-        if epi == "res_relu":
-            kw = dict(res=torch.rand(M, N, generator=g).cuda(), ldres=N)
-        E.gemm(A, W, b, None if epi == "relu_dot" else C, M, N, K, code, stream_k=sk, **kw)
-        torch.cuda.synchronize()
-        if epi == "relu_dot":
-            return extra["dot"].sum(dim=0), None
-        return C, extra.get("raw")
-
-    g = torch.Generator().manual_seed(1); c0, r0 = run(0)
-    g = torch.Generator().manual_seed(1); c1, r1 = run(G)
-    g = torch.Generator().manual_seed(1); c2, r2 = run(G)
-    scale = max(c0.abs().max().item(), 1.0)
-    assert (c1 - c0).abs().max().item() <= 2e-6 * scale * (4 if epi == "relu_dot" else 1), (c1 - c0).abs().max().item()
-    assert torch.equal(c1, c2)                                   # deterministic whichever workgroup arrives last
-    if r0 is not None:
-        assert (r1 - r0).abs().max().item() <= 2e-6 * max(r0.abs().max().item(), 1.0)
-    ws = E.stream_k_workspace(torch.device("cuda", 0), G, M, N)
-    assert int(ws[:16384].view(torch.int32).abs().sum()) == 0     # tickets restored
