@@ -10,6 +10,7 @@
 // the one skghoi_amd/train_fused.py (TrainJob) describes; the algebra is DESIGN.md section 3.
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <stdlib.h>
 #include "skghoi.h"
 
 namespace {
@@ -78,12 +79,22 @@ static skg_gemmx_desc WG(const Mat& dz, const Mat& x, const Mat& dW, float* db, 
     return d;
 }
 
-// Split-K factor of one product: measured on MI355X at the training shapes (tools/gemmx_split_sweep.py) -- the exact fp32
-// loop is best at ~1000 workgroups, the bf16 loop at ~450; slices keep >= 128 k.
+// Split-K factor of one product: measured on MI355X at the training shapes (tools/gemmx_split_sweep.py; re-swept on the whole
+// batch-4 step in round 3: 200 ... 800 / 500 ... 1400 workgroups and a per-LAUNCH instead of per-product count all came out
+// level or slower) -- the exact fp32 loop is best at ~1000 workgroups, the bf16 loop at ~450; slices keep >= 128 k.
+static int split_target(int bk) {
+    static int t16 = 0, t32 = 0;
+    if (!t16) {
+        const char* a = getenv("SKG_SPLIT_TARGET_F32"); const char* b = getenv("SKG_SPLIT_TARGET_BF16");    // developer knobs
+        t16 = a && atoi(a) > 0 ? atoi(a) : 1000;
+        t32 = b && atoi(b) > 0 ? atoi(b) : 448;
+    }
+    return bk == 16 ? t16 : t32;
+}
 static int pick_split(const skg_gemmx_desc& o, int bk) {
     int64_t tiles = (int64_t)((o.M + 127) / 128) * ((o.N + 127) / 128);
     int kt = (o.K + bk - 1) / bk;
-    int target = bk == 16 ? 1000 : 448;
+    int target = split_target(bk);
     int cap = kt * bk / 128; if (cap > 64) cap = 64;
     if (tiles == 0 || cap < 2) return 1;
     int sk = (int)((double)target / (double)tiles + 0.5);
