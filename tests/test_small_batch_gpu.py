@@ -270,3 +270,30 @@ def test_engine_rebuild_tears_plans_down_through_the_idle_path():
     assert new is not old and len(old.plans) == 0 and not old.retired and len(new.plans) == 1
     want, lw, _ = _run(head, case, 5, small=False)
     _same(b, want)
+
+
+@pytest.mark.parametrize("name", ["tiny", "nanbox", "nms", "iter1", "iter0", "full20"])
+def test_bucket_plans_reproduce_the_reference_goldens(name, precision):
+    """Every single-image eval case through a BUCKET plan (capacity >= the image's graph; padded tails in every row space):
+    integer outputs equal the eager path's and the reference's golden, floats to rounding -- including the zero-area boxes of
+    `nanbox` (NaN scrub next to the zero-filled padding), NMS + top-k truncation, num_iter 0 / 1 and the full 20 x 20 graph."""
+    case = cases.build_case(name)
+    assert len(case["detections"]) == 1
+    head = gpu_run.build_head(case).eval()
+    want, wl, wa = _run(head, case, case["rng_seed"], small=False)
+    got, gl, ga = _run(head, case, case["rng_seed"], small=True, buckets=True)
+    got2, gl2, _ = _run(head, case, case["rng_seed"], small=True, buckets=True)              # replay
+    plan = next(iter(head.engine()._small.plans.values()))
+    assert plan.caps is not None and head.engine()._small.stats()["captures"] == 1
+    _close(got, want); _close(got2, want)
+    assert torch.equal(ga, wa)
+    for a, b in zip(got, got2):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k                                              # capture call == replay, bit for bit
+    g = helpers.load_golden(name)
+    for k in ("index", "prediction", "object"):
+        assert np.array_equal(got[0][k].cpu().numpy(), g["res0.%s" % k]), k
+    if name != "nanbox":
+        assert np.abs(got[0]["scores"].cpu().numpy() - g["res0.scores"]).max() <= 1e-5
+    K = case["cfg"]["K"]
+    assert np.abs(gl[:, :K].cpu().numpy() - g["logits_p"]).max() <= 1e-4

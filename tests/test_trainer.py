@@ -369,3 +369,60 @@ def test_prefetched_steps_equal_inline_steps_bit_for_bit(precision):
     lo, hi = st.buf.data_ptr(), st.buf.data_ptr() + 4 * st.total
     assert all(lo <= p.data_ptr() < hi for p in h1.parameters())
     assert sum(p.numel() for p in h1.parameters()) <= st.total
+
+
+@pytest.mark.gpu
+def test_training_in_the_arena_keeps_eval_and_checkpoints_consistent():
+    """After training steps the 408 parameters are views of the flat arena the optimizer updates in place.  The eval engine
+    must notice every update (its packed copies are rebuilt), a checkpoint written from the arena-backed module must load
+    into a fresh head and give bit-identical eval results, and loading a checkpoint INTO the arena-backed head (in-place
+    copy through the views) must be seen by the next training step."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    import io
+    import cases
+    import gpu_run
+    from collections import OrderedDict
+    tcase = cases.build_case("train_tiny")
+    ecase = cases.build_case("tiny")
+    head = gpu_run.build_head(tcase)
+    net = trainer.wrap_ddp(head, torch.device("cuda", 0))
+    opt = trainer.build_optimizer(net, lr=1e-2)
+    feats = OrderedDict((k, tcase["feat3"].cuda()) for k in "0123")
+    det = gpu_run.to_cuda(tcase["detections"]); tg = gpu_run.to_cuda(tcase["targets"])
+    efeats = OrderedDict((k, ecase["feat3"].cuda()) for k in "0123")
+    edet = gpu_run.to_cuda(ecase["detections"])
+
+    def evaluate(h):
+        pool = h.box_roi_pool
+        h.box_roi_pool = gpu_run.CachedPool(ecase)
+        h.eval()
+        with torch.no_grad():
+            torch.manual_seed(3)
+            r = h(efeats, edet, ecase["shapes"])
+        h.train(); h.box_roi_pool = pool
+        return r
+
+    before = evaluate(head)
+    torch.manual_seed(5)
+    for _ in range(2):
+        trainer.train_step(net, opt, feats, det, tcase["shapes"], targets=tg)
+    assert head._stacked.aliased()
+    after = evaluate(head)
+    assert not torch.equal(before[0]["scores"], after[0]["scores"])          # the engine saw the in-place updates
+    buf = io.BytesIO(); torch.save(head.state_dict(), buf); buf.seek(0)
+    fresh = gpu_run.build_head(tcase)
+    fresh.load_state_dict(torch.load(buf))
+    ref = evaluate(fresh)
+    for k in after[0]:
+        assert torch.equal(after[0][k], ref[0][k]), k
+    # a checkpoint loaded INTO the arena-backed head: the next step trains on it
+    other = gpu_run.build_head(tcase)                                        # the initial weights again
+    head.load_state_dict(other.state_dict())
+    assert head._stacked.aliased()                                           # load_state_dict copies through the views
+    torch.manual_seed(5)
+    l1, _ = trainer.train_step(net, trainer.build_optimizer(net, lr=1e-2), feats, det, tcase["shapes"], targets=tg)
+    torch.manual_seed(5)
+    onet = trainer.wrap_ddp(other, torch.device("cuda", 0))
+    l2, _ = trainer.train_step(onet, trainer.build_optimizer(onet, lr=1e-2), feats, det, tcase["shapes"], targets=tg)
+    assert l1 == l2
