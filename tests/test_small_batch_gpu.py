@@ -296,4 +296,5 @@ def test_bucket_plans_reproduce_the_reference_goldens(name, precision):
     if name != "nanbox":
         assert np.abs(got[0]["scores"].cpu().numpy() - g["res0.scores"]).max() <= 1e-5
     K = case["cfg"]["K"]
-    assert np.abs(gl[:, :K].cpu().numpy() - g["logits_p"]).max() <= 1e-4
+    # (nanbox: the scrubbed +-FLT_MAX features drive the logits to ~1e9; the bar is relative there)
+    assert np.abs(gl[:, :K].cpu().numpy() - g["logits_p"]).max() <= 1e-4 * max(1.0, np.abs(g["logits_p"]).max())
