@@ -494,7 +494,6 @@ class HeadEngine:
         self._cnt_host = None
         self._cnt_event = None
         self._cnt_host_dev = None
-        self._cs_stream = None      # stream of the parameter checksum of small forwards (beside the selection kernel)
         self.plan_epoch = 0
         self.small_batch_max = 8    # eval batches of up to this many images replay a captured hipGraph (skghoi_amd/small.py); 0: off
         self.small_batch_buckets = True   # single images share one plan per BUCKET of (humans, nodes) instead of one per shape
@@ -657,21 +656,7 @@ class HeadEngine:
         watch = None
         if check_weights and self._pw is not None and self._pw.device == dev and self._pw.watch.table is not None:
             watch = self._pw.watch
-            # rides on the one D2H copy below.  A few images: on a stream of its own, beside the selection kernel -- that one
-            # is a single workgroup per image (26 us of one CU), the checksum reads 118 MB on every CU (19 us): side by side
-            # they cost the longer of the two (one image per forward: 4 % of the forward)
-            side_done = None
-            if B <= self.small_batch_max:
-                main = torch.cuda.current_stream()
-                if self._cs_stream is None or self._cs_stream.device != dev:
-                    self._cs_stream = torch.cuda.Stream(device=dev)
-                fork = torch.cuda.Event(); fork.record(main)
-                self._cs_stream.wait_event(fork)                   # (sees every parameter write already enqueued)
-                with torch.cuda.stream(self._cs_stream):
-                    watch.enqueue(countx.data_ptr() + 16 * B)
-                    side_done = torch.cuda.Event(); side_done.record(self._cs_stream)
-            else:
-                watch.enqueue(countx.data_ptr() + 16 * B)
+            watch.enqueue(countx.data_ptr() + 16 * B)                      # rides on the one D2H copy below
         prior_pow = 1.0 if training else 2.8                                    # HEAD:742
         if boxes.numel() == 0:
             boxes = torch.zeros(1, 4, device=dev); scores = torch.zeros(1, device=dev)
@@ -681,8 +666,6 @@ class HeadEngine:
                                            self.max_human, self.max_object, vt.nverbs.data_ptr(), vt.num_obj,
                                            prior_pow, index.data_ptr(), countx.data_ptr(), _stream()),
                     "skg_preprocess_f32")
-        if watch is not None and side_done is not None:
-            torch.cuda.current_stream().wait_event(side_done)      # the count copy below carries the checksum partials too
         if defer:
             # the caller goes on with other host work while the kernel runs and comes back with pre_launch_end()
             return dict(pending=self._read_counts(countx, defer=True), countx=countx, watch=watch, B=B, dev=dev,
