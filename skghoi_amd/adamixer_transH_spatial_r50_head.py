@@ -274,6 +274,22 @@ class _Prefetch:
         self.done = True
 
 
+class _Ready:
+    """A finished preparation handed back for the next `forward` (same interface as _Prefetch)."""
+
+    def __init__(self, prep):
+        self.prep, self.inputs = prep, prep.inputs
+
+    def finish(self):
+        return self.prep
+
+    def advance(self):
+        return False
+
+    def abandon(self):
+        pass
+
+
 class InteractionHead(Module):
     """Interaction head that constructs and classifies box pairs (HEAD:29-429): same constructor keywords, forward
     signature and result dictionaries.
@@ -444,6 +460,25 @@ class InteractionHead(Module):
         h.advance()                            # launches the detection-selection kernel; its counts are read later
         self._prefetched = h
         return h
+
+    def fused_step(self, features, detections, image_shapes, targets, after_forward=None):
+        """Forward + backward of one training step without the autograd engine (skghoi_amd.train_fused.fused_step) for a
+        trainer that owns the loop: gradients of the summed losses land in `p.grad` (overwritten, not accumulated).
+        Returns the result list with the (detached) loss dict appended, or None when this call has to go through
+        `forward` + `backward()` instead."""
+        from skghoi_amd import train_fused
+        if not (self.training and self.fused_training and train_fused.supported(self)) or targets is None:
+            return None
+        dev = features["3"].device
+        if dev.type != "cuda":
+            return None
+        with torch.cuda.device(dev):
+            out, prep = train_fused.fused_step(self, self.engine(), features, detections, image_shapes, targets,
+                                               prep=self._take_prefetched(detections, image_shapes, targets),
+                                               after_forward=after_forward)
+            if out is None and prep is not None:
+                self._prefetched = _Ready(prep)       # prepared but not consumed here: the `forward` that follows takes it
+        return out
 
     def _prefetch_stream(self, dev):
         st = getattr(self, "_pf_stream", None)

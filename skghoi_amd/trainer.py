@@ -263,6 +263,11 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
     """utils.py:213-229: zero_grad -> forward -> NaN guard -> sum of the loss dict -> backward -> step.  Returns the loss
     dict (detached floats) and the per-image results.
 
+    When `net` is the bare interaction head in its fused training configuration the forward and the backward run as one
+    call without the autograd engine (`InteractionHead.fused_step`: same kernels, same order, the upstream gradient of the
+    summed losses fixed at one, gradients OVERWRITE `p.grad` -- so nothing is zeroed first); every other case goes
+    `zero_grad -> net(...) -> backward()` like the reference.
+
     prefetch = the NEXT batch (features, detections, image_shapes, targets), or None: once this step is enqueued the
     head prepares that batch on a side stream (selection, pairs, labels, host RNG draws), so that the next call starts
     its dense forward at once instead of paying two host synchronisations with an idle GPU (`prefetch_batch`).
@@ -271,16 +276,33 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
     left to whoever reads them (Trainer does, at its print interval / end of epoch) -- the reference's per-iteration
     `isnan` test and `.item()` are two host synchronisations per step, ~0.5 ms of a ~4 ms batch-4 step during which
     nothing is queued behind the optimizer kernels."""
-    optimizer.zero_grad(set_to_none=True)
-    out = net(*inputs, targets)
+    # the next batch's preparation is interleaved with this step's host work: each of its two device round trips (selection
+    # counts, positive counts) runs on the side stream while this thread enqueues the backward resp. the optimizer
+    ahead = [None]
+
+    def look_ahead():
+        if prefetch is not None and ahead[0] is None:
+            ahead[0] = prefetch_batch(net, *prefetch)                               # selection kernel launched
+    out = None
+    fused = getattr(net, "fused_step", None)            # the bare interaction head: forward + backward without the autograd
+    if fused is not None and len(inputs) == 3:          # engine (gradients overwrite p.grad: nothing to zero beforehand)
+        out = fused(*inputs, targets, after_forward=look_ahead)
+    fused_ran = out is not None
+    if out is None:
+        optimizer.zero_grad(set_to_none=True)
+        out = net(*inputs, targets)
     loss_dict = out.pop()
     if not lazy and torch.isnan(loss_dict["hoi_loss"]):
         raise ValueError(f"The HOI loss is NaN")
-    total = sum(loss for loss in loss_dict.values())
-    # the next batch's preparation is interleaved with this step's host work: each of its two device round trips (selection
-    # counts, positive counts) runs on the side stream while this thread enqueues the backward resp. the optimizer
-    ahead = prefetch_batch(net, *prefetch) if prefetch is not None else None       # selection kernel launched
-    total.backward()
+    look_ahead()
+    if any(v.requires_grad for v in loss_dict.values()):
+        if fused_ran:
+            # fused_step handed the losses back on the autograd route (a differentiable RoI pooling in front of the head):
+            # whatever the parameters still hold from the step before must not be added to
+            optimizer.zero_grad(set_to_none=True)
+        total = sum(loss for loss in loss_dict.values())
+        total.backward()
+    ahead = ahead[0]
     if ahead is not None:
         ahead.advance()                  # counts read (ready by now), pairs + association launched
     for ex in exchanges(net):            # data parallel: a rank whose batch bypassed the fused node joins its peers here

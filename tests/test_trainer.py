@@ -426,3 +426,45 @@ def test_training_in_the_arena_keeps_eval_and_checkpoints_consistent():
     onet = trainer.wrap_ddp(other, torch.device("cuda", 0))
     l2, _ = trainer.train_step(onet, trainer.build_optimizer(onet, lr=1e-2), feats, det, tcase["shapes"], targets=tg)
     assert l1 == l2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_engine_free_fused_step_equals_the_autograd_route(precision):
+    """trainer.train_step on the bare head takes InteractionHead.fused_step (forward + backward in one call, no autograd
+    engine, gradients overwritten in a persistent arena).  Against the same steps through `net(...)` + `backward()`: the same
+    losses at every step and bit-identical weights after four steps (two different batches, look-ahead on)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    import cases
+    import gpu_run
+    from collections import OrderedDict
+    cs = [cases.build_case("train_tiny"), cases.build_case("train_skips")]
+    batches = [(OrderedDict((k, c["feat3"].cuda()) for k in "0123"), gpu_run.to_cuda(c["detections"]), c["shapes"],
+                gpu_run.to_cuda(c["targets"]), c) for c in (cs[0], cs[1], cs[0], cs[1])]
+
+    def run(engine_free):
+        head = gpu_run.build_head(cs[0])
+        head.precision = precision
+        net = trainer.wrap_ddp(head, torch.device("cuda", 0))
+        opt = trainer.build_optimizer(net, lr=1e-3)
+        if not engine_free:
+            head.fused_step = lambda *a, **k: None                  # every step through forward + backward()
+        torch.manual_seed(11)
+        losses = []
+        for i, (f, d, s, t, c) in enumerate(batches):
+            head.box_roi_pool = gpu_run.CachedPool(c)
+            nxt = batches[i + 1][:4] if i + 1 < len(batches) else None
+            l, res = trainer.train_step(net, opt, f, d, s, targets=t, lazy=True, prefetch=nxt)
+            losses.append(trainer.read_losses(l))
+            assert len(res) == len(d)
+        return head, losses
+
+    h0, l0 = run(False)
+    h1, l1 = run(True)
+    assert l0 == l1
+    for (k, a), (_, b) in zip(h0.state_dict().items(), h1.state_dict().items()):
+        assert torch.equal(a, b), k
+    st = h1._stacked
+    ga, views = st.persistent_grads()
+    assert all(p.grad is v for p, v in zip(st.src, views))           # the gradients stayed assigned across the steps
