@@ -146,6 +146,11 @@ class GraphHead(Module):
         self.fc_tail = nn.Sequential(nn.Linear(1074, 1024), nn.ReLU())
         self._engine = None
 
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_engine"] = None                 # run-time cache (streams, packed weights): never copied or pickled
+        return state
+
     # The engine of a stand-alone GraphHead (InteractionHead installs its own, with its predictor/suppressor).
     def _own_engine(self):
         if self._engine is None:
@@ -332,6 +337,17 @@ class InteractionHead(Module):
         self.fused_training = True      # False: training through autograd over per-layer Functions (skghoi_amd/train_graph.py)
         self.grad_mode = "autograd"     # "direct": the fused step writes p.grad itself (skghoi_amd/train_fused.py, StepFn)
         self._engine = None
+
+    # run-time caches (engine with its streams / captured plans, parameter arena bookkeeping, prefetch state): never part of
+    # a copy or a pickle of the module -- they are rebuilt on first use
+    _RUNTIME = ("_engine", "_stacked", "_pf_stream", "_prefetched", "_last_train", "_last_train_plan", "_train_params")
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for k in self._RUNTIME:
+            if k in state:
+                state[k] = None
+        return state
 
     def engine(self) -> HeadEngine:
         e = self._engine

@@ -300,3 +300,24 @@ def test_registration_epoch_tracks_parameter_and_module_replacement():
         lin.weight.mul_(2.0)           # in-place writes do not register anything (the device checksum sees those)
     lin.weight.data.mul_(2.0)
     assert engine._REG_EPOCH[0] == e2
+
+
+def test_copies_and_pickles_of_the_head_drop_runtime_caches():
+    """deepcopy / pickle of the module (EMA copies, checkpoints of whole modules) must not drag the run-time caches along --
+    the engine holds HIP streams and captured plans, the prefetch state holds events -- and must not share them either."""
+    import copy
+    import pickle
+    import threading
+    from skghoi_amd import GraphHead, InteractionHead, synth
+    gh = GraphHead(8, 2, 1024, 1024, 117, 49, synth.hico_object_to_verb())
+    head = InteractionHead(torch.nn.Identity(), gh, torch.nn.Linear(2048, 1), torch.nn.Linear(2048, 117), 49, 117)
+    unpicklable = threading.Lock()                              # stands in for streams / graphs / events
+    head._engine = unpicklable; head._stacked = unpicklable; head._pf_stream = unpicklable; head._prefetched = unpicklable
+    gh._engine = unpicklable
+    twin = copy.deepcopy(head)
+    assert twin._engine is None and twin._stacked is None and twin._prefetched is None and twin.box_pair_head._engine is None
+    assert head._engine is unpicklable                          # the original keeps its caches
+    assert all(torch.equal(a, b) for a, b in zip(head.state_dict().values(), twin.state_dict().values()))
+    blob = pickle.dumps(head)
+    back = pickle.loads(blob)
+    assert back._engine is None and set(back.state_dict()) == set(head.state_dict())
