@@ -486,11 +486,6 @@ typedef struct {
 } skg_adamw_chunk;
 int skg_adamw_f32(const skg_adamw_chunk* chunks, int n_chunks, double lr, double beta1, double beta2, double eps,
                   double weight_decay, double bias1, double bias2, void* stream);
-/* The same update over a contiguous range of n floats (n % 4 == 0, 16-byte aligned) of four flat arenas laid out alike
- * (parameters, gradients, exp_avg, exp_avg_sq: the training step's arenas): a data-parallel or overlapped trainer updates the
- * arena prefix a backward stage has just completed while the later stages still run.                                   */
-int skg_adamw_flat_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
-                       double eps, double weight_decay, double bias1, double bias2, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Native launch plan of the fused TRAINING step's dense part: GraphHead.forward in training mode (HEAD:769-993; the

@@ -101,7 +101,6 @@ PROTOTYPES = {
     "skg_gemm_group_tile": (C.c_int, [C.POINTER(GemmDesc), C.c_int]),
     "skg_row_exponents_f32": (C.c_int, [_vp, C.c_int64, _vp, C.c_int, C.c_int, _vp, _vp]),
     "skg_adamw_f32": (C.c_int, [_vp, C.c_int] + [C.c_double] * 7 + [_vp]),
-    "skg_adamw_flat_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64] + [C.c_double] * 7 + [_vp]),
     "skg_gemm_small_mode": (C.c_int, [C.c_int]),
     "skg_gemm_small_tiles": (C.c_int, [C.c_int]),
     "skg_gemmx_ws_floats": (C.c_int64, [C.POINTER(GemmXDesc)]),

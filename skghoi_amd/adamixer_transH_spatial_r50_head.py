@@ -477,7 +477,7 @@ class InteractionHead(Module):
         self._prefetched = h
         return h
 
-    def fused_step(self, features, detections, image_shapes, targets, after_forward=None, updater=None):
+    def fused_step(self, features, detections, image_shapes, targets, after_forward=None):
         """Forward + backward of one training step without the autograd engine (skghoi_amd.train_fused.fused_step) for a
         trainer that owns the loop: gradients of the summed losses land in `p.grad` (overwritten, not accumulated).
         Returns the result list with the (detached) loss dict appended, or None when this call has to go through
@@ -491,7 +491,7 @@ class InteractionHead(Module):
         with torch.cuda.device(dev):
             out, prep = train_fused.fused_step(self, self.engine(), features, detections, image_shapes, targets,
                                                prep=self._take_prefetched(detections, image_shapes, targets),
-                                               after_forward=after_forward, updater=updater)
+                                               after_forward=after_forward)
             if out is None and prep is not None:
                 self._prefetched = _Ready(prep)       # prepared but not consumed here: the `forward` that follows takes it
         return out

@@ -112,41 +112,3 @@ extern "C" int skg_adamw_f32(const skg_adamw_chunk* chunks, int n_chunks, double
                        (float)(lr / bias1), (float)(1.0 / sqrt(bias2)), (float)eps);
     return skg_launch_status();
 }
-
-
-// AdamW over a contiguous RANGE of flat arenas (parameters, gradients and both moments laid out alike: the training step's
-// parameter arena, skghoi_amd/train_fused.py).  Same arithmetic per element as skg_adamw_kernel.  Used to update the arena
-// prefix whose gradients a backward stage has just completed, on a side stream, while the later stages still run.
-__global__ __launch_bounds__(256) void skg_adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                             float* __restrict__ m, float* __restrict__ v, int64_t n4,
-                                                             float decay, float c1, float beta2, float c2, float step_size,
-                                                             float inv_sqrt_b2, float eps) {
-    float4* p4 = reinterpret_cast<float4*>(p); const float4* g4 = reinterpret_cast<const float4*>(g);
-    float4* m4 = reinterpret_cast<float4*>(m); float4* v4 = reinterpret_cast<float4*>(v);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 pp = p4[i], mm = m4[i], vv = v4[i];
-        const float4 gg = g4[i];
-        skg_adamw_one(pp.x, gg.x, mm.x, vv.x, decay, c1, beta2, c2, step_size, inv_sqrt_b2, eps);
-        skg_adamw_one(pp.y, gg.y, mm.y, vv.y, decay, c1, beta2, c2, step_size, inv_sqrt_b2, eps);
-        skg_adamw_one(pp.z, gg.z, mm.z, vv.z, decay, c1, beta2, c2, step_size, inv_sqrt_b2, eps);
-        skg_adamw_one(pp.w, gg.w, mm.w, vv.w, decay, c1, beta2, c2, step_size, inv_sqrt_b2, eps);
-        p4[i] = pp; m4[i] = mm; v4[i] = vv;
-    }
-}
-
-extern "C" int skg_adamw_flat_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
-                                  double beta2, double eps, double weight_decay, double bias1, double bias2, void* stream) {
-    if (n < 0 || (n & 3)) return SKG_E_ARG;
-    if (!(bias1 > 0.0) || !(bias2 > 0.0) || !(eps >= 0.0)) return SKG_E_ARG;
-    if (n == 0) return 0;
-    if (!p || !g || !m || !v) return SKG_E_ARG;
-    if (!skg_aligned16(p) || !skg_aligned16(g) || !skg_aligned16(m) || !skg_aligned16(v)) return SKG_E_ALIGN;
-    const int64_t n4 = n >> 2;
-    int64_t blocks = (n4 + 256 * 4 - 1) / (256 * 4);
-    if (blocks > 8192) blocks = 8192;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(skg_adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4,
-                       (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                       (float)(lr / bias1), (float)(1.0 / sqrt(bias2)), (float)eps);
-    return skg_launch_status();
-}

@@ -711,18 +711,17 @@ class NativeJob(TrainJob):
         pl.dx0, pl.dgfeat = _ptr(dx0), _ptr(dgfeat)
         stream = _stream()
         ex = getattr(self.head, "grad_exchange", None)
-        hook = ex if ex is not None else getattr(self, "stage_hook", None)
-        if hook is None:
+        if ex is None:
             _check(lib.skg_train_backward_f32(C.byref(pl), 0, _capi.TRAIN_BWD_STAGES, stream), "skg_train_backward_f32")
         else:
-            # after every stage the gradient-arena prefix that stage completed is handed on, concurrent with the stages still
-            # to run: to the peers (data parallel: skghoi_amd/trainer.py ArenaExchange) or to the optimizer (ArenaUpdater)
-            hook.begin(ga)
+            # data parallel: after every stage the gradient-arena prefix that stage completed goes out to the peers
+            # (skghoi_amd/trainer.py, ArenaExchange), concurrent with the stages still to run
+            ex.begin(ga)
             n = _capi.TRAIN_BWD_STAGES
             for s_ in range(n):
                 _check(lib.skg_train_backward_f32(C.byref(pl), s_, s_ + 1, stream), "skg_train_backward_f32[%d]" % s_)
-                hook.on_stage(s_, ga, st.milestone_end[s_], last=(s_ == n - 1))
-            hook.finish()
+                ex.on_stage(s_, ga, st.milestone_end[s_], last=(s_ == n - 1))
+            ex.finish()
         out = []
         for p in self.params:
             k = st.ids.get(id(p))
@@ -1000,7 +999,7 @@ class TrainRun:
         return results
 
 
-def fused_step(head, eng, features, detections, image_shapes, targets, prep=None, after_forward=None, updater=None):
+def fused_step(head, eng, features, detections, image_shapes, targets, prep=None, after_forward=None):
     """One whole forward + backward of the training step WITHOUT the autograd engine, for a trainer that owns the loop
     (skghoi_amd.trainer.train_step): the same kernels in the same order as `StepFn`, with the upstream gradient of the
     three summed losses (utils.py:221: their plain sum) fixed at one, the gradients written into a persistent arena whose
@@ -1008,9 +1007,7 @@ def fused_step(head, eng, features, detections, image_shapes, targets, prep=None
     thread and 2 x 408 attribute writes per step (~0.2 ms of a 2 ms step).  Returns (results with the loss dict appended --
     detached scalars --, prep) or (None, prep) when this batch / configuration needs the autograd route: inputs that require
     grad (a trainable detector in front), the Python launch plan, a batch without pairs.
-    after_forward(): called once the forward is enqueued (the trainer starts the next batch's preparation there).
-    updater: trainer.ArenaUpdater or None -- the optimizer update of every arena prefix right behind the backward stage that
-    completes it (then `optimizer.step()` has nothing left to do)."""
+    after_forward(): called once the forward is enqueued (the trainer starts the next batch's preparation there)."""
     if job_class(head) is not NativeJob or getattr(head, "grad_mode", "autograd") != "direct":
         return None, prep
     if any(getattr(t, "requires_grad", False) for t in features.values()):
@@ -1051,7 +1048,6 @@ def fused_step(head, eng, features, detections, image_shapes, targets, prep=None
         _check(_capi.lib().skg_scale_dlogits_f32(src.data_ptr(), src.stride(0), src.shape[0], job.K,
                                                  job.loss_scale.data_ptr(), one.data_ptr(), one.data_ptr(), d.data_ptr(),
                                                  _stream()), "skg_scale_dlogits_f32")
-        job.stage_hook = updater                   # (optimizer update behind the backward stages, or None)
         job.backward(d, False, False, arena=(ga, views))
         if not all(map(_is, map(_grad_of, st.src), views)):       # (first step, or someone re-pointed / cleared a .grad)
             for p, v in zip(st.src, views):

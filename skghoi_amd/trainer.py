@@ -17,8 +17,6 @@ import torch.distributed as dist
 from torch import nn
 
 _data_ptr = torch.Tensor.data_ptr
-import os as _os
-OVERLAP_OPTIMIZER = _os.environ.get("SKG_OVERLAP_OPT", "1") == "1"      # developer switch: ArenaUpdater on / off
 
 
 def limit_host_threads(ranks_on_host: int = 1, cap: int = 4) -> int:
@@ -117,80 +115,6 @@ def build_scheduler(optimizer, milestone: int = 6, lr_decay: float = 0.1):
 def _interaction_heads(module: nn.Module):
     from .adamixer_transH_spatial_r50_head import InteractionHead
     return [m for m in module.modules() if isinstance(m, InteractionHead)]
-
-
-class ArenaUpdater:
-    """AdamW of the head's parameter arena, prefix by prefix, on a side stream BEHIND the backward stages (single process).
-
-    The backward finishes the gradient arena front to back (train_fused._ORDER) and reads every weight segment for the last
-    time in the stage that completes its gradient, so the segment can be updated right then: the update (HBM-bound, 28 bytes
-    per parameter, 0.14 ms for the whole head) runs beside the later stages' GEMMs (latency-bound at batch 4) instead of
-    after them.  Parameters, gradients and both moments are flat arenas with one layout (the optimizer's per-parameter
-    `exp_avg` / `exp_avg_sq` / `step` state tensors become views of flat buffers: same `state_dict`), so a prefix is one
-    launch of `skg_adamw_flat_f32` -- the same arithmetic per element as `skg_adamw_f32`; results are bit-identical to the
-    one-launch optimizer step.  `optimizer.step()` that follows sees the step as applied."""
-
-    def __init__(self, opt, gi, st, min_chunk=1 << 21):
-        self.opt, self.gi, self.st, self.min_chunk = opt, gi, st, int(min_chunk)
-        dev = st.device
-        self.M = torch.zeros(st.total, device=dev, dtype=torch.float32)
-        self.V = torch.zeros(st.total, device=dev, dtype=torch.float32)
-        mv, vv = st.grad_views(self.M), st.grad_views(self.V)
-        steps = []
-        with torch.no_grad():
-            for p, m, v in zip(st.src, mv, vv):
-                s = opt.state[p]
-                m.copy_(s["exp_avg"]); v.copy_(s["exp_avg_sq"])
-                s["exp_avg"], s["exp_avg_sq"] = m, v
-                steps.append(s["step"])
-            self.host_step = int(torch.stack([x.reshape(()) for x in steps]).max().item())
-            self.flat_step = torch.stack([x.reshape(()) for x in steps]).contiguous()
-            for p, x in zip(st.src, self.flat_step.unbind(0)):
-                opt.state[p]["step"] = x
-        self.first, self.last = opt.state[st.src[0]]["exp_avg"], opt.state[st.src[-1]]["exp_avg_sq"]
-        self.step0 = opt.state[st.src[0]]["step"]
-        self.stream = torch.cuda.Stream(device=dev)
-        opt._plans.clear(); opt._lists.clear()                 # the cached per-parameter lists held the old state tensors
-        self.done, self.ga = 0, None
-
-    def valid(self):
-        o, st = self.opt, self.st
-        g = o.param_groups[self.gi]
-        return (o.state[st.src[0]].get("exp_avg") is self.first and o.state[st.src[-1]].get("exp_avg_sq") is self.last
-                and o.state[st.src[0]].get("step") is self.step0          # (the one-launch path re-points the counters)
-                and len(g["params"]) == len(st.src) and not torch.is_tensor(g["lr"]))
-
-    # -- driven by NativeJob.backward
-    def begin(self, ga):
-        g = self.opt.param_groups[self.gi]
-        self.t = self.host_step + 1
-        b1, b2 = g["betas"]
-        self.hp = (float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), 1.0 - b1 ** self.t,
-                   1.0 - b2 ** self.t)
-        self.done, self.ga = 0, ga
-
-    def on_stage(self, s, ga, end, last=False):
-        if end - self.done >= self.min_chunk or (last and end > self.done):
-            from . import _capi
-            main = torch.cuda.current_stream()
-            ev = torch.cuda.Event(); ev.record(main)
-            self.stream.wait_event(ev)                         # the stage that completed these gradients
-            lo, n = self.done, end - self.done
-            _capi.check(_capi.lib().skg_adamw_flat_f32(self.st.buf.data_ptr() + 4 * lo, ga.data_ptr() + 4 * lo,
-                                                       self.M.data_ptr() + 4 * lo, self.V.data_ptr() + 4 * lo, n, *self.hp,
-                                                       self.stream.cuda_stream), "skg_adamw_flat_f32")
-            self.done = end
-
-    def finish(self):
-        st = self.st
-        if self.done < st.total:
-            self.on_stage(-1, self.ga, st.total, last=True)
-        main = torch.cuda.current_stream()
-        ev = torch.cuda.Event(); ev.record(self.stream)
-        main.wait_event(ev)                                    # the next forward reads the updated arena
-        self.flat_step.add_(1)
-        self.host_step = self.t
-        self.opt._applied_by_updater = True
 
 
 class ArenaExchange:
@@ -374,10 +298,7 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
     out = None
     fused = getattr(net, "fused_step", None)            # the bare interaction head: forward + backward without the autograd
     if fused is not None and len(inputs) == 3:          # engine (gradients overwrite p.grad: nothing to zero beforehand)
-        upd = None
-        if OVERLAP_OPTIMIZER and hasattr(optimizer, "arena_updater") and not exchanges(net):
-            upd = optimizer.arena_updater(net)          # AdamW prefix by prefix behind the backward stages (side stream)
-        out = fused(*inputs, targets, after_forward=look_ahead, updater=upd)
+        out = fused(*inputs, targets, after_forward=look_ahead)
     fused_ran = out is not None
     if out is None:
         optimizer.zero_grad(set_to_none=True)
@@ -432,31 +353,6 @@ class SkgAdamW(CachedFusedAdamW):
     def __init__(self, *args, **kw):
         super().__init__(*args, **kw)
         self._plans = {}
-        self._updaters = {}
-        self._applied_by_updater = False
-
-    def arena_updater(self, head):
-        """An ArenaUpdater for `head` (its parameter arena updated prefix by prefix behind the backward stages), or None when
-        this optimizer / state does not qualify: exactly one fused, non-amsgrad group holding exactly the arena's parameters,
-        state present (from the second step on) with equal step counts."""
-        st = getattr(head, "_stacked", None)
-        if st is None or len(self.param_groups) != 1:
-            return None
-        u = self._updaters.get(id(st))
-        if u is not None:
-            return u if (u.st is st and u.valid()) else None
-        g = self.param_groups[0]
-        if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable") or not g.get("fused") \
-                or torch.is_tensor(g["lr"]) or len(g["params"]) != len(st.src) \
-                or set(map(id, g["params"])) != set(map(id, st.src)):
-            return None
-        states = [self.state.get(p) for p in st.src]
-        if any(x is None or "exp_avg" not in x or not torch.is_tensor(x.get("step")) or not x["step"].is_cuda for x in states):
-            return None
-        if len({float(v) for v in torch.stack([x["step"].reshape(()) for x in states]).tolist()}) != 1:
-            return None
-        self._updaters = {id(st): ArenaUpdater(self, 0, st)}
-        return self._updaters[id(st)]
 
     def _plan(self, gi, c):
         """Static part of a group's chunk table; None if the group does not qualify."""
@@ -514,9 +410,6 @@ class SkgAdamW(CachedFusedAdamW):
         import numpy as np
         from . import _capi
         from .engine import _stream
-        if self._applied_by_updater:                 # this step's update already ran behind the backward (ArenaUpdater)
-            self._applied_by_updater = False
-            return None
         if closure is not None or getattr(self, "grad_scale", None) is not None or getattr(self, "found_inf", None) is not None:
             self._plans.clear()
             return super().step(closure)

@@ -468,47 +468,3 @@ def test_engine_free_fused_step_equals_the_autograd_route(precision):
     st = h1._stacked
     ga, views = st.persistent_grads()
     assert all(p.grad is v for p, v in zip(st.src, views))           # the gradients stayed assigned across the steps
-
-
-@pytest.mark.gpu
-def test_optimizer_update_behind_the_backward_equals_the_one_launch_step(monkeypatch):
-    """trainer.ArenaUpdater: AdamW of every parameter-arena prefix right behind the backward stage that completes its
-    gradients, on a side stream.  Against the same run with the update as one launch after the backward: identical losses,
-    bit-identical weights AND optimizer state (exp_avg, exp_avg_sq, step) after five steps; a checkpoint of the state written
-    from the flat moment arenas loads into a stock torch AdamW."""
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
-    import cases
-    import gpu_run
-    from collections import OrderedDict
-    cs = [cases.build_case("train_tiny"), cases.build_case("train_skips")]
-    batches = [(OrderedDict((k, c["feat3"].cuda()) for k in "0123"), gpu_run.to_cuda(c["detections"]), c["shapes"],
-                gpu_run.to_cuda(c["targets"]), c) for c in (cs[0], cs[1], cs[0], cs[1], cs[0])]
-
-    def run(overlap):
-        monkeypatch.setattr(trainer, "OVERLAP_OPTIMIZER", overlap)
-        head = gpu_run.build_head(cs[0])
-        net = trainer.wrap_ddp(head, torch.device("cuda", 0))
-        opt = trainer.build_optimizer(net, lr=1e-3)
-        torch.manual_seed(3)
-        losses = []
-        for f, d, s, t, c in batches:
-            head.box_roi_pool = gpu_run.CachedPool(c)
-            l, _ = trainer.train_step(net, opt, f, d, s, targets=t, lazy=True)
-            losses.append(trainer.read_losses(l))
-        torch.cuda.synchronize()
-        return head, opt, losses
-
-    h0, o0, l0 = run(False)
-    h1, o1, l1 = run(True)
-    assert l0 == l1
-    assert o1._updaters and next(iter(o1._updaters.values())).host_step == 5 and not o0._updaters
-    for (k, a), (_, b) in zip(h0.state_dict().items(), h1.state_dict().items()):
-        assert torch.equal(a, b), k
-    s0, s1 = o0.state_dict()["state"], o1.state_dict()["state"]
-    assert set(s0) == set(s1)
-    for i in s0:
-        for k in ("exp_avg", "exp_avg_sq", "step"):
-            assert torch.equal(s0[i][k].float(), s1[i][k].float()), (i, k)
-    stock = torch.optim.AdamW([{"params": list(h1.parameters())}], lr=1e-3, weight_decay=1e-4, fused=True)
-    stock.load_state_dict(o1.state_dict())
