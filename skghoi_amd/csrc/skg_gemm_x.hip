@@ -32,11 +32,14 @@
 #define XBK 16
 #define XLD 130
 #define XTILE (XBK * XLD)
+#ifndef SKG_XXCD
+#define SKG_XXCD 1
+#endif
 
 struct skg_gemmx_group {
     skg_gemmx_desc d[SKG_GEMMX_GROUP_MAX];
     int start[SKG_GEMMX_GROUP_MAX + 1];      // block ranges
-    int vec[SKG_GEMMX_GROUP_MAX];            // bit 0: A 16-byte loads allowed, bit 1: B, bit 2: C 8-byte stores allowed
+    int vec[SKG_GEMMX_GROUP_MAX];            // bit 0: A fast loop allowed, bit 1: B, bit 2: C 8-byte stores, bit 3: staged epilogue
     int n;
 };
 
@@ -53,20 +56,38 @@ struct XOperand {
     int64_t rstride, kstride;
     int rows;                    // extent of the own index (M or N)
     bool vec;                    // 16-byte loads allowed
-};
-
-// Loop-invariant part of one thread's loads of one operand (fast tiles).  Addresses along the operand's own index are
-// formed once; rows outside the operand are clamped to a valid row and their values zeroed after the load.
-struct XLane {
-    const float* p0; const float* p1; const float* p2; const float* p3;
-    int ok;              // bit u: quad u lies inside the operand along its own index
-    int kloc;
+    __amdgpu_buffer_rsrc_t rsrc; // buffer descriptor over the operand (fast loop)
 };
 
 struct XQ2 { float4 a, b; };
 
+// Fast tiles address their loads as  (uniform byte offset of the k-step) + (loop-invariant 32-bit byte offset of the
+// lane) through a buffer descriptor of the operand (buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen): the step offset
+// advances on the scalar unit, so a k-step spends no vector instruction on addresses.  The first version formed a 64-bit address per load per step and zeroed
+// clamped rows with 32 selects per step: ~110 vector instructions beside 8 MFMAs, and a lone wave per SIMD issues them
+// one after the other (1200 cycles per step for 256 cycles of MFMA, measured from a K sweep on captured launches).
+// Rows outside the operand are clamped to a valid row and NOT zeroed: they only feed output rows / columns >= M / N,
+// which the epilogue never stores (nor the bias gradient of rows >= M).
+struct XFast { uint32_t o[4]; };
+#ifndef SKG_XBUF
+#define SKG_XBUF 1
+#endif
+__device__ __forceinline__ float4 xldo(const XOperand& op, uint32_t soff, uint32_t voff) {
+#if SKG_XBUF
+    typedef unsigned int xu4 __attribute__((__vector_size__(16)));
+    const xu4 r = __builtin_amdgcn_raw_buffer_load_b128(op.rsrc, (int)voff, (int)soff, 0);
+    return make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
+#else
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(op.base) + soff + voff);
+#endif
+}
+// uniform byte offset of the k-step starting at k0 (k0 a multiple of the k-tile; k blocks, when present, are multiples of it)
+template <bool KC>
+__device__ __forceinline__ uint32_t xstepbase(const XOperand& op, int k0) {
+    return (uint32_t)(xoff(k0, op.kshift, op.kstride, KC ? 1 : op.s_k) * 4);
+}
+
 __device__ __forceinline__ float4 xzero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-__device__ __forceinline__ float4 xsel(bool ok, float4 v) { return ok ? v : xzero4(); }
 __device__ __forceinline__ float4 xld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // Four consecutive elements along the contiguous index c (extent cend); zero outside.
@@ -100,6 +121,79 @@ __device__ __forceinline__ bool xfast_ok(const XOperand& op, int row0) {
     return op.vec && (KC || (op.rows & 3) == 0 || row0 + 128 <= op.rows);
 }
 
+// ================================================================================================ block -> tile
+// Workgroups are dealt round-robin over the 8 XCDs, each with a private 4 MiB L2.  Walking N fastest (the first version)
+// gave XCD x the column tiles tn = x mod 8 of EVERY row panel: all eight XCDs fetched the whole A operand.  Here the
+// product's blocks are renumbered so that an XCD owns one contiguous range of a tile order made of column GROUPS: g
+// column tiles whose B slice (g x 128 x K fp32) fits in ~2 MiB, all row panels of the group, the g tiles and the split
+// slices of one panel adjacent.  An XCD then keeps its B slice L2-resident and an A panel is fetched by the XCDs of
+// nbn / g groups instead of 8 (M = 102400, N = K = 1024, bf16: 569 -> 502 us).  The renumbering is a bijection for every
+// block count (the remainder is spread over the first XCDs).
+struct XTileId { int tm, tn, slice; };
+__device__ __forceinline__ XTileId xtile_of(int b, int nb, int nbm, int nbn, int S, int K) {
+#if SKG_XXCD
+    {
+        const int q = nb >> 3, r = nb & 7, x = b & 7;
+        b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    int g = (int)((2 << 20) / ((int64_t)XBN * 4 * max(K, 1)));
+    g = max(1, min(g, nbn));
+    const int per_group = nbm * g * S;
+    const int grp = min(b / per_group, (nbn - 1) / g);
+    const int w = min(g, nbn - grp * g);                  // the last group may be narrower
+    const int rr = b - grp * per_group;
+    XTileId t;
+    t.slice = rr % S;
+    t.tn = grp * g + (rr / S) % w;
+    t.tm = rr / (S * w);
+    return t;
+#else
+    XTileId t;
+    t.slice = b % S; b /= S;
+    t.tn = b % nbn; t.tm = b / nbn;                       // consecutive blocks walk N
+    return t;
+#endif
+}
+
+// ================================================================================================ epilogue
+// The accumulators of a wave (64 x 64 outputs) leave through LDS, 32 rows at a time: the MFMA layout gives a lane ONE
+// element per row (32 lanes = 128 bytes of a row), and 64 dword stores per thread kept the store unit busy for ~20 us
+// on a 3200 x 1024 output -- half of the whole product (measured with the k loop / the epilogue compiled out).  From
+// the staged image a lane reads four consecutive columns: 16 dwordx4 stores per thread, 256 contiguous bytes per row,
+// and bias / accumulate / mask travel as 16-byte loads as well.  Each wave stages in its own XEP_WAVE floats (no
+// barrier: the LDS serves one wave's instructions in order).  Needs N % 4 == 0 and 16-byte aligned C / bias / mask /
+// workspace rows (bit 3 of the product's `vec`); anything else takes the element-wise epilogue.
+#define XEP_LD 72                            // floats per staged row: 64 + 8 (rows r and r + 4 land 32 banks apart)
+#define XEP_WAVE (32 * XEP_LD)
+#define XEP_FLOATS (4 * XEP_WAVE)            // 36 KiB per workgroup
+
+// Rows [row0, row0 + 32) x columns [col0, col0 + 64) of the product from the wave's staged block.
+__device__ __forceinline__ void xep_rows(const skg_gemmx_desc& d, const float* stage, int lane, int row0, int col0,
+                                         float* ws) {
+    const int c4 = 4 * (lane & 15), rr = lane >> 4, col = col0 + c4;
+    if (col >= d.N) return;
+    const bool hb = !ws && d.bias;
+    float4 bv = xzero4();
+    if (hb) bv = xld4(d.bias + col);
+    const int64_t coff = xoff(col, d.c_nshift, d.c_nstride, 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = row0 + 4 * i + rr;
+        if (row >= d.M) continue;
+        float4 v = *reinterpret_cast<const float4*>(stage + (4 * i + rr) * XEP_LD + c4);
+        if (ws) { *reinterpret_cast<float4*>(ws + (int64_t)row * d.N + col) = v; continue; }
+        if (hb) { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+        if (d.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        float* p = d.C + coff + (int64_t)row * d.ldc;
+        if (d.accumulate) { const float4 o = xld4(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        if (d.mask) {                                      // accumulate first, mask last
+            const float4 m = xld4(d.mask + (int64_t)row * d.ldmask + col);
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(p) = v;
+    }
+}
+
 // ================================================================================================ exact fp32
 // Operand tiles live in LDS K-MAJOR ([16 k][128 rows], row stride 130 dwords): a lane's fragment is ONE ds_read_b64 =
 // two adjacent rows at its k (the rows a MFMA tile covers are interleaved -- the tile does not care which rows it is
@@ -109,34 +203,26 @@ __device__ __forceinline__ bool xfast_ok(const XOperand& op, int row0) {
 //   thread -> quads of a 128 x 16 tile:   KC : quad u = k0 + 4 (tid & 3) .. +3 of row (tid >> 2) + 64 u
 //                                          RC : quad u = rows 4 (tid & 31) .. +3 at k = k0 + (tid >> 5) + 8 u
 template <bool KC>
-__device__ __forceinline__ void xprep(const XOperand& op, int row0, int tid, XLane& L) {
-    L.p2 = L.p3 = nullptr;
+__device__ __forceinline__ void xprep(const XOperand& op, int row0, int tid, XFast& F) {
+    F.o[2] = F.o[3] = 0;
     if (KC) {
-        const int r = row0 + (tid >> 2), last = op.rows - 1;
-        L.kloc = 4 * (tid & 3);
-        L.p0 = op.base + xoff(min(r, last), op.rshift, op.rstride, op.s_row);
-        L.p1 = op.base + xoff(min(r + 64, last), op.rshift, op.rstride, op.s_row);
-        L.ok = (r < op.rows ? 1 : 0) | (r + 64 < op.rows ? 2 : 0);
+        const int r = row0 + (tid >> 2), last = op.rows - 1, kl = 4 * (tid & 3);
+        F.o[0] = (uint32_t)((xoff(min(r, last), op.rshift, op.rstride, op.s_row) + kl) * 4);
+        F.o[1] = (uint32_t)((xoff(min(r + 64, last), op.rshift, op.rstride, op.s_row) + kl) * 4);
     } else {
-        const int row = row0 + 4 * (tid & 31);
-        L.kloc = tid >> 5;
-        L.p0 = op.base + xoff(max(0, min(row, op.rows - 4)), op.rshift, op.rstride, 1);
-        L.p1 = nullptr;
-        L.ok = row + 3 < op.rows ? 3 : 0;
+        const int64_t ro = xoff(max(0, min(row0 + 4 * (tid & 31), op.rows - 4)), op.rshift, op.rstride, 1);
+        const int kl = tid >> 5;
+        F.o[0] = (uint32_t)((ro + (int64_t)kl * op.s_k) * 4);
+        F.o[1] = (uint32_t)((ro + (int64_t)(kl + 8) * op.s_k) * 4);
     }
 }
 
 template <bool KC, bool FAST>
-__device__ __forceinline__ XQ2 xtile(const XOperand& op, const XLane& L, int row0, int k0, int kend, int tid) {
+__device__ __forceinline__ XQ2 xtile(const XOperand& op, const XFast& F, int row0, int k0, int kend, int tid) {
     XQ2 v;
     if (FAST) {
-        if (KC) {
-            const int64_t ko = xoff(k0 + L.kloc, op.kshift, op.kstride, 1);
-            v.a = xld4(L.p0 + ko); v.b = xld4(L.p1 + ko);
-        } else {
-            v.a = xld4(L.p0 + xoff(k0 + L.kloc, op.kshift, op.kstride, op.s_k));
-            v.b = xld4(L.p0 + xoff(k0 + L.kloc + 8, op.kshift, op.kstride, op.s_k));
-        }
+        const uint32_t sb = xstepbase<KC>(op, k0);
+        v.a = xldo(op, sb, F.o[0]); v.b = xldo(op, sb, F.o[1]);
     } else if (KC) {
         v.a = xgen<true>(op, row0 + (tid >> 2), k0 + 4 * (tid & 3), kend);
         v.b = xgen<true>(op, row0 + (tid >> 2) + 64, k0 + 4 * (tid & 3), kend);
@@ -146,8 +232,6 @@ __device__ __forceinline__ XQ2 xtile(const XOperand& op, const XLane& L, int row
     }
     return v;
 }
-
-__device__ __forceinline__ void xmask2(int ok, XQ2& v) { v.a = xsel(ok & 1, v.a); v.b = xsel(ok & 2, v.b); }
 
 template <bool KC>
 __device__ __forceinline__ void xstore_lds(float* tile, int tid, const XQ2& v) {
@@ -175,7 +259,7 @@ struct XCtx {
 // (~1 us each) to arrive -- one stage (the first version) left the HBM / L2 round trip exposed in every step.
 #define XNST 3
 template <bool AK, bool BK_, bool FAST>
-__device__ __forceinline__ void xrun(const XOperand& A, const XOperand& B, const XLane& LA, const XLane& LB, const XCtx& c,
+__device__ __forceinline__ void xrun(const XOperand& A, const XOperand& B, const XFast& LA, const XFast& LB, const XCtx& c,
                                      int ka, int kb, int& par, float* smem, f32x16 (&acc)[2][2], float& rsum) {
     if (ka >= kb) return;
     const int tid = c.tid;
@@ -186,9 +270,6 @@ __device__ __forceinline__ void xrun(const XOperand& A, const XOperand& B, const
         b = xtile<BK_, FAST>(B, LB, c.n0, tt * XBK, c.kend, tid);
     };
     auto store = [&](XQ2& a, XQ2& b, int buf) {
-        // rows outside the operand were loaded from a clamped address: zeroed here, long after the load was issued (a
-        // select right behind the load makes the wave wait for it first)
-        if (FAST) { xmask2(LA.ok, a); xmask2(LB.ok, b); }
         xstore_lds<AK>(smem + buf * 2 * XTILE, tid, a);
         xstore_lds<BK_>(smem + buf * 2 * XTILE + XTILE, tid, b);
     };
@@ -237,7 +318,7 @@ __device__ __forceinline__ void xrun(const XOperand& A, const XOperand& B, const
 template <bool AK, bool BK_>
 __device__ __forceinline__ void xmain(const XOperand& A, const XOperand& B, const XCtx& c, int kt0, int kt1, float* smem,
                                       f32x16 (&acc)[2][2], float& rsum) {
-    XLane LA, LB;
+    XFast LA, LB;
     xprep<AK>(A, c.m0, c.tid, LA);
     xprep<BK_>(B, c.n0, c.tid, LB);
     int ktf = kt0;                                         // [kt0, ktf): tiles inside the slice, fast loop
@@ -250,12 +331,15 @@ __device__ __forceinline__ void xmain(const XOperand& A, const XOperand& B, cons
 __device__ __forceinline__ void xoperands(const skg_gemmx_desc& d, int vecbits, XOperand& A, XOperand& B) {
     A.base = d.A; A.s_row = d.a_sm; A.s_k = d.a_sk; A.rshift = 0; A.kshift = 0; A.rstride = 0; A.kstride = 0;
     A.rows = d.M; A.vec = vecbits & 1;
+    A.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.A), 0, 0x7fffffff, 0x00020000);
+    B.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.B), 0, 0x7fffffff, 0x00020000);
     B.base = d.B; B.s_row = d.b_sn; B.s_k = d.b_sk; B.rshift = d.b_nshift; B.kshift = d.b_kshift;
     B.rstride = d.b_nstride; B.kstride = d.b_kstride; B.rows = d.N; B.vec = (vecbits >> 1) & 1;
 }
 
 __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group g) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * XTILE];      // A0 | B0 | A1 | B1
+    static_assert(XEP_FLOATS >= 4 * XTILE, "the staged epilogue reuses the operand tiles' LDS");
+    __shared__ __attribute__((aligned(16))) float smem[XEP_FLOATS];     // A0 | B0 | A1 | B1, then the staged epilogue
     int gi = 0;
 #pragma unroll
     for (int t = 1; t < SKG_GEMMX_GROUP_MAX; ++t)
@@ -264,9 +348,8 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
     const int vecbits = g.vec[gi];
     const int S = d.split_k > 1 ? d.split_k : 1;
     const int nbn = (d.N + XBN - 1) / XBN;
-    int b = blockIdx.x - g.start[gi];
-    const int slice = b % S; b /= S;
-    const int tn = b % nbn, tm = b / nbn;                 // consecutive blocks walk N: they share the A panel in L2
+    const XTileId tid3 = xtile_of(blockIdx.x - g.start[gi], g.start[gi + 1] - g.start[gi], (d.M + XBM - 1) / XBM, nbn, S, d.K);
+    const int slice = tid3.slice, tn = tid3.tn, tm = tid3.tm;
     // k range of this slice, in whole k-tiles
     const int nkt = (d.K + XBK - 1) / XBK;
     const int per = (nkt + S - 1) / S;
@@ -302,7 +385,29 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
     //      row m0 + wm*64 + 2*(8*gq + 4*lk + t) + mb,  column n0 + wn*64 + 2*li + nb.
     const bool split = S > 1;
     const int64_t MN = (int64_t)d.M * d.N;
-    float* ws = split ? d.split_ws + (int64_t)slice * (MN + d.M) : nullptr;
+    float* ws = split ? d.split_ws + (int64_t)slice * MN : nullptr;           // [S][M * N] then [S][M] row sums
+    if (c.do_rowsum && tid < XBM && m0 + tid < d.M) {
+        if (split) d.split_ws[(int64_t)S * MN + (int64_t)slice * d.M + m0 + tid] = rsum;
+        else d.a_rowsum[m0 + tid] = d.accumulate ? d.a_rowsum[m0 + tid] + rsum : rsum;
+    }
+    if (vecbits & 8) {                                     // staged: the k loop ended on a barrier, LDS is free
+        float* stage = smem + wave * XEP_WAVE;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        const int e = 4 * (2 * ps + g2) + t;
+                        *reinterpret_cast<float2*>(stage + (2 * (8 * g2 + 4 * lk + t) + mb) * XEP_LD + 2 * li) =
+                            make_float2(acc[mb][0][e], acc[mb][1][e]);
+                    }
+            xep_rows(d, stage, lane, m0 + wm * 64 + 32 * ps, n0 + wn * 64, ws);
+        }
+        return;
+    }
     const bool vecC = (vecbits >> 2) & 1;
     const int col = n0 + wn * 64 + 2 * li;
 #pragma unroll
@@ -346,10 +451,6 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
                     }
                 }
             }
-    if (c.do_rowsum && tid < XBM && m0 + tid < d.M) {
-        if (split) ws[MN + m0 + tid] = rsum;
-        else d.a_rowsum[m0 + tid] = d.accumulate ? d.a_rowsum[m0 + tid] + rsum : rsum;
-    }
 }
 
 // ================================================================================================ bf16 operands
@@ -384,35 +485,26 @@ __device__ __forceinline__ int yrq(int tid) { return (tid & 7) | (((tid >> 4) & 
 __device__ __forceinline__ int ykq4(int tid) { return ((tid >> 3) & 1) | ((tid >> 6) << 1); }
 
 template <bool KC>
-__device__ __forceinline__ void yprep(const XOperand& op, int row0, int tid, XLane& L) {
+__device__ __forceinline__ void yprep(const XOperand& op, int row0, int tid, XFast& F) {
     if (KC) {
-        const int r = row0 + (tid >> 3), last = op.rows - 1;
-        L.kloc = 4 * (tid & 7);
-        L.p0 = op.base + xoff(min(r, last), op.rshift, op.rstride, op.s_row);
-        L.p1 = op.base + xoff(min(r + 32, last), op.rshift, op.rstride, op.s_row);
-        L.p2 = op.base + xoff(min(r + 64, last), op.rshift, op.rstride, op.s_row);
-        L.p3 = op.base + xoff(min(r + 96, last), op.rshift, op.rstride, op.s_row);
-        L.ok = (r < op.rows ? 1 : 0) | (r + 32 < op.rows ? 2 : 0) | (r + 64 < op.rows ? 4 : 0) | (r + 96 < op.rows ? 8 : 0);
+        const int r = row0 + (tid >> 3), last = op.rows - 1, kl = 4 * (tid & 7);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            F.o[u] = (uint32_t)((xoff(min(r + 32 * u, last), op.rshift, op.rstride, op.s_row) + kl) * 4);
     } else {
-        const int row = row0 + 4 * yrq(tid);
-        L.kloc = 4 * ykq4(tid);
-        L.p0 = op.base + xoff(max(0, min(row, op.rows - 4)), op.rshift, op.rstride, 1);
-        L.p1 = L.p2 = L.p3 = nullptr;
-        L.ok = row + 3 < op.rows ? 15 : 0;
+        const int64_t ro = xoff(max(0, min(row0 + 4 * yrq(tid), op.rows - 4)), op.rshift, op.rstride, 1);
+        const int kl = 4 * ykq4(tid);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) F.o[u] = (uint32_t)((ro + (int64_t)(kl + u) * op.s_k) * 4);
     }
 }
 
 template <bool KC, bool FAST>
-__device__ __forceinline__ void ytile(const XOperand& op, const XLane& L, int row0, int k0, int kend, int tid, float4& va,
+__device__ __forceinline__ void ytile(const XOperand& op, const XFast& F, int row0, int k0, int kend, int tid, float4& va,
                                       float4& vb, float4& vc, float4& vd) {
     if (FAST) {
-        if (KC) {
-            const int64_t ko = xoff(k0 + L.kloc, op.kshift, op.kstride, 1);
-            va = xld4(L.p0 + ko); vb = xld4(L.p1 + ko); vc = xld4(L.p2 + ko); vd = xld4(L.p3 + ko);
-        } else {                                           // a 4-aligned group of k never crosses a k block
-            const float* q = L.p0 + xoff(k0 + L.kloc, op.kshift, op.kstride, op.s_k);
-            va = xld4(q); vb = xld4(q + op.s_k); vc = xld4(q + 2 * op.s_k); vd = xld4(q + 3 * op.s_k);
-        }
+        const uint32_t sb = xstepbase<KC>(op, k0);
+        va = xldo(op, sb, F.o[0]); vb = xldo(op, sb, F.o[1]); vc = xldo(op, sb, F.o[2]); vd = xldo(op, sb, F.o[3]);
     } else if (KC) {
         const int r = row0 + (tid >> 3), k = k0 + 4 * (tid & 7);
         va = xgen<true>(op, r, k, kend); vb = xgen<true>(op, r + 32, k, kend);
@@ -422,10 +514,6 @@ __device__ __forceinline__ void ytile(const XOperand& op, const XLane& L, int ro
         va = xgen<false>(op, row, k, kend); vb = xgen<false>(op, row, k + 1, kend);
         vc = xgen<false>(op, row, k + 2, kend); vd = xgen<false>(op, row, k + 3, kend);
     }
-}
-
-__device__ __forceinline__ void ymask4(int ok, float4& a, float4& b, float4& c, float4& d) {
-    a = xsel(ok & 1, a); b = xsel(ok & 2, b); c = xsel(ok & 4, c); d = xsel(ok & 8, d);
 }
 
 template <bool KC>
@@ -464,7 +552,7 @@ __device__ __forceinline__ void yrowsum(float4 va, float4 vb, float4 vc, float4 
 // (475 -> 295 TFLOP/s: eight more 16-byte loads per thread in flight, two 512-byte segments each), while it gains the
 // k-contiguous layouts 15-35 %.
 template <bool AK, bool BK_, bool FAST>
-__device__ __forceinline__ void yrun1(const XOperand& A, const XOperand& B, const XLane& LA, const XLane& LB, const XCtx& c,
+__device__ __forceinline__ void yrun1(const XOperand& A, const XOperand& B, const XFast& LA, const XFast& LB, const XCtx& c,
                                      int ka, int kb, int& par, uint16_t* smem, f32x16 (&acc)[2][2], float4& rs) {
     if (ka >= kb) return;
     const int tid = c.tid;
@@ -474,7 +562,6 @@ __device__ __forceinline__ void yrun1(const XOperand& A, const XOperand& B, cons
     float4 a0, a1, a2, a3, b0, b1, b2, b3;
     ytile<AK, FAST>(A, LA, c.m0, ka * YBK, c.kend, tid, a0, a1, a2, a3);
     ytile<BK_, FAST>(B, LB, c.n0, ka * YBK, c.kend, tid, b0, b1, b2, b3);
-    if (FAST) { ymask4(LA.ok, a0, a1, a2, a3); ymask4(LB.ok, b0, b1, b2, b3); }
     if (c.do_rowsum) yrowsum<AK>(a0, a1, a2, a3, rs);
     ystore_lds<AK>(smem + par * 2 * YTILE, tid, a0, a1, a2, a3);
     ystore_lds<BK_>(smem + par * 2 * YTILE + YTILE, tid, b0, b1, b2, b3);
@@ -503,8 +590,6 @@ __device__ __forceinline__ void yrun1(const XOperand& A, const XOperand& B, cons
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, b11, acc[1][1], 0, 0, 0);
         if (more) {
             uint16_t* An = smem + (par ^ 1) * 2 * YTILE;
-            // zeroing of clamped rows AFTER the MFMAs: the loads stay in flight across them
-            if (FAST) { ymask4(LA.ok, a0, a1, a2, a3); ymask4(LB.ok, b0, b1, b2, b3); }
             if (c.do_rowsum) yrowsum<AK>(a0, a1, a2, a3, rs);
             ystore_lds<AK>(An, tid, a0, a1, a2, a3);
             ystore_lds<BK_>(An + YTILE, tid, b0, b1, b2, b3);
@@ -518,8 +603,11 @@ __device__ __forceinline__ void yrun1(const XOperand& A, const XOperand& B, cons
 // round trip per step unless several tiles are in flight; two stages (64 VGPRs) are what the register budget of two
 // waves per SIMD leaves next to the 64 accumulators.
 #define YNST 2
+#ifndef SKG_YORDER
+#define SKG_YORDER 1
+#endif
 template <bool AK, bool BK_, bool FAST>
-__device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const XLane& LA, const XLane& LB, const XCtx& c,
+__device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const XFast& LA, const XFast& LB, const XCtx& c,
                                      int ka, int kb, int& par, uint16_t* smem, f32x16 (&acc)[2][2], float4& rs) {
     if (ka >= kb) return;
     const int tid = c.tid;
@@ -535,8 +623,6 @@ __device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const
     };
     auto store = [&](auto S, int buf) {
         constexpr int g = decltype(S)::value;
-        // zeroing of clamped rows long after the load was issued: the loads stay in flight across the MFMAs
-        if (FAST) { ymask4(LA.ok, sa[g][0], sa[g][1], sa[g][2], sa[g][3]); ymask4(LB.ok, sb[g][0], sb[g][1], sb[g][2], sb[g][3]); }
         if (c.do_rowsum) yrowsum<AK>(sa[g][0], sa[g][1], sa[g][2], sa[g][3], rs);
         ystore_lds<AK>(smem + buf * 2 * YTILE, tid, sa[g][0], sa[g][1], sa[g][2], sa[g][3]);
         ystore_lds<BK_>(smem + buf * 2 * YTILE + YTILE, tid, sb[g][0], sb[g][1], sb[g][2], sb[g][3]);
@@ -558,6 +644,12 @@ __device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const
         const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(As + 2 * YPLANE + fa1);
         const bf16x8 b10 = *reinterpret_cast<const bf16x8*>(Bs + 2 * YPLANE + fb0);
         const bf16x8 b11 = *reinterpret_cast<const bf16x8*>(Bs + 2 * YPLANE + fb1);
+#if SKG_YORDER == 1
+        // the next tile goes to the other LDS buffer while this tile's fragments are still on their way to registers
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < kb) store(NX, par ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, b00, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, b01, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, b00, acc[1][0], 0, 0, 0);
@@ -566,7 +658,9 @@ __device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, b11, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, b10, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, b11, acc[1][1], 0, 0, 0);
+#if SKG_YORDER != 1
         if (kt + 1 < kb) store(NX, par ^ 1);
+#endif
         load(NX, kt + 1 + YNST);
         __syncthreads();
         par ^= 1;
@@ -582,7 +676,7 @@ __device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const
 template <bool AK, bool BK_>
 __device__ __forceinline__ void ymain(const XOperand& A, const XOperand& B, const XCtx& c, int kt0, int kt1, uint16_t* smem,
                                       f32x16 (&acc)[2][2], float4& rs) {
-    XLane LA, LB;
+    XFast LA, LB;
     yprep<AK>(A, c.m0, c.tid, LA);
     yprep<BK_>(B, c.n0, c.tid, LB);
     int ktf = kt0;
@@ -609,7 +703,8 @@ __device__ __forceinline__ void ymain(const XOperand& A, const XOperand& B, cons
 }
 
 __global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_group g) {
-    __shared__ __attribute__((aligned(16))) uint16_t smem[4 * YTILE];      // A0 | B0 | A1 | B1
+    static_assert(2 * XEP_FLOATS >= 4 * YTILE, "the staged epilogue reuses the operand tiles' LDS");
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * XEP_FLOATS];  // A0 | B0 | A1 | B1, then the staged epilogue
     int gi = 0;
 #pragma unroll
     for (int t = 1; t < SKG_GEMMX_GROUP_MAX; ++t)
@@ -618,12 +713,15 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_
     const int vecbits = g.vec[gi];
     const int S = d.split_k > 1 ? d.split_k : 1;
     const int nbn = (d.N + XBN - 1) / XBN;
-    int b = blockIdx.x - g.start[gi];
-    const int slice = b % S; b /= S;
-    const int tn = b % nbn, tm = b / nbn;
+    const XTileId tid3 = xtile_of(blockIdx.x - g.start[gi], g.start[gi + 1] - g.start[gi], (d.M + XBM - 1) / XBM, nbn, S, d.K);
+    const int slice = tid3.slice, tn = tid3.tn, tm = tid3.tm;
     const int nkt = (d.K + YBK - 1) / YBK;
     const int per = (nkt + S - 1) / S;
+#ifdef SKG_XPROBE_NOLOOP                                   // timing builds (tools/build_gemmx_variants.sh): what the k loop costs
+    const int kt0 = slice * per, kt1 = kt0;
+#else
     const int kt0 = slice * per, kt1 = min(nkt, kt0 + per);
+#endif
 
     XOperand A, B;
     xoperands(d, vecbits, A, B);
@@ -651,10 +749,39 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_
         else ymain<false, false>(A, B, c, kt0, kt1, smem, acc, rs);
     }
 
+#ifdef SKG_XPROBE_NOEPI                                    // timing builds: what the epilogue costs
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
     // ---- epilogue.  acc[mi][ni][4*gq + t] = row m0 + wm*64 + mi*32 + 8*gq + 4*lk + t, column n0 + wn*64 + ni*32 + li.
     const bool split = S > 1;
     const int64_t MN = (int64_t)d.M * d.N;
-    float* ws = split ? d.split_ws + (int64_t)slice * (MN + d.M) : nullptr;
+    float* ws = split ? d.split_ws + (int64_t)slice * MN : nullptr;           // [S][M * N] then [S][M] row sums
+    if (c.do_rowsum) {                                     // uniform per workgroup; ymain left the partial sums in LDS
+        if (tid < XBM && m0 + tid < d.M) {
+            const float* part = reinterpret_cast<const float*>(smem);
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += part[q * 128 + tid];
+            if (split) d.split_ws[(int64_t)S * MN + (int64_t)slice * d.M + m0 + tid] = s;
+            else d.a_rowsum[m0 + tid] = d.accumulate ? d.a_rowsum[m0 + tid] + s : s;
+        }
+        __syncthreads();                                   // read before the staged epilogue overwrites them
+    }
+    if (vecbits & 8) {
+        float* stage = reinterpret_cast<float*>(smem) + wave * XEP_WAVE;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        stage[(8 * gq + 4 * lk + t) * XEP_LD + ni * 32 + li] = acc[mi][ni][4 * gq + t];
+            xep_rows(d, stage, lane, m0 + wm * 64 + mi * 32, n0 + wn * 64, ws);
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -677,14 +804,6 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_
                     *p = v;
                 }
             }
-    if (c.do_rowsum && tid < XBM && m0 + tid < d.M) {
-        const float* part = reinterpret_cast<const float*>(smem);
-        float s = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s += part[q * 128 + tid];
-        if (split) ws[MN + m0 + tid] = s;
-        else d.a_rowsum[m0 + tid] = d.accumulate ? d.a_rowsum[m0 + tid] + s : s;
-    }
 }
 
 // Adds the split-K slices in slice order and applies the epilogue.  One thread per output element (coalesced along n).
@@ -695,16 +814,39 @@ __global__ __launch_bounds__(256) void skg_gemmx_reduce_kernel(const skg_gemmx_g
         if (t < g.n && (int)blockIdx.x >= g.start[t]) gi = t;
     const skg_gemmx_desc& d = g.d[gi];
     const int64_t MN = (int64_t)d.M * d.N;
-    const int64_t total = MN + (d.a_rowsum ? d.M : 0);
-    const int64_t i = (int64_t)(blockIdx.x - g.start[gi]) * 256 + threadIdx.x;
-    if (i >= total) return;
-    float v = 0.f;
-    for (int s = 0; s < d.split_k; ++s) v += d.split_ws[(int64_t)s * (MN + d.M) + i];
-    if (i >= MN) {                                         // bias gradient (row sums of A)
-        const int m = (int)(i - MN);
+    const int64_t w = (int64_t)(blockIdx.x - g.start[gi]) * 256 + threadIdx.x;
+    const bool quads = g.vec[gi] & 8;                     // four columns per thread, 16-byte loads and stores
+    const int64_t nmat = quads ? MN / 4 : MN;
+    if (w >= nmat) {                                       // bias gradient (row sums of A)
+        const int64_t m = w - nmat;
+        if (m >= d.M || !d.a_rowsum) return;
+        float v = 0.f;
+        for (int s = 0; s < d.split_k; ++s) v += d.split_ws[(int64_t)d.split_k * MN + (int64_t)s * d.M + m];
         d.a_rowsum[m] = d.accumulate ? d.a_rowsum[m] + v : v;
         return;
     }
+    if (quads) {
+        const int64_t i = 4 * w;
+        float4 v = xzero4();
+        for (int s = 0; s < d.split_k; ++s) {
+            const float4 q = xld4(d.split_ws + (int64_t)s * MN + i);
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        const int row = (int)(i / d.N), col = (int)(i % d.N);
+        if (d.bias) { const float4 bv = xld4(d.bias + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+        if (d.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        float* p = d.C + xoff(col, d.c_nshift, d.c_nstride, 1) + (int64_t)row * d.ldc;
+        if (d.accumulate) { const float4 o = xld4(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        if (d.mask) {                                      // accumulate first, mask last
+            const float4 m = xld4(d.mask + (int64_t)row * d.ldmask + col);
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(p) = v;
+        return;
+    }
+    const int64_t i = w;
+    float v = 0.f;
+    for (int s = 0; s < d.split_k; ++s) v += d.split_ws[(int64_t)s * MN + i];
     const int row = (int)(i / d.N), col = (int)(i % d.N);
     if (d.bias) v += d.bias[col];
     if (d.relu) v = fmaxf(v, 0.f);
@@ -731,6 +873,14 @@ static int skg_gemmx_validate(const skg_gemmx_desc& d) {
 
 static bool xmul4(int64_t v) { return (v & 3) == 0; }
 
+// Largest element offset an operand reaches (host copy of xoff): the fast loop keeps 32-bit byte offsets per lane.
+static int64_t xspan(int64_t idx, int shift, int64_t bstride, int64_t estride) {
+    if (idx <= 0) return 0;
+    if (shift <= 0) return idx * estride;
+    return (idx >> shift) * bstride + (idx & ((1LL << shift) - 1)) * estride;
+}
+static bool xfits32(int64_t elems) { return elems >= 0 && elems < (1LL << 29); }     // < 2 GiB in bytes
+
 extern "C" int64_t skg_gemmx_ws_floats(const skg_gemmx_desc* d) {
     if (!d) return SKG_E_ARG;
     return d->split_k > 1 ? (int64_t)d->split_k * ((int64_t)d->M * d->N + d->M) : 0;
@@ -750,15 +900,25 @@ static int skg_gemmx_launch(const skg_gemmx_desc* descs_host, int n, void* strea
         const int64_t nb = (int64_t)((d.M + XBM - 1) / XBM) * ((d.N + XBN - 1) / XBN) * S;
         if (blocks + nb > 0x7fffffffLL) return SKG_E_LIMIT;
         int vec = 0;
-        if (skg_aligned16(d.A) && (d.a_sk == 1 ? xmul4(d.a_sm) : xmul4(d.a_sk))) vec |= 1;
+        // bits 0 / 1 admit an operand to the fast loop: 16-byte loads, 32-bit byte offsets, k blocks of whole k-tiles
+        if (skg_aligned16(d.A) && (d.a_sk == 1 ? xmul4(d.a_sm) : xmul4(d.a_sk)) &&
+            xfits32((int64_t)(d.M - 1) * d.a_sm + (int64_t)(d.K - 1) * d.a_sk + 4))
+            vec |= 1;
         if (skg_aligned16(d.B) && (d.b_sk == 1 ? xmul4(d.b_sn) : xmul4(d.b_sk)) &&
-            (d.b_kshift == 0 || xmul4(d.b_kstride)) && (d.b_nshift == 0 || xmul4(d.b_nstride)))
+            (d.b_kshift == 0 || (xmul4(d.b_kstride) && d.b_kshift >= 5)) && (d.b_nshift == 0 || xmul4(d.b_nstride)) &&
+            xfits32(xspan(d.N - 1, d.b_nshift, d.b_nstride, d.b_sn) + xspan(d.K - 1, d.b_kshift, d.b_kstride, d.b_sk) + 4))
             vec |= 2;
         if ((((uintptr_t)d.C) & 7u) == 0 && (d.ldc & 1) == 0 && (d.c_nshift == 0 || (d.c_nstride & 1) == 0)) vec |= 4;
+        // bit 3: the staged epilogue / four-column reduce (16-byte accesses to C, bias, mask and the workspace rows)
+        if ((d.N & 3) == 0 && skg_aligned16(d.C) && xmul4(d.ldc) &&
+            (d.c_nshift == 0 || (d.c_nshift >= 2 && xmul4(d.c_nstride))) && skg_aligned16(d.bias) &&
+            skg_aligned16(d.mask) && (!d.mask || xmul4(d.ldmask)) && (S == 1 || skg_aligned16(d.split_ws)))
+            vec |= 8;
         g.d[g.n] = d; g.vec[g.n] = vec; g.start[g.n] = (int)blocks; ++g.n;
         blocks += nb;
         if (S > 1) {
-            const int64_t total = (int64_t)d.M * d.N + (d.a_rowsum ? d.M : 0);
+            const int64_t MN = (int64_t)d.M * d.N;
+            const int64_t total = ((vec & 8) ? MN / 4 : MN) + (d.a_rowsum ? d.M : 0);
             const int64_t nr = (total + 255) / 256;
             if (rblocks + nr > 0x7fffffffLL) return SKG_E_LIMIT;
             r.d[r.n] = d; r.vec[r.n] = vec; r.start[r.n] = (int)rblocks; ++r.n;

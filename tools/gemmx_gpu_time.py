@@ -1,0 +1,64 @@
+"""Developer aid (GPU box): GPU-side duration of one skg_gemmx product, free of the host's launch rate -- `reps` launches are
+captured into a hipGraph and the replay is timed (a Python loop of ctypes launches tops out near 25-40 us per launch, which
+is longer than the batch-4 products themselves).
+usage: gemmx_gpu_time.py [bf16|fp32] [kind ...]      prints a K sweep and the aliased-operand variants per kind"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.dont_write_bytecode = True
+import torch
+from skghoi_amd import gemmx
+
+
+def gpu_us(ops, bf16, reps=20, rounds=5):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            gemmx.launch(ops, bf16=bf16)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(reps):
+                gemmx.launch(ops, bf16=bf16)
+        g.replay(); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        best = 1e9
+        for _ in range(rounds):
+            e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / reps * 1e3)
+    return best
+
+
+def make(kind, M, N, K):
+    x = torch.randn(M, K).cuda(); W = torch.randn(N, K).cuda() * 0.03; b = torch.randn(N).cuda()
+    y = torch.empty(M, N).cuda(); dz = torch.randn(M, N).cuda(); dx = torch.empty(M, K).cuda()
+    dW = torch.empty(N, K).cuda(); db = torch.empty(N).cuda()
+    if kind == "fwd":
+        return gemmx.forward(x, W, y, bias=b, relu=True), 2.0 * M * N * K
+    if kind == "dx":
+        return gemmx.input_grad(dz, W, dx, mask=x), 2.0 * M * N * K
+    return gemmx.weight_grad(dz, x, dW, db=db), 2.0 * M * N * K
+
+
+if __name__ == "__main__":
+    bf16 = not (len(sys.argv) > 1 and sys.argv[1] == "fp32")
+    kinds = sys.argv[2:] or ["fwd", "dx", "dw"]
+    tag = "bf16" if bf16 else "fp32"
+    for kind in kinds:
+        for M, N, K, S in [(3200, 1024, 128, 1), (3200, 1024, 256, 1), (3200, 1024, 512, 1), (3200, 1024, 1024, 1),
+                           (3200, 1024, 2048, 1), (3200, 1024, 1024, 2), (3200, 1024, 1024, 0), (3200, 4096, 1024, 1),
+                           (3200, 256, 1024, 0), (25600, 1024, 1024, 1), (102400, 1024, 1024, 1)]:
+            op, f = make(kind, M, N, K)
+            op.split_k = S
+            line = "%s %-3s M=%6d N=%4d K=%4d S=%d:" % (tag, kind, M, N, K, S)
+            us = gpu_us([op], bf16)
+            line += "  %7.1f us %6.1f TF" % (us, f / us / 1e6)
+            if kind == "fwd":
+                for name, za, zb in (("B aliased", False, True), ("A+B aliased", True, True)):
+                    op2, _ = make(kind, M, N, K)
+                    op2.split_k = S
+                    if za:
+                        op2.a_sm = 0
+                    if zb:
+                        op2.b_sn = 0
+                    us = gpu_us([op2], bf16)
+                    line += "  | %s %7.1f us %6.1f TF" % (name, us, f / us / 1e6)
+            print(line, flush=True)
