@@ -81,13 +81,16 @@ static skg_gemmx_desc WG(const Mat& dz, const Mat& x, const Mat& dW, float* db, 
 
 // Split-K factor of one product: measured on MI355X at the training shapes (tools/gemmx_split_sweep.py; re-swept on the whole
 // batch-4 step in round 3: 200 ... 800 / 500 ... 1400 workgroups and a per-LAUNCH instead of per-product count all came out
-// level or slower) -- the exact fp32 loop is best at ~1000 workgroups, the bf16 loop at ~450; slices keep >= 128 k.
+// level or slower) -- the exact fp32 loop was best at ~1000 workgroups, the bf16 loop at ~450; slices keep >= 128 k.
+// With the staged epilogue and the four-column reduce a workgroup costs less and a slice's round trip relatively more:
+// re-swept on the step, bf16 128 / 192 / 256 / 320 / 448 / 640 -> 1.503 / 1.489 / 1.486 / 1.555 / 1.546 / 1.61 ms,
+// fp32 300 / 500 / 750 / 1000 / 1400 -> 2.676 / 2.672 / 2.703 / 2.696 / 2.81 ms.
 static int split_target(int bk) {
     static int t16 = 0, t32 = 0;
     if (!t16) {
         const char* a = getenv("SKG_SPLIT_TARGET_F32"); const char* b = getenv("SKG_SPLIT_TARGET_BF16");    // developer knobs
-        t16 = a && atoi(a) > 0 ? atoi(a) : 1000;
-        t32 = b && atoi(b) > 0 ? atoi(b) : 448;
+        t16 = a && atoi(a) > 0 ? atoi(a) : 500;
+        t32 = b && atoi(b) > 0 ? atoi(b) : 256;
     }
     return bk == 16 ? t16 : t32;
 }

@@ -92,12 +92,13 @@ def weight_grad(dz, x, dW, db=None, accumulate=False, rows=None, n_out=None, k_i
 
 def pick_split(op, blocks_so_far=0, target=None, bk=16):
     """Split-K factor of one product.  Measured on MI355X (tools/gemmx_split_sweep.py, training shapes at 3200 grid
-    rows): the exact fp32 loop is best at ~1000 workgroups (its k-tiles are long: 32 MFMAs of 64 cycles), the bf16 loop
-    at ~450; slices keep >= 128 k; products with more than ~1.5x fewer tiles than the target are not split."""
+    rows, re-swept on the whole training step after the staged epilogue: skg_train_plan.hip split_target): the exact fp32
+    loop is best at ~500 workgroups, the bf16 loop at ~256; slices keep >= 128 k; products with more than ~1.5x fewer
+    tiles than the target are not split."""
     tiles = ((op.M + 127) // 128) * ((op.N + 127) // 128)
     kt = (op.K + bk - 1) // bk
     if target is None:
-        target = 1000 if bk == 16 else 448
+        target = 500 if bk == 16 else 256
     cap = min(kt * bk // 128, 64)
     if tiles == 0 or cap < 2:
         return 1
