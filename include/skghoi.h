@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SKG_ABI_VERSION 9
+#define SKG_ABI_VERSION 10
 #define SKG_E_ARG   (-1)   /* null pointer / negative size / unsupported shape            */
 #define SKG_E_ALIGN (-2)   /* pointer or leading dimension not 16-byte aligned            */
 #define SKG_E_LIMIT (-3)   /* exceeds a compiled-in limit (boxes per image, verbs, ...)   */
@@ -405,7 +405,7 @@ int skg_entity_rows_bwd_f32(const float* dX, int64_t ldx, const int32_t* hum_of,
  * {sum of the cell losses, sum of the pair losses, number of positive cells, number of positive pairs} (to be added up;
  * the counts are the normalisers n_p of HEAD:162-165),
  * dlogits [sumP, ldl] (ZERO-FILLED by the caller): columns < K d(cell loss sum)/dlogit, column K d(pair loss sum).    */
-#define SKG_LOSS_CHUNKS 16
+#define SKG_LOSS_CHUNKS 64
 int skg_hoi_loss_f32(const float* logits, int64_t ldl, int K, const skg_image_meta* meta, int n_active,
                      int64_t cells_total, const int64_t* index, const int64_t* pred, const float* scores,
                      const float* labels, float* cell_labels, float* unary, float* partial, float* dlogits,
@@ -543,6 +543,14 @@ int skg_train_forward_f32(const skg_train_plan* plan_host, int part, void* strea
  * the segments in the arena follows the stages: read-out layers first, box_head last), so a data-parallel caller can
  * exchange the arena chunk by chunk between calls.                                                                      */
 int skg_train_backward_f32(const skg_train_plan* plan_host, int first_stage, int last_stage, void* stream);
+/* The same call issued from a worker thread of the library (one job at a time; the plan is copied, the worker selects
+ * the caller's current device): returns at once -- 0, or SKG_E_* for a rejected plan / SKG_E_LIMIT while a job is
+ * pending.  skg_train_backward_join() blocks until every launch of the job has been enqueued and returns what
+ * skg_train_backward_f32 returned (0 when no job was pending).  Between the two calls the caller may enqueue work on
+ * OTHER streams and do host work; it must not enqueue anything ordered after the gradients, nor release a buffer the
+ * plan names.  For step loops bound by their own host thread (a Python trainer at batch 4: ~0.2 ms of launch calls). */
+int skg_train_backward_async_f32(const skg_train_plan* plan_host, int first_stage, int last_stage, void* stream);
+int skg_train_backward_join(void);
 /* Arithmetic of the plan: 2 M N K summed over every dense product it issues (which = 0 forward, 1 backward, 2 both; the
  * backward is counted with dx0 / dgfeat requested).  For roofline records.                                              */
 double skg_train_flops(const skg_train_plan* plan_host, int which);

@@ -12,10 +12,10 @@ MAX_NODES = 160
 SPATIAL_LD = 48
 TRANSH_DIM = 50
 TRANSH_ENT = 80
-ABI_VERSION = 9
+ABI_VERSION = 10
 GEMM_GROUP_MAX = 4
 CHECKSUM_PARTIALS = 1024
-LOSS_CHUNKS = 16
+LOSS_CHUNKS = 64
 
 _vp = C.c_void_p
 _i32 = C.c_int32
@@ -145,6 +145,8 @@ PROTOTYPES = {
     "skg_train_ws_floats": (C.c_int64, [C.POINTER(TrainPlan)]),
     "skg_train_forward_f32": (C.c_int, [C.POINTER(TrainPlan), C.c_int, _vp]),
     "skg_train_backward_f32": (C.c_int, [C.POINTER(TrainPlan), C.c_int, C.c_int, _vp]),
+    "skg_train_backward_async_f32": (C.c_int, [C.POINTER(TrainPlan), C.c_int, C.c_int, _vp]),
+    "skg_train_backward_join": (C.c_int, []),
     "skg_train_ws_offset": (C.c_int64, [C.POINTER(TrainPlan), C.c_int]),
     "skg_train_flops": (C.c_double, [C.POINTER(TrainPlan), C.c_int]),
 }

@@ -477,11 +477,14 @@ class InteractionHead(Module):
         self._prefetched = h
         return h
 
-    def fused_step(self, features, detections, image_shapes, targets, after_forward=None):
+    def fused_step(self, features, detections, image_shapes, targets, after_forward=None, defer_backward=False):
         """Forward + backward of one training step without the autograd engine (skghoi_amd.train_fused.fused_step) for a
         trainer that owns the loop: gradients of the summed losses land in `p.grad` (overwritten, not accumulated).
         Returns the result list with the (detached) loss dict appended, or None when this call has to go through
-        `forward` + `backward()` instead."""
+        `forward` + `backward()` instead.
+        defer_backward=True: the backward's launches may still be on their way to the stream when this returns (the
+        library's worker thread issues them); the caller runs `skghoi_amd.train_fused.join_backward()` before it
+        enqueues anything behind the gradients (trainer.train_step does, in front of the optimizer)."""
         from skghoi_amd import train_fused
         if not (self.training and self.fused_training and train_fused.supported(self)) or targets is None:
             return None
@@ -491,7 +494,7 @@ class InteractionHead(Module):
         with torch.cuda.device(dev):
             out, prep = train_fused.fused_step(self, self.engine(), features, detections, image_shapes, targets,
                                                prep=self._take_prefetched(detections, image_shapes, targets),
-                                               after_forward=after_forward)
+                                               after_forward=after_forward, defer_backward=defer_backward)
             if out is None and prep is not None:
                 self._prefetched = _Ready(prep)       # prepared but not consumed here: the `forward` that follows takes it
         return out

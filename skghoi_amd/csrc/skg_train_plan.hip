@@ -11,6 +11,9 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <stdlib.h>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include "skghoi.h"
 
 namespace {
@@ -562,6 +565,67 @@ int skg_train_backward_f32(const skg_train_plan* P, int first_stage, int last_st
     backward(c, w, first_stage, last_stage);
     if (!c.rc) { hipError_t e = hipGetLastError(); if (e != hipSuccess) c.rc = (int)e; }
     return c.rc;
+}
+
+/* ---- the backward enqueued from a worker thread of the library.  Issuing the ~60 launches of a backward costs the
+ * calling thread ~0.2 ms; a Python step loop that is bound by its own thread (the batch-4 step: 1.45 ms of host work per
+ * step, measured with time.thread_time) hands the call to this thread and keeps preparing the next batch meanwhile.
+ * One job at a time; the plan is copied; the worker selects the submitting thread's device.  The caller must not enqueue
+ * anything that depends on the gradients, nor free a buffer the plan names, before skg_train_backward_join().          */
+namespace {
+struct AsyncBackward {
+    std::mutex m;
+    std::condition_variable cv;
+    bool started = false, pending = false;
+    skg_train_plan plan;
+    int first = 0, last = 0, device = 0, rc = 0;
+    void* stream = nullptr;
+    void loop() {
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return pending; });
+            lk.unlock();
+            int r = (int)hipSetDevice(device);
+            if (!r) r = skg_train_backward_f32(&plan, first, last, stream);
+            lk.lock();
+            rc = r; pending = false;
+            cv.notify_all();
+        }
+    }
+};
+AsyncBackward* async_backward() {
+    static AsyncBackward* a = new AsyncBackward;               // never destroyed: its thread outlives static destruction
+    return a;
+}
+}  // namespace
+
+int skg_train_backward_async_f32(const skg_train_plan* P, int first_stage, int last_stage, void* stream) {
+    int rc = check_plan(P);
+    if (rc) return rc;
+    AsyncBackward* a = async_backward();
+    std::unique_lock<std::mutex> lk(a->m);
+    if (a->pending) return SKG_E_LIMIT;                        // one job at a time: join first
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    a->plan = *P; a->first = first_stage; a->last = last_stage; a->stream = stream; a->device = dev; a->rc = 0;
+    a->pending = true;
+    if (!a->started) {
+        a->started = true;
+        std::thread(&AsyncBackward::loop, a).detach();
+    }
+    lk.unlock();
+    a->cv.notify_all();
+    return 0;
+}
+
+int skg_train_backward_join(void) {
+    AsyncBackward* a = async_backward();
+    std::unique_lock<std::mutex> lk(a->m);
+    a->cv.wait(lk, [&] { return !a->pending; });
+    const int rc = a->rc;
+    a->rc = 0;
+    return rc;
 }
 
 /* 2 M N K summed over every dense product of the step: which = 0 forward (both parts), 1 backward, 2 both */

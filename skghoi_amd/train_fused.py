@@ -697,7 +697,11 @@ class NativeJob(TrainJob):
                           adjacency=(lay.sum_g, 1))[which]
         return self.ws[off:off + rows * cols].view(rows, cols)
 
-    def backward(self, dlogits, need_dx0, need_dgfeat, arena=None):
+    def backward(self, dlogits, need_dx0, need_dgfeat, arena=None, defer=False):
+        """defer=True (single process, engine-free step): the launches are issued by the library's worker thread
+        (skg_train_backward_async_f32) while this thread goes on with host work; `join_backward()` must run before
+        anything is enqueued behind the gradients.  Returns (dx0, dgfeat, gradient views in parameter order | None)."""
+        join_backward()
         lib = _capi.lib()
         st, S, pl = self.st, self.S, self.plan
         ga, sviews = arena if arena is not None else st.grad_arena()
@@ -711,6 +715,14 @@ class NativeJob(TrainJob):
         pl.dx0, pl.dgfeat = _ptr(dx0), _ptr(dgfeat)
         stream = _stream()
         ex = getattr(self.head, "grad_exchange", None)
+        if ex is None and defer:
+            _check(lib.skg_train_backward_async_f32(C.byref(pl), 0, _capi.TRAIN_BWD_STAGES, stream),
+                   "skg_train_backward_async_f32")
+            # everything the plan names stays alive until the worker has enqueued the last launch
+            _PENDING.append((self, self.S, self.ws, dlogits, ga, dx0, dgfeat))
+            self.S = None
+            self.ws = None
+            return dx0, dgfeat, None
         if ex is None:
             _check(lib.skg_train_backward_f32(C.byref(pl), 0, _capi.TRAIN_BWD_STAGES, stream), "skg_train_backward_f32")
         else:
@@ -729,6 +741,20 @@ class NativeJob(TrainJob):
         self.S = None                                            # the saved activations die with the step
         self.ws = None
         return dx0, dgfeat, out
+
+
+_PENDING = []          # what a deferred backward still reads (at most one job)
+
+
+def join_backward():
+    """Waits until the library's worker thread has enqueued every launch of a deferred backward (NativeJob.backward
+    defer=True); a no-op otherwise.  Called before the optimizer step, before the next backward and by anything that
+    enqueues work behind the gradients."""
+    if _PENDING:
+        try:
+            _check(_capi.lib().skg_train_backward_join(), "skg_train_backward_f32 (deferred)")
+        finally:
+            _PENDING.clear()
 
 
 def job_class(head):
@@ -999,7 +1025,8 @@ class TrainRun:
         return results
 
 
-def fused_step(head, eng, features, detections, image_shapes, targets, prep=None, after_forward=None):
+def fused_step(head, eng, features, detections, image_shapes, targets, prep=None, after_forward=None,
+               defer_backward=False):
     """One whole forward + backward of the training step WITHOUT the autograd engine, for a trainer that owns the loop
     (skghoi_amd.trainer.train_step): the same kernels in the same order as `StepFn`, with the upstream gradient of the
     three summed losses (utils.py:221: their plain sum) fixed at one, the gradients written into a persistent arena whose
@@ -1007,7 +1034,10 @@ def fused_step(head, eng, features, detections, image_shapes, targets, prep=None
     thread and 2 x 408 attribute writes per step (~0.2 ms of a 2 ms step).  Returns (results with the loss dict appended --
     detached scalars --, prep) or (None, prep) when this batch / configuration needs the autograd route: inputs that require
     grad (a trainable detector in front), the Python launch plan, a batch without pairs.
-    after_forward(): called once the forward is enqueued (the trainer starts the next batch's preparation there)."""
+    after_forward(): called once the forward is enqueued (the trainer starts the next batch's preparation there).
+    defer_backward: the backward's launch calls go to the library's worker thread (NativeJob.backward defer=True) and this
+    thread carries on -- the next batch's preparation, the result dicts -- while they are issued; without it the call
+    returns with everything enqueued."""
     if job_class(head) is not NativeJob or getattr(head, "grad_mode", "autograd") != "direct":
         return None, prep
     if any(getattr(t, "requires_grad", False) for t in features.values()):
@@ -1036,7 +1066,7 @@ def fused_step(head, eng, features, detections, image_shapes, targets, prep=None
         job.direct = True
         S = job.forward(run.box_features, run.gfeat)
         losses = run.tail(prep, S["logits"])
-        if after_forward is not None:
+        if after_forward is not None and not defer_backward:
             after_forward()
         st = job.st
         ga, views = st.persistent_grads()
@@ -1048,7 +1078,13 @@ def fused_step(head, eng, features, detections, image_shapes, targets, prep=None
         _check(_capi.lib().skg_scale_dlogits_f32(src.data_ptr(), src.stride(0), src.shape[0], job.K,
                                                  job.loss_scale.data_ptr(), one.data_ptr(), one.data_ptr(), d.data_ptr(),
                                                  _stream()), "skg_scale_dlogits_f32")
-        job.backward(d, False, False, arena=(ga, views))
+        job.backward(d, False, False, arena=(ga, views), defer=defer_backward)
+        if _PENDING:
+            # the index arrays and tables of the prepared batch are named by the plan too: dropping them now would let the
+            # allocator hand their blocks out behind an event recorded in the MIDDLE of the backward
+            _PENDING.append((prep, run, features))
+        if after_forward is not None and defer_backward:
+            after_forward()                                       # (host work beside the worker's launch calls)
         if not all(map(_is, map(_grad_of, st.src), views)):       # (first step, or someone re-pointed / cleared a .grad)
             for p, v in zip(st.src, views):
                 if p.requires_grad:

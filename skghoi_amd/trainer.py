@@ -260,6 +260,11 @@ def wrap_ddp(module: nn.Module, device=None):
     return nn.parallel.DistributedDataParallel(module, device_ids=ids, find_unused_parameters=True)
 
 
+def _join_backward():
+    from .train_fused import join_backward
+    join_backward()
+
+
 def prefetch_batch(net, features, detections, image_shapes, targets):
     """Hands the NEXT batch to the head for preparation on its side stream (InteractionHead.prefetch_train) while the GPU
     works on the step just enqueued; returns the handle of the preparation in progress (advance() / finish()) or None.  Only when `net` IS the interaction head (training from cached detections /
@@ -298,7 +303,7 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
     out = None
     fused = getattr(net, "fused_step", None)            # the bare interaction head: forward + backward without the autograd
     if fused is not None and len(inputs) == 3:          # engine (gradients overwrite p.grad: nothing to zero beforehand)
-        out = fused(*inputs, targets, after_forward=look_ahead)
+        out = fused(*inputs, targets, after_forward=look_ahead, defer_backward=True)
     fused_ran = out is not None
     if out is None:
         optimizer.zero_grad(set_to_none=True)
@@ -319,6 +324,8 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
         ahead.advance()                  # counts read (ready by now), pairs + association launched
     for ex in exchanges(net):            # data parallel: a rank whose batch bypassed the fused node joins its peers here
         ex.after_backward()
+    if fused_ran:
+        _join_backward()                 # the backward's launches are all on the stream before the optimizer's
     optimizer.step()
     if ahead is not None:
         ahead.finish()                   # positive counts read, host RNG draws, uploads, TransH term

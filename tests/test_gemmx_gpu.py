@@ -52,6 +52,25 @@ def test_forward_layer(M, N, K, split, bf16):
     _close(out, torch.relu(_q(x, bf16) @ _q(W, bf16).t() + b.double()), "forward")
 
 
+@pytest.mark.parametrize("split", [0, 2])
+@pytest.mark.parametrize("M,N,K,col0,ldc", [(200, 132, 96, 0, 132),      # staged epilogue, N edge inside a tile's quads
+                                            (200, 132, 96, 0, 136),      # staged, padded rows
+                                            (131, 256, 64, 1, 260),      # C not 16-byte aligned: element-wise epilogue
+                                            (131, 256, 64, 0, 258)])     # ldc not a multiple of 4: element-wise epilogue
+def test_forward_epilogue_variants(M, N, K, col0, ldc, split, bf16):
+    """The staged (16-byte stores from LDS) and the element-wise epilogue must agree with the reference on every
+    alignment: which one runs is decided per product from N, the alignment of C / bias / mask and ldc."""
+    x, W, b = _rnd(M, K, seed=31), _rnd(N, K, seed=32), _rnd(N, seed=33)
+    big = torch.full((M, ldc), float("nan")).cuda()
+    out = big[:, col0:col0 + N]
+    op = gemmx.forward(x, W, out, bias=b, relu=True)
+    op.split_k = split
+    gemmx.launch([op], bf16=bf16)
+    _close(out, torch.relu(_q(x, bf16) @ _q(W, bf16).t() + b.double()), "forward")
+    rest = torch.cat([big[:, :col0], big[:, col0 + N:]], 1)
+    assert torch.isnan(rest).all(), "stores outside the product's columns"
+
+
 @pytest.mark.parametrize("split", [0, 3])
 def test_forward_with_branch_major_weight(split, bf16):
     M, N, K = 200, 1024, 1024

@@ -43,17 +43,6 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print("host %.3f ms/step, with final sync %.3f ms/step" % ((t1 - t0) / N * 1e3, (t2 - t0) / N * 1e3))
-# the backward runs on autograd's own thread: profile it there
-from skghoi_amd import train_fused
-_orig = train_fused.TrainJob.backward
-bpr = cProfile.Profile()
-def _wrapped(self, *a, **k):
-    bpr.enable()
-    try:
-        return _orig(self, *a, **k)
-    finally:
-        bpr.disable()
-train_fused.TrainJob.backward = _wrapped
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(N):
@@ -61,8 +50,13 @@ for _ in range(N):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(35)
-st.sort_stats("cumulative").print_stats(45)
-
-print("=" * 30, "TrainJob.backward (autograd thread)")
-pstats.Stats(bpr).sort_stats("tottime").print_stats(25)
+rows = []
+for (fn, line, name), (cc, nc, tt, ct, callers) in st.stats.items():
+    rows.append((tt / N * 1e6, ct / N * 1e6, nc / N, "%s:%d(%s)" % (fn.replace(os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/", ""), line, name)))
+print("total under the profiler: %.0f us/step" % sum(r[0] for r in rows))
+print("--- by own time (us/step own, us/step cumulative, calls/step)")
+for r in sorted(rows, key=lambda r: -r[0])[:70]:
+    print("%8.1f %8.1f %7.1f  %s" % r)
+print("--- by cumulative time")
+for r in sorted(rows, key=lambda r: -r[1])[:60]:
+    print("%8.1f %8.1f %7.1f  %s" % r)
