@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SKG_ABI_VERSION 10
+#define SKG_ABI_VERSION 11
 #define SKG_E_ARG   (-1)   /* null pointer / negative size / unsupported shape            */
 #define SKG_E_ALIGN (-2)   /* pointer or leading dimension not 16-byte aligned            */
 #define SKG_E_LIMIT (-3)   /* exceeds a compiled-in limit (boxes per image, verbs, ...)   */
@@ -342,6 +342,15 @@ typedef struct {
     float*  a_rowsum;
     int32_t split_k, reserved;
     float*  split_ws;
+    /* bf16 twins (optional, may be NULL).  A16 / B16: the operand rounded to bf16 (round to nearest even), stored with the
+     * SAME element indexing as A / B (strides and blocking count elements); skg_gemmx_bf16 reads the twin instead of the
+     * fp32 array wherever its fast loop runs -- the result is bit-identical (the fp32 array is rounded the same way on
+     * its way to the matrix core), the loop moves half the bytes.  The fp32 arrays stay mandatory (ragged tiles, the bias
+     * gradient's row sums).  C16: receives the bf16 rounding of every value stored to C, same indexing as C -- the twin
+     * the next product reads.  skg_gemmx_f32 ignores A16 / B16 and honours C16.                                       */
+    const uint16_t* A16;
+    const uint16_t* B16;
+    uint16_t* C16;
 } skg_gemmx_desc;
 #define SKG_GEMMX_GROUP_MAX 8
 int64_t skg_gemmx_ws_floats(const skg_gemmx_desc* desc_host);

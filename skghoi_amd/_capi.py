@@ -12,7 +12,7 @@ MAX_NODES = 160
 SPATIAL_LD = 48
 TRANSH_DIM = 50
 TRANSH_ENT = 80
-ABI_VERSION = 10
+ABI_VERSION = 11
 GEMM_GROUP_MAX = 4
 CHECKSUM_PARTIALS = 1024
 LOSS_CHUNKS = 64
@@ -39,7 +39,8 @@ class GemmXDesc(C.Structure):
                 ("b_kshift", _i32), ("b_nshift", _i32), ("b_kstride", _i64), ("b_nstride", _i64),
                 ("C", _vp), ("ldc", _i64), ("c_nshift", _i32), ("accumulate", _i32), ("c_nstride", _i64),
                 ("M", _i32), ("N", _i32), ("K", _i32), ("relu", _i32), ("bias", _vp), ("mask", _vp), ("ldmask", _i64),
-                ("a_rowsum", _vp), ("split_k", _i32), ("reserved", _i32), ("split_ws", _vp)]
+                ("a_rowsum", _vp), ("split_k", _i32), ("reserved", _i32), ("split_ws", _vp),
+                ("A16", _vp), ("B16", _vp), ("C16", _vp)]
 
 
 GEMMX_GROUP_MAX = 8

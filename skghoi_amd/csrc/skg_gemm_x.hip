@@ -39,7 +39,8 @@
 struct skg_gemmx_group {
     skg_gemmx_desc d[SKG_GEMMX_GROUP_MAX];
     int start[SKG_GEMMX_GROUP_MAX + 1];      // block ranges
-    int vec[SKG_GEMMX_GROUP_MAX];            // bit 0: A fast loop allowed, bit 1: B, bit 2: C 8-byte stores, bit 3: staged epilogue
+    int vec[SKG_GEMMX_GROUP_MAX];            // bit 0: A fast loop allowed, bit 1: B, bit 2: C 8-byte stores, bit 3: staged
+                                             // epilogue, bit 4 / 5: bf16 twin of A / B readable by the fast loop
     int n;
 };
 
@@ -57,6 +58,8 @@ struct XOperand {
     int rows;                    // extent of the own index (M or N)
     bool vec;                    // 16-byte loads allowed
     __amdgpu_buffer_rsrc_t rsrc; // buffer descriptor over the operand (fast loop)
+    __amdgpu_buffer_rsrc_t rsrc16;   // ... over its bf16 twin (skg_gemmx_bf16 only)
+    bool vec16;                  // the twin exists and may be read with 16-byte loads
 };
 
 struct XQ2 { float4 a, b; };
@@ -68,7 +71,7 @@ struct XQ2 { float4 a, b; };
 // one after the other (1200 cycles per step for 256 cycles of MFMA, measured from a K sweep on captured launches).
 // Rows outside the operand are clamped to a valid row and NOT zeroed: they only feed output rows / columns >= M / N,
 // which the epilogue never stores (nor the bias gradient of rows >= M).
-struct XFast { uint32_t o[4]; };
+struct XFast { uint32_t o0, o1, o2, o3; };       // (scalars: an array member ended up in scratch memory)
 #ifndef SKG_XBUF
 #define SKG_XBUF 1
 #endif
@@ -155,6 +158,13 @@ __device__ __forceinline__ XTileId xtile_of(int b, int nb, int nbm, int nbn, int
 #endif
 }
 
+typedef __bf16 xbf2 __attribute__((ext_vector_type(2)));
+typedef float xf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t ypack(float a, float b) {          // two floats -> two bf16 (round to nearest even)
+    const xf2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, xbf2));
+}
+
 // ================================================================================================ epilogue
 // The accumulators of a wave (64 x 64 outputs) leave through LDS, 32 rows at a time: the MFMA layout gives a lane ONE
 // element per row (32 lanes = 128 bytes of a row), and 64 dword stores per thread kept the store unit busy for ~20 us
@@ -191,6 +201,8 @@ __device__ __forceinline__ void xep_rows(const skg_gemmx_desc& d, const float* s
             v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         }
         *reinterpret_cast<float4*>(p) = v;
+        if (d.C16)                                         // the bf16 twin of what was just stored (next product's operand)
+            *reinterpret_cast<uint2*>(d.C16 + coff + (int64_t)row * d.ldc) = make_uint2(ypack(v.x, v.y), ypack(v.z, v.w));
     }
 }
 
@@ -204,16 +216,16 @@ __device__ __forceinline__ void xep_rows(const skg_gemmx_desc& d, const float* s
 //                                          RC : quad u = rows 4 (tid & 31) .. +3 at k = k0 + (tid >> 5) + 8 u
 template <bool KC>
 __device__ __forceinline__ void xprep(const XOperand& op, int row0, int tid, XFast& F) {
-    F.o[2] = F.o[3] = 0;
+    F.o2 = F.o3 = 0;
     if (KC) {
         const int r = row0 + (tid >> 2), last = op.rows - 1, kl = 4 * (tid & 3);
-        F.o[0] = (uint32_t)((xoff(min(r, last), op.rshift, op.rstride, op.s_row) + kl) * 4);
-        F.o[1] = (uint32_t)((xoff(min(r + 64, last), op.rshift, op.rstride, op.s_row) + kl) * 4);
+        F.o0 = (uint32_t)((xoff(min(r, last), op.rshift, op.rstride, op.s_row) + kl) * 4);
+        F.o1 = (uint32_t)((xoff(min(r + 64, last), op.rshift, op.rstride, op.s_row) + kl) * 4);
     } else {
         const int64_t ro = xoff(max(0, min(row0 + 4 * (tid & 31), op.rows - 4)), op.rshift, op.rstride, 1);
         const int kl = tid >> 5;
-        F.o[0] = (uint32_t)((ro + (int64_t)kl * op.s_k) * 4);
-        F.o[1] = (uint32_t)((ro + (int64_t)(kl + 8) * op.s_k) * 4);
+        F.o0 = (uint32_t)((ro + (int64_t)kl * op.s_k) * 4);
+        F.o1 = (uint32_t)((ro + (int64_t)(kl + 8) * op.s_k) * 4);
     }
 }
 
@@ -222,7 +234,7 @@ __device__ __forceinline__ XQ2 xtile(const XOperand& op, const XFast& F, int row
     XQ2 v;
     if (FAST) {
         const uint32_t sb = xstepbase<KC>(op, k0);
-        v.a = xldo(op, sb, F.o[0]); v.b = xldo(op, sb, F.o[1]);
+        v.a = xldo(op, sb, F.o0); v.b = xldo(op, sb, F.o1);
     } else if (KC) {
         v.a = xgen<true>(op, row0 + (tid >> 2), k0 + 4 * (tid & 3), kend);
         v.b = xgen<true>(op, row0 + (tid >> 2) + 64, k0 + 4 * (tid & 3), kend);
@@ -333,6 +345,9 @@ __device__ __forceinline__ void xoperands(const skg_gemmx_desc& d, int vecbits, 
     A.rows = d.M; A.vec = vecbits & 1;
     A.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.A), 0, 0x7fffffff, 0x00020000);
     B.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.B), 0, 0x7fffffff, 0x00020000);
+    A.rsrc16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(d.A16), 0, 0x7fffffff, 0x00020000);
+    B.rsrc16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(d.B16), 0, 0x7fffffff, 0x00020000);
+    A.vec16 = (vecbits >> 4) & 1; B.vec16 = (vecbits >> 5) & 1;
     B.base = d.B; B.s_row = d.b_sn; B.s_k = d.b_sk; B.rshift = d.b_nshift; B.kshift = d.b_kshift;
     B.rstride = d.b_nstride; B.kstride = d.b_kstride; B.rows = d.N; B.vec = (vecbits >> 1) & 1;
 }
@@ -440,14 +455,20 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
                 if (two && vecC) {
                     float2* p2 = reinterpret_cast<float2*>(p);
                     if (d.accumulate) { const float2 o = *p2; v0 += o.x; v1 += o.y; }
-                    *p2 = make_float2(k0 ? v0 : 0.f, k1 ? v1 : 0.f);
+                    v0 = k0 ? v0 : 0.f; v1 = k1 ? v1 : 0.f;
+                    *p2 = make_float2(v0, v1);
+                    if (d.C16) *reinterpret_cast<uint32_t*>(d.C16 + (p - d.C)) = ypack(v0, v1);
                 } else {
                     if (d.accumulate) v0 += p[0];
-                    p[0] = k0 ? v0 : 0.f;
+                    v0 = k0 ? v0 : 0.f;
+                    p[0] = v0;
+                    if (d.C16) d.C16[p - d.C] = (uint16_t)ypack(v0, 0.f);
                     if (two) {
                         float* q = d.C + xoff(col + 1, d.c_nshift, d.c_nstride, 1) + (int64_t)row * d.ldc;
                         if (d.accumulate) v1 += q[0];
-                        q[0] = k1 ? v1 : 0.f;
+                        v1 = k1 ? v1 : 0.f;
+                        q[0] = v1;
+                        if (d.C16) d.C16[q - d.C] = (uint16_t)ypack(v1, 0.f);
                     }
                 }
             }
@@ -473,51 +494,93 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
 #define YTILE (4 * YPLANE)
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 xbf2 __attribute__((ext_vector_type(2)));
-typedef float xf2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t ypack(float a, float b) {
-    const xf2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, xbf2));
-}
 __device__ __forceinline__ int yslot(int row) { return row ^ ((row >> 3) & 3); }
 __device__ __forceinline__ int yrq(int tid) { return (tid & 7) | (((tid >> 4) & 3) << 3); }
 __device__ __forceinline__ int ykq4(int tid) { return ((tid >> 3) & 1) | ((tid >> 6) << 1); }
 
-template <bool KC>
+// ---- operand tiles in flight.  H = false: the fp32 source (four 16-byte loads per thread, rounded on the way into LDS);
+// H = true: the operand's bf16 TWIN in memory (skg_gemmx_desc.A16 / B16: two 16-byte loads per thread, no conversion) --
+// half the bytes through the L2 -> CU path, which is what bounds this loop (one workgroup per CU draws ~22 B/clk of the
+// ~29 B/clk a CU can fetch from L2; measured from K sweeps with the loop / the epilogue compiled out).
+typedef uint32_t xu4v __attribute__((ext_vector_type(4)));
+template <bool H> struct YStage;
+typedef float xf4v __attribute__((ext_vector_type(4)));
+// (native vectors as named members: with HIP's float4 -- a struct around a union -- or with array members the stages of
+// the mixed fp32 / twin loops were kept in scratch memory)
+template <> struct YStage<false> { xf4v a, b, c, d; };
+template <> struct YStage<true> { xu4v a, b; };
+__device__ __forceinline__ xf4v xnat(float4 t) { xf4v o; o.x = t.x; o.y = t.y; o.z = t.z; o.w = t.w; return o; }
+
+__device__ __forceinline__ xu4v xldo16(const XOperand& op, uint32_t soff, uint32_t voff) {
+    typedef unsigned int xu4 __attribute__((__vector_size__(16)));
+    const xu4 r = __builtin_amdgcn_raw_buffer_load_b128(op.rsrc16, (int)voff, (int)soff, 0);
+    xu4v o; o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
+    return o;
+}
+
+//   thread -> pieces of a 128 x 32 bf16 tile (16 bytes = 8 elements each):
+//     KC : piece u = 8 k of plane (tid & 3) of row (tid >> 2) + 64 u                    (4 lanes = the row's 64 bytes)
+//     RC : piece u = rows 8 (tid >> 4) .. +7 at k = k0 + 2 (tid & 15) + u              (a k pair per thread)
+template <bool KC, bool H>
 __device__ __forceinline__ void yprep(const XOperand& op, int row0, int tid, XFast& F) {
-    if (KC) {
-        const int r = row0 + (tid >> 3), last = op.rows - 1, kl = 4 * (tid & 7);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            F.o[u] = (uint32_t)((xoff(min(r + 32 * u, last), op.rshift, op.rstride, op.s_row) + kl) * 4);
+    if (!H) {
+        if (KC) {
+            const int r = row0 + (tid >> 3), last = op.rows - 1, kl = 4 * (tid & 7);
+            F.o0 = (uint32_t)((xoff(min(r, last), op.rshift, op.rstride, op.s_row) + kl) * 4);
+            F.o1 = (uint32_t)((xoff(min(r + 32, last), op.rshift, op.rstride, op.s_row) + kl) * 4);
+            F.o2 = (uint32_t)((xoff(min(r + 64, last), op.rshift, op.rstride, op.s_row) + kl) * 4);
+            F.o3 = (uint32_t)((xoff(min(r + 96, last), op.rshift, op.rstride, op.s_row) + kl) * 4);
+        } else {
+            const int64_t ro = xoff(max(0, min(row0 + 4 * yrq(tid), op.rows - 4)), op.rshift, op.rstride, 1);
+            const int kl = 4 * ykq4(tid);
+            F.o0 = (uint32_t)((ro + (int64_t)kl * op.s_k) * 4);
+            F.o1 = (uint32_t)((ro + (int64_t)(kl + 1) * op.s_k) * 4);
+            F.o2 = (uint32_t)((ro + (int64_t)(kl + 2) * op.s_k) * 4);
+            F.o3 = (uint32_t)((ro + (int64_t)(kl + 3) * op.s_k) * 4);
+        }
     } else {
-        const int64_t ro = xoff(max(0, min(row0 + 4 * yrq(tid), op.rows - 4)), op.rshift, op.rstride, 1);
-        const int kl = 4 * ykq4(tid);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) F.o[u] = (uint32_t)((ro + (int64_t)(kl + u) * op.s_k) * 4);
+        F.o2 = F.o3 = 0;
+        if (KC) {
+            const int r = row0 + (tid >> 2), last = op.rows - 1, kl = 8 * (tid & 3);
+            F.o0 = (uint32_t)((xoff(min(r, last), op.rshift, op.rstride, op.s_row) + kl) * 2);
+            F.o1 = (uint32_t)((xoff(min(r + 64, last), op.rshift, op.rstride, op.s_row) + kl) * 2);
+        } else {
+            const int64_t ro = xoff(max(0, min(row0 + 8 * (tid >> 4), op.rows - 8)), op.rshift, op.rstride, 1);
+            const int kl = 2 * (tid & 15);
+            F.o0 = (uint32_t)((ro + (int64_t)kl * op.s_k) * 2);
+            F.o1 = (uint32_t)((ro + (int64_t)(kl + 1) * op.s_k) * 2);
+        }
     }
 }
 
 template <bool KC, bool FAST>
-__device__ __forceinline__ void ytile(const XOperand& op, const XFast& F, int row0, int k0, int kend, int tid, float4& va,
-                                      float4& vb, float4& vc, float4& vd) {
+__device__ __forceinline__ void ytile(const XOperand& op, const XFast& F, int row0, int k0, int kend, int tid,
+                                      YStage<false>& s) {
     if (FAST) {
         const uint32_t sb = xstepbase<KC>(op, k0);
-        va = xldo(op, sb, F.o[0]); vb = xldo(op, sb, F.o[1]); vc = xldo(op, sb, F.o[2]); vd = xldo(op, sb, F.o[3]);
+        s.a = xnat(xldo(op, sb, F.o0)); s.b = xnat(xldo(op, sb, F.o1));
+        s.c = xnat(xldo(op, sb, F.o2)); s.d = xnat(xldo(op, sb, F.o3));
     } else if (KC) {
         const int r = row0 + (tid >> 3), k = k0 + 4 * (tid & 7);
-        va = xgen<true>(op, r, k, kend); vb = xgen<true>(op, r + 32, k, kend);
-        vc = xgen<true>(op, r + 64, k, kend); vd = xgen<true>(op, r + 96, k, kend);
+        s.a = xnat(xgen<true>(op, r, k, kend)); s.b = xnat(xgen<true>(op, r + 32, k, kend));
+        s.c = xnat(xgen<true>(op, r + 64, k, kend)); s.d = xnat(xgen<true>(op, r + 96, k, kend));
     } else {
         const int row = row0 + 4 * yrq(tid), k = k0 + 4 * ykq4(tid);
-        va = xgen<false>(op, row, k, kend); vb = xgen<false>(op, row, k + 1, kend);
-        vc = xgen<false>(op, row, k + 2, kend); vd = xgen<false>(op, row, k + 3, kend);
+        s.a = xnat(xgen<false>(op, row, k, kend)); s.b = xnat(xgen<false>(op, row, k + 1, kend));
+        s.c = xnat(xgen<false>(op, row, k + 2, kend)); s.d = xnat(xgen<false>(op, row, k + 3, kend));
     }
+}
+template <bool KC, bool FAST>
+__device__ __forceinline__ void ytile(const XOperand& op, const XFast& F, int row0, int k0, int kend, int tid,
+                                      YStage<true>& s) {
+    static_assert(FAST, "the bf16 twin is read by the fast loop only");
+    const uint32_t sb = xstepbase<KC>(op, k0) >> 1;         // the same element offset, two bytes per element
+    s.a = xldo16(op, sb, F.o0); s.b = xldo16(op, sb, F.o1);
 }
 
 template <bool KC>
-__device__ __forceinline__ void ystore_lds(uint16_t* tile, int tid, float4 va, float4 vb, float4 vc, float4 vd) {
+__device__ __forceinline__ void ystore_lds(uint16_t* tile, int tid, const YStage<false>& s) {
+    const xf4v va = s.a, vb = s.b, vc = s.c, vd = s.d;
     if (KC) {
         const int kq4 = tid & 7, r = tid >> 3;
         uint16_t* base = tile + (kq4 >> 1) * YPLANE + (kq4 & 1) * 4;
@@ -534,10 +597,28 @@ __device__ __forceinline__ void ystore_lds(uint16_t* tile, int tid, float4 va, f
         *reinterpret_cast<uint2*>(base + yslot(row + 3) * 8) = make_uint2(ypack(va.w, vb.w), ypack(vc.w, vd.w));
     }
 }
+template <bool KC>
+__device__ __forceinline__ void ystore_lds(uint16_t* tile, int tid, const YStage<true>& s) {
+    if (KC) {                                              // a piece IS a plane entry: one ds_write_b128 each
+        const int pl = tid & 3, r = tid >> 2;
+        *reinterpret_cast<xu4v*>(tile + pl * YPLANE + yslot(r) * 8) = s.a;
+        *reinterpret_cast<xu4v*>(tile + pl * YPLANE + yslot(r + 64) * 8) = s.b;
+    } else {                                               // rows r8 .. r8 + 7 at k and k + 1: one dword {k, k + 1} per row
+        const int kp = tid & 15, r8 = 8 * (tid >> 4);
+        uint16_t* base = tile + (kp >> 2) * YPLANE + 2 * (kp & 3);
+        const xu4v a = s.a, b = s.b;
+#define YROWPAIR(j, aw, bw)                                                                                              \
+        *reinterpret_cast<uint32_t*>(base + yslot(r8 + 2 * (j)) * 8) = __builtin_amdgcn_perm(bw, aw, 0x05040100u);       \
+        *reinterpret_cast<uint32_t*>(base + yslot(r8 + 2 * (j) + 1) * 8) = __builtin_amdgcn_perm(bw, aw, 0x07060302u);
+        YROWPAIR(0, a.x, b.x) YROWPAIR(1, a.y, b.y) YROWPAIR(2, a.z, b.z) YROWPAIR(3, a.w, b.w)
+#undef YROWPAIR
+    }
+}
 
 // fp32 row sums of the thread's share of an A tile (before rounding)
 template <bool KC>
-__device__ __forceinline__ void yrowsum(float4 va, float4 vb, float4 vc, float4 vd, float4& rs) {
+__device__ __forceinline__ void yrowsum(const YStage<false>& s, float4& rs) {
+    const xf4v va = s.a, vb = s.b, vc = s.c, vd = s.d;
     if (KC) {
         rs.x += (va.x + va.y) + (va.z + va.w); rs.y += (vb.x + vb.y) + (vb.z + vb.w);
         rs.z += (vc.x + vc.y) + (vc.z + vc.w); rs.w += (vd.x + vd.y) + (vd.z + vd.w);
@@ -546,33 +627,35 @@ __device__ __forceinline__ void yrowsum(float4 va, float4 vb, float4 vc, float4 
         rs.z += (va.z + vb.z) + (vc.z + vd.z); rs.w += (va.w + vb.w) + (vc.w + vd.w);
     }
 }
+template <bool KC>
+__device__ __forceinline__ void yrowsum(const YStage<true>&, float4&) {}     // (row-sum workgroups read the fp32 operand)
 
 // One register stage (the next tile in flight across the MFMAs): kept for products whose operands are both contiguous
-// along their own index (dW = dZ^T X) -- measured, a second stage costs them a third of their rate at 102400 rows
-// (475 -> 295 TFLOP/s: eight more 16-byte loads per thread in flight, two 512-byte segments each), while it gains the
-// k-contiguous layouts 15-35 %.
+// along their own index and fp32 (dW = dZ^T X) -- measured, a second stage costs them a third of their rate at 102400
+// rows (475 -> 295 TFLOP/s: eight more 16-byte loads per thread in flight, two 512-byte segments each), while it gains
+// the k-contiguous layouts 15-35 %.
 template <bool AK, bool BK_, bool FAST>
 __device__ __forceinline__ void yrun1(const XOperand& A, const XOperand& B, const XFast& LA, const XFast& LB, const XCtx& c,
-                                     int ka, int kb, int& par, uint16_t* smem, f32x16 (&acc)[2][2], float4& rs) {
+                                      int ka, int kb, int& par, uint16_t* smem, f32x16 (&acc)[2][2], float4& rs) {
     if (ka >= kb) return;
     const int tid = c.tid;
     // fragment addresses (bf16 elements) inside a tile; k-step ks adds 2 ks planes
     const int fa0 = c.lk * YPLANE + yslot(c.wm * 64 + c.li) * 8, fa1 = c.lk * YPLANE + yslot(c.wm * 64 + 32 + c.li) * 8;
     const int fb0 = c.lk * YPLANE + yslot(c.wn * 64 + c.li) * 8, fb1 = c.lk * YPLANE + yslot(c.wn * 64 + 32 + c.li) * 8;
-    float4 a0, a1, a2, a3, b0, b1, b2, b3;
-    ytile<AK, FAST>(A, LA, c.m0, ka * YBK, c.kend, tid, a0, a1, a2, a3);
-    ytile<BK_, FAST>(B, LB, c.n0, ka * YBK, c.kend, tid, b0, b1, b2, b3);
-    if (c.do_rowsum) yrowsum<AK>(a0, a1, a2, a3, rs);
-    ystore_lds<AK>(smem + par * 2 * YTILE, tid, a0, a1, a2, a3);
-    ystore_lds<BK_>(smem + par * 2 * YTILE + YTILE, tid, b0, b1, b2, b3);
+    YStage<false> sa, sb;
+    ytile<AK, FAST>(A, LA, c.m0, ka * YBK, c.kend, tid, sa);
+    ytile<BK_, FAST>(B, LB, c.n0, ka * YBK, c.kend, tid, sb);
+    if (c.do_rowsum) yrowsum<AK>(sa, rs);
+    ystore_lds<AK>(smem + par * 2 * YTILE, tid, sa);
+    ystore_lds<BK_>(smem + par * 2 * YTILE + YTILE, tid, sb);
     __syncthreads();
     for (int kt = ka; kt < kb; ++kt) {
         const uint16_t* As = smem + par * 2 * YTILE;
         const uint16_t* Bs = As + YTILE;
         const bool more = kt + 1 < kb;
         if (more) {
-            ytile<AK, FAST>(A, LA, c.m0, (kt + 1) * YBK, c.kend, tid, a0, a1, a2, a3);
-            ytile<BK_, FAST>(B, LB, c.n0, (kt + 1) * YBK, c.kend, tid, b0, b1, b2, b3);
+            ytile<AK, FAST>(A, LA, c.m0, (kt + 1) * YBK, c.kend, tid, sa);
+            ytile<BK_, FAST>(B, LB, c.n0, (kt + 1) * YBK, c.kend, tid, sb);
         }
         const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(As + fa0), a01 = *reinterpret_cast<const bf16x8*>(As + fa1);
         const bf16x8 b00 = *reinterpret_cast<const bf16x8*>(Bs + fb0), b01 = *reinterpret_cast<const bf16x8*>(Bs + fb1);
@@ -590,9 +673,9 @@ __device__ __forceinline__ void yrun1(const XOperand& A, const XOperand& B, cons
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, b11, acc[1][1], 0, 0, 0);
         if (more) {
             uint16_t* An = smem + (par ^ 1) * 2 * YTILE;
-            if (c.do_rowsum) yrowsum<AK>(a0, a1, a2, a3, rs);
-            ystore_lds<AK>(An, tid, a0, a1, a2, a3);
-            ystore_lds<BK_>(An + YTILE, tid, b0, b1, b2, b3);
+            if (c.do_rowsum) yrowsum<AK>(sa, rs);
+            ystore_lds<AK>(An, tid, sa);
+            ystore_lds<BK_>(An + YTILE, tid, sb);
         }
         __syncthreads();
         par ^= 1;
@@ -600,13 +683,13 @@ __device__ __forceinline__ void yrun1(const XOperand& A, const XOperand& B, cons
 }
 
 // YNST register stages of global prefetch (see xrun): here a step's MFMAs take 256 cycles, so the loop is a pure memory
-// round trip per step unless several tiles are in flight; two stages (64 VGPRs) are what the register budget of two
-// waves per SIMD leaves next to the 64 accumulators.
+// round trip per step unless several tiles are in flight; two stages (64 VGPRs of fp32 operands) are what the register
+// budget of two waves per SIMD leaves next to the 64 accumulators.
 #define YNST 2
 #ifndef SKG_YORDER
 #define SKG_YORDER 1
 #endif
-template <bool AK, bool BK_, bool FAST>
+template <bool AK, bool BK_, bool FAST, bool AH, bool BH>
 __device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const XFast& LA, const XFast& LB, const XCtx& c,
                                      int ka, int kb, int& par, uint16_t* smem, f32x16 (&acc)[2][2], float4& rs) {
     if (ka >= kb) return;
@@ -614,18 +697,28 @@ __device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const
     // fragment addresses (bf16 elements) inside a tile; k-step ks adds 2 ks planes
     const int fa0 = c.lk * YPLANE + yslot(c.wm * 64 + c.li) * 8, fa1 = c.lk * YPLANE + yslot(c.wm * 64 + 32 + c.li) * 8;
     const int fb0 = c.lk * YPLANE + yslot(c.wn * 64 + c.li) * 8, fb1 = c.lk * YPLANE + yslot(c.wn * 64 + 32 + c.li) * 8;
-    float4 sa[YNST][4], sb[YNST][4];
+    YStage<AH> sa0, sa1;                                   // (separate objects: arrays of stages ended up in scratch memory)
+    YStage<BH> sb0, sb1;
     auto load = [&](auto S, int t) {                      // past the end: the last tile again (never stored)
-        constexpr int g = decltype(S)::value;
         const int tt = min(t, kb - 1);
-        ytile<AK, FAST>(A, LA, c.m0, tt * YBK, c.kend, tid, sa[g][0], sa[g][1], sa[g][2], sa[g][3]);
-        ytile<BK_, FAST>(B, LB, c.n0, tt * YBK, c.kend, tid, sb[g][0], sb[g][1], sb[g][2], sb[g][3]);
+        if constexpr (decltype(S)::value == 0) {
+            ytile<AK, FAST>(A, LA, c.m0, tt * YBK, c.kend, tid, sa0);
+            ytile<BK_, FAST>(B, LB, c.n0, tt * YBK, c.kend, tid, sb0);
+        } else {
+            ytile<AK, FAST>(A, LA, c.m0, tt * YBK, c.kend, tid, sa1);
+            ytile<BK_, FAST>(B, LB, c.n0, tt * YBK, c.kend, tid, sb1);
+        }
     };
     auto store = [&](auto S, int buf) {
-        constexpr int g = decltype(S)::value;
-        if (c.do_rowsum) yrowsum<AK>(sa[g][0], sa[g][1], sa[g][2], sa[g][3], rs);
-        ystore_lds<AK>(smem + buf * 2 * YTILE, tid, sa[g][0], sa[g][1], sa[g][2], sa[g][3]);
-        ystore_lds<BK_>(smem + buf * 2 * YTILE + YTILE, tid, sb[g][0], sb[g][1], sb[g][2], sb[g][3]);
+        if constexpr (decltype(S)::value == 0) {
+            if (c.do_rowsum) yrowsum<AK>(sa0, rs);
+            ystore_lds<AK>(smem + buf * 2 * YTILE, tid, sa0);
+            ystore_lds<BK_>(smem + buf * 2 * YTILE + YTILE, tid, sb0);
+        } else {
+            if (c.do_rowsum) yrowsum<AK>(sa1, rs);
+            ystore_lds<AK>(smem + buf * 2 * YTILE, tid, sa1);
+            ystore_lds<BK_>(smem + buf * 2 * YTILE + YTILE, tid, sb1);
+        }
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -673,21 +766,43 @@ __device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const
     if (kt < kb) step(I1{}, kt);
 }
 
+// 16-bit reads of an operand from row0: the twin exists, its descriptor passed the host's alignment checks, and no
+// 8-row piece straddles the operand's end (row-contiguous layout)
+template <bool KC>
+__device__ __forceinline__ bool yhalf_ok(const XOperand& op, int row0) {
+    return op.vec16 && (KC || (op.rows & 7) == 0 || row0 + 128 <= op.rows);
+}
+
+template <bool AK, bool BK_, bool AH, bool BH>
+__device__ __forceinline__ void yfast(const XOperand& A, const XOperand& B, const XCtx& c, int kt0, int ktf, int& par,
+                                      uint16_t* smem, f32x16 (&acc)[2][2], float4& rs) {
+    XFast LA, LB;
+    yprep<AK, AH>(A, c.m0, c.tid, LA);
+    yprep<BK_, BH>(B, c.n0, c.tid, LB);
+    if (!AK && !BK_ && !AH && !BH) yrun1<AK, BK_, true>(A, B, LA, LB, c, kt0, ktf, par, smem, acc, rs);
+    else yrun<AK, BK_, true, AH, BH>(A, B, LA, LB, c, kt0, ktf, par, smem, acc, rs);
+}
+
 template <bool AK, bool BK_>
 __device__ __forceinline__ void ymain(const XOperand& A, const XOperand& B, const XCtx& c, int kt0, int kt1, uint16_t* smem,
                                       f32x16 (&acc)[2][2], float4& rs) {
-    XFast LA, LB;
-    yprep<AK>(A, c.m0, c.tid, LA);
-    yprep<BK_>(B, c.n0, c.tid, LB);
     int ktf = kt0;
     if (xfast_ok<AK>(A, c.m0) && xfast_ok<BK_>(B, c.n0) && kt1 > kt0) ktf = (c.kend == kt1 * YBK) ? kt1 : kt1 - 1;
     int par = 0;
-    if (!AK && !BK_) {
-        yrun1<AK, BK_, true>(A, B, LA, LB, c, kt0, ktf, par, smem, acc, rs);
-        yrun1<AK, BK_, false>(A, B, LA, LB, c, ktf, kt1, par, smem, acc, rs);
+    // the workgroups that form the bias gradient sum the UNROUNDED fp32 operand: they keep the fp32 source of A
+    const bool ah = yhalf_ok<AK>(A, c.m0) && !c.do_rowsum, bh = yhalf_ok<BK_>(B, c.n0);
+    if (ah) {
+        if (bh) yfast<AK, BK_, true, true>(A, B, c, kt0, ktf, par, smem, acc, rs);
+        else yfast<AK, BK_, true, false>(A, B, c, kt0, ktf, par, smem, acc, rs);
     } else {
-        yrun<AK, BK_, true>(A, B, LA, LB, c, kt0, ktf, par, smem, acc, rs);
-        yrun<AK, BK_, false>(A, B, LA, LB, c, ktf, kt1, par, smem, acc, rs);
+        if (bh) yfast<AK, BK_, false, true>(A, B, c, kt0, ktf, par, smem, acc, rs);
+        else yfast<AK, BK_, false, false>(A, B, c, kt0, ktf, par, smem, acc, rs);
+    }
+    {
+        XFast LA, LB;                                      // (unused by the generic loop)
+        LA.o0 = LA.o1 = LA.o2 = LA.o3 = 0; LB.o0 = LB.o1 = LB.o2 = LB.o3 = 0;
+        if (!AK && !BK_) yrun1<AK, BK_, false>(A, B, LA, LB, c, ktf, kt1, par, smem, acc, rs);
+        else yrun<AK, BK_, false, false, false>(A, B, LA, LB, c, ktf, kt1, par, smem, acc, rs);
     }
     if (c.do_rowsum) {                                     // uniform per workgroup; the k loop ended on a barrier
         float* part = reinterpret_cast<float*>(smem);      // [8][128] partial sums
@@ -802,6 +917,7 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_
                     if (d.accumulate) v += *p;
                     if (d.mask && !(d.mask[(int64_t)row * d.ldmask + col] > 0.f)) v = 0.f;
                     *p = v;
+                    if (d.C16) d.C16[p - d.C] = (uint16_t)ypack(v, 0.f);
                 }
             }
 }
@@ -842,6 +958,7 @@ __global__ __launch_bounds__(256) void skg_gemmx_reduce_kernel(const skg_gemmx_g
             v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         }
         *reinterpret_cast<float4*>(p) = v;
+        if (d.C16) *reinterpret_cast<uint2*>(d.C16 + (p - d.C)) = make_uint2(ypack(v.x, v.y), ypack(v.z, v.w));
         return;
     }
     const int64_t i = w;
@@ -854,6 +971,7 @@ __global__ __launch_bounds__(256) void skg_gemmx_reduce_kernel(const skg_gemmx_g
     if (d.accumulate) v += *p;
     if (d.mask && !(d.mask[(int64_t)row * d.ldmask + col] > 0.f)) v = 0.f;      // accumulate first, mask last
     *p = v;
+    if (d.C16) d.C16[p - d.C] = (uint16_t)ypack(v, 0.f);
 }
 
 static int skg_gemmx_validate(const skg_gemmx_desc& d) {
@@ -868,10 +986,12 @@ static int skg_gemmx_validate(const skg_gemmx_desc& d) {
     if ((d.b_kshift == 1) || (d.b_nshift == 1)) return SKG_E_ARG;            // blocks of at least 4 (16-byte quads)
     if (d.mask && d.ldmask < d.N) return SKG_E_ARG;
     if (d.split_k > 1 && (!d.split_ws || d.split_k > 256)) return SKG_E_ARG;
+    if ((((uintptr_t)d.C16) & 1u) || (((uintptr_t)d.A16) & 1u) || (((uintptr_t)d.B16) & 1u)) return SKG_E_ALIGN;
     return 0;
 }
 
 static bool xmul4(int64_t v) { return (v & 3) == 0; }
+static bool xmul8(int64_t v) { return (v & 7) == 0; }
 
 // Largest element offset an operand reaches (host copy of xoff): the fast loop keeps 32-bit byte offsets per lane.
 static int64_t xspan(int64_t idx, int shift, int64_t bstride, int64_t estride) {
@@ -912,8 +1032,14 @@ static int skg_gemmx_launch(const skg_gemmx_desc* descs_host, int n, void* strea
         // bit 3: the staged epilogue / four-column reduce (16-byte accesses to C, bias, mask and the workspace rows)
         if ((d.N & 3) == 0 && skg_aligned16(d.C) && xmul4(d.ldc) &&
             (d.c_nshift == 0 || (d.c_nshift >= 2 && xmul4(d.c_nstride))) && skg_aligned16(d.bias) &&
-            skg_aligned16(d.mask) && (!d.mask || xmul4(d.ldmask)) && (S == 1 || skg_aligned16(d.split_ws)))
+            skg_aligned16(d.mask) && (!d.mask || xmul4(d.ldmask)) && (S == 1 || skg_aligned16(d.split_ws)) &&
+            (((uintptr_t)d.C16) & 7u) == 0)
             vec |= 8;
+        // bits 4 / 5: the bf16 twin of A / B may feed the fast loop (16-byte pieces of 8 elements)
+        if (bf16 && d.A16 && (vec & 1) && skg_aligned16(d.A16) && (d.a_sk == 1 ? xmul8(d.a_sm) : xmul8(d.a_sk))) vec |= 16;
+        if (bf16 && d.B16 && (vec & 2) && skg_aligned16(d.B16) && (d.b_sk == 1 ? xmul8(d.b_sn) : xmul8(d.b_sk)) &&
+            (d.b_kshift == 0 || xmul8(d.b_kstride)) && (d.b_nshift == 0 || (d.b_nshift >= 3 && xmul8(d.b_nstride))))
+            vec |= 32;
         g.d[g.n] = d; g.vec[g.n] = vec; g.start[g.n] = (int)blocks; ++g.n;
         blocks += nb;
         if (S > 1) {

@@ -21,7 +21,7 @@ class Op:
     """One product.  Set fields directly or through the constructors below."""
     __slots__ = ("A", "a_sm", "a_sk", "B", "b_sn", "b_sk", "b_kshift", "b_kstride", "b_nshift", "b_nstride", "C", "ldc",
                  "c_nshift", "c_nstride", "M", "N", "K", "bias", "relu", "mask", "ldmask", "accumulate", "a_rowsum",
-                 "split_k", "keep")
+                 "split_k", "keep", "A16", "B16", "C16")
 
     def __init__(self, **kw):
         self.b_kshift = self.b_nshift = self.c_nshift = 0
@@ -30,6 +30,7 @@ class Op:
         self.ldmask = 0
         self.relu = self.accumulate = False
         self.split_k = 0                       # 0: chosen by launch()
+        self.A16 = self.B16 = self.C16 = None  # bf16 twins (torch.bfloat16 tensors laid out like A / B / C), optional
         self.keep = []
         for k, v in kw.items():
             setattr(self, k, v)
@@ -123,6 +124,7 @@ def launch(ops, bf16=False):
             d.accumulate = int(bool(o.accumulate))
             d.M, d.N, d.K, d.relu = o.M, o.N, o.K, int(bool(o.relu))
             d.bias = _p(o.bias); d.mask = _p(o.mask); d.ldmask = o.ldmask; d.a_rowsum = _p(o.a_rowsum)
+            d.A16, d.B16, d.C16 = _p(o.A16), _p(o.B16), _p(o.C16)
             sk = o.split_k or pick_split(o, bk=bk)
             d.split_k = sk if sk > 1 else 0
             if sk > 1:

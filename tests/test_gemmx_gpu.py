@@ -71,6 +71,76 @@ def test_forward_epilogue_variants(M, N, K, col0, ldc, split, bf16):
     assert torch.isnan(rest).all(), "stores outside the product's columns"
 
 
+def _twin(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("which", ["A", "B", "AB"])
+@pytest.mark.parametrize("kind,M,N,K", [("fwd", 300, 256, 128), ("fwd", 1, 1024, 256), ("fwd", 513, 72, 1032),
+                                        ("dx", 300, 256, 128), ("dx", 130, 1024, 56), ("dw", 3200, 256, 128),
+                                        ("dw", 500, 1024, 48), ("dw", 77, 120, 2048)])
+@pytest.mark.parametrize("split", [0, 3])
+def test_bf16_twins_change_nothing(kind, M, N, K, which, split):
+    """skg_gemmx_bf16 with the operands' bf16 twins (A16 / B16: the same values rounded by torch, same layout) returns
+    bit-for-bit what it returns from the fp32 arrays -- every operand layout, ragged edges (the twin is read by the
+    fast loop only), split-K, the bias gradient's workgroups (which keep the fp32 operand) -- and C16 receives the bf16
+    rounding of C."""
+    def build(twins):
+        if kind == "fwd":
+            x, W, b = _rnd(M, K, seed=41), _rnd(N, K, seed=42), _rnd(N, seed=43)
+            out = torch.full((M, N), float("nan")).cuda()
+            op = gemmx.forward(x, W, out, bias=b, relu=True)
+            a, bb = x, W
+        elif kind == "dx":
+            dz, W, x = _rnd(M, N, seed=44), _rnd(N, K, seed=45), _rnd(M, K, seed=46)
+            out = torch.full((M, K), float("nan")).cuda()
+            op = gemmx.input_grad(dz, W, out, mask=x)
+            a, bb = dz, W
+        else:
+            dz, x = _rnd(M, N, seed=47), _rnd(M, K, seed=48)
+            out = torch.full((N, K), float("nan")).cuda()
+            db = torch.full((N,), float("nan")).cuda()
+            op = gemmx.weight_grad(dz, x, out, db=db)
+            a, bb = dz, x
+        op.split_k = split
+        c16 = torch.full(out.shape, float("nan"), dtype=torch.bfloat16).cuda()
+        op.C16 = c16
+        if twins:
+            if "A" in which:
+                op.A16 = _twin(a)
+            if "B" in which:
+                op.B16 = _twin(bb)
+        gemmx.launch([op], bf16=True)
+        return out, c16, (db if kind == "dw" else None)
+
+    ref, ref16, refdb = build(False)
+    got, got16, gotdb = build(True)
+    assert torch.equal(got, ref), "C differs with twins (%s)" % which
+    assert torch.equal(got16.view(torch.int16), ref16.view(torch.int16))
+    assert torch.equal(got16.view(torch.int16), got.to(torch.bfloat16).view(torch.int16)), "C16 is not the rounding of C"
+    if refdb is not None:
+        assert torch.equal(gotdb, refdb)
+
+
+def test_bf16_twins_through_branch_major_weight():
+    M, N, K = 200, 1024, 1024
+    x, W, b = _rnd(M, K, seed=51), _rnd(N, K, seed=52) * 0.05, _rnd(N, seed=53)
+    Wb = _blocked(W)
+    outs = []
+    for twins in (False, True):
+        out = torch.empty(M, N).cuda()
+        op = gemmx.forward(x, Wb, out, bias=b, relu=True, K=K, N=N, w_blocks=(6, N * 64))
+        dz = _rnd(M, N, seed=54)
+        dx = torch.empty(M, K).cuda()
+        op2 = gemmx.input_grad(dz, Wb, dx, N_in=K, K_out=N, w_blocks=(6, N * 64))
+        if twins:
+            op.A16, op.B16 = _twin(x), _twin(Wb)
+            op2.A16, op2.B16 = _twin(dz), _twin(Wb)
+        gemmx.launch([op, op2], bf16=True)
+        outs.append((out, dx))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("split", [0, 3])
 def test_forward_with_branch_major_weight(split, bf16):
     M, N, K = 200, 1024, 1024

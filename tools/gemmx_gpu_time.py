@@ -27,20 +27,26 @@ def gpu_us(ops, bf16, reps=20, rounds=5):
     return best
 
 
-def make(kind, M, N, K):
+def make(kind, M, N, K, twins=False):
     x = torch.randn(M, K).cuda(); W = torch.randn(N, K).cuda() * 0.03; b = torch.randn(N).cuda()
     y = torch.empty(M, N).cuda(); dz = torch.randn(M, N).cuda(); dx = torch.empty(M, K).cuda()
     dW = torch.empty(N, K).cuda(); db = torch.empty(N).cuda()
     if kind == "fwd":
-        return gemmx.forward(x, W, y, bias=b, relu=True), 2.0 * M * N * K
-    if kind == "dx":
-        return gemmx.input_grad(dz, W, dx, mask=x), 2.0 * M * N * K
-    return gemmx.weight_grad(dz, x, dW, db=db), 2.0 * M * N * K
+        op, a, bb, c = gemmx.forward(x, W, y, bias=b, relu=True), x, W, y
+    elif kind == "dx":
+        op, a, bb, c = gemmx.input_grad(dz, W, dx, mask=x), dz, W, dx
+    else:
+        op, a, bb, c = gemmx.weight_grad(dz, x, dW, db=db), dz, x, dW
+    if twins:                                              # bf16 twins of both operands, and the twin of the output
+        op.A16, op.B16 = a.to(torch.bfloat16), bb.to(torch.bfloat16)
+        op.C16 = torch.empty(c.shape, dtype=torch.bfloat16, device=c.device)
+        op.keep += [op.A16, op.B16, op.C16]
+    return op, 2.0 * M * N * K
 
 
 if __name__ == "__main__":
     bf16 = not (len(sys.argv) > 1 and sys.argv[1] == "fp32")
-    kinds = sys.argv[2:] or ["fwd", "dx", "dw"]
+    kinds = [a for a in sys.argv[2:] if not a.startswith("--")] or ["fwd", "dx", "dw"]
     tag = "bf16" if bf16 else "fp32"
     for kind in kinds:
         for M, N, K, S in [(3200, 1024, 128, 1), (3200, 1024, 256, 1), (3200, 1024, 512, 1), (3200, 1024, 1024, 1),
@@ -51,7 +57,12 @@ if __name__ == "__main__":
             line = "%s %-3s M=%6d N=%4d K=%4d S=%d:" % (tag, kind, M, N, K, S)
             us = gpu_us([op], bf16)
             line += "  %7.1f us %6.1f TF" % (us, f / us / 1e6)
-            if kind == "fwd":
+            if bf16:
+                op3, _ = make(kind, M, N, K, twins=True)
+                op3.split_k = S
+                us = gpu_us([op3], bf16)
+                line += "  | bf16 twins %7.1f us %6.1f TF" % (us, f / us / 1e6)
+            if kind == "fwd" and "--aliased" in sys.argv:
                 for name, za, zb in (("B aliased", False, True), ("A+B aliased", True, True)):
                     op2, _ = make(kind, M, N, K)
                     op2.split_k = S
