@@ -700,6 +700,9 @@ __device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const
     YStage<AH> sa0, sa1;                                   // (separate objects: arrays of stages ended up in scratch memory)
     YStage<BH> sb0, sb1;
     auto load = [&](auto S, int t) {                      // past the end: the last tile again (never stored)
+#ifdef SKG_YKNOCK_LOAD                                     // timing builds (tools/build_gemmx_variants.sh): one piece of the step removed
+        if (t > ka + 2) return;
+#endif
         const int tt = min(t, kb - 1);
         if constexpr (decltype(S)::value == 0) {
             ytile<AK, FAST>(A, LA, c.m0, tt * YBK, c.kend, tid, sa0);
@@ -710,6 +713,9 @@ __device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const
         }
     };
     auto store = [&](auto S, int buf) {
+#ifdef SKG_YKNOCK_STORE
+        if (buf >= 0) return;
+#endif
         if constexpr (decltype(S)::value == 0) {
             if (c.do_rowsum) yrowsum<AK>(sa0, rs);
             ystore_lds<AK>(smem + buf * 2 * YTILE, tid, sa0);
@@ -728,7 +734,10 @@ __device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const
     store(I0{}, par);
     load(I0{}, ka + 2);
     __syncthreads();
-    auto step = [&](auto NX, int kt) {                     // tile kt is in LDS[par]; tile kt + 1 in stage NX
+    // MORE: a tile follows (known at compile time inside the main loop: a branch around the store would cut the
+    // scheduling region the interleave below needs)
+    auto step = [&](auto NX, auto MORE, int kt) {          // tile kt is in LDS[par]; tile kt + 1 in stage NX
+        constexpr bool more_ct = decltype(MORE)::value;
         const uint16_t* As = smem + par * 2 * YTILE;
         const uint16_t* Bs = As + YTILE;
         const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(As + fa0), a01 = *reinterpret_cast<const bf16x8*>(As + fa1);
@@ -740,9 +749,15 @@ __device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const
 #if SKG_YORDER == 1
         // the next tile goes to the other LDS buffer while this tile's fragments are still on their way to registers
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < kb) store(NX, par ^ 1);
+        if (more_ct || kt + 1 < kb) store(NX, par ^ 1);
         __builtin_amdgcn_sched_barrier(0);
 #endif
+#ifdef SKG_YKNOCK_MFMA
+        acc[0][0][0] += (float)a00[0] + (float)b00[0] + (float)a01[0] + (float)b01[0] + (float)a10[0] + (float)b10[0] +
+                        (float)a11[0] + (float)b11[0];
+        if (false)
+#endif
+        {
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, b00, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, b01, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, b00, acc[1][0], 0, 0, 0);
@@ -751,19 +766,36 @@ __device__ __forceinline__ void yrun(const XOperand& A, const XOperand& B, const
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, b11, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, b10, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, b11, acc[1][1], 0, 0, 0);
+        }
 #if SKG_YORDER != 1
-        if (kt + 1 < kb) store(NX, par ^ 1);
+        if (more_ct || kt + 1 < kb) store(NX, par ^ 1);
+#endif
+#if SKG_YORDER == 2
+        // conversions and LDS writes of the next tile issued in the shadow of the MFMAs (an MFMA holds the matrix pipe for 32
+        // cycles; two packed conversions and one ds_write fit behind each)
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
 #endif
         load(NX, kt + 1 + YNST);
+#ifndef SKG_YKNOCK_BARRIER
         __syncthreads();
+#endif
         par ^= 1;
     };
+    using Yes = std::integral_constant<bool, true>;
+    using Maybe = std::integral_constant<bool, false>;
     int kt = ka;
-    for (; kt + 1 < kb; kt += 2) {
-        step(I1{}, kt);
-        step(I0{}, kt + 1);
+    for (; kt + 2 < kb; kt += 2) {
+        step(I1{}, Yes{}, kt);
+        step(I0{}, Yes{}, kt + 1);
     }
-    if (kt < kb) step(I1{}, kt);
+    if (kt < kb) step(I1{}, Maybe{}, kt);
+    if (kt + 1 < kb) step(I0{}, Maybe{}, kt + 1);
 }
 
 // 16-bit reads of an operand from row0: the twin exists, its descriptor passed the host's alignment checks, and no

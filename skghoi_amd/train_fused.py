@@ -757,6 +757,10 @@ def join_backward():
             _PENDING.clear()
 
 
+import atexit
+atexit.register(join_backward)          # (a worker still issuing launches must not race the runtime's teardown)
+
+
 def job_class(head):
     """NativeJob (default) or the Python-issued TrainJob (`head.train_plan = "python"` / SKG_TRAIN_PLAN=python: the same
     kernels launched one by one from Python -- kept as the readable statement of the sequence and as a cross-check)."""
