@@ -204,6 +204,11 @@ int skg_gemm_small_mode(int mode);
 /* Developer switch: a launch / group takes the 64 x 64 tiles below this many 128 x 128 tiles (default 384); returns the
  * previous bound, tiles <= 0 only queries.                                                                          */
 int skg_gemm_small_tiles(int tiles);
+/* Launches (and grouped launches) that are "small" by the rule above but have at least this many 128 x 128 tiles (split-K
+ * slices counted) run on skg_gemmx_f32's register-pipelined 128 x 128 loop, their fused epilogue included -- the regime
+ * of 2-8 images, where it beats both eval loops (csrc/skg_gemm.hip, g_route_tiles).  Returns the previous value;
+ * tiles <= 0 only reads it.  A developer switch (SKG_ROUTE_TILES); a very large value turns the routing off.           */
+int skg_gemm_route_tiles(int tiles);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * fc_head / fc_tail input rows (HEAD:884-885): out[r] = [ enc[enc_row[r], 0:1024] | ent[ent_img[r], ent_row[r], 0:50]

@@ -104,6 +104,7 @@ PROTOTYPES = {
     "skg_adamw_f32": (C.c_int, [_vp, C.c_int] + [C.c_double] * 7 + [_vp]),
     "skg_gemm_small_mode": (C.c_int, [C.c_int]),
     "skg_gemm_small_tiles": (C.c_int, [C.c_int]),
+    "skg_gemm_route_tiles": (C.c_int, [C.c_int]),
     "skg_gemmx_ws_floats": (C.c_int64, [C.POINTER(GemmXDesc)]),
     "skg_gemmx_f32": (C.c_int, [C.POINTER(GemmXDesc), C.c_int, _vp]),
     "skg_gemmx_bf16": (C.c_int, [C.POINTER(GemmXDesc), C.c_int, _vp]),
@@ -178,6 +179,8 @@ def lib():
         l.skg_gemm_small_mode(int(os.environ["SKG_SMALL_MODE"]))
     if os.environ.get("SKG_SMALL_TILES"):                # developer switch: bound of the 64 x 64-tile launches
         l.skg_gemm_small_tiles(int(os.environ["SKG_SMALL_TILES"]))
+    if os.environ.get("SKG_ROUTE_TILES"):                # developer switch: mid-size launches on the free-layout GEMM from here up
+        l.skg_gemm_route_tiles(int(os.environ["SKG_ROUTE_TILES"]))
     _LIB = l
     return l
 

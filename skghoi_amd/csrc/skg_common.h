@@ -37,3 +37,22 @@ __device__ __forceinline__ float skg_block_sum256(float v, float* red) {
     __syncthreads();
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
+
+// ---- eval-path epilogues on the free-layout GEMM (skg_gemm_x.hip), used when skg_gemm.hip routes a mid-size exact-fp32
+// launch there (a few images: 100-400 tiles of 128 x 128, where the register-pipelined 128 x 128 loop beats both eval loops).
+// Semantics of include/skghoi.h skg_gemm_desc: kind = SKG_EPI_MUL_RELU (C[out_rows[r]] = relu((acc + bias) * (mbias +
+// P[p_idx[r]] + Q[q_idx[r]])), optional raw copy of acc + bias to C_raw[r]) or SKG_EPI_BIAS_RES_RELU (C = relu(acc + bias)
+// + res[r]); kind 0 with out_rows = a plain product whose rows are scattered.  Only with the staged epilogue (16-byte
+// aligned everything, N % 4 == 0) and without split-K.
+struct skg_gemmx_fused {
+    int kind;
+    const float* P; const int32_t* p_idx; int64_t ldp;
+    const float* Q; const int32_t* q_idx; int64_t ldq;
+    const float* mbias;
+    float* C_raw; int64_t ldc_raw;
+    const int32_t* out_rows;
+    const float* res; int64_t ldres;
+};
+// 1 if the product (with these fused parameters, NULL = none) can take skg_gemmx_f32's staged epilogue
+int skg_gemmx_can_fuse(const skg_gemmx_desc* d, const skg_gemmx_fused* f);
+int skg_gemmx_f32_fused(const skg_gemmx_desc* descs_host, const skg_gemmx_fused* fused_host, int n, void* stream);

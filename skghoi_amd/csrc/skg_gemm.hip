@@ -28,6 +28,7 @@
 //     accesses; interior tiles take a guard-free path.  Split-K (plain epilogues) and a grouped launch cover the
 //     small-M layers.
 #include "skg_common.h"
+#include <string.h>
 #include <type_traits>
 
 // 2^e for e in [-126, 127], exactly
@@ -1058,6 +1059,40 @@ static int skg_gemm_validate(const skg_gemm_desc& d) {
     return 0;
 }
 
+// ---- mid-size launches on the free-layout GEMM.  Between "a few hundred workgroups of 64 x 64" (one image: the latency loop)
+// and "thousands of 128 x 128 tiles" (the DMA-staged loop, two workgroups per CU) lies the regime of 2-8 images: 100-400
+// tiles of 128 x 128, at most one workgroup per CU.  There skg_gemmx_f32's loop (three register stages of prefetch, double
+// LDS buffer, staged epilogue) is the fastest of the three: M = 1600, N = K = 1024 split in two 50 us against 80-92 us on
+// either eval loop; the three fc_2 products of four images as one launch ~2.5x faster than the grouped eval kernel.  A launch
+// goes there when it has at least g_route_tiles tiles of 128 x 128 (split slices counted) but is still "small", carries
+// no weight twin / row gather / dot epilogue, and its fused epilogue can run in the staged epilogue (skg_gemmx_can_fuse).
+// The summation order over k differs from the eval loops (as theirs do from each other): results agree to rounding.
+static int g_route_tiles = 200;
+extern "C" int skg_gemm_route_tiles(int tiles) {
+    const int old = g_route_tiles;
+    if (tiles > 0) g_route_tiles = tiles;
+    return old;
+}
+
+static bool skg_route_desc(const skg_gemm_desc& d, skg_gemmx_desc& x, skg_gemmx_fused& f) {
+    if (d.w_split || d.a_rows || d.a_exp || d.epilogue == SKG_EPI_RELU_DOT) return false;
+    memset(&x, 0, sizeof(x)); memset(&f, 0, sizeof(f));
+    x.A = d.A; x.a_sm = d.lda; x.a_sk = 1;
+    x.B = d.W; x.b_sn = d.ldw; x.b_sk = 1;
+    x.C = d.C; x.ldc = d.ldc; x.M = d.M; x.N = d.N; x.K = d.K;
+    x.bias = d.bias; x.relu = d.epilogue == SKG_EPI_BIAS_RELU ? 1 : 0;
+    x.split_k = d.split_k > 1 ? d.split_k : 0; x.split_ws = d.split_ws;       // same [slice][M][N] workspace layout
+    f.out_rows = d.out_rows;
+    if (d.epilogue == SKG_EPI_MUL_RELU) {
+        f.kind = SKG_EPI_MUL_RELU;
+        f.P = d.P; f.p_idx = d.p_idx; f.ldp = d.ldp; f.Q = d.Q; f.q_idx = d.q_idx; f.ldq = d.ldq; f.mbias = d.mbias;
+        f.C_raw = d.C_raw; f.ldc_raw = d.ldc_raw;
+    } else if (d.epilogue == SKG_EPI_BIAS_RES_RELU) {
+        f.kind = SKG_EPI_BIAS_RES_RELU; f.res = d.res; f.ldres = d.ldres;
+    }
+    return skg_gemmx_can_fuse(&x, &f) != 0;
+}
+
 // 64 x 64 tiles for a whole group?  Every member must be able to take the DMA-staged loop, none may carry a weight twin,
 // and together they must be small (the same bound as a single launch: fewer than 384 tiles of 128 x 128).
 static bool skg_gemm_group_small(const skg_gemm_desc* descs, int n) {
@@ -1089,6 +1124,18 @@ extern "C" int skg_gemm_group_f32(const skg_gemm_desc* descs_host, int n, void* 
         if (rc) return rc;
     }
     const bool small = skg_gemm_group_small(descs_host, n);
+    if (n <= SKG_GEMMX_GROUP_MAX) {                        // mid-size group: the free-layout GEMM (see g_route_tiles)
+        skg_gemmx_desc xs[SKG_GEMMX_GROUP_MAX];
+        skg_gemmx_fused fs[SKG_GEMMX_GROUP_MAX];
+        int64_t tiles128 = 0;
+        bool ok = true;
+        for (int i = 0; i < n && ok; ++i) {
+            const skg_gemm_desc& d = descs_host[i];
+            ok = skg_route_desc(d, xs[i], fs[i]);
+            tiles128 += (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * (d.split_k > 1 ? d.split_k : 1);
+        }
+        if (ok && tiles128 >= g_route_tiles && tiles128 < 4 * g_small_tiles) return skg_gemmx_f32_fused(xs, fs, n, stream);
+    }
     for (int i = 0; i < n; ++i) {
         const skg_gemm_desc& d = descs_host[i];
         if (d.split_k > 1 && !small) return SKG_E_ARG;                     // split-K only with the 64 x 64 tiles
@@ -1130,6 +1177,11 @@ extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
                       (int64_t)BM * d.lda * 4 < 0xffffffffLL && (int64_t)BN * d.ldw * 4 < 0xffffffffLL;
     const bool split = d.w_split && (d.K % 16) == 0 && d.w_scale > 0.f;
     const int T = split ? 2 : skg_gemm_tile_scale(&d);
+    if (!split && T == 1 && d.M > 64) {                    // mid-size launch: the free-layout GEMM (see g_route_tiles)
+        const int64_t tiles128 = (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * (d.split_k > 1 ? d.split_k : 1);
+        skg_gemmx_desc x; skg_gemmx_fused f;
+        if (tiles128 >= g_route_tiles && skg_route_desc(d, x, f)) return skg_gemmx_f32_fused(&x, &f, 1, stream);
+    }
     const int64_t nblk = skg_gemm_blocks(d.M, d.N, d.K, T) * (d.split_k > 1 ? d.split_k : 1);
     if (nblk > 0x7fffffffLL) return SKG_E_LIMIT;
     dim3 grid((unsigned)nblk), block(256);

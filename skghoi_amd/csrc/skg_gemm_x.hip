@@ -25,6 +25,7 @@
 // per quad serialises them behind s_waitcnt and runs at a fraction of the speed).  A ragged last tile, operands
 // without 16-byte alignment and row-contiguous operands whose extent is not a multiple of 4 take the generic loop.
 #include "skg_common.h"
+#include <string.h>
 #include <type_traits>
 
 #define XBM 128
@@ -39,6 +40,7 @@
 struct skg_gemmx_group {
     skg_gemmx_desc d[SKG_GEMMX_GROUP_MAX];
     int start[SKG_GEMMX_GROUP_MAX + 1];      // block ranges
+    skg_gemmx_fused f[SKG_GEMMX_GROUP_MAX];  // eval-path epilogues (kind 0: none), staged epilogue only
     int vec[SKG_GEMMX_GROUP_MAX];            // bit 0: A fast loop allowed, bit 1: B, bit 2: C 8-byte stores, bit 3: staged
                                              // epilogue, bit 4 / 5: bf16 twin of A / B readable by the fast loop
     int n;
@@ -178,13 +180,14 @@ __device__ __forceinline__ uint32_t ypack(float a, float b) {          // two fl
 #define XEP_FLOATS (4 * XEP_WAVE)            // 36 KiB per workgroup
 
 // Rows [row0, row0 + 32) x columns [col0, col0 + 64) of the product from the wave's staged block.
-__device__ __forceinline__ void xep_rows(const skg_gemmx_desc& d, const float* stage, int lane, int row0, int col0,
-                                         float* ws) {
+__device__ __forceinline__ void xep_rows(const skg_gemmx_desc& d, const skg_gemmx_fused& f, const float* stage, int lane,
+                                         int row0, int col0, float* ws) {
     const int c4 = 4 * (lane & 15), rr = lane >> 4, col = col0 + c4;
     if (col >= d.N) return;
     const bool hb = !ws && d.bias;
-    float4 bv = xzero4();
+    float4 bv = xzero4(), mb = xzero4();
     if (hb) bv = xld4(d.bias + col);
+    if (f.kind == SKG_EPI_MUL_RELU && f.mbias) mb = xld4(f.mbias + col);
     const int64_t coff = xoff(col, d.c_nshift, d.c_nstride, 1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -193,6 +196,35 @@ __device__ __forceinline__ void xep_rows(const skg_gemmx_desc& d, const float* s
         float4 v = *reinterpret_cast<const float4*>(stage + (4 * i + rr) * XEP_LD + c4);
         if (ws) { *reinterpret_cast<float4*>(ws + (int64_t)row * d.N + col) = v; continue; }
         if (hb) { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+        if (f.kind | (f.out_rows != nullptr)) {            // eval-path epilogues (skg_gemm_desc), uniform per product
+            const int orow = f.out_rows ? f.out_rows[row] : row;
+            if (f.kind == SKG_EPI_MUL_RELU) {
+                if (f.C_raw) *reinterpret_cast<float4*>(f.C_raw + (int64_t)row * f.ldc_raw + col) = v;
+                if (orow < 0) continue;
+                float4 m = mb;
+                if (f.P) {
+                    const float4 t = xld4(f.P + (int64_t)(f.p_idx ? f.p_idx[row] : row) * f.ldp + col);
+                    m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
+                }
+                if (f.Q) {
+                    const float4 t = xld4(f.Q + (int64_t)(f.q_idx ? f.q_idx[row] : row) * f.ldq + col);
+                    m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
+                }
+                *reinterpret_cast<float4*>(d.C + coff + (int64_t)orow * d.ldc) =
+                    make_float4(fmaxf(v.x * m.x, 0.f), fmaxf(v.y * m.y, 0.f), fmaxf(v.z * m.z, 0.f), fmaxf(v.w * m.w, 0.f));
+                continue;
+            }
+            if (orow < 0) continue;
+            if (d.relu || f.kind == SKG_EPI_BIAS_RES_RELU) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            if (f.kind == SKG_EPI_BIAS_RES_RELU) {
+                const float4 t = xld4(f.res + (int64_t)row * f.ldres + col);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            *reinterpret_cast<float4*>(d.C + coff + (int64_t)orow * d.ldc) = v;
+            continue;
+        }
         if (d.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         float* p = d.C + coff + (int64_t)row * d.ldc;
         if (d.accumulate) { const float4 o = xld4(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
@@ -419,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
                         *reinterpret_cast<float2*>(stage + (2 * (8 * g2 + 4 * lk + t) + mb) * XEP_LD + 2 * li) =
                             make_float2(acc[mb][0][e], acc[mb][1][e]);
                     }
-            xep_rows(d, stage, lane, m0 + wm * 64 + 32 * ps, n0 + wn * 64, ws);
+            xep_rows(d, g.f[gi], stage, lane, m0 + wm * 64 + 32 * ps, n0 + wn * 64, ws);
         }
         return;
     }
@@ -925,7 +957,7 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
                         stage[(8 * gq + 4 * lk + t) * XEP_LD + ni * 32 + li] = acc[mi][ni][4 * gq + t];
-            xep_rows(d, stage, lane, m0 + wm * 64 + mi * 32, n0 + wn * 64, ws);
+            xep_rows(d, g.f[gi], stage, lane, m0 + wm * 64 + mi * 32, n0 + wn * 64, ws);
         }
         return;
     }
@@ -1038,9 +1070,16 @@ extern "C" int64_t skg_gemmx_ws_floats(const skg_gemmx_desc* d) {
     return d->split_k > 1 ? (int64_t)d->split_k * ((int64_t)d->M * d->N + d->M) : 0;
 }
 
-static int skg_gemmx_launch(const skg_gemmx_desc* descs_host, int n, void* stream, bool bf16) {
+static bool xfused_ptrs_ok(const skg_gemmx_fused& f) {
+    return skg_aligned16(f.P) && skg_aligned16(f.Q) && skg_aligned16(f.mbias) && skg_aligned16(f.C_raw) &&
+           skg_aligned16(f.res) && xmul4(f.ldp) && xmul4(f.ldq) && xmul4(f.ldc_raw) && xmul4(f.ldres);
+}
+
+static int skg_gemmx_launch(const skg_gemmx_desc* descs_host, int n, void* stream, bool bf16,
+                            const skg_gemmx_fused* fused_host = nullptr) {
     if (!descs_host || n < 1 || n > SKG_GEMMX_GROUP_MAX) return SKG_E_ARG;
     skg_gemmx_group g, r;
+    memset(g.f, 0, sizeof(g.f)); memset(r.f, 0, sizeof(r.f));
     g.n = r.n = 0;
     int64_t blocks = 0, rblocks = 0;
     for (int i = 0; i < n; ++i) {
@@ -1072,6 +1111,12 @@ static int skg_gemmx_launch(const skg_gemmx_desc* descs_host, int n, void* strea
         if (bf16 && d.B16 && (vec & 2) && skg_aligned16(d.B16) && (d.b_sk == 1 ? xmul8(d.b_sn) : xmul8(d.b_sk)) &&
             (d.b_kshift == 0 || xmul8(d.b_kstride)) && (d.b_nshift == 0 || (d.b_nshift >= 3 && xmul8(d.b_nstride))))
             vec |= 32;
+        if (fused_host && (fused_host[i].kind || fused_host[i].out_rows)) {
+            // eval-path epilogues exist in the staged epilogue only, and not behind a split-K reduce
+            if (!(vec & 8) || S > 1 || d.c_nshift || d.accumulate || d.mask || d.C16 || !xfused_ptrs_ok(fused_host[i]))
+                return SKG_E_ARG;
+            g.f[g.n] = fused_host[i];
+        }
         g.d[g.n] = d; g.vec[g.n] = vec; g.start[g.n] = (int)blocks; ++g.n;
         blocks += nb;
         if (S > 1) {
@@ -1096,6 +1141,18 @@ static int skg_gemmx_launch(const skg_gemmx_desc* descs_host, int n, void* strea
 
 extern "C" int skg_gemmx_f32(const skg_gemmx_desc* descs_host, int n, void* stream) {
     return skg_gemmx_launch(descs_host, n, stream, false);
+}
+
+int skg_gemmx_f32_fused(const skg_gemmx_desc* descs_host, const skg_gemmx_fused* fused_host, int n, void* stream) {
+    return skg_gemmx_launch(descs_host, n, stream, false, fused_host);
+}
+
+int skg_gemmx_can_fuse(const skg_gemmx_desc* dp, const skg_gemmx_fused* f) {
+    const skg_gemmx_desc& d = *dp;
+    if (skg_gemmx_validate(d)) return 0;
+    const bool staged = (d.N & 3) == 0 && skg_aligned16(d.C) && xmul4(d.ldc) && d.c_nshift == 0 && skg_aligned16(d.bias);
+    if (!f || !(f->kind || f->out_rows)) return 1;
+    return staged && d.split_k <= 1 && !d.accumulate && !d.mask && xfused_ptrs_ok(*f);
 }
 
 extern "C" int skg_gemmx_bf16(const skg_gemmx_desc* descs_host, int n, void* stream) {

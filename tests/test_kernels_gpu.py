@@ -274,6 +274,57 @@ def test_gemm_large_gather_scatter_and_fallback():
     assert rel < 1e-5, rel
 
 
+def test_mid_size_launches_on_the_free_layout_kernel_agree_with_the_eval_loops():
+    """2-8 images (200-383 tiles of 128 x 128): skg_gemm_f32 / skg_gemm_group_f32 hand the launch to skg_gemmx_f32's loop
+    with the eval epilogue fused into its staged epilogue (csrc/skg_gemm.hip g_route_tiles).  Every routable epilogue --
+    bias, bias + ReLU (also split-K), fc_1 * fc_2 -> ReLU with both tables / raw copy / row scatter, residual -- against
+    float64 and against the same call with the routing switched off."""
+    lib = _capi.lib()
+    M, N, K = 3300, 1024, 256                     # 26 x 8 = 208 tiles
+    A = _rand(M, K, seed=1); W = _rand(N, K, seed=2) / 16; b = _rand(N, seed=3)
+    P = _rand(17, N, seed=4); Q = _rand(29, N, seed=5); mb = _rand(N, seed=6); res = _rand(M, N, seed=7)
+    g = torch.Generator().manual_seed(3)
+    pi = torch.randint(0, 17, (M,), generator=g).int().cuda(); qi = torch.randint(0, 29, (M,), generator=g).int().cuda()
+    orow = torch.randperm(M, generator=g).int(); orow[::7] = -1; orow = orow.cuda()
+    v = A.double() @ W.double().t() + b.double()
+
+    def run():
+        out = {}
+        C = torch.zeros(M, N, device="cuda"); raw = torch.zeros(M, N, device="cuda")
+        gemm(A, W, b, C, M, N, K, _capi.EPI_MUL_RELU, P=P, p_idx=pi, ldp=N, Q=Q, q_idx=qi, ldq=N, mbias=mb, C_raw=raw,
+             ldc_raw=N, out_rows=orow)
+        out["mul"], out["raw"] = C, raw
+        C = torch.zeros(M, N, device="cuda")
+        gemm(A, W, b, C, M, N, K, _capi.EPI_BIAS_RES_RELU, res=res, ldres=N)
+        out["res"] = C
+        C = torch.zeros(M, N, device="cuda"); ws = torch.empty(2 * M * N, device="cuda")
+        gemm(A, W, b, C, M, N, K, _capi.EPI_BIAS_RELU, split_k=2, split_ws=ws)
+        out["split"] = C
+        Cs = [torch.zeros(M, N, device="cuda") for _ in range(3)]
+        gemm_group([((A, W, b, Cs[0], M, N, K, _capi.EPI_MUL_RELU), dict(P=P, p_idx=pi, ldp=N)),
+                    ((A, W, None, Cs[1], M, N, K, _capi.EPI_BIAS), {}),
+                    ((A, W, b, Cs[2], M, N, K, _capi.EPI_BIAS_RELU), dict(out_rows=orow))])
+        out["g0"], out["g1"], out["g2"] = Cs
+        torch.cuda.synchronize()
+        return out
+
+    routed = run()
+    old = lib.skg_gemm_route_tiles(1 << 30)
+    try:
+        plain = run()
+    finally:
+        lib.skg_gemm_route_tiles(old)
+    keep = orow >= 0
+    mul = torch.relu(v * (P[pi.long()] + Q[qi.long()] + mb).double()).float()
+    ref_mul = torch.zeros(M, N, device="cuda"); ref_mul[orow[keep].long()] = mul[keep]
+    ref_g2 = torch.zeros(M, N, device="cuda"); ref_g2[orow[keep].long()] = torch.relu(v).float()[keep]
+    refs = dict(mul=ref_mul, raw=v.float(), res=(res.double() + torch.relu(v)).float(), split=torch.relu(v).float(),
+                g0=torch.relu(v * P[pi.long()].double()).float(), g1=(v - b.double()).float(), g2=ref_g2)
+    for k, r in refs.items():
+        _close(routed[k], r, 2e-5)
+        _close(routed[k], plain[k], 2e-5)
+
+
 def test_gemm_group_matches_single_launches(gemm_mode):
     K = 256
     specs, refs, outs = [], [], []

@@ -473,4 +473,6 @@ def test_native_training_plan_equals_the_python_issued_sequence(name, precision)
         if k == "box_pair_head.adjacency.bias":          # exactly zero: rounding noise on both sides
             continue
         scale = max(np.abs(ga[k]).max(), 1e-6)
-        assert np.abs(ga[k] - gb[k]).max() <= tol_g * scale + 1e-9, k
+        # 1e-8 absolute: adjacency.weight (|g| ~ 2e-4 after heavy cancellation) moves by ~2e-9 with the summation order of
+        # the fc_2 products, which the two plans may run on different loops (mid-size launches: csrc/skg_gemm.hip)
+        assert np.abs(ga[k] - gb[k]).max() <= tol_g * scale + 1e-8, k
