@@ -500,10 +500,15 @@ __global__ __launch_bounds__(256) void skg_hoi_loss_kernel(
         const float sg = 1.f / (1.f + expf(-logits[p * ldl + v]));
         dlogits[p * ldl + v] = dldx * x * (1.f - sg);
     }
-    for (int pl = first; pl < P; pl += stride) {
+    // a wave per pair: its lanes read the K labels of the row side by side (one thread walking a row alone was 117 loads, each
+    // from another cache line than its neighbours' -- 25 of the kernel's 35 us); the labels are 0 / 1, their sum is exact in any order
+    const int lane = threadIdx.x & 63;
+    for (int pl = blockIdx.y * 4 + (threadIdx.x >> 6); pl < P; pl += 4 * gridDim.y) {
         const int64_t p = (int64_t)mt.pair_off + pl;
         float ys = 0.f;
-        for (int v = 0; v < K; ++v) ys += labels[p * K + v];
+        for (int v = lane; v < K; v += 64) ys += labels[p * K + v];
+        ys = skg_wave_sum(ys);
+        if (lane != 0) continue;
         const float y = fminf(ys, 1.f);
         unary[p] = y;
         if (y != 0.f) n2 += 1.f;
