@@ -624,8 +624,8 @@ def main():
             except Exception:
                 busy = {}
         for prec in ("fp32", "bf16"):
-            ks = 30
-            el_t, losses, inf = run_train(4, prec, ks, 8, device, rank, world, False)
+            ks = 60                                                          # (steady state: the first ~10 steps still grow pools)
+            el_t, losses, inf = run_train(4, prec, ks, 12, device, rank, world, False)
             ms = el_t / ks * 1e3
             rec = dict(ms_per_step=round(ms, 3), images_per_s=round(4 * ks / el_t, 2), batch=4, steps=ks,
                        losses={k: round(v, 6) for k, v in losses.items()})
