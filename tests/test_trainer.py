@@ -372,6 +372,49 @@ def test_prefetched_steps_equal_inline_steps_bit_for_bit(precision):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_worker_thread_backward_changes_nothing(precision):
+    """trainer.train_step lets a thread of the library issue the backward's launches (skg_train_backward_async_f32) while
+    the Python thread prepares the next batch, and joins in front of the optimizer.  Forty steps over alternating batch
+    shapes with the look-ahead on, against the same run with the backward issued inline: same losses at every step, same
+    weights at the end, bit for bit -- the buffers the plan names (workspace, saved activations, the prepared batch) must
+    outlive the worker's launch calls, whatever the allocator does in between."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    import cases
+    import gpu_run
+    from collections import OrderedDict
+    from skghoi_amd import train_fused
+    cs = [cases.build_case("train_tiny"), cases.build_case("train_skips")]
+    batches = [(OrderedDict((k, c["feat3"].cuda()) for k in "0123"), gpu_run.to_cuda(c["detections"]), c["shapes"],
+                gpu_run.to_cuda(c["targets"]), c) for c in cs]
+
+    def run(defer):
+        head = gpu_run.build_head(cs[0])
+        head.precision = precision
+        if not defer:
+            inner = head.fused_step
+            head.fused_step = lambda *a, defer_backward=False, **k: inner(*a, defer_backward=False, **k)
+        net = trainer.wrap_ddp(head, torch.device("cuda", 0))
+        opt = trainer.build_optimizer(net, lr=1e-3)
+        torch.manual_seed(11)
+        losses, deferred = [], 0
+        for i in range(40):
+            f, d, s, t, c = batches[i % 2]
+            head.box_roi_pool = gpu_run.CachedPool(c)
+            l, _ = trainer.train_step(net, opt, f, d, s, targets=t, lazy=True, prefetch=batches[(i + 1) % 2][:4])
+            assert not train_fused._PENDING                      # joined in front of the optimizer
+            losses.append(l)
+        return head, [trainer.read_losses(l) for l in losses]
+
+    h0, l0 = run(False)
+    h1, l1 = run(True)
+    assert l0 == l1
+    for (k, a), (_, b) in zip(h0.state_dict().items(), h1.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+@pytest.mark.gpu
 def test_training_in_the_arena_keeps_eval_and_checkpoints_consistent():
     """After training steps the 408 parameters are views of the flat arena the optimizer updates in place.  The eval engine
     must notice every update (its packed copies are rebuilt), a checkpoint written from the arena-backed module must load
