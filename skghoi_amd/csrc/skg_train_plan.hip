@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <stdlib.h>
+#include <pthread.h>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -593,9 +594,18 @@ struct AsyncBackward {
         }
     }
 };
+AsyncBackward* g_async = nullptr;
+void async_after_fork_in_child() {                             // threads do not survive fork(): a child starts without a worker
+    if (g_async) g_async = new AsyncBackward;                  // (the parent's object, and whatever its mutex held, is abandoned)
+}
 AsyncBackward* async_backward() {
-    static AsyncBackward* a = new AsyncBackward;               // never destroyed: its thread outlives static destruction
-    return a;
+    static bool once = [] {
+        g_async = new AsyncBackward;                           // never destroyed: its thread outlives static destruction
+        pthread_atfork(nullptr, nullptr, async_after_fork_in_child);
+        return true;
+    }();
+    (void)once;
+    return g_async;
 }
 }  // namespace
 
