@@ -56,3 +56,34 @@ struct skg_gemmx_fused {
 // 1 if the product (with these fused parameters, NULL = none) can take skg_gemmx_f32's staged epilogue
 int skg_gemmx_can_fuse(const skg_gemmx_desc* d, const skg_gemmx_fused* f);
 int skg_gemmx_f32_fused(const skg_gemmx_desc* descs_host, const skg_gemmx_fused* fused_host, int n, void* stream);
+
+// ---- several independent launches of one per-row kernel as ONE launch (blockIdx.y picks the call).  A dependent chain of
+// ~100 kernels pays ~4.5 us per kernel boundary whatever the kernel does (a 1-wave kernel takes 4.7 us here): the training
+// plan (skg_train_plan.hip) issues its back-to-back calls of these kernels through the *_multi forms.  Same arithmetic,
+// same results; the calls of one launch must not depend on each other.  n <= SKG_MULTI_MAX.
+#define SKG_MULTI_MAX 4
+struct skg_rows_mul_args {
+    const float* P; const int32_t* p_idx; int64_t ldp; const float* Q; const int32_t* q_idx; int64_t ldq; const float* mbias;
+    const float* F; const int32_t* f_idx; int64_t ldf; int rows, cols; float* out; int64_t ldo;
+};
+int skg_rows_mul_relu_multi(const skg_rows_mul_args* calls, int n, void* stream);
+struct skg_mul_bwd_args {
+    float* g; int64_t ldg; const float* F; const int32_t* f_idx; int64_t ldf; const float* P; const int32_t* p_idx; int64_t ldp;
+    const float* Q; const int32_t* q_idx; int64_t ldq; const float* mbias; int rows; float* dF; int64_t lddf; int accumulate;
+};
+int skg_mul_bwd_multi(const skg_mul_bwd_args* calls, int n, void* stream);
+struct skg_segment_sum_args {           // modes 0 / 1 of skg_segment_sum_f32 (mode 2 has a grid of its own)
+    const float* src; int64_t ld; int mode; float* outH; float* outN; int accumulate;
+};
+int skg_segment_sum_multi(const skg_segment_sum_args* calls, int n, const skg_image_meta* meta, const int32_t* hum_img,
+                          const int32_t* node_img, int sum_h, int sum_n, void* stream);
+struct skg_add_layernorm_args {
+    const float* a; int64_t lda; const float* b; int64_t ldb; const float* gamma; const float* beta; int rows;
+    float* xsum; float* y; float* stats;
+};
+int skg_add_layernorm_multi(const skg_add_layernorm_args* calls, int n, float eps, void* stream);
+struct skg_layernorm_bwd_args {
+    const float* dy; int64_t lddy; const float* x; const float* stats; const float* gamma; int rows; float* dx;
+    const float* relu_src; float* dx_masked; float* dgamma; float* dbeta;
+};
+int skg_layernorm_bwd_multi(const skg_layernorm_bwd_args* calls, int n, void* stream);

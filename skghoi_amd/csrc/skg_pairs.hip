@@ -228,6 +228,51 @@ __global__ __launch_bounds__(256) void skg_rows_mul_relu_kernel(const float* __r
     }
 }
 
+struct skg_rows_mul_pack { skg_rows_mul_args a[SKG_MULTI_MAX]; };
+__global__ __launch_bounds__(256) void skg_rows_mul_relu_multi_kernel(const skg_rows_mul_pack pk) {
+    const skg_rows_mul_args& a = pk.a[blockIdx.y];
+    const int r = blockIdx.x;
+    if (r >= a.rows) return;
+    const float* p = a.P + (int64_t)(a.p_idx ? a.p_idx[r] : r) * a.ldp;
+    const float* q = a.Q ? a.Q + (int64_t)(a.q_idx ? a.q_idx[r] : r) * a.ldq : nullptr;
+    const float* f = a.F + (int64_t)(a.f_idx ? a.f_idx[r] : r) * a.ldf;
+    float* o = a.out + (int64_t)r * a.ldo;
+    for (int c = threadIdx.x * 4; c < a.cols; c += 1024) {
+        float4 m = *reinterpret_cast<const float4*>(p + c);
+        if (q) {
+            const float4 t = *reinterpret_cast<const float4*>(q + c);
+            m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
+        }
+        if (a.mbias) {
+            const float4 t = *reinterpret_cast<const float4*>(a.mbias + c);
+            m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
+        }
+        const float4 v = *reinterpret_cast<const float4*>(f + c);
+        *reinterpret_cast<float4*>(o + c) = make_float4(fmaxf(m.x * v.x, 0.f), fmaxf(m.y * v.y, 0.f),
+                                                        fmaxf(m.z * v.z, 0.f), fmaxf(m.w * v.w, 0.f));
+    }
+}
+
+int skg_rows_mul_relu_multi(const skg_rows_mul_args* calls, int n, void* stream) {
+    if (!calls || n < 1 || n > SKG_MULTI_MAX) return SKG_E_ARG;
+    skg_rows_mul_pack pk;
+    int m = 0, rows = 0;
+    for (int i = 0; i < n; ++i) {
+        const skg_rows_mul_args& a = calls[i];
+        if (a.rows < 0 || a.cols <= 0 || (a.cols & 3)) return SKG_E_ARG;
+        if (a.rows == 0) continue;
+        if (!a.P || !a.F || !a.out) return SKG_E_ARG;
+        if ((a.ldp & 3) || (a.ldf & 3) || (a.ldo & 3) || (a.Q && (a.ldq & 3))) return SKG_E_ALIGN;
+        if (!skg_aligned16(a.P) || !skg_aligned16(a.F) || !skg_aligned16(a.out) || !skg_aligned16(a.Q) || !skg_aligned16(a.mbias))
+            return SKG_E_ALIGN;
+        pk.a[m++] = a;
+        rows = a.rows > rows ? a.rows : rows;
+    }
+    if (m == 0) return 0;
+    hipLaunchKernelGGL(skg_rows_mul_relu_multi_kernel, dim3(rows, m), dim3(256), 0, (hipStream_t)stream, pk);
+    return skg_launch_status();
+}
+
 extern "C" int skg_rows_mul_relu_f32(const float* P, const int32_t* p_idx, int64_t ldp, const float* Q,
                                      const int32_t* q_idx, int64_t ldq, const float* mbias, const float* F,
                                      const int32_t* f_idx, int64_t ldf, int rows, int cols, float* out, int64_t ldo,

@@ -40,14 +40,12 @@ extern "C" int skg_rowdot_f32(const float* X, int64_t ld, const float* w, int ro
 
 // ------------------------------------------------------------------------------------------------ add + LayerNorm
 // x = a + b (node + message, HEAD:912-914 / 923-925), y = LayerNorm(x); keeps x and (mean, rstd) for the backward.
-__global__ __launch_bounds__(256) void skg_add_layernorm_kernel(const float* __restrict__ a, int64_t lda,
-                                                                const float* __restrict__ b, int64_t ldb,
-                                                                const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, float eps,
-                                                                float* __restrict__ xsum, float* __restrict__ y,
-                                                                float* __restrict__ stats) {
+__device__ __forceinline__ void skg_add_layernorm_row(const float* __restrict__ a, int64_t lda,
+                                                      const float* __restrict__ b, int64_t ldb,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float eps, float* __restrict__ xsum, float* __restrict__ y,
+                                                      float* __restrict__ stats, int r) {
     __shared__ float sred[4];
-    const int r = blockIdx.x;
     const int c = threadIdx.x * 4;
     const float4 va = *reinterpret_cast<const float4*>(a + (int64_t)r * lda + c);
     const float4 vb = *reinterpret_cast<const float4*>(b + (int64_t)r * ldb + c);
@@ -62,6 +60,42 @@ __global__ __launch_bounds__(256) void skg_add_layernorm_kernel(const float* __r
     *reinterpret_cast<float4*>(y + (int64_t)r * TR_COLS + c) =
         make_float4(d.x * rstd * g.x + bb.x, d.y * rstd * g.y + bb.y, d.z * rstd * g.z + bb.z, d.w * rstd * g.w + bb.w);
     if (threadIdx.x == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+}
+
+__global__ __launch_bounds__(256) void skg_add_layernorm_kernel(const float* __restrict__ a, int64_t lda,
+                                                                const float* __restrict__ b, int64_t ldb,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps,
+                                                                float* __restrict__ xsum, float* __restrict__ y,
+                                                                float* __restrict__ stats) {
+    skg_add_layernorm_row(a, lda, b, ldb, gamma, beta, eps, xsum, y, stats, (int)blockIdx.x);
+}
+
+struct skg_add_layernorm_pack { skg_add_layernorm_args a[SKG_MULTI_MAX]; };
+__global__ __launch_bounds__(256) void skg_add_layernorm_multi_kernel(const skg_add_layernorm_pack pk, float eps) {
+    const skg_add_layernorm_args& a = pk.a[blockIdx.y];
+    if ((int)blockIdx.x >= a.rows) return;                 // (uniform per workgroup)
+    skg_add_layernorm_row(a.a, a.lda, a.b, a.ldb, a.gamma, a.beta, eps, a.xsum, a.y, a.stats, (int)blockIdx.x);
+}
+
+int skg_add_layernorm_multi(const skg_add_layernorm_args* calls, int n, float eps, void* stream) {
+    if (!calls || n < 1 || n > SKG_MULTI_MAX) return SKG_E_ARG;
+    skg_add_layernorm_pack pk;
+    int m = 0, rows = 0;
+    for (int i = 0; i < n; ++i) {
+        const skg_add_layernorm_args& a = calls[i];
+        if (a.rows < 0) return SKG_E_ARG;
+        if (a.rows == 0) continue;
+        if (!a.a || !a.b || !a.gamma || !a.beta || !a.xsum || !a.y || !a.stats) return SKG_E_ARG;
+        if ((a.lda & 3) || (a.ldb & 3) || !skg_aligned16(a.a) || !skg_aligned16(a.b) || !skg_aligned16(a.gamma) ||
+            !skg_aligned16(a.beta) || !skg_aligned16(a.xsum) || !skg_aligned16(a.y))
+            return SKG_E_ALIGN;
+        pk.a[m++] = a;
+        rows = a.rows > rows ? a.rows : rows;
+    }
+    if (m == 0) return 0;
+    hipLaunchKernelGGL(skg_add_layernorm_multi_kernel, dim3(rows, m), dim3(256), 0, (hipStream_t)stream, pk, eps);
+    return skg_launch_status();
 }
 
 extern "C" int skg_add_layernorm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gamma,
@@ -79,15 +113,12 @@ extern "C" int skg_add_layernorm_f32(const float* a, int64_t lda, const float* b
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mean) * rstd.
-__global__ __launch_bounds__(256) void skg_layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
-                                                                const float* __restrict__ x,
-                                                                const float* __restrict__ stats,
-                                                                const float* __restrict__ gamma,
-                                                                float* __restrict__ dx,
-                                                                const float* __restrict__ relu_src,
-                                                                float* __restrict__ dx_masked) {
+__device__ __forceinline__ void skg_layernorm_bwd_row(const float* __restrict__ dy, int64_t lddy,
+                                                      const float* __restrict__ x, const float* __restrict__ stats,
+                                                      const float* __restrict__ gamma, float* __restrict__ dx,
+                                                      const float* __restrict__ relu_src, float* __restrict__ dx_masked,
+                                                      int r) {
     __shared__ float sred[4];
-    const int r = blockIdx.x;
     const int c = threadIdx.x * 4;
     const float mean = stats[2 * r], rstd = stats[2 * r + 1];
     const float4 vx = *reinterpret_cast<const float4*>(x + (int64_t)r * TR_COLS + c);
@@ -107,16 +138,26 @@ __global__ __launch_bounds__(256) void skg_layernorm_bwd_kernel(const float* __r
     }
 }
 
+__global__ __launch_bounds__(256) void skg_layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                                const float* __restrict__ x,
+                                                                const float* __restrict__ stats,
+                                                                const float* __restrict__ gamma,
+                                                                float* __restrict__ dx,
+                                                                const float* __restrict__ relu_src,
+                                                                float* __restrict__ dx_masked) {
+    skg_layernorm_bwd_row(dy, lddy, x, stats, gamma, dx, relu_src, dx_masked, (int)blockIdx.x);
+}
+
 // dgamma[c] = sum_r dy[r, c] * xhat[r, c],  dbeta[c] = sum_r dy[r, c]: one thread per column, rows in order.
 // 64 columns x 4 row groups per workgroup (16 workgroups): rows r = g, g + 4, ... per group, groups added in order.
-__global__ __launch_bounds__(256) void skg_layernorm_param_grad_kernel(const float* __restrict__ dy, int64_t lddy,
-                                                                       const float* __restrict__ x,
-                                                                       const float* __restrict__ stats, int rows,
-                                                                       float* __restrict__ dgamma,
-                                                                       float* __restrict__ dbeta) {
+__device__ __forceinline__ void skg_layernorm_param_grad_cols(const float* __restrict__ dy, int64_t lddy,
+                                                              const float* __restrict__ x,
+                                                              const float* __restrict__ stats, int rows,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              int blk) {
     __shared__ float sg_s[4][64], sb_s[4][64];
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    const int c = blk * 64 + cl;
     float sg = 0.f, sb = 0.f;
     for (int r = g; r < rows; r += 4) {
         const float d = dy[(int64_t)r * lddy + c];
@@ -129,6 +170,46 @@ __global__ __launch_bounds__(256) void skg_layernorm_param_grad_kernel(const flo
         dgamma[c] = (sg_s[0][cl] + sg_s[1][cl]) + (sg_s[2][cl] + sg_s[3][cl]);
         dbeta[c] = (sb_s[0][cl] + sb_s[1][cl]) + (sb_s[2][cl] + sb_s[3][cl]);
     }
+}
+
+__global__ __launch_bounds__(256) void skg_layernorm_param_grad_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                                       const float* __restrict__ x,
+                                                                       const float* __restrict__ stats, int rows,
+                                                                       float* __restrict__ dgamma,
+                                                                       float* __restrict__ dbeta) {
+    skg_layernorm_param_grad_cols(dy, lddy, x, stats, rows, dgamma, dbeta, (int)blockIdx.x);
+}
+
+// Both LayerNorms of the step in two launches instead of four: (a) every row's input gradient, (b) the parameter gradients
+struct skg_layernorm_bwd_pack { skg_layernorm_bwd_args a[SKG_MULTI_MAX]; };
+__global__ __launch_bounds__(256) void skg_layernorm_bwd_multi_kernel(const skg_layernorm_bwd_pack pk) {
+    const skg_layernorm_bwd_args& a = pk.a[blockIdx.y];
+    if ((int)blockIdx.x >= a.rows) return;                 // (uniform per workgroup)
+    skg_layernorm_bwd_row(a.dy, a.lddy, a.x, a.stats, a.gamma, a.dx, a.relu_src, a.dx_masked, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(256) void skg_layernorm_param_grad_multi_kernel(const skg_layernorm_bwd_pack pk) {
+    const skg_layernorm_bwd_args& a = pk.a[blockIdx.y];
+    skg_layernorm_param_grad_cols(a.dy, a.lddy, a.x, a.stats, a.rows, a.dgamma, a.dbeta, (int)blockIdx.x);
+}
+
+int skg_layernorm_bwd_multi(const skg_layernorm_bwd_args* calls, int n, void* stream) {
+    if (!calls || n < 1 || n > SKG_MULTI_MAX) return SKG_E_ARG;
+    skg_layernorm_bwd_pack pk;
+    int rows = 0;
+    for (int i = 0; i < n; ++i) {
+        const skg_layernorm_bwd_args& a = calls[i];
+        if (a.rows < 0) return SKG_E_ARG;
+        if (!a.dy || !a.x || !a.stats || !a.gamma || !a.dx || !a.dgamma || !a.dbeta || (a.dx_masked && !a.relu_src)) return SKG_E_ARG;
+        if ((a.lddy & 3) || !skg_aligned16(a.dy) || !skg_aligned16(a.x) || !skg_aligned16(a.gamma) || !skg_aligned16(a.dx) ||
+            !skg_aligned16(a.relu_src) || !skg_aligned16(a.dx_masked))
+            return SKG_E_ALIGN;
+        pk.a[i] = a;
+        rows = a.rows > rows ? a.rows : rows;
+    }
+    if (rows)
+        hipLaunchKernelGGL(skg_layernorm_bwd_multi_kernel, dim3(rows, n), dim3(256), 0, (hipStream_t)stream, pk);
+    hipLaunchKernelGGL(skg_layernorm_param_grad_multi_kernel, dim3(TR_COLS / 64, n), dim3(256), 0, (hipStream_t)stream, pk);
+    return skg_launch_status();
 }
 
 extern "C" int skg_layernorm_bwd_f32(const float* dy, int64_t lddy, const float* x, const float* stats,
@@ -179,6 +260,53 @@ __global__ __launch_bounds__(256) void skg_mul_bwd_kernel(float* __restrict__ g,
     *gp = make_float4(gv.x * fv.x, gv.y * fv.y, gv.z * fv.z, gv.w * fv.w);
 }
 
+struct skg_mul_bwd_pack { skg_mul_bwd_args a[SKG_MULTI_MAX]; };
+__global__ __launch_bounds__(256) void skg_mul_bwd_multi_kernel(const skg_mul_bwd_pack pk) {
+    const skg_mul_bwd_args& a = pk.a[blockIdx.y];
+    const int r = blockIdx.x;
+    if (r >= a.rows) return;
+    const int c = threadIdx.x * 4;
+    const int fi = a.f_idx ? a.f_idx[r] : r;
+    float4 m = *reinterpret_cast<const float4*>(a.P + (int64_t)(a.p_idx ? a.p_idx[r] : r) * a.ldp + c);
+    if (a.Q) {
+        const float4 t = *reinterpret_cast<const float4*>(a.Q + (int64_t)(a.q_idx ? a.q_idx[r] : r) * a.ldq + c);
+        m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
+    }
+    if (a.mbias) {
+        const float4 t = *reinterpret_cast<const float4*>(a.mbias + c);
+        m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
+    }
+    float4* gp = reinterpret_cast<float4*>(a.g + (int64_t)r * a.ldg + c);
+    const float4 gv = *gp;
+    const float4 fv = *reinterpret_cast<const float4*>(a.F + (int64_t)fi * a.ldf + c);
+    float4* dp = reinterpret_cast<float4*>(a.dF + (int64_t)fi * a.lddf + c);
+    float4 o = make_float4(gv.x * m.x, gv.y * m.y, gv.z * m.z, gv.w * m.w);
+    if (a.accumulate) { const float4 t = *dp; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+    *dp = o;
+    *gp = make_float4(gv.x * fv.x, gv.y * fv.y, gv.z * fv.z, gv.w * fv.w);
+}
+
+int skg_mul_bwd_multi(const skg_mul_bwd_args* calls, int n, void* stream) {
+    if (!calls || n < 1 || n > SKG_MULTI_MAX) return SKG_E_ARG;
+    skg_mul_bwd_pack pk;
+    int m = 0, rows = 0;
+    for (int i = 0; i < n; ++i) {
+        const skg_mul_bwd_args& a = calls[i];
+        if (a.rows < 0) return SKG_E_ARG;
+        if (a.rows == 0) continue;
+        if (!a.g || !a.F || !a.P || !a.dF) return SKG_E_ARG;
+        if ((a.ldg & 3) || (a.ldf & 3) || (a.ldp & 3) || (a.lddf & 3) || (a.Q && (a.ldq & 3))) return SKG_E_ALIGN;
+        if (!skg_aligned16(a.g) || !skg_aligned16(a.F) || !skg_aligned16(a.P) || !skg_aligned16(a.dF) || !skg_aligned16(a.Q) ||
+            !skg_aligned16(a.mbias))
+            return SKG_E_ALIGN;
+        pk.a[m++] = a;
+        rows = a.rows > rows ? a.rows : rows;
+    }
+    if (m == 0) return 0;
+    hipLaunchKernelGGL(skg_mul_bwd_multi_kernel, dim3(rows, m), dim3(256), 0, (hipStream_t)stream, pk);
+    return skg_launch_status();
+}
+
 extern "C" int skg_mul_bwd_f32(float* g, int64_t ldg, const float* F, const int32_t* f_idx, int64_t ldf, const float* P,
                                const int32_t* p_idx, int64_t ldp, const float* Q, const int32_t* q_idx, int64_t ldq,
                                const float* mbias, int rows, float* dF, int64_t lddf, int accumulate, void* stream) {
@@ -201,14 +329,14 @@ extern "C" int skg_mul_bwd_f32(float* g, int64_t ldg, const float* F, const int3
 //                                                          outN[(a, j)] = sum_{i != j} src[pair of (i, j)]
 //   mode 2  src = kept pairs:  outH[meta[a].image] = sum of all pairs of active image a   (outN unused)
 // One workgroup per destination row, rows added in index order.
-__global__ __launch_bounds__(256) void skg_segment_sum_kernel(const float* __restrict__ src, int64_t ld,
-                                                              const skg_image_meta* __restrict__ meta,
-                                                              const int32_t* __restrict__ hum_img,
-                                                              const int32_t* __restrict__ node_img, int n_dst_h, int mode,
-                                                              float* __restrict__ outH, float* __restrict__ outN,
-                                                              int accumulate) {
-    const bool to_h = (int)blockIdx.x < n_dst_h;
-    const int dst = to_h ? blockIdx.x : blockIdx.x - n_dst_h;
+__device__ __forceinline__ void skg_segment_sum_body(const float* __restrict__ src, int64_t ld,
+                                                     const skg_image_meta* __restrict__ meta,
+                                                     const int32_t* __restrict__ hum_img,
+                                                     const int32_t* __restrict__ node_img, int n_dst_h, int mode,
+                                                     float* __restrict__ outH, float* __restrict__ outN, int accumulate,
+                                                     int blk) {
+    const bool to_h = blk < n_dst_h;
+    const int dst = to_h ? blk : blk - n_dst_h;
     float* out = to_h ? outH : outN;
     if (!out) return;
     const int a = mode == 2 ? dst : (to_h ? hum_img[dst] : node_img[dst]);
@@ -252,6 +380,41 @@ __global__ __launch_bounds__(256) void skg_segment_sum_kernel(const float* __res
     float4* o = reinterpret_cast<float4*>(out + (int64_t)(mode == 2 ? mt.image : dst) * TR_COLS + c);
     if (accumulate) { const float4 t = *o; acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
     *o = acc;
+}
+
+__global__ __launch_bounds__(256) void skg_segment_sum_kernel(const float* __restrict__ src, int64_t ld,
+                                                              const skg_image_meta* __restrict__ meta,
+                                                              const int32_t* __restrict__ hum_img,
+                                                              const int32_t* __restrict__ node_img, int n_dst_h, int mode,
+                                                              float* __restrict__ outH, float* __restrict__ outN,
+                                                              int accumulate) {
+    skg_segment_sum_body(src, ld, meta, hum_img, node_img, n_dst_h, mode, outH, outN, accumulate, (int)blockIdx.x);
+}
+
+struct skg_segment_sum_pack { skg_segment_sum_args a[SKG_MULTI_MAX]; };
+__global__ __launch_bounds__(256) void skg_segment_sum_multi_kernel(const skg_segment_sum_pack pk,
+                                                                    const skg_image_meta* __restrict__ meta,
+                                                                    const int32_t* __restrict__ hum_img,
+                                                                    const int32_t* __restrict__ node_img, int n_dst_h) {
+    const skg_segment_sum_args& a = pk.a[blockIdx.y];
+    skg_segment_sum_body(a.src, a.ld, meta, hum_img, node_img, n_dst_h, a.mode, a.outH, a.outN, a.accumulate, (int)blockIdx.x);
+}
+
+int skg_segment_sum_multi(const skg_segment_sum_args* calls, int n, const skg_image_meta* meta, const int32_t* hum_img,
+                          const int32_t* node_img, int sum_h, int sum_n, void* stream) {
+    if (!calls || n < 1 || n > SKG_MULTI_MAX || sum_h < 0 || sum_n < 0) return SKG_E_ARG;
+    if (sum_h + sum_n == 0) return 0;
+    if (!meta || !hum_img || !node_img) return SKG_E_ARG;
+    skg_segment_sum_pack pk;
+    for (int i = 0; i < n; ++i) {
+        const skg_segment_sum_args& a = calls[i];
+        if (a.mode < 0 || a.mode > 1 || !a.src || (!a.outH && !a.outN)) return SKG_E_ARG;
+        if ((a.ld & 3) || !skg_aligned16(a.src) || !skg_aligned16(a.outH) || !skg_aligned16(a.outN)) return SKG_E_ALIGN;
+        pk.a[i] = a;
+    }
+    hipLaunchKernelGGL(skg_segment_sum_multi_kernel, dim3(sum_h + sum_n, n), dim3(256), 0, (hipStream_t)stream, pk, meta,
+                       hum_img, node_img, sum_h);
+    return skg_launch_status();
 }
 
 // mode 2 on its own grid: (active image, block of 64 columns).  One workgroup per image pulls hundreds of 4-KB rows through

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <thread>
 #include "skghoi.h"
+#include "skg_common.h"
 
 namespace {
 
@@ -201,8 +202,9 @@ static void layout_ws(const skg_train_plan* P, float* base, Ws& w) {
     w.M1 = take(Mh, 1024); w.M2 = take(Mn, 1024); w.Hp = take(Mh, 1024); w.h_node = take(Mh, 1024); w.st_h = take(Mh, 2);
     w.Op = take(Mn, 1024); w.node = take(Mn, 1024); w.st_o = take(Mn, 2); w.B1h = take(Mh, 1024); w.B1o = take(Mn, 1024);
     w.Tp = take(Mp, 1024); w.b3sum = take(4, 1024);
-    w.dPF = take(Mp, 2048); w.dTp = take(Mp, 1024); w.dTg = take(Mp, 1024); w.dF = take(Mg, 4096);
-    w.dB1h = take(Mh, 1024); w.dB1o = take(Mn, 1024); w.dG1 = take(Bf, 1024); w.dh_node = take(Mh, 1024);
+    w.dPF = take(Mp, 2048); w.dTp = take(Mp, 1024); w.dTg = take(Mp, 1024);
+    w.dF = take(Mg, 4096); w.dG1 = take(Bf, 1024);      // (adjacent: zero-filled by ONE memset in backward stage 1)
+    w.dB1h = take(Mh, 1024); w.dB1o = take(Mn, 1024); w.dh_node = take(Mh, 1024);
     w.dnode = take(Mn, 1024); w.dHp = take(Mh, 1024); w.dHm = take(Mh, 1024); w.dOp = take(Mn, 1024); w.dOm = take(Mn, 1024);
     w.dU = take(Mh, 1024); w.dV = take(Mn, 1024); w.dTos = take(Mg, 1024); w.dTso = take(Mg, 1024); w.da = take(4, Mg);
     w.dadj = take(Mg, 1); w.dWt = take(Mg, 1024); w.dT = take(Mg, 1024); w.dA1h = take(Mh, 1024); w.dA1o = take(Mn, 1024);
@@ -283,15 +285,14 @@ static void forward(Ctx& c, const Ws& w, int part) {
     if (P->bf16) {
         skg_gemmx_desc l[1] = {FWD(Sp, cm(W2, 4096, 1024), F, b2, false)};            // all four fc_2 as ONE N = 4096 product
         launch(c, l, 1);
-        CK(skg_rows_mul_relu_f32(w.A1h, P->grid_h, 1024, w.A1o, P->grid_o, 1024, b1[ATT], w.F, nullptr, 4096, Mg, 1024,
-                                 w.T, 1024, c.stream));
-        CK(skg_rows_mul_relu_f32(w.C1o, P->grid_o, 1024, nullptr, nullptr, 1024, nullptr, w.F + 1024, nullptr, 4096, Mg,
-                                 1024, w.Tos, 1024, c.stream));
-        CK(skg_rows_mul_relu_f32(w.C1h, P->grid_h, 1024, nullptr, nullptr, 1024, nullptr, w.F + 2048, nullptr, 4096, Mg,
-                                 1024, w.Tso, 1024, c.stream));
-        if (Mp > 0)
-            CK(skg_rows_mul_relu_f32(w.G1, P->pair_img, 1024, nullptr, nullptr, 1024, nullptr, w.F + 3072, P->pair_grid,
-                                     4096, Mp, 1024, w.Tg, 1024, c.stream));
+        {   // the four fc_1 * fc_2 -> ReLU products as one launch
+            skg_rows_mul_args m[4] = {
+                {w.A1h, P->grid_h, 1024, w.A1o, P->grid_o, 1024, b1[ATT], w.F, nullptr, 4096, Mg, 1024, w.T, 1024},
+                {w.C1o, P->grid_o, 1024, nullptr, nullptr, 1024, nullptr, w.F + 1024, nullptr, 4096, Mg, 1024, w.Tos, 1024},
+                {w.C1h, P->grid_h, 1024, nullptr, nullptr, 1024, nullptr, w.F + 2048, nullptr, 4096, Mg, 1024, w.Tso, 1024},
+                {w.G1, P->pair_img, 1024, nullptr, nullptr, 1024, nullptr, w.F + 3072, P->pair_grid, 4096, Mp, 1024, w.Tg, 1024}};
+            CK(skg_rows_mul_relu_multi(m, Mp > 0 ? 4 : 3, c.stream));
+        }
     } else {
         // exact fp32: the eval kernel with the fc_1 * fc_2 -> ReLU product fused in its epilogue, raw output stored too
         for (int i = 0; i < 4; ++i) {
@@ -325,10 +326,12 @@ static void forward(Ctx& c, const Ws& w, int part) {
                                FWD(V, W3[SO], M2, b3 + 1024 * SO, true, -1, -1, -1, true)};
         launch(c, l, 2);
     }
-    CK(skg_add_layernorm_f32(w.GH, 1024, w.M1, 1024, W.at(SKG_SEG_NH_W), W.at(SKG_SEG_NH_B), Mh, 1e-5f, w.Hp, w.h_node,
-                             w.st_h, c.stream));
-    CK(skg_add_layernorm_f32(w.GO, 1024, w.M2, 1024, W.at(SKG_SEG_NO_W), W.at(SKG_SEG_NO_B), Mn, 1e-5f, w.Op, w.node,
-                             w.st_o, c.stream));
+    {
+        skg_add_layernorm_args ln[2] = {
+            {w.GH, 1024, w.M1, 1024, W.at(SKG_SEG_NH_W), W.at(SKG_SEG_NH_B), Mh, w.Hp, w.h_node, w.st_h},
+            {w.GO, 1024, w.M2, 1024, W.at(SKG_SEG_NO_W), W.at(SKG_SEG_NO_B), Mn, w.Op, w.node, w.st_o}};
+        CK(skg_add_layernorm_multi(ln, 2, 1e-5f, c.stream));
+    }
     // ---- read-out on the kept pairs (HEAD:966-973)
     Mat h_node(w.h_node, Mh, 1024), node(w.node, Mn, 1024), B1h(w.B1h, Mh, 1024), B1o(w.B1o, Mn, 1024);
     {
@@ -411,15 +414,15 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
         launch(c, l, 4);
         // ---- read-out fc_1 * fc_2 products: dF at the pairs' grid rows (self-pair rows stay zero), dm in place
         if (!c.dry) {
-            hipError_t e = hipMemsetAsync(w.dF, 0, sizeof(float) * (size_t)Mg * 4096, c.stream);
-            if (e == hipSuccess) e = hipMemsetAsync(w.dG1, 0, sizeof(float) * (size_t)Bf * 1024, c.stream);
+            hipError_t e = hipMemsetAsync(w.dF, 0, sizeof(float) * (size_t)((w.dG1 - w.dF) + (int64_t)Bf * 1024), c.stream);
             if (e != hipSuccess) { c.rc = (int)e; break; }
         }
         if (Mp > 0) {
-            CK(skg_mul_bwd_f32(w.dTp, 1024, w.F, P->pair_grid, 4096, w.B1h, P->pair_h, 1024, w.B1o, P->pair_o, 1024,
-                               b1[ATT], Mp, w.dF, 4096, 0, c.stream));
-            CK(skg_mul_bwd_f32(w.dTg, 1024, w.F + 3072, P->pair_grid, 4096, w.G1, P->pair_img, 1024, nullptr, nullptr, 0,
-                               nullptr, Mp, w.dF + 3072, 4096, 0, c.stream));
+            skg_mul_bwd_args m[2] = {       // (disjoint column blocks of dF: one launch)
+                {w.dTp, 1024, w.F, P->pair_grid, 4096, w.B1h, P->pair_h, 1024, w.B1o, P->pair_o, 1024, b1[ATT], Mp, w.dF, 4096, 0},
+                {w.dTg, 1024, w.F + 3072, P->pair_grid, 4096, w.G1, P->pair_img, 1024, nullptr, nullptr, 0, nullptr, Mp,
+                 w.dF + 3072, 4096, 0}};
+            CK(skg_mul_bwd_multi(m, 2, c.stream));
         }
         CK(skg_segment_sum_f32(w.dTp, 1024, P->meta, A, P->hum_img, P->node_img, Mh, Mn, 1, w.dB1h, w.dB1o, 0, c.stream));
         CK(skg_segment_sum_f32(w.dTg, 1024, P->meta, A, nullptr, nullptr, 0, 0, 2, w.dG1, nullptr, 0, c.stream));
@@ -431,10 +434,10 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
     } break;
     case 2: {
         // ---- LayerNorm + residual: dHp continues to the node, dHp cut by the message's ReLU goes to fc_3
-        CK(skg_layernorm_bwd_f32(w.dh_node, 1024, w.Hp, w.st_h, W.at(SKG_SEG_NH_W), Mh, w.dHp, w.M1, w.dHm,
-                                 G.at(SKG_SEG_NH_W), G.at(SKG_SEG_NH_B), c.stream));
-        CK(skg_layernorm_bwd_f32(w.dnode, 1024, w.Op, w.st_o, W.at(SKG_SEG_NO_W), Mn, w.dOp, w.M2, w.dOm,
-                                 G.at(SKG_SEG_NO_W), G.at(SKG_SEG_NO_B), c.stream));
+        skg_layernorm_bwd_args ln[2] = {
+            {w.dh_node, 1024, w.Hp, w.st_h, W.at(SKG_SEG_NH_W), Mh, w.dHp, w.M1, w.dHm, G.at(SKG_SEG_NH_W), G.at(SKG_SEG_NH_B)},
+            {w.dnode, 1024, w.Op, w.st_o, W.at(SKG_SEG_NO_W), Mn, w.dOp, w.M2, w.dOm, G.at(SKG_SEG_NO_W), G.at(SKG_SEG_NO_B)}};
+        CK(skg_layernorm_bwd_multi(ln, 2, c.stream));
     } break;
     case 3: {
         // ---- message fc_3
@@ -458,15 +461,18 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
     } break;
     case 5: {
         // ---- in-loop fc_1 * fc_2 products
-        CK(skg_mul_bwd_f32(w.dT, 1024, w.F, nullptr, 4096, w.A1h, P->grid_h, 1024, w.A1o, P->grid_o, 1024, b1[ATT], Mg,
-                           w.dF, 4096, 1, c.stream));
-        CK(skg_mul_bwd_f32(w.dTos, 1024, w.F + 1024, nullptr, 4096, w.C1o, P->grid_o, 1024, nullptr, nullptr, 0, nullptr, Mg,
-                           w.dF + 1024, 4096, 0, c.stream));
-        CK(skg_mul_bwd_f32(w.dTso, 1024, w.F + 2048, nullptr, 4096, w.C1h, P->grid_h, 1024, nullptr, nullptr, 0, nullptr, Mg,
-                           w.dF + 2048, 4096, 0, c.stream));
-        CK(skg_segment_sum_f32(w.dT, 1024, P->meta, A, P->hum_img, P->node_img, Mh, Mn, 0, w.dA1h, w.dA1o, 0, c.stream));
-        CK(skg_segment_sum_f32(w.dTos, 1024, P->meta, A, P->hum_img, P->node_img, Mh, Mn, 0, nullptr, w.dC1o, 0, c.stream));
-        CK(skg_segment_sum_f32(w.dTso, 1024, P->meta, A, P->hum_img, P->node_img, Mh, Mn, 0, w.dC1h, nullptr, 0, c.stream));
+        {   // three products into disjoint column blocks of dF, then their three neighbourhood sums: one launch each
+            skg_mul_bwd_args m[3] = {
+                {w.dT, 1024, w.F, nullptr, 4096, w.A1h, P->grid_h, 1024, w.A1o, P->grid_o, 1024, b1[ATT], Mg, w.dF, 4096, 1},
+                {w.dTos, 1024, w.F + 1024, nullptr, 4096, w.C1o, P->grid_o, 1024, nullptr, nullptr, 0, nullptr, Mg, w.dF + 1024,
+                 4096, 0},
+                {w.dTso, 1024, w.F + 2048, nullptr, 4096, w.C1h, P->grid_h, 1024, nullptr, nullptr, 0, nullptr, Mg, w.dF + 2048,
+                 4096, 0}};
+            CK(skg_mul_bwd_multi(m, 3, c.stream));
+            skg_segment_sum_args g[3] = {{w.dT, 1024, 0, w.dA1h, w.dA1o, 0}, {w.dTos, 1024, 0, nullptr, w.dC1o, 0},
+                                         {w.dTso, 1024, 0, w.dC1h, nullptr, 0}};
+            CK(skg_segment_sum_multi(g, 3, P->meta, P->hum_img, P->node_img, Mh, Mn, c.stream));
+        }
         // the multiplier bias of attention_head's fc_1 is added once per row: its gradient is the sum over all rows
         if (!c.dry)
             hipLaunchKernelGGL(colsum2_kernel, dim3(16), dim3(256), 0, c.stream, w.dA1h, Mh, w.dB1h, Mh, db1[ATT]);
