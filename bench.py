@@ -29,6 +29,10 @@ from collections import OrderedDict
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
+# Before the HIP runtime starts: at most three hardware queues per priority class instead of four ("hardware
+# queues").  With four, a process that has captured or replayed ONE hipGraph -- or keeps a few more streams alive -- runs
+# the training step's kernels 0.5 ms per step slower from then on (1.40 -> 1.98 ms; the legs of this file share a process).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
 
 import numpy as np
 import torch
@@ -419,7 +423,20 @@ def b1_stream(device, n_forwards=2048, n_images=256, seed=2024):
     out.update(distinct_shapes=len(shapes_seen), plans=runner["plans"], max_human=15, max_object=15, precision=head.precision,
                note="single-image eval forwards over %d synthetic images with a HICO-like spread of graph sizes; one "
                     "captured launch plan per bucket of (humans, nodes), true sizes in the device-side meta record" % n_images)
+    release_plans(head)
     return out
+
+
+def release_plans(head):
+    """Destroys the head's captured launch plans (idle device).  Every live hipGraphExec holds streams of its own, i.e.
+    hardware queues; with the ~45 plans of the small-batch legs alive the training legs that follow IN THIS PROCESS ran the
+    same kernels 0.5 ms per step slower (1.97 instead of 1.40 ms; tools/_trainleg_probe.py, engine.shared_side_stream).
+    A training job never holds evaluation graphs: the legs release theirs when they are done."""
+    eng = getattr(head, "_engine", None)
+    small = getattr(eng, "_small", None)
+    if small is not None:
+        small.close()
+        eng._small = None
 
 
 def main():
@@ -614,6 +631,7 @@ def main():
                                   b4_images_per_s=round(4e3 / out["b4_latency_ms"], 1),
                                   note="mean wall time per eval forward, 200 back-to-back forwards after 30 warm-ups")
         # (c) the training step at the reference's batch 4 per GPU (main:158): fwd + bwd + AdamW
+        release_plans(head)
         _trainer.limit_host_threads(world)
         train = {}
         busy = {}

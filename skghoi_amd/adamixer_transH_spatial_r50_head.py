@@ -502,7 +502,8 @@ class InteractionHead(Module):
     def _prefetch_stream(self, dev):
         st = getattr(self, "_pf_stream", None)
         if st is None or st.device != dev:
-            st = self._pf_stream = torch.cuda.Stream(device=dev, priority=-1)
+            from skghoi_amd import engine as _engine
+            st = self._pf_stream = _engine.shared_side_stream(dev, priority=-1)     # one per process (see there)
         return st
 
     def _take_prefetched(self, detections, image_shapes, targets):

@@ -35,6 +35,26 @@ _PIN_TABLES = _os.environ.get("SKG_PIN_TABLES", "1") == "1"     # developer swit
 _NO_SPIN = _os.environ.get("SKG_NO_SPIN", "0") == "1"           # developer switch: blocking count read at every batch size
 
 
+_SHARED_STREAMS = {}
+
+
+def shared_side_stream(dev, priority=0, slot=0):
+    """ONE side stream per (device, priority, slot) for the whole process.
+
+    Every stream of a new priority class / every few streams make the HIP runtime open another hardware queue, and a
+    process that keeps more than a handful of them alive gets its kernels scheduled noticeably worse.  Measured on the
+    training step: every head used to make its own high-priority look-ahead stream; with the streams of three earlier heads
+    still alive (bench.py's training legs after its eval legs; any loop that rebuilds the head) the 4th and 5th head ran the
+    SAME kernels at 1.98 instead of 1.40 ms per step (fp32: 3.13 instead of 2.65) -- and so did every head when six such
+    streams were opened up front (tools/_trainleg_probe.py).  One stream, made once, keeps the first head's speed."""
+    dev = torch.device(dev)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), priority, slot)
+    st = _SHARED_STREAMS.get(key)
+    if st is None:
+        st = _SHARED_STREAMS[key] = torch.cuda.Stream(device=dev, priority=priority)
+    return st
+
+
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
@@ -806,7 +826,7 @@ class HeadEngine:
             ns = max(1, int(self.n_streams)) if len(bounds) > 1 else 1
             if ns > 1:
                 if self._streams is None or len(self._streams) < ns:
-                    self._streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+                    self._streams = [shared_side_stream(dev, 0, slot=i) for i in range(ns)]    # (process-wide: see there)
                 ev0 = torch.cuda.Event(); ev0.record(main)
                 for st_ in self._streams[:ns]:
                     st_.wait_event(ev0)

@@ -174,7 +174,8 @@ class SmallBatchRunner:
         NA, Mp = lay.sum_all, lay.sum_p
         main = torch.cuda.current_stream()
         if self.side is None:
-            self.side = torch.cuda.Stream(device=dev)
+            from .engine import shared_side_stream
+            self.side = shared_side_stream(dev, 0, slot=0)      # (process-wide: every live stream costs a hardware queue)
         side = self.side
         with eng._split_ctx(pw):
             enc = torch.empty(max(NA, 1), 1024, **f32)

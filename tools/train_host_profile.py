@@ -13,6 +13,10 @@ LAZY = not (len(sys.argv) > 3 and sys.argv[3] == "eager")
 PF = len(sys.argv) > 4 and sys.argv[4] == "prefetch"
 trainer.limit_host_threads()
 device = torch.device("cuda:0")
+if os.environ.get("SKG_PROFILE_AFTER_GC"):        # a first training run, then gc.collect() + empty_cache(): the slow mode
+    import gc
+    bench.run_train(B, prec, 20, 5, device, 0, 1, False)
+    gc.collect(); torch.cuda.empty_cache()
 head = bench.build_head(device).train()
 head.precision = prec
 dets, pooled, feats, shapes = bench.make_inputs(B, 0, device)
