@@ -32,7 +32,8 @@ sys.dont_write_bytecode = True
 # Before the HIP runtime starts: at most three hardware queues per priority class instead of four ("hardware
 # queues").  With four, a process that has captured or replayed ONE hipGraph -- or keeps a few more streams alive -- runs
 # the training step's kernels 0.5 ms per step slower from then on (1.40 -> 1.98 ms; the legs of this file share a process).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
+if os.environ.get("WORLD_SIZE", "1") == "1":              # (ranks of a multi-GPU run keep the runtime's default: they run
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")       #  the headline leg only, and RCCL opens queues of its own)
 
 import numpy as np
 import torch

@@ -15,7 +15,8 @@ __version__ = "0.1.0"
 # measured case fast and costs the eval paths nothing (values below three crash the runtime's graph path: do not use).
 # Only effective if set before the first HIP call of the process -- i.e. import skghoi_amd (or export it) before
 # touching the GPU; an explicit setting of the variable is respected.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
+if _os.environ.get("WORLD_SIZE", "1") == "1":            # (multi-process runs keep the runtime's default beside RCCL's queues)
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
 
 
 def __getattr__(name):
