@@ -295,8 +295,9 @@ static void forward(Ctx& c, const Ws& w, int part) {
         }
     } else {
         // exact fp32: the eval kernel with the fc_1 * fc_2 -> ReLU product fused in its epilogue, raw output stored too
+        skg_gemm_desc ds[4];
         for (int i = 0; i < 4; ++i) {
-            skg_gemm_desc d; memset(&d, 0, sizeof(d));
+            skg_gemm_desc& d = ds[i]; memset(&d, 0, sizeof(d));
             d.A = w.Sp; d.lda = 1024; d.W = W2 + (int64_t)1024 * 1024 * i; d.ldw = 1024; d.bias = b2 + 1024 * i;
             d.ldc = 1024; d.M = Mg; d.N = 1024; d.K = 1024; d.epilogue = SKG_EPI_MUL_RELU;
             d.C_raw = w.F + 1024 * i; d.ldc_raw = 4096;
@@ -306,7 +307,13 @@ static void forward(Ctx& c, const Ws& w, int part) {
             else if (i == SO) { d.C = w.Tso; d.P = w.C1h; d.p_idx = P->grid_h; d.ldp = 1024; }
             else { d.C = w.Tg; d.P = w.G1; d.p_idx = P->grid_img; d.ldp = 1024; d.out_rows = P->grid_pair; }
             c.flops += 2.0 * Mg * 1024.0 * 1024.0;
-            CK(skg_gemm_f32(&d, c.stream));
+        }
+        // up to ~6000 grid rows the four products together are a mid-size group (csrc/skg_gemm.hip, g_route_tiles): ONE launch on
+        // the free-layout GEMM fills the CUs that each 200-tile product alone leaves idle; larger steps keep one launch each
+        if ((int64_t)((Mg + 127) / 128) * 8 * 4 < 1536) {
+            CK(skg_gemm_group_f32(ds, 4, c.stream));
+        } else {
+            for (int i = 0; i < 4; ++i) CK(skg_gemm_f32(&ds[i], c.stream));
         }
     }
     // ---- attention fc_3 + ReLU, adjacency logits (HEAD:896-897)
