@@ -29,11 +29,11 @@ from collections import OrderedDict
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
-# Before the HIP runtime starts: at most three hardware queues per priority class instead of four ("hardware
-# queues").  With four, a process that has captured or replayed ONE hipGraph -- or keeps a few more streams alive -- runs
-# the training step's kernels 0.5 ms per step slower from then on (1.40 -> 1.98 ms; the legs of this file share a process).
-if os.environ.get("WORLD_SIZE", "1") == "1":              # (ranks of a multi-GPU run keep the runtime's default: they run
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")       #  the headline leg only, and RCCL opens queues of its own)
+# Before the HIP runtime starts: the hardware-queue setting of this process (skghoi_amd/runtime.py).  The same call
+# runs in every form this script is started in -- alone, as a rank under torch.distributed.run, as a rank of `--gpus N`
+# (those are children of a parent that never touches the GPU) -- so every rank of every launch form gets the same setting.
+from skghoi_amd import runtime as _runtime
+_runtime.configure()
 
 import numpy as np
 import torch
@@ -133,13 +133,17 @@ def cpu_baseline(budget_s=40.0):
                        "threads" % (full["images"], one["images"], cores, cores))
 
 
-def run_train(B, precision, steps, warmup, device, rank, world, dist_on, prefetch=True):
-    """The data-parallel training step (forward + backward on the HIP GEMMs, AdamW, DDP gradient all-reduce over RCCL
-    when world > 1) on B synthetic 20x20 images per GPU with ground truth appended.  Returns (elapsed seconds of `steps`
-    steps on this rank, last loss dict)."""
+def run_train(B, precision, steps, warmup, device, rank, world, dist_on, prefetch=True, force_exchange=False,
+              measure=False):
+    """The data-parallel training step (forward + backward on the HIP GEMMs, AdamW; with a process group: the gradient
+    arena exchanged chunk by chunk behind the backward + the fused normaliser all-reduce, over RCCL) on B synthetic 20x20
+    images per GPU with ground truth appended.  force_exchange: take the data-parallel route in a process group of ONE rank
+    too.  measure: a few more, untimed steps with HIP events at the phase boundaries of the step's stream and around every
+    dense product (skg_train_timer).  Returns (elapsed seconds of `steps` steps on this rank, last loss dict, info)."""
     from skghoi_amd import synth, trainer
     head = build_head(device).train()
     head.distributed = dist_on
+    head.force_collectives = force_exchange
     head.precision = precision
     dets, pooled, feats, shapes = make_inputs(B, rank, device)
     o2v = synth.hico_object_to_verb()
@@ -154,7 +158,7 @@ def run_train(B, precision, steps, warmup, device, rank, world, dist_on, prefetc
             return pooled.repeat(reps, 1, 1, 1)[:n]
 
     head.box_roi_pool = Pool()
-    net = trainer.wrap_ddp(head, device)
+    net = trainer.wrap_ddp(head, device, force_exchange=force_exchange)
     opt = trainer.build_optimizer(net, lr=1e-4)
     torch.manual_seed(1234 + rank)
     # lazy=True: the losses stay on the device (no per-step .item() / isnan round trip); all the work of the K steps is
@@ -170,31 +174,67 @@ def run_train(B, precision, steps, warmup, device, rank, world, dist_on, prefetc
     torch.cuda.synchronize()
     if dist_on:
         torch.distributed.barrier()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=nxt)
     torch.cuda.synchronize()
     if dist_on:
         torch.distributed.barrier()
+        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     info = {}
+    import ctypes
+    from skghoi_amd import _capi
     pl = getattr(head, "_last_train_plan", None)
     if pl is not None:
-        import ctypes
-        from skghoi_amd import _capi
         info["gflop_per_step"] = round(float(_capi.lib().skg_train_flops(ctypes.byref(pl), 2)) / 1e9, 3)
     exs = trainer.exchanges(net)
     if exs:
-        # one more step, untimed, with HIP events around the point where the step's stream waits for the gradient exchange:
-        # the part of the all-reduce that the backward did not cover
+        # a few more steps, untimed, with HIP events around the point where the step's stream waits for the gradient
+        # exchange: the part of the all-reduce that the backward did not cover
         exs[0].timing = True
-        trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=None)
+        waits = []
+        for _ in range(5):
+            trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=nxt)
+            waits.append(exs[0].read_timing())
         info["grad_exchange"] = dict(collectives_per_step=exs[0].collectives + 1,
-                                     exposed_wait_ms=round(exs[0].read_timing(), 4),
-                                     note="1 fused normaliser all-reduce + the gradient arena in chunks issued from inside "
-                                          "the backward (skghoi_amd.trainer.ArenaExchange); exposed_wait = device time the "
-                                          "step's stream waited for the chunks after its last backward kernel")
+                                     exposed_wait_ms=round(float(np.median(waits)), 4),
+                                     arena_mb=round(exs[0].ga.numel() * 4 / 2 ** 20, 1),
+                                     note="1 fused normaliser all-reduce + the gradient arena in chunks, each ordered behind "
+                                          "the event of the backward stage that completes it (the backward itself is ONE call "
+                                          "issued by the library's worker thread; skghoi_amd.trainer.ArenaExchange.drive); "
+                                          "exposed_wait = device time the step's stream waited for the chunks after its "
+                                          "last backward kernel + the averaging pass, median of 5 untimed steps")
         exs[0].timing = False
+    if measure:
+        lib = _capi.lib()
+        n_meas = 10
+        tm = lib.skg_train_timer_create(256 * n_meas)
+        head._train_spans = []
+        head._train_timer = tm
+        try:
+            for _ in range(n_meas):
+                trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=nxt)
+            torch.cuda.synchronize()
+            out3 = (ctypes.c_double * 3)()
+            _capi.check(lib.skg_train_timer_read(tm, out3), "skg_train_timer_read")
+        finally:
+            spans, head._train_spans, head._train_timer = head._train_spans, None, None
+            head.__dict__.pop("_train_spans", None); head.__dict__.pop("_train_timer", None)
+            torch.cuda.synchronize()
+            lib.skg_train_timer_destroy(tm)
+        ok = [sp for sp in spans if all(k in sp for k in ("f0", "b0", "b1", "o1"))]
+        med = lambda xs: round(float(np.median(xs)), 4) if xs else None
+        info["phases_ms"] = dict(forward=med([sp["f0"].elapsed_time(sp["b0"]) for sp in ok]),
+                                 backward=med([sp["b0"].elapsed_time(sp["b1"]) for sp in ok]),
+                                 optimizer=med([sp["b1"].elapsed_time(sp["o1"]) for sp in ok]), steps=len(ok),
+                                 note="HIP-event spans on the step's stream in %d untimed steps of this same process: f0 "
+                                      "forward begins -> b0 losses done -> b1 behind the backward's last launch (recorded by "
+                                      "the worker thread) -> o1 behind AdamW; gaps where the stream waits for the host are "
+                                      "inside the spans" % n_meas)
+        info["dense_products"] = dict(ms_per_step=round(out3[0] / n_meas, 4), launches_per_step=round(out3[1] / n_meas, 1),
+                                      gflop_per_step=round(out3[2] / n_meas / 1e9, 3))
     return elapsed, trainer.read_losses(losses), info
 
 
@@ -204,7 +244,8 @@ def train_mode(args, device, rank, world, dist_on):
     from skghoi_amd import dist as skd
     B = args.batch if args.batch != 256 else 4
     args.precision = args.precision or "fp32"
-    elapsed, losses, info = run_train(B, args.precision, args.steps, args.warmup, device, rank, world, dist_on)
+    elapsed, losses, info = run_train(B, args.precision, args.steps, args.warmup, device, rank, world,
+                                      dist_on or args.dp_world1, force_exchange=args.dp_world1, measure=args.measure)
     elapsed = skd.max_over_ranks(elapsed, device=device)
     if rank == 0:
         print(json.dumps(dict(metric="images/sec through the interaction-head TRAINING step (20x20 pairs)",
@@ -215,9 +256,37 @@ def train_mode(args, device, rank, world, dist_on):
                               config=dict(workload="train step: fwd + bwd + AdamW, NegativeSampling + MarginLoss + "
                                                    "two focal terms, 20x20 synthetic images with GT appended",
                                           batch_per_gpu=B, parallelism="dp%d" % world),
-                              losses=losses, dist=dist_info(world), **info)))
-    if dist_on:
+                              losses=losses, dist=dist_info(world, args.dp_world1), runtime=runtime_info(), **info)))
+    if dist_on or args.dp_world1:
         dist.destroy_process_group()
+
+
+def runtime_info():
+    from skghoi_amd import runtime
+    return runtime.info()
+
+
+def dp_world1_child(precision, steps, warmup):
+    """The data-parallel route of the training step timed on ONE GPU: a child process of this script that opens an RCCL
+    process group of world size 1 (RCCL's streams exist, its kernels run) and installs the gradient exchange -- the code
+    path a rank of BASELINE config 4 runs, minus the wire.  Returns the child's JSON record (or an error note)."""
+    import socket
+    import subprocess
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "train", "--precision", precision, "--dp-world1",
+           "--steps", str(steps), "--warmup", str(warmup)]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    except subprocess.TimeoutExpired:
+        return dict(error="timeout")
+    for line in r.stdout.decode(errors="replace").splitlines():
+        if line.startswith("{"):
+            return json.loads(line)
+    return dict(error="rc %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:]))
 
 
 GEMM_NAMES = {0: "skg_gemm_kernel<BIAS>", 1: "skg_gemm_kernel<BIAS_RELU>", 2: "skg_gemm_kernel<MUL_RELU>",
@@ -364,12 +433,13 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
-def dist_info(world):
+def dist_info(world, forced=False):
     """What the process group itself reports (not what the flags asked for)."""
     import torch.distributed as dist
-    if world > 1 and dist.is_initialized():
+    if (world > 1 or forced) and dist.is_initialized():
         return dict(world_size=dist.get_world_size(), backend=dist.get_backend(),
-                    launcher=os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run" or "bench.py --gpus N")
+                    launcher=os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run" or
+                    ("bench.py --dp-world1" if forced else "bench.py --gpus N"))
     return dict(world_size=1, backend=None, launcher=None)
 
 
@@ -428,6 +498,31 @@ def b1_stream(device, n_forwards=2048, n_images=256, seed=2024):
     return out
 
 
+def train_roofline(prec, ms, inf):
+    """Roofline record of one training leg, everything measured in this run: whole-step fraction (plan arithmetic / step
+    time) and the dense products' own fraction (HIP events around every skg_gemmx launch of a few untimed steps)."""
+    gf = inf.get("gflop_per_step")
+    if not gf:
+        return None
+    peak = PEAK_F16_MFMA_TFLOPS if prec == "bf16" else PEAK_F32_MFMA_TFLOPS
+    ach = gf / ms                                                # GFLOP / ms = TFLOP/s
+    rec = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+               gflop_per_step=gf,
+               note="2MNK of every dense product of the step (forward + backward, from the launch plan: skg_train_flops) / "
+                    "step time / dense MFMA peak of the operand type; a batch-4 step is ~100 dependent launches of 2-120 us")
+    dp = inf.get("dense_products")
+    if dp and dp["ms_per_step"]:
+        a2 = dp["gflop_per_step"] / dp["ms_per_step"]
+        rec["dominant_kernel"] = dict(kernel="skg_gemmx_bf16_kernel" if prec == "bf16" else "skg_gemmx_kernel",
+                                      ms_per_step=dp["ms_per_step"], launches_per_step=dp["launches_per_step"],
+                                      gflop_per_step=dp["gflop_per_step"], achieved=round(a2, 2),
+                                      dominant_kernel_frac=round(a2 / peak, 4),
+                                      note="HIP events around every skg_gemmx launch of the plan (main kernel + its split-K "
+                                           "reduce) in 10 untimed steps of this process; fp32: the four exact fc_2 products "
+                                           "of the forward run on skg_gemm_kernel and are not in this figure")
+    return rec
+
+
 def release_plans(head):
     """Destroys the head's captured launch plans (idle device).  Every live hipGraphExec holds streams of its own, i.e.
     hardware queues; with the ~45 plans of the small-batch legs alive the training legs that follow IN THIS PROCESS ran the
@@ -459,6 +554,11 @@ def main():
     ap.add_argument("--b1-stream", action="store_true", help="only the single-image shape-stream leg (prints its record)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="train: NegativeSampling+MarginLoss training step (fwd+bwd+AdamW) as the headline instead")
+    ap.add_argument("--dp-world1", action="store_true",
+                    help="with --mode train on one GPU: open an RCCL process group of world size 1 and take the data-parallel "
+                         "route (staged backward on the worker thread, arena chunks + normaliser through RCCL)")
+    ap.add_argument("--measure", action="store_true",
+                    help="with --mode train: add the phase spans and the dense-product timing of a few untimed steps")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher rehearsal on a box without a GPU: the ranks rendezvous (SKG_BENCH_BACKEND=gloo), run the "
                          "barrier / max-over-ranks / gather plumbing around an empty step and print the line; no head, no "
@@ -495,6 +595,13 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+    elif args.dp_world1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s_.getsockname()[1]); s_.close()
+        dist.init_process_group(os.environ.get("SKG_BENCH_BACKEND", "nccl"), rank=0, world_size=1, device_id=device)
 
     if args.mode == "train":
         return train_mode(args, device, rank, world, dist_on)
@@ -635,42 +742,56 @@ def main():
         release_plans(head)
         _trainer.limit_host_threads(world)
         train = {}
-        busy = {}
-        bpath = os.path.join(ROOT, "profiles", "train_gpu_busy.json")    # kernel time per step from the rocprofv3 run
-        if os.path.isfile(bpath):
-            try:
-                busy = json.load(open(bpath))
-            except Exception:
-                busy = {}
         for prec in ("fp32", "bf16"):
             ks = 60                                                          # (steady state: the first ~10 steps still grow pools)
-            el_t, losses, inf = run_train(4, prec, ks, 12, device, rank, world, False)
+            el_t, losses, inf = run_train(4, prec, ks, 12, device, rank, world, False, measure=True)
             ms = el_t / ks * 1e3
             rec = dict(ms_per_step=round(ms, 3), images_per_s=round(4 * ks / el_t, 2), batch=4, steps=ks,
                        losses={k: round(v, 6) for k, v in losses.items()})
             el_i, _, _ = run_train(4, prec, 10, 4, device, rank, world, False, prefetch=False)
             rec["inline_ms_per_step"] = round(el_i / 10 * 1e3, 3)           # the same step without the look-ahead
-            gf = inf.get("gflop_per_step")
-            if gf:
-                peak = PEAK_F16_MFMA_TFLOPS if prec == "bf16" else PEAK_F32_MFMA_TFLOPS
-                ach = gf / ms                                                # GFLOP / ms = TFLOP/s
-                b = busy.get(prec)
-                rec["roofline"] = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
-                                       frac=round(ach / peak, 4), gflop_per_step=gf,
-                                       gpu_busy_ms=(b or {}).get("ms_per_step"),
-                                       gpu_busy_share=(round(b["ms_per_step"] / ms, 3) if b else None),
-                                       gpu_busy_source=(b or {}).get("source"),
-                                       note="2MNK of every dense product of the step (forward + backward, from the launch "
-                                            "plan: skg_train_flops) / step time / dense MFMA peak of the operand type; "
-                                            "a batch-4 step is ~110 dependent launches of 2-120 us: launch- and "
-                                            "latency-bound, not MFMA-bound")
+            rec["roofline"] = train_roofline(prec, ms, inf)
+            if inf.get("phases_ms"):
+                rec["phases_ms"] = inf["phases_ms"]
             train[prec] = rec
+        # (d) the DATA-PARALLEL route of the bf16 step on this one GPU: RCCL process group of world size 1, arena exchange
+        # installed, in a child process (RCCL's queues stay out of this one)
+        dp = dp_world1_child("bf16", 60, 12)
+        if "error" in dp:
+            train["bf16"]["dp_world1"] = dp
+        else:
+            train["bf16"]["dp_world1"] = dict(ms_per_step=dp["ms_per_step"], images_per_s=dp["value"],
+                                              vs_single_process=round(dp["ms_per_step"] / train["bf16"]["ms_per_step"], 4),
+                                              grad_exchange=dp.get("grad_exchange"), dist=dp.get("dist"),
+                                              runtime=dp.get("runtime"),
+                                              note="same step through the data-parallel code path (staged backward on the "
+                                                   "worker thread, 1 normaliser + k arena all-reduces through RCCL) in a "
+                                                   "process group of ONE rank, child process of this run")
         train["note"] = ("NegativeSampling + MarginLoss + two focal terms, forward + backward + AdamW, 4 synthetic 20x20 "
                          "images with ground truth appended; bf16 = bf16 GEMM operands, fp32 accumulation / master weights; "
                          "every step hands the next batch to the head for preparation (prefetch), as a trainer over a "
                          "loader of cached detections does")
         out["train"] = train
         torch.set_num_threads(max(1, host_cpu_share() // world))
+    elif world > 1 and not args.no_legs:
+        # ---- N > 1: the data-parallel TRAINING step too (BASELINE config 4: batch 4 per GPU, bf16, gradient all-reduce over
+        # RCCL / xGMI) -- every rank runs it; value = whole-job images/s over the max-over-ranks time
+        _trainer.limit_host_threads(world)
+        ks = 40
+        el_t, losses, inf = run_train(4, "bf16", ks, 10, device, rank, world, True, measure=(rank == 0))
+        el_t = skd.max_over_ranks(el_t, device=device)
+        ms = el_t / ks * 1e3
+        rec = dict(ms_per_step=round(ms, 3), images_per_s=round(4 * world * ks / el_t, 2), batch_per_gpu=4, steps=ks,
+                   n_gpus=world, scaling="weak", losses={k: round(v, 6) for k, v in losses.items()},
+                   grad_exchange=inf.get("grad_exchange"), dist=dist_info(world))
+        rec["roofline"] = train_roofline("bf16", ms, inf)
+        if inf.get("phases_ms"):
+            rec["phases_ms"] = inf["phases_ms"]
+        out["train"] = dict(bf16=rec, note="data-parallel training step on every rank: fwd + bwd + AdamW at batch 4 per GPU, "
+                                           "gradient arena exchanged in chunks behind the backward + one fused normaliser "
+                                           "all-reduce (RCCL); ms_per_step = max over ranks; roofline of rank 0")
+        torch.set_num_threads(max(1, host_cpu_share() // world))
+    out["runtime"] = runtime_info()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

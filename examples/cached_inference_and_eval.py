@@ -19,8 +19,10 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from skghoi_amd import GraphHead, InteractionHead, cache, evaluate, synth
+from skghoi_amd import GraphHead, InteractionHead, cache, evaluate, runtime, synth
 from skghoi_amd.roi_pool import MultiScaleRoIAlign
+
+runtime.configure()           # process-level HIP runtime settings, before the first GPU use
 
 
 def main(n_images=16, batch=8, out_dir=None, seed=0):

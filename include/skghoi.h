@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SKG_ABI_VERSION 11
+#define SKG_ABI_VERSION 12
 #define SKG_E_ARG   (-1)   /* null pointer / negative size / unsupported shape            */
 #define SKG_E_ALIGN (-2)   /* pointer or leading dimension not 16-byte aligned            */
 #define SKG_E_LIMIT (-3)   /* exceeds a compiled-in limit (boxes per image, verbs, ...)   */
@@ -525,6 +525,7 @@ enum {
     SKG_SEG_BH3_W, SKG_SEG_BH3_B, SKG_SEG_BH1_W, SKG_SEG_BH1_B, SKG_TRAIN_SEGS
 };
 #define SKG_TRAIN_BWD_STAGES 12
+typedef struct skg_train_timer skg_train_timer;     /* optional per-launch timing of the plan's dense products, see below */
 typedef struct {
     int32_t NA, Mg, Mp, Mh, Mn, A, K, Bf, Cf;   /* row-space sizes, verbs, feature maps [Bf, Cf] after the global pool   */
     int32_t x0_k;                               /* columns of the flattened pooled box features (256 * 7 * 7)            */
@@ -545,6 +546,7 @@ typedef struct {
     float* logits;                              /* out [max(Mp, 1), ld_logits], ZERO-FILLED by the caller                */
     const float* dlogits;                       /* backward in: [max(Mp, 1), ld_logits]                                  */
     float* dx0; float* dgfeat;                  /* backward out, optional: gradients of x0 / gfeat                       */
+    skg_train_timer* timer;                     /* NULL, or: HIP events around every skg_gemmx launch of the plan          */
 } skg_train_plan;
 /* Floats of workspace the plan needs (activations kept for the backward, backward temporaries, split-K scratch);
  * < 0: rejected plan.  Only the sizes, bf16 and params (non-null) are read.                                              */
@@ -557,14 +559,42 @@ int skg_train_forward_f32(const skg_train_plan* plan_host, int part, void* strea
  * the segments in the arena follows the stages: read-out layers first, box_head last), so a data-parallel caller can
  * exchange the arena chunk by chunk between calls.                                                                      */
 int skg_train_backward_f32(const skg_train_plan* plan_host, int first_stage, int last_stage, void* stream);
-/* The same call issued from a worker thread of the library (one job at a time; the plan is copied, the worker selects
- * the caller's current device): returns at once -- 0, or SKG_E_* for a rejected plan / SKG_E_LIMIT while a job is
- * pending.  skg_train_backward_join() blocks until every launch of the job has been enqueued and returns what
- * skg_train_backward_f32 returned (0 when no job was pending).  Between the two calls the caller may enqueue work on
- * OTHER streams and do host work; it must not enqueue anything ordered after the gradients, nor release a buffer the
- * plan names.  For step loops bound by their own host thread (a Python trainer at batch 4: ~0.2 ms of launch calls). */
+/* ---- contexts.  Everything of the library that outlives a call -- today: the worker thread that issues a backward, its
+ * one job slot and the job's progress -- belongs to a context the CALLER creates: one per trainer / device / host thread,
+ * so that two hosts in one process (two trainers, two devices) never share state.  Every skg_ctx_* entry point accepts
+ * NULL for the process's default context, which is what the context-free forms below use.  A context must be destroyed
+ * by the process that created it (fork(): the child starts with a fresh default context and must not touch others).   */
+typedef struct skg_context skg_context;
+skg_context* skg_context_create(void);
+void skg_context_destroy(skg_context* ctx);       /* waits for a job in flight, stops and joins the worker */
+/* skg_train_backward_f32 issued from the context's worker thread (one job at a time per context; the plan is copied, the
+ * worker selects the caller's current device): returns at once -- 0, SKG_E_* for a plan / stage range / workspace that
+ * skg_train_backward_f32 would reject (checked HERE, before the job is queued), SKG_E_LIMIT while a job is pending.
+ * stage_events_host: NULL, or last_stage - first_stage hipEvent_t handles (entries may be NULL): the worker records
+ * events[s - first_stage] on `stream` right behind stage s.  skg_ctx_train_backward_stage_wait(ctx, s) blocks until stage s
+ * has been enqueued (and its event recorded) and returns 0, or the job's error if it ended before reaching s: a
+ * data-parallel caller then orders the collective of the gradient-arena prefix stage s completed behind that event, while
+ * the worker keeps issuing the later stages (reference: DistributedDataParallel's bucket all-reduces behind autograd,
+ * utils.py:202-205).  skg_ctx_train_backward_join blocks until every launch of the job has been enqueued and returns what
+ * skg_train_backward_f32 returned (0 when no job was pending).  Between submit and join the caller may enqueue work on
+ * OTHER streams and do host work; it must not enqueue anything ordered after the gradients on `stream`, nor release a
+ * buffer the plan names.  For step loops bound by their own host thread (a Python trainer at batch 4: ~0.2 ms of launch
+ * calls).                                                                                                              */
+int skg_ctx_train_backward_async_f32(skg_context* ctx, const skg_train_plan* plan_host, int first_stage, int last_stage,
+                                     void* stream, void* const* stage_events_host);
+int skg_ctx_train_backward_stage_wait(skg_context* ctx, int stage);
+int skg_ctx_train_backward_join(skg_context* ctx);
+/* The same on the default context, without stage events. */
 int skg_train_backward_async_f32(const skg_train_plan* plan_host, int first_stage, int last_stage, void* stream);
 int skg_train_backward_join(void);
+/* Measurement aid (bench.py's training roofline): a timer named by plan.timer makes every skg_gemmx launch the plan issues
+ * (main kernel + its split-K reduce) sit between two HIP events on the plan's stream -- a few microseconds each, so it is
+ * switched on for a handful of untimed steps only.  `capacity` = launches it can hold between two reads; further launches
+ * go untimed.  skg_train_timer_read waits for the recorded launches and returns out3_host = {summed milliseconds, launches,
+ * 2 M N K of those launches}, then starts over.  Owned by the caller: no global state.                               */
+skg_train_timer* skg_train_timer_create(int capacity);
+void skg_train_timer_destroy(skg_train_timer* timer);
+int skg_train_timer_read(skg_train_timer* timer, double* out3_host);
 /* Arithmetic of the plan: 2 M N K summed over every dense product it issues (which = 0 forward, 1 backward, 2 both; the
  * backward is counted with dx0 / dgfeat requested).  For roofline records.                                              */
 double skg_train_flops(const skg_train_plan* plan_host, int which);

@@ -12,7 +12,7 @@ MAX_NODES = 160
 SPATIAL_LD = 48
 TRANSH_DIM = 50
 TRANSH_ENT = 80
-ABI_VERSION = 11
+ABI_VERSION = 12
 GEMM_GROUP_MAX = 4
 CHECKSUM_PARTIALS = 1024
 LOSS_CHUNKS = 64
@@ -69,7 +69,7 @@ class TrainPlan(C.Structure):
                                    "grid_pair", "grid_img", "pair_grid", "pair_h", "pair_o", "pair_img", "hum_of",
                                    "node_of")] + \
                [("ws", _vp), ("ws_floats", _i64), ("pair_features", _vp), ("logits", _vp), ("dlogits", _vp),
-                ("dx0", _vp), ("dgfeat", _vp)]
+                ("dx0", _vp), ("dgfeat", _vp), ("timer", _vp)]
 
 
 # numpy dtype of skg_image_meta (12 x 4 bytes)
@@ -149,6 +149,14 @@ PROTOTYPES = {
     "skg_train_backward_f32": (C.c_int, [C.POINTER(TrainPlan), C.c_int, C.c_int, _vp]),
     "skg_train_backward_async_f32": (C.c_int, [C.POINTER(TrainPlan), C.c_int, C.c_int, _vp]),
     "skg_train_backward_join": (C.c_int, []),
+    "skg_train_timer_create": (_vp, [C.c_int]),
+    "skg_train_timer_destroy": (None, [_vp]),
+    "skg_train_timer_read": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "skg_context_create": (_vp, []),
+    "skg_context_destroy": (None, [_vp]),
+    "skg_ctx_train_backward_async_f32": (C.c_int, [_vp, C.POINTER(TrainPlan), C.c_int, C.c_int, _vp, _vp]),
+    "skg_ctx_train_backward_stage_wait": (C.c_int, [_vp, C.c_int]),
+    "skg_ctx_train_backward_join": (C.c_int, [_vp]),
     "skg_train_ws_offset": (C.c_int64, [C.POINTER(TrainPlan), C.c_int]),
     "skg_train_flops": (C.c_double, [C.POINTER(TrainPlan), C.c_int]),
 }

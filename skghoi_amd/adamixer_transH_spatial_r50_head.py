@@ -244,6 +244,22 @@ def _graph_lists(gh, eng, pre, g):
     return feats, bh, bo, oc, labels, prior, [], []
 
 
+_GRAPHS_OK = []
+
+
+def _graphs_allowed():
+    """skghoi_amd.runtime.graphs_allowed(), asked once per process (with a warning when the answer is no)."""
+    if not _GRAPHS_OK:
+        from skghoi_amd import runtime
+        ok = runtime.graphs_allowed()
+        if not ok:
+            import warnings
+            warnings.warn("GPU_MAX_HW_QUEUES < 3: the HIP runtime's graph path has crashed in this configuration; small eval "
+                          "batches enqueue their kernels one by one instead of replaying captured graphs")
+        _GRAPHS_OK.append(ok)
+    return _GRAPHS_OK[0]
+
+
 class _Prefetch:
     """A training batch being prepared ahead of its forward (InteractionHead.prefetch_train): the steps of
     train_fused.prepare_steps, each resumed on the head's side stream.  advance() runs up to the next host
@@ -424,7 +440,7 @@ class InteractionHead(Module):
             with torch.no_grad():
                 return self._forward_train(features, detections, image_shapes, targets, with_losses=False)
         eng = self.engine()
-        if eng.small_batch_max and len(detections) <= eng.small_batch_max:
+        if eng.small_batch_max and len(detections) <= eng.small_batch_max and _graphs_allowed():
             # a few images (the reference evaluates ONE per forward, utils.py:166-167): replay the captured launch plan
             # of this batch shape instead of ~40 individually enqueued kernels (skghoi_amd/small.py)
             from skghoi_amd.small import SmallBatchRunner
@@ -455,15 +471,22 @@ class InteractionHead(Module):
         return self._results(lay, r, dev)
 
     # ------------------------------------------------------------------------------------------ prefetch
-    def prefetch_train(self, detections: List[dict], image_shapes: List[Tuple[int, int]], targets: List[dict]) -> bool:
+    def prefetch_train(self, detections: List[dict], image_shapes: List[Tuple[int, int]], targets: List[dict],
+                       after=None) -> bool:
         """Prepares the NEXT training batch while the GPU is busy with the current step: detection selection (HEAD:92-151),
         pairs + spatial encoding, label association and the host RNG draws of the forward (TransH tables, negative
         permutations) run now, on a high-priority side stream; the next `forward(features, detections, image_shapes,
         targets)` called with these same objects picks the result up instead of paying the forward's two host
-        synchronisations with an idle GPU.  The inputs must be complete on the device (the trainer copies them on the
-        same side stream).  The host RNG is consumed here, in the order the forward would: call it once per batch, in
-        batch order, with no other consumer of the global generator in between.  Returns False (nothing done) when the
-        head is not in the fused training configuration."""
+        synchronisations with an idle GPU.
+
+        Ordering against whoever produced the inputs: the side stream first waits for `after` -- an event recorded behind
+        the inputs' producer (a loader's non-blocking uploads); `trainer.train_step` passes one recorded at its entry, i.e.
+        behind everything enqueued before the step and in front of the step's own kernels.  Without it the side stream waits
+        for everything the caller's current stream holds right now (always safe; the preparation then starts behind the step
+        in flight).  The inputs are marked as in use by the side stream (record_stream), so their memory is not recycled
+        under the preparation.  The host RNG is consumed here, in the order the forward would: call it once per batch, in
+        batch order, with no other consumer of the global generator in between.  Returns False (nothing done) when the head
+        is not in the fused training configuration."""
         from skghoi_amd import train_fused
         if not (self.training and self.fused_training and train_fused.supported(self)) or not detections:
             return False
@@ -471,8 +494,18 @@ class InteractionHead(Module):
         if dev.type != "cuda":
             raise _capi.SkgError("the interaction head runs on a HIP device only (detections on %s)" % dev)
         eng = self.engine()
+        side = self._prefetch_stream(dev)
+        if after is None:
+            after = torch.cuda.Event()
+            after.record(torch.cuda.current_stream(dev))
+        side.wait_event(after)
+        for group in (detections, targets):
+            for d in group:
+                for t in d.values():
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(side)
         h = _Prefetch(self, train_fused.prepare_steps(self, eng, detections, image_shapes, targets), dev,
-                      self._prefetch_stream(dev), (detections, image_shapes, targets))
+                      side, (detections, image_shapes, targets))
         h.advance()                            # launches the detection-selection kernel; its counts are read later
         self._prefetched = h
         return h

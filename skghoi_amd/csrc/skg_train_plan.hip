@@ -14,9 +14,18 @@
 #include <pthread.h>
 #include <condition_variable>
 #include <mutex>
+#include <new>
 #include <thread>
 #include "skghoi.h"
 #include "skg_common.h"
+
+// ---- optional per-launch timing of the plan's dense products (skg_train_plan.timer; bench.py's roofline record) ----------
+struct skg_train_timer {
+    std::mutex m;
+    int cap = 0, n = 0;
+    hipEvent_t* ev = nullptr;        // 2 * cap events, timing enabled
+    double* flops = nullptr;
+};
 
 namespace {
 
@@ -135,7 +144,17 @@ static void launch(Ctx& c, skg_gemmx_desc* ops, int n) {
         if (used > c.scratch_need) c.scratch_need = used;
         for (int i = 0; i < cnt; ++i) c.flops += 2.0 * live[i0 + i].M * (double)live[i0 + i].N * live[i0 + i].K;
         if (c.dry) continue;
+        skg_train_timer* tm = c.P->timer;
+        int slot = -1;
+        double fl = 0.0;
+        if (tm) {
+            for (int i = 0; i < cnt; ++i) fl += 2.0 * live[i0 + i].M * (double)live[i0 + i].N * live[i0 + i].K;
+            std::lock_guard<std::mutex> g(tm->m);
+            if (tm->n < tm->cap) { slot = tm->n++; tm->flops[slot] = fl; }
+        }
+        if (slot >= 0) (void)hipEventRecord(tm->ev[2 * slot], c.stream);
         int rc = bf16 ? skg_gemmx_bf16(live + i0, cnt, c.stream) : skg_gemmx_f32(live + i0, cnt, c.stream);
+        if (slot >= 0) (void)hipEventRecord(tm->ev[2 * slot + 1], c.stream);
         if (rc) { c.rc = rc; return; }
     }
 }
@@ -565,7 +584,9 @@ int skg_train_forward_f32(const skg_train_plan* P, int part, void* stream) {
     return c.rc;
 }
 
-int skg_train_backward_f32(const skg_train_plan* P, int first_stage, int last_stage, void* stream) {
+// what both the direct and the worker-thread entry check BEFORE anything is enqueued or queued: arguments, stage range and
+// the workspace bound (a sizing pass over the requested stages)
+static int validate_backward(const skg_train_plan* P, int first_stage, int last_stage) {
     int rc = check_plan(P);
     if (rc) return rc;
     if (!P->ws || !P->grads || !P->dlogits || !P->pair_features || first_stage < 0 || last_stage > SKG_TRAIN_BWD_STAGES ||
@@ -575,80 +596,184 @@ int skg_train_backward_f32(const skg_train_plan* P, int first_stage, int last_st
     Ctx d{P, nullptr, true, 0, nullptr, 0, 0.0};
     backward(d, w, first_stage, last_stage);
     if (w.total + d.scratch_need > P->ws_floats) return SKG_E_LIMIT;
+    return 0;
+}
+
+int skg_train_backward_f32(const skg_train_plan* P, int first_stage, int last_stage, void* stream) {
+    int rc = validate_backward(P, first_stage, last_stage);
+    if (rc) return rc;
+    Ws w; layout_ws(P, P->ws, w);
     Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0, 0.0};
     backward(c, w, first_stage, last_stage);
     if (!c.rc) { hipError_t e = hipGetLastError(); if (e != hipSuccess) c.rc = (int)e; }
     return c.rc;
 }
 
-/* ---- the backward enqueued from a worker thread of the library.  Issuing the ~60 launches of a backward costs the
- * calling thread ~0.2 ms; a Python step loop that is bound by its own thread (the batch-4 step: 1.45 ms of host work per
- * step, measured with time.thread_time) hands the call to this thread and keeps preparing the next batch meanwhile.
- * One job at a time; the plan is copied; the worker selects the submitting thread's device.  The caller must not enqueue
- * anything that depends on the gradients, nor free a buffer the plan names, before skg_train_backward_join().          */
-namespace {
-struct AsyncBackward {
+}  // extern "C"
+
+/* ---- the backward enqueued from a worker thread.  Issuing the ~60 launches of a backward costs the calling thread
+ * ~0.2 ms; a Python step loop that is bound by its own thread (the batch-4 step: 1.45 ms of host work per step, measured
+ * with time.thread_time) hands the call to this thread and keeps preparing the next batch meanwhile.  The worker, its one
+ * job slot and the job's progress belong to a CONTEXT (skg_context: one per trainer / device / host thread, created by the
+ * caller); the context-free entry points use a default context of the process.  One job at a time per context; the plan
+ * is copied; the worker selects the submitting thread's device.  With stage events the worker records events[s - first]
+ * on the stream behind stage s and publishes the stage count: a data-parallel caller waits for "stage s issued"
+ * (skg_ctx_train_backward_stage_wait) and orders its gradient collective behind that event, so the exchange runs chunk
+ * by chunk behind a backward that is issued in ONE call.                                                                 */
+struct skg_context {
     std::mutex m;
     std::condition_variable cv;
-    bool started = false, pending = false;
+    std::thread worker;
+    bool started = false, pending = false, quit = false;
     skg_train_plan plan;
     int first = 0, last = 0, device = 0, rc = 0;
+    int issued = 0;                      // stages [first, issued) of the current / last job are on the stream
     void* stream = nullptr;
+    hipEvent_t events[SKG_TRAIN_BWD_STAGES];
+    bool with_events = false;
     void loop() {
         for (;;) {
             std::unique_lock<std::mutex> lk(m);
-            cv.wait(lk, [&] { return pending; });
+            cv.wait(lk, [&] { return pending || quit; });
+            if (quit && !pending) return;
             lk.unlock();
             int r = (int)hipSetDevice(device);
-            if (!r) r = skg_train_backward_f32(&plan, first, last, stream);
-            lk.lock();
+            if (!with_events) {
+                if (!r) r = skg_train_backward_f32(&plan, first, last, stream);
+                lk.lock();
+                issued = last;
+            } else {
+                for (int s = first; s < last && !r; ++s) {
+                    r = skg_train_backward_f32(&plan, s, s + 1, stream);
+                    if (!r && events[s - first]) r = (int)hipEventRecord(events[s - first], (hipStream_t)stream);
+                    if (r) break;
+                    lk.lock(); issued = s + 1; lk.unlock();
+                    cv.notify_all();
+                }
+                lk.lock();
+            }
             rc = r; pending = false;
+            lk.unlock();
             cv.notify_all();
         }
     }
 };
-AsyncBackward* g_async = nullptr;
-void async_after_fork_in_child() {                             // threads do not survive fork(): a child starts without a worker
-    if (g_async) g_async = new AsyncBackward;                  // (the parent's object, and whatever its mutex held, is abandoned)
+
+namespace {
+skg_context* g_default_ctx = nullptr;
+void default_ctx_after_fork_in_child() {                       // threads do not survive fork(): a child starts without a worker
+    if (g_default_ctx) g_default_ctx = new skg_context;        // (the parent's object, and whatever its mutex held, is abandoned)
 }
-AsyncBackward* async_backward() {
+skg_context* default_ctx() {
     static bool once = [] {
-        g_async = new AsyncBackward;                           // never destroyed: its thread outlives static destruction
-        pthread_atfork(nullptr, nullptr, async_after_fork_in_child);
+        g_default_ctx = new skg_context;                       // never destroyed: its thread outlives static destruction
+        pthread_atfork(nullptr, nullptr, default_ctx_after_fork_in_child);
         return true;
     }();
     (void)once;
-    return g_async;
+    return g_default_ctx;
 }
+inline skg_context* ctx_or_default(skg_context* c) { return c ? c : default_ctx(); }
 }  // namespace
 
-int skg_train_backward_async_f32(const skg_train_plan* P, int first_stage, int last_stage, void* stream) {
-    int rc = check_plan(P);
+extern "C" {
+
+skg_context* skg_context_create(void) { return new (std::nothrow) skg_context; }
+
+void skg_context_destroy(skg_context* c) {
+    if (!c) return;
+    {
+        std::unique_lock<std::mutex> lk(c->m);
+        c->cv.wait(lk, [&] { return !c->pending; });           // a job in flight finishes issuing first
+        c->quit = true;
+    }
+    c->cv.notify_all();
+    if (c->started && c->worker.joinable()) c->worker.join();
+    delete c;
+}
+
+int skg_ctx_train_backward_async_f32(skg_context* ctx, const skg_train_plan* P, int first_stage, int last_stage,
+                                     void* stream, void* const* stage_events_host) {
+    int rc = validate_backward(P, first_stage, last_stage);    // rejected here, at submit -- not at the join
     if (rc) return rc;
-    AsyncBackward* a = async_backward();
+    skg_context* a = ctx_or_default(ctx);
     std::unique_lock<std::mutex> lk(a->m);
-    if (a->pending) return SKG_E_LIMIT;                        // one job at a time: join first
+    if (a->pending || a->quit) return SKG_E_LIMIT;             // one job at a time per context: join first
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
     a->plan = *P; a->first = first_stage; a->last = last_stage; a->stream = stream; a->device = dev; a->rc = 0;
+    a->issued = first_stage;
+    a->with_events = stage_events_host != nullptr;
+    for (int s = 0; s < SKG_TRAIN_BWD_STAGES; ++s)
+        a->events[s] = (stage_events_host && s < last_stage - first_stage) ? (hipEvent_t)stage_events_host[s] : nullptr;
     a->pending = true;
     if (!a->started) {
         a->started = true;
-        std::thread(&AsyncBackward::loop, a).detach();
+        a->worker = std::thread(&skg_context::loop, a);
+        if (a == g_default_ctx) a->worker.detach();
     }
     lk.unlock();
     a->cv.notify_all();
     return 0;
 }
 
-int skg_train_backward_join(void) {
-    AsyncBackward* a = async_backward();
+int skg_ctx_train_backward_stage_wait(skg_context* ctx, int stage) {
+    skg_context* a = ctx_or_default(ctx);
+    std::unique_lock<std::mutex> lk(a->m);
+    a->cv.wait(lk, [&] { return a->issued > stage || !a->pending; });
+    if (a->issued > stage) return 0;
+    return a->rc ? a->rc : SKG_E_ARG;                          // the job ended without reaching that stage
+}
+
+int skg_ctx_train_backward_join(skg_context* ctx) {
+    skg_context* a = ctx_or_default(ctx);
     std::unique_lock<std::mutex> lk(a->m);
     a->cv.wait(lk, [&] { return !a->pending; });
     const int rc = a->rc;
     a->rc = 0;
     return rc;
+}
+
+int skg_train_backward_async_f32(const skg_train_plan* P, int first_stage, int last_stage, void* stream) {
+    return skg_ctx_train_backward_async_f32(nullptr, P, first_stage, last_stage, stream, nullptr);
+}
+
+int skg_train_backward_join(void) { return skg_ctx_train_backward_join(nullptr); }
+
+skg_train_timer* skg_train_timer_create(int capacity) {
+    if (capacity <= 0) return nullptr;
+    skg_train_timer* t = new (std::nothrow) skg_train_timer;
+    if (!t) return nullptr;
+    t->cap = capacity;
+    t->ev = new hipEvent_t[2 * (size_t)capacity];
+    t->flops = new double[capacity];
+    for (int i = 0; i < 2 * capacity; ++i)
+        if (hipEventCreate(&t->ev[i]) != hipSuccess) { t->cap = i / 2; break; }
+    return t;
+}
+
+void skg_train_timer_destroy(skg_train_timer* t) {
+    if (!t) return;
+    for (int i = 0; i < 2 * t->cap; ++i) (void)hipEventDestroy(t->ev[i]);
+    delete[] t->ev; delete[] t->flops;
+    delete t;
+}
+
+int skg_train_timer_read(skg_train_timer* t, double* out3_host) {
+    if (!t || !out3_host) return SKG_E_ARG;
+    std::lock_guard<std::mutex> g(t->m);
+    double ms = 0.0, fl = 0.0;
+    for (int i = 0; i < t->n; ++i) {
+        hipError_t e = hipEventSynchronize(t->ev[2 * i + 1]);
+        float d = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&d, t->ev[2 * i], t->ev[2 * i + 1]);
+        if (e != hipSuccess) { t->n = 0; return (int)e; }
+        ms += d; fl += t->flops[i];
+    }
+    out3_host[0] = ms; out3_host[1] = (double)t->n; out3_host[2] = fl;
+    t->n = 0;
+    return 0;
 }
 
 /* 2 M N K summed over every dense product of the step: which = 0 forward (both parts), 1 backward, 2 both */

@@ -95,13 +95,13 @@ class Normalisers:
         return self._out
 
 
-def start_normalisers(counts, distributed=True, group=None):
+def start_normalisers(counts, distributed=True, group=None, force=False):
     """counts: device (or CPU, for gloo) tensor of the three per-rank normaliser counts {#positive scored cells,
     #positive pairs, #positive pairs}.  Starts ONE 3-element all-reduce (async) when a process group with more than
     one rank is up and `distributed`; returns a Normalisers handle."""
     vals = counts.to(torch.float64).reshape(3).clone()
     work, world = None, 1
-    if distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if distributed and dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         world = dist.get_world_size(group)
         work = dist.all_reduce(vals, op=dist.ReduceOp.SUM, group=group, async_op=True)
     return Normalisers(vals, work, world)

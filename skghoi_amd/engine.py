@@ -16,6 +16,7 @@ fixed sequence of batched launches over concatenated row spaces (skghoi_amd/layo
 There is no CPU fallback: the library must be built and tensors must live on a HIP device.
 """
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -515,6 +516,7 @@ class HeadEngine:
         self._cnt_event = None
         self._cnt_host_dev = None
         self.plan_epoch = 0
+        self.small_two_branches = os.environ.get("SKG_SMALL_ONE_BRANCH") != "1"    # captured plans: spatial chain beside the box_head chain
         self.small_batch_max = 8    # eval batches of up to this many images replay a captured hipGraph (skghoi_amd/small.py); 0: off
         self.small_batch_buckets = True   # single images share one plan per BUCKET of (humans, nodes) instead of one per shape
         self._small = None

@@ -177,6 +177,8 @@ class SmallBatchRunner:
             from .engine import shared_side_stream
             self.side = shared_side_stream(dev, 0, slot=0)      # (process-wide: every live stream costs a hardware queue)
         side = self.side
+        if not eng.small_two_branches:
+            side = main                        # one chain: the captured graph needs no stream of its own beside the caller's
         with eng._split_ctx(pw):
             enc = torch.empty(max(NA, 1), 1024, **f32)
             Bf, Cf = p.gfeat.shape

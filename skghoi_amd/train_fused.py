@@ -21,6 +21,7 @@ Parameter gradients are returned to autograd as views of one gradient arena laid
 branches = 16 contiguous slices), so `loss.backward()`, DDP and the optimizer see the reference's 408 parameters.
 """
 import ctypes as C
+import threading
 from operator import attrgetter, is_ as _is
 
 import numpy as np
@@ -648,6 +649,7 @@ class NativeJob(TrainJob):
         for k in ("grid_h", "grid_o", "grid_pair", "grid_img", "pair_grid", "pair_h", "pair_o"):
             setattr(pl, k, S[k].data_ptr())
         pl.pair_img, pl.hum_of, pl.node_of = self.pair_img.data_ptr(), self.hum_of.data_ptr(), self.node_of.data_ptr()
+        pl.timer = self.head.__dict__.get("_train_timer")      # measurement aid (bench.py): events around every gemmx launch
         return pl
 
     def forward_a(self, x0, gfeat):
@@ -697,13 +699,14 @@ class NativeJob(TrainJob):
                           adjacency=(lay.sum_g, 1))[which]
         return self.ws[off:off + rows * cols].view(rows, cols)
 
-    def backward(self, dlogits, need_dx0, need_dgfeat, arena=None, defer=False):
-        """defer=True (single process, engine-free step): the launches are issued by the library's worker thread
-        (skg_train_backward_async_f32) while this thread goes on with host work; `join_backward()` must run before
-        anything is enqueued behind the gradients.  Returns (dx0, dgfeat, gradient views in parameter order | None)."""
-        join_backward()
+    def backward(self, dlogits, need_dx0, need_dgfeat, arena=None, defer=False, span=None):
+        """defer=True (engine-free step): the launches are issued by the worker thread of the head's context
+        (skg_ctx_train_backward_async_f32) while this thread goes on with host work; `join_backward()` must run before
+        anything is enqueued behind the gradients.  span: a dict that receives "b1", a timing event the worker records behind
+        the last stage (measurement).  Returns (dx0, dgfeat, gradient views in parameter order | None)."""
         lib = _capi.lib()
         st, S, pl = self.st, self.S, self.plan
+        context_for(self.head).join()
         ga, sviews = arena if arena is not None else st.grad_arena()
         pl.grads = ga.data_ptr()
         dlogits = dlogits.contiguous()
@@ -715,21 +718,40 @@ class NativeJob(TrainJob):
         pl.dx0, pl.dgfeat = _ptr(dx0), _ptr(dgfeat)
         stream = _stream()
         ex = getattr(self.head, "grad_exchange", None)
-        if ex is None and defer:
-            _check(lib.skg_train_backward_async_f32(C.byref(pl), 0, _capi.TRAIN_BWD_STAGES, stream),
+        n = _capi.TRAIN_BWD_STAGES
+        if defer:
+            # ONE call hands the whole backward to the worker thread of this head's context.  Data parallel: the worker
+            # records an event behind every stage; the exchange (skghoi_amd/trainer.py, ArenaExchange.drive) waits for
+            # "stage s issued" and orders the collective of the arena prefix that stage completed behind its event.
+            ctx = context_for(self.head)
+            ctx.join()
+            ctx.owner = threading.get_ident()
+            events = None
+            if ex is not None:
+                ex.begin(ga)
+                events = ex.stage_events(self.dev, n, timing=span is not None)
+                if span is not None:
+                    span["b1"] = ex.stage_event(n - 1)
+            elif span is not None:
+                span["b1"] = torch.cuda.Event(enable_timing=True)
+                span["b1"].record()                              # (torch creates the HIP event at its first record)
+                events = (C.c_void_p * n)()
+                events[n - 1] = span["b1"].cuda_event
+            _check(lib.skg_ctx_train_backward_async_f32(ctx.handle(), C.byref(pl), 0, n, stream, events),
                    "skg_train_backward_async_f32")
             # everything the plan names stays alive until the worker has enqueued the last launch
-            _PENDING.append((self, self.S, self.ws, dlogits, ga, dx0, dgfeat))
+            ctx.pending.append((self, self.S, self.ws, dlogits, ga, dx0, dgfeat))
+            if ex is not None:
+                ctx.exchange = (ex, list(st.milestone_end))
             self.S = None
             self.ws = None
             return dx0, dgfeat, None
         if ex is None:
-            _check(lib.skg_train_backward_f32(C.byref(pl), 0, _capi.TRAIN_BWD_STAGES, stream), "skg_train_backward_f32")
+            _check(lib.skg_train_backward_f32(C.byref(pl), 0, n, stream), "skg_train_backward_f32")
         else:
-            # data parallel: after every stage the gradient-arena prefix that stage completed goes out to the peers
-            # (skghoi_amd/trainer.py, ArenaExchange), concurrent with the stages still to run
+            # data parallel on the autograd route (a trainable detector in front of the head): the stages are issued from
+            # this thread, and after every stage the gradient-arena prefix that stage completed goes out to the peers
             ex.begin(ga)
-            n = _capi.TRAIN_BWD_STAGES
             for s_ in range(n):
                 _check(lib.skg_train_backward_f32(C.byref(pl), s_, s_ + 1, stream), "skg_train_backward_f32[%d]" % s_)
                 ex.on_stage(s_, ga, st.milestone_end[s_], last=(s_ == n - 1))
@@ -743,22 +765,102 @@ class NativeJob(TrainJob):
         return dx0, dgfeat, out
 
 
-_PENDING = []          # what a deferred backward still reads (at most one job)
+class TrainContext:
+    """The skg_context (include/skghoi.h) of one head: the library-side worker thread that issues a deferred backward, its
+    one job slot, and -- on this side -- what that job still reads.  One per head, so two trainers in one process (two
+    host threads, two devices) never share a job slot."""
+    live = None
 
+    def __init__(self):
+        import os
+        import weakref
+        self._h = None
+        self.pid = os.getpid()
+        self.pending = []             # what the deferred backward still reads (tensors the plan names)
+        self.exchange = None          # (ArenaExchange, milestone ends) of a data-parallel job whose collectives are not out yet
+        self.driven = None            # the exchange once its collectives are out: finish() at the join
+        self.owner = None             # host thread that submitted the pending job (its stream is the one to order)
+        if TrainContext.live is None:
+            TrainContext.live = weakref.WeakSet()
+        TrainContext.live.add(self)
 
-def join_backward():
-    """Waits until the library's worker thread has enqueued every launch of a deferred backward (NativeJob.backward
-    defer=True); a no-op otherwise.  Called before the optimizer step, before the next backward and by anything that
-    enqueues work behind the gradients."""
-    if _PENDING:
+    def handle(self):
+        import os
+        if self._h is None or self.pid != os.getpid():          # (a forked child: the parent's worker does not exist here)
+            self._h = _capi.lib().skg_context_create()
+            self.pid = os.getpid()
+            if not self._h:
+                raise _capi.SkgError("skg_context_create failed")
+        return self._h
+
+    def drive(self):
+        """Data parallel: sends the gradient-arena chunks out behind the stages the worker is issuing (no-op otherwise)."""
+        if self.exchange is not None:
+            ex, ends = self.exchange
+            self.exchange = None
+            self.driven = ex
+            ex.drive(self, ends)
+
+    def join(self):
+        """Waits until the worker has enqueued every launch of the pending job; with a gradient exchange, sends whatever
+        chunks are still to go and orders the caller's stream behind all of them."""
+        if not self.pending:
+            return
         try:
-            _check(_capi.lib().skg_train_backward_join(), "skg_train_backward_f32 (deferred)")
+            self.drive()
+            _check(_capi.lib().skg_ctx_train_backward_join(self.handle()), "skg_train_backward_f32 (deferred)")
         finally:
-            _PENDING.clear()
+            self.pending.clear()
+            ex, self.driven, self.exchange = self.driven, None, None
+        if ex is not None:
+            ex.finish()
+
+    def stage_wait(self, s):
+        _check(_capi.lib().skg_ctx_train_backward_stage_wait(self.handle(), s), "skg_train_backward_f32 (deferred, stage %d)" % s)
+
+    def close(self):
+        import os
+        h, self._h = self._h, None
+        if h and self.pid == os.getpid():
+            try:
+                _capi.lib().skg_context_destroy(h)
+            except Exception:
+                pass
+
+    def __del__(self):
+        self.close()
+
+
+def context_for(head):
+    c = head.__dict__.get("_train_ctx")
+    if c is None:
+        c = head.__dict__["_train_ctx"] = TrainContext()
+    return c
+
+
+def _mine(every_thread=False):
+    me = threading.get_ident()
+    return [c for c in list(TrainContext.live or ()) if c.pending and (every_thread or c.owner == me)]
+
+
+def drive_exchanges():
+    """Data parallel: hands the gradient chunks of every deferred backward this thread has in flight to the process group
+    (the trainer calls it as soon as the step's other host work is queued; join_backward() would do it too, later)."""
+    for c in _mine():
+        c.drive()
+
+
+def join_backward(every_thread=False):
+    """Waits until the library's worker threads have enqueued every launch of the deferred backwards THIS host thread
+    submitted (NativeJob.backward defer=True) and, data parallel, until the step's stream is ordered behind the gradient
+    exchange; a no-op otherwise.  Called before the optimizer step, before the next backward and by anything that enqueues
+    work behind the gradients."""
+    for c in _mine(every_thread):
+        c.join()
 
 
 import atexit
-atexit.register(join_backward)          # (a worker still issuing launches must not race the runtime's teardown)
+atexit.register(join_backward, True)          # (a worker still issuing launches must not race the runtime's teardown)
 
 
 def job_class(head):
@@ -997,11 +1099,15 @@ class TrainRun:
         #      mean(max(p - n, -margin)) + margin, divided by n_p (HEAD:228-234)
         rows = partial.shape[0]
         norm = None
-        if head.distributed and skd.dist.is_available() and skd.dist.is_initialized() and skd.dist.get_world_size() > 1:
+        # (force_collectives: a process group of ONE rank still runs its collectives -- bench.py times the data-parallel
+        #  route on a single GPU that way)
+        force = getattr(head, "force_collectives", False)
+        if head.distributed and skd.dist.is_available() and skd.dist.is_initialized() and \
+                (skd.dist.get_world_size() > 1 or force):
             counts = torch.empty(3, **f32)
             _check(lib.skg_loss_finish_f32(partial.data_ptr(), rows, mpart.data_ptr(), A, M_pos, 1.0, None, None, None,
                                            counts.data_ptr(), stream), "skg_loss_finish_f32")
-            norm = skd.start_normalisers(counts, True).get().contiguous()     # ONE fused 3-element all-reduce
+            norm = skd.start_normalisers(counts, True, force=force).get().contiguous()     # ONE fused 3-element all-reduce
         _check(lib.skg_loss_finish_f32(partial.data_ptr(), rows, mpart.data_ptr(), A, M_pos, 1.0, _ptr(norm),
                                        losses.data_ptr(), job.loss_scale.data_ptr(), None, stream), "skg_loss_finish_f32")
         self.pos_s, self.neg_s = prep.pos_s, prep.neg_s
@@ -1047,7 +1153,16 @@ def fused_step(head, eng, features, detections, image_shapes, targets, prep=None
     if any(getattr(t, "requires_grad", False) for t in features.values()):
         return None, prep
     run = TrainRun(head, eng, features, image_shapes)
+    # measurement (bench.py): HIP events on the step's stream at the phase boundaries -- f0 forward begins, b0 backward
+    # begins (= forward + losses done), b1 behind the backward's last launch, o1 behind the optimizer (trainer.train_step)
+    spans = head.__dict__.get("_train_spans")
+    sp = None
+    if spans is not None:
+        sp = dict(f0=torch.cuda.Event(enable_timing=True), b0=torch.cuda.Event(enable_timing=True))
+        spans.append(sp)
     if prep is None:
+        if sp is not None:
+            sp["f0"].record()
         prep = prepare_train(head, eng, detections, image_shapes, targets, before_sync=run.start)
         if prep.empty:
             return None, prep
@@ -1059,6 +1174,8 @@ def fused_step(head, eng, features, detections, image_shapes, targets, prep=None
             main.wait_event(prep.ready)
             for t in prep.cross:
                 t.record_stream(main)
+        if sp is not None:
+            sp["f0"].record()
         run.start(prep)
     if run.box_features.requires_grad:
         # a differentiable RoI pooling in front: its backward belongs to autograd.  (start() has run: finish on that route)
@@ -1082,11 +1199,16 @@ def fused_step(head, eng, features, detections, image_shapes, targets, prep=None
         _check(_capi.lib().skg_scale_dlogits_f32(src.data_ptr(), src.stride(0), src.shape[0], job.K,
                                                  job.loss_scale.data_ptr(), one.data_ptr(), one.data_ptr(), d.data_ptr(),
                                                  _stream()), "skg_scale_dlogits_f32")
-        job.backward(d, False, False, arena=(ga, views), defer=defer_backward)
-        if _PENDING:
+        if sp is not None:
+            sp["b0"].record()
+        job.backward(d, False, False, arena=(ga, views), defer=defer_backward, span=sp if defer_backward else None)
+        if sp is not None and "b1" not in sp:
+            sp["b1"] = torch.cuda.Event(enable_timing=True); sp["b1"].record()
+        ctx = context_for(head)
+        if ctx.pending:
             # the index arrays and tables of the prepared batch are named by the plan too: dropping them now would let the
             # allocator hand their blocks out behind an event recorded in the MIDDLE of the backward
-            _PENDING.append((prep, run, features))
+            ctx.pending.append((prep, run, features))
         if after_forward is not None and defer_backward:
             after_forward()                                       # (host work beside the worker's launch calls)
         if not all(map(_is, map(_grad_of, st.src), views)):       # (first step, or someone re-pointed / cleared a .grad)

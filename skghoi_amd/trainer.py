@@ -142,6 +142,8 @@ class ArenaExchange:
         self.collectives = 0                  # arena collectives of the last step
         self.timing = False
         self.last_ms = None                   # with timing: (device time the step's stream waited for the exchange, ms)
+        self._stage_events = None             # one HIP event per backward stage (the library's worker records them)
+        self._xstream = None                  # stream the collectives are issued on: ordered behind ONE stage event each
 
     # -- driven by NativeJob.backward
     def begin(self, ga):
@@ -153,6 +155,40 @@ class ArenaExchange:
             self.works.append(dist.all_reduce(ga[self.done:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.done = end
             self.collectives += 1
+
+    def stage_events(self, dev, n, timing=False):
+        """ctypes array of `n` hipEvent_t handles for skg_ctx_train_backward_async_f32 (reused from step to step; with
+        timing -- a measurement run reads them afterwards -- fresh, timing-enabled events every step)."""
+        import ctypes
+        if timing or self._stage_events is None or len(self._stage_events[0]) != n or self._stage_events[2]:
+            evs = [torch.cuda.Event(enable_timing=timing) for _ in range(n)]
+            for e in evs:
+                e.record()                    # (torch creates the HIP event at its first record)
+            arr = (ctypes.c_void_p * n)(*[e.cuda_event for e in evs])
+            self._stage_events = (evs, arr, timing)
+        return self._stage_events[1]
+
+    def stage_event(self, s):
+        return self._stage_events[0][s]
+
+    def drive(self, ctx, ends):
+        """The backward was handed to the library's worker thread in ONE call (train_fused.NativeJob.backward, defer=True).
+        For every arena chunk: wait (on the host, without the GIL) until the worker has issued the stage that completes the
+        chunk, order the exchange stream behind THAT stage's event -- not behind whatever else the worker has put on the
+        step's stream since -- and start the collective there.  The chunk boundaries are those of `on_stage`."""
+        ga, evs = self.ga, self._stage_events[0]
+        if self._xstream is None:
+            from .engine import shared_side_stream
+            self._xstream = shared_side_stream(ga.device, 0, slot=1)
+        xs = self._xstream
+        n = len(ends)
+        for s_, end in enumerate(ends):
+            last = s_ == n - 1
+            if end - self.done >= self.min_chunk or (last and end > self.done):
+                ctx.stage_wait(s_)
+                xs.wait_event(evs[s_])
+                with torch.cuda.stream(xs):
+                    self.on_stage(s_, ga, end, last=last)
 
     def finish(self):
         """Orders the step's stream behind every chunk and forms the average."""
@@ -223,12 +259,15 @@ def exchanges(module: nn.Module):
 _WRAP_EPOCH = [0]
 
 
-def wrap_ddp(module: nn.Module, device=None):
+def wrap_ddp(module: nn.Module, device=None, force_exchange=False):
     """utils.py:202-205 (pocket's engine wraps the net in DDP with find_unused_parameters=True).  A single process needs
     no gradient hooks: the head's fused step then writes p.grad directly (grad_mode "direct", ~1 ms of autograd
-    bookkeeping per step saved); under DDP the gradients go through the autograd engine, whose hooks DDP listens to."""
+    bookkeeping per step saved); under DDP the gradients go through the autograd engine, whose hooks DDP listens to.
+    force_exchange: install the arena exchange even in a process group of ONE rank (bench.py times the data-parallel route
+    -- RCCL's streams, kernels and the staged backward -- on a single GPU that way)."""
     _WRAP_EPOCH[0] += 1
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    up = dist.is_available() and dist.is_initialized()
+    if not up or (dist.get_world_size() == 1 and not force_exchange):
         for h in _interaction_heads(module):
             h.grad_mode = "direct"
         return module
@@ -238,21 +277,29 @@ def wrap_ddp(module: nn.Module, device=None):
     ignore = []
     heads = _interaction_heads(module)
     names = {id(m): n for n, m in module.named_modules()}
+    fused = []
     for h in heads:
         dev = next(h.parameters()).device
         if train_fused.supported(h) and h.fused_training and dev.type == "cuda":
-            h.grad_mode = "direct"
-            st = train_fused._stacked_for(h, dev)
-            if not st.aliased():
-                st.adopt()
-            dist.broadcast(st.buf, 0)                       # DDP's constructor broadcast: rank 0's parameters everywhere
-            h.grad_exchange = ArenaExchange(h)
+            fused.append(h)
             prefix = names[id(h)]
             ignore += [(prefix + "." if prefix else "") + n for n, _ in h.named_parameters()]
         else:
             h.grad_mode = "autograd"
     rest = [n for n, p in module.named_parameters() if p.requires_grad and n not in set(ignore)]
-    if not rest:
+    # With a DDP remainder the arena collectives get a process group of their OWN: a rank whose batch bypassed the fused node
+    # issues them in after_backward(), i.e. AFTER DDP's bucket all-reduces, its peers from inside the backward, BEFORE --
+    # on one communicator that order mismatch hangs or mixes buffers; two communicators are independent.
+    group = dist.new_group() if (rest and fused and dist.get_world_size() > 1) else None
+    for h in fused:
+        dev = next(h.parameters()).device
+        h.grad_mode = "direct"
+        st = train_fused._stacked_for(h, dev)
+        if not st.aliased():
+            st.adopt()
+        dist.broadcast(st.buf, 0, group=group)              # DDP's constructor broadcast: rank 0's parameters everywhere
+        h.grad_exchange = ArenaExchange(h, group=group)
+    if not rest or dist.get_world_size() == 1:
         return module
     if ignore:
         nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(module, ignore)
@@ -265,15 +312,29 @@ def _join_backward():
     join_backward()
 
 
-def prefetch_batch(net, features, detections, image_shapes, targets):
+def _drive_exchanges():
+    from .train_fused import drive_exchanges
+    drive_exchanges()
+
+
+def prefetch_batch(net, *batch, after=None):
     """Hands the NEXT batch to the head for preparation on its side stream (InteractionHead.prefetch_train) while the GPU
-    works on the step just enqueued; returns the handle of the preparation in progress (advance() / finish()) or None.  Only when `net` IS the interaction head (training from cached detections /
-    features): inside a full detector the head's inputs exist only after the detector has run."""
+    works on the step just enqueued; returns the handle of the preparation in progress (advance() / finish()) or None.
+    Only when `net` IS the interaction head (training from cached detections / features) and the batch has the head's own
+    call shape (features, detections, image_shapes, targets): inside a full detector the head's inputs exist only after the
+    detector has run, and a loader that yields (images, detections, targets) (utils.py:34-42) has nothing the head could
+    prepare.  A look-ahead is an optimisation: anything it cannot use it leaves alone -- it never raises for the batch's
+    shape."""
     mod = net.module if isinstance(net, nn.parallel.DistributedDataParallel) else net
     fn = getattr(mod, "prefetch_train", None)
-    if fn is None or not detections or not detections[0]["boxes"].is_cuda:
+    if fn is None or len(batch) != 4:
         return None
-    return fn(detections, image_shapes, targets) or None
+    features, detections, image_shapes, targets = batch
+    if not isinstance(detections, (list, tuple)) or not detections or not isinstance(detections[0], dict) \
+            or not torch.is_tensor(detections[0].get("boxes")) or not detections[0]["boxes"].is_cuda or targets is None:
+        return None
+    return (fn(detections, image_shapes, targets, after=after) if after is not None
+            else fn(detections, image_shapes, targets)) or None
 
 
 def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
@@ -296,39 +357,53 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
     # the next batch's preparation is interleaved with this step's host work: each of its two device round trips (selection
     # counts, positive counts) runs on the side stream while this thread enqueues the backward resp. the optimizer
     ahead = [None]
+    entry = None
+    if prefetch is not None and torch.cuda.is_available():
+        # behind whatever produced the next batch (a loader's non-blocking uploads were enqueued before this call), in front
+        # of this step's own kernels: what the side stream's preparation has to wait for, and no more
+        entry = torch.cuda.Event()
+        entry.record()
 
     def look_ahead():
         if prefetch is not None and ahead[0] is None:
-            ahead[0] = prefetch_batch(net, *prefetch)                               # selection kernel launched
+            ahead[0] = prefetch_batch(net, *prefetch, after=entry)                  # selection kernel launched
     out = None
     fused = getattr(net, "fused_step", None)            # the bare interaction head: forward + backward without the autograd
-    if fused is not None and len(inputs) == 3:          # engine (gradients overwrite p.grad: nothing to zero beforehand)
-        out = fused(*inputs, targets, after_forward=look_ahead, defer_backward=True)
-    fused_ran = out is not None
-    if out is None:
-        optimizer.zero_grad(set_to_none=True)
-        out = net(*inputs, targets)
-    loss_dict = out.pop()
-    if not lazy and torch.isnan(loss_dict["hoi_loss"]):
-        raise ValueError(f"The HOI loss is NaN")
-    look_ahead()
-    if any(v.requires_grad for v in loss_dict.values()):
-        if fused_ran:
-            # fused_step handed the losses back on the autograd route (a differentiable RoI pooling in front of the head):
-            # whatever the parameters still hold from the step before must not be added to
+    try:
+        if fused is not None and len(inputs) == 3:      # engine (gradients overwrite p.grad: nothing to zero beforehand)
+            out = fused(*inputs, targets, after_forward=look_ahead, defer_backward=True)
+        fused_ran = out is not None
+        if out is None:
             optimizer.zero_grad(set_to_none=True)
-        total = sum(loss for loss in loss_dict.values())
-        total.backward()
-    ahead = ahead[0]
-    if ahead is not None:
-        ahead.advance()                  # counts read (ready by now), pairs + association launched
-    for ex in exchanges(net):            # data parallel: a rank whose batch bypassed the fused node joins its peers here
-        ex.after_backward()
-    if fused_ran:
+            out = net(*inputs, targets)
+        loss_dict = out.pop()
+        if not lazy and torch.isnan(loss_dict["hoi_loss"]):
+            raise ValueError(f"The HOI loss is NaN")
+        look_ahead()
+        if fused_ran:
+            _drive_exchanges()           # data parallel: the arena chunks go out behind the stages the worker is issuing
+        if any(v.requires_grad for v in loss_dict.values()):
+            if fused_ran:
+                # fused_step handed the losses back on the autograd route (a differentiable RoI pooling in front of the
+                # head): whatever the parameters still hold from the step before must not be added to
+                optimizer.zero_grad(set_to_none=True)
+            total = sum(loss for loss in loss_dict.values())
+            total.backward()
+        if ahead[0] is not None:
+            ahead[0].advance()           # counts read (ready by now), pairs + association launched
+        for ex in exchanges(net):        # data parallel: a rank whose batch bypassed the fused node joins its peers here
+            ex.after_backward()
+    finally:
+        # whatever happened above (the NaN guard, a failing look-ahead): a backward handed to the worker thread is joined
+        # before this frame's tensors go away -- the plan names them
         _join_backward()                 # the backward's launches are all on the stream before the optimizer's
     optimizer.step()
-    if ahead is not None:
-        ahead.finish()                   # positive counts read, host RNG draws, uploads, TransH term
+    spans = getattr(net, "_train_spans", None)
+    if spans and "o1" not in spans[-1]:
+        spans[-1]["o1"] = torch.cuda.Event(enable_timing=True)
+        spans[-1]["o1"].record()
+    if ahead[0] is not None:
+        ahead[0].finish()                # positive counts read, host RNG draws, uploads, TransH term
     if lazy:
         return {k: v.detach() for k, v in loss_dict.items()}, out
     return {k: float(v.detach()) for k, v in loss_dict.items()}, out
@@ -583,6 +658,7 @@ class Trainer:
         # device tensors until the end of the epoch, where they are read back at once -- and the NaN guard fires there
         self.lazy_losses = lazy_losses
         # the default step takes a one-batch look-ahead and lets the head prepare it while this step runs on the GPU
+        # (prefetch_batch: only for batches of the head's own call shape; any other batch shape is simply not prepared)
         self.lookahead = step_fn is None
         self.step_fn = step_fn or (lambda n, o, b, nxt=None: train_step(n, o, *b[:-1], targets=b[-1], lazy=lazy_losses,
                                                                         prefetch=nxt))

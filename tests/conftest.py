@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
 
+# the process-level HIP runtime setting of the product (hardware queues), made the way an application makes it: one
+# explicit call before anything touches the GPU
+from skghoi_amd import runtime as _runtime  # noqa: E402
+_runtime.configure()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -110,6 +110,172 @@ def test_two_rank_ddp_train_step_on_one_gpu():
     assert np.array_equal(v0, v1)            # gradients were averaged: both replicas took the same step
 
 
+
+def _offset_pool(case, first_row):
+    """box_roi_pool stand-in of ONE rank of a sharded batch: the cached rows of its images start at `first_row`."""
+    import cases as _cases
+
+    class Pool(nn.Module):
+        def forward(self, features, boxes, image_shapes):
+            n = sum(len(b) for b in boxes)
+            return _cases.pooled_for(case, first_row + n)[first_row:].cuda()
+    return Pool()
+
+
+def _dp_equiv_worker(rank, world, port, ref_path, q):
+    """One rank of test_two_ranks_through_the_hip_arena_equal_the_unsharded_step: image `rank` of train_tiny through
+    trainer.train_step (fused step, backward on the library's worker thread, arena chunks behind its stage events)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from collections import OrderedDict
+    import cases, gpu_run
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    ref = torch.load(ref_path)
+    case = cases.build_case("train_tiny")
+    full = case
+    case = dict(case)
+    for k in ("detections", "targets", "shapes"):
+        case[k] = full[k][rank:rank + 1]
+    case["feat3"] = full["feat3"][rank:rank + 1]
+    head = gpu_run.build_head(case)
+    head.distributed = True
+    head.box_roi_pool = _offset_pool(full, ref["n0"] * rank)
+    net = trainer.wrap_ddp(head, torch.device("cuda", 0))
+    assert net is head and head.grad_exchange is not None
+    opt = trainer.build_optimizer(net, lr=1e-3)
+    feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
+    torch.manual_seed(7 + rank)
+    from skghoi_amd import train_fused
+    staged = []
+    orig = train_fused.TrainContext.stage_wait
+    train_fused.TrainContext.stage_wait = lambda self, s: (staged.append(s), orig(self, s))[1]
+    try:
+        losses, _ = trainer.train_step(net, opt, feats, gpu_run.to_cuda(case["detections"]), case["shapes"],
+                                       targets=gpu_run.to_cuda(case["targets"]))
+    finally:
+        train_fused.TrainContext.stage_wait = orig
+    torch.cuda.synchronize()
+    worst_g = worst_o = worst_w = 0.0
+    for name, p in head.named_parameters():
+        g = p.grad.detach().cpu()
+        w = ref["grads"][name]
+        scale = max(float(w.abs().max()), 1e-6)
+        worst_g = max(worst_g, max(float((g - w).abs().max()) - 1e-9, 0.0) / scale)
+        if name in ref["oracle"]:
+            o = ref["oracle"][name]
+            so = max(float(o.abs().max()), 1e-6)
+            worst_o = max(worst_o, max(float((g - o).abs().max()) - 1e-9, 0.0) / so)
+        worst_w = max(worst_w, float((p.detach().cpu() - ref["weights"][name]).abs().max()))
+    q.put((rank, losses, worst_g, worst_o, worst_w, staged, head.grad_exchange.collectives))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_through_the_hip_arena_equal_the_unsharded_step(tmp_path):
+    """The data-parallel step as a rank of BASELINE config 4 runs it -- one image per rank, the HIP backward issued by the
+    library's worker thread in one call, the gradient arena leaving chunk by chunk behind its stage events, the fused
+    3-element normaliser all-reduce -- against the SAME two images as one batch in a single process: gradients of all 408
+    parameters (after the exchange) and the weights after one AdamW step agree, and both agree with the oracle's autograd
+    (main:26-31,175-179; utils.py:202-229).  Two ranks share the one GPU of the test box and talk over gloo."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.multiprocessing as mp
+    from collections import OrderedDict
+    import cases, gpu_run, helpers
+    case = cases.build_case("train_tiny")
+    head = gpu_run.build_head(case)
+    net = trainer.wrap_ddp(head, torch.device("cuda", 0))
+    opt = trainer.build_optimizer(net, lr=1e-3)
+    feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
+    det, tg = gpu_run.to_cuda(case["detections"]), gpu_run.to_cuda(case["targets"])
+    n0 = int(head.engine().preprocess(det[:1], tg[:1], True, True).sizes[0])      # rows of image 0 in the pooled cache
+    torch.manual_seed(7)
+    single, _ = trainer.train_step(net, opt, feats, det, case["shapes"], targets=tg)
+    torch.cuda.synchronize()
+    want, _ = helpers.oracle_train_grads(case)
+    # the transH term has no gradient towards the head (SURVEY 8a-17); hoi + interactiveness are what the ranks share
+    ref = dict(n0=n0, grads={n: p.grad.detach().cpu().clone() for n, p in head.named_parameters()},
+               weights={n: p.detach().cpu().clone() for n, p in head.named_parameters()},
+               oracle={n: torch.from_numpy(np.ascontiguousarray(g)) for n, g in want.items()})
+    path = str(tmp_path / "unsharded.pt")
+    torch.save(ref, path)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_equiv_worker, args=(r, 2, port, path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, losses, worst_g, worst_o, worst_w, staged, k in res:
+        assert worst_g <= 1e-5, (rank, worst_g)          # exchanged arena == un-sharded arena (fp32 summation order)
+        assert worst_o <= 1e-4, (rank, worst_o)          # ... == oracle autograd of the two-image batch
+        assert worst_w <= 1e-6, (rank, worst_w)          # the replicas took the un-sharded step
+        assert staged == sorted(staged) and len(staged) == k and 2 <= k <= 12, (staged, k)    # one host wait per chunk
+    # data-parallel normaliser: local sum / (all_reduce_sum(n_p) / world)  ->  the mean over ranks is the batch loss
+    for key in ("hoi_loss", "interactiveness_loss"):
+        mean = 0.5 * (res[0][1][key] + res[1][1][key])
+        assert abs(mean - single[key]) <= 1e-5 * max(1.0, abs(single[key])), key
+
+
+@pytest.mark.gpu
+def test_two_trainers_on_two_host_threads_do_not_share_a_job_slot():
+    """no global state behind the C ABI.  Each head owns a skg_context (worker thread + job slot); two
+    trainers stepping concurrently from two Python threads end with the weights of the same trainers run one after the
+    other."""
+    import sys
+    import threading
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from collections import OrderedDict
+    import cases, gpu_run
+    from skghoi_amd import train_fused
+    case = cases.build_case("train_tiny")
+    feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
+    det, tg = gpu_run.to_cuda(case["detections"]), gpu_run.to_cuda(case["targets"])
+
+    def make(lr):
+        head = gpu_run.build_head(case)
+        net = trainer.wrap_ddp(head, torch.device("cuda", 0))
+        return head, net, trainer.build_optimizer(net, lr=lr)
+
+    def steps(net, opt, stream, errs, tables):
+        try:
+            with torch.cuda.stream(stream):
+                for _ in range(12):
+                    trainer.train_step(net, opt, feats, det, case["shapes"], targets=tg, lazy=True)
+                stream.synchronize()
+        except Exception as e:                      # noqa: BLE001
+            errs.append(e)
+
+    # the TransH draws consume the global CPU generator: they do not reach the weights (SURVEY 8a-17), so two threads
+    # interleaving their draws still have to end with the sequential weights
+    seq = []
+    for lr in (1e-3, 3e-4):
+        head, net, opt = make(lr)
+        errs = []
+        steps(net, opt, torch.cuda.current_stream(), errs, None)
+        assert not errs
+        seq.append({k: v.detach().clone() for k, v in head.state_dict().items()})
+    pairs = [make(1e-3), make(3e-4)]
+    assert train_fused.context_for(pairs[0][0]) is not train_fused.context_for(pairs[1][0])
+    errs = []
+    ths = [threading.Thread(target=steps, args=(net, opt, torch.cuda.Stream(), errs, None)) for _, net, opt in pairs]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    torch.cuda.synchronize()
+    for (head, _, _), want in zip(pairs, seq):
+        for k, v in head.state_dict().items():
+            assert torch.equal(v, want[k]), k
+
 # ---------------------------------------------------------------------------------------------------- shell (CPU)
 def test_filter_flip_and_collate():
     det = dict(boxes=[[10., 5., 50., 40.], [0., 0., 20., 20.], [30., 10., 90., 70.], [5., 5., 9., 9.]],
@@ -179,6 +345,73 @@ def test_trainer_epochs_checkpoint_and_resume(tmp_path):
     tr2(3)
     for k, v in net2.state_dict().items():
         assert torch.equal(v, want[k]), k                                    # same shuffles, same optimizer state
+
+
+
+class _HeadLike(nn.Module):
+    """A net with the head's call shapes and hooks, on the CPU: forward(*inputs, targets) -> [..., loss dict]."""
+
+    def __init__(self, n_inputs):
+        super().__init__()
+        self.lin = nn.Linear(4, 2)
+        self.n_inputs = n_inputs
+        self.prefetched = []
+
+    def prefetch_train(self, detections, image_shapes, targets):
+        self.prefetched.append((detections, image_shapes, targets))
+        return None
+
+    def forward(self, *args):
+        assert len(args) == self.n_inputs + 1
+        x, targets = args[0], args[-1]
+        x = torch.stack(list(x)) if isinstance(x, (list, tuple)) else x
+        loss = (self.lin(x) - torch.stack(list(targets))).pow(2).mean()
+        z = loss.detach() * 0
+        return [dict(), dict(hoi_loss=loss, interactiveness_loss=z, transH_loss=z)]
+
+
+def test_trainer_default_step_takes_the_reference_loaders_three_tuple_batches():
+    """The reference's loader yields (images, detections, targets) (utils.py:34-42, custom_collate): the default step runs
+    `net(images, detections, targets)` on it, and the one-batch look-ahead -- which can only prepare batches of the head's
+    own call shape -- leaves such batches alone instead of raising (round-3 advisor finding: TypeError on the first step
+    of every epoch with two or more batches)."""
+    net = _HeadLike(2)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-2)
+    loader = trainer.make_loader(_ToyData(), batch_size=4, shuffle=False)
+    assert len(loader) == 3
+    tr = trainer.Trainer(net, opt, None, loader)
+    tr(2)
+    assert tr.iteration == 6 and tr.epoch == 2 and not net.prefetched
+    assert all(set(h) == {"hoi_loss", "interactiveness_loss", "transH_loss"} and np.isfinite(h["hoi_loss"])
+               for h in tr.history)
+    assert tr.history[-1]["hoi_loss"] < tr.history[0]["hoi_loss"]
+
+
+def test_trainer_default_step_takes_four_tuple_batches_and_only_prefetches_device_batches():
+    """Batches of the head's call shape (features, detections, image_shapes, targets).  On the CPU (detections not on a
+    HIP device) the look-ahead declines without raising; prefetch_batch hands over exactly the batch's last three parts when
+    the detections live on a device."""
+    net = _HeadLike(3)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(0)
+    batches = [(torch.randn(4, 4, generator=g), [dict(boxes=torch.zeros(1, 4))] * 4, [(8, 8)] * 4,
+                list(torch.randn(4, 2, generator=g))) for _ in range(3)]
+    tr = trainer.Trainer(net, opt, None, batches)
+    tr(1)
+    assert tr.iteration == 3 and not net.prefetched                 # CPU detections: nothing to prepare, nothing raised
+    # every malformed look-ahead is declined, never raised
+    assert trainer.prefetch_batch(net, 1, 2, 3) is None
+    assert trainer.prefetch_batch(net, None, [], [], []) is None
+    assert trainer.prefetch_batch(net, None, [dict(boxes=None)], [], []) is None
+    assert trainer.prefetch_batch(nn.Linear(2, 2), *batches[0]) is None
+
+    class _OnDevice:                                                 # (stands in for a device tensor on a box without one)
+        is_cuda = True
+    import unittest.mock as mock
+    with mock.patch.object(torch, "is_tensor", lambda t: isinstance(t, _OnDevice) or isinstance(t, torch.Tensor)):
+        dets = [dict(boxes=_OnDevice())]
+        trainer.prefetch_batch(net, "features", dets, [(8, 8)], ["t"])
+    assert net.prefetched == [(dets, [(8, 8)], ["t"])]
 
 
 def test_wrap_ddp_single_process_switches_direct_gradients():
@@ -403,7 +636,7 @@ def test_worker_thread_backward_changes_nothing(precision):
             f, d, s, t, c = batches[i % 2]
             head.box_roi_pool = gpu_run.CachedPool(c)
             l, _ = trainer.train_step(net, opt, f, d, s, targets=t, lazy=True, prefetch=batches[(i + 1) % 2][:4])
-            assert not train_fused._PENDING                      # joined in front of the optimizer
+            assert not train_fused.context_for(head).pending     # joined in front of the optimizer
             losses.append(l)
         return head, [trainer.read_losses(l) for l in losses]
 

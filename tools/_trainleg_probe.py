@@ -3,6 +3,7 @@ depend on what the caching allocator holds?   usage: _trainleg_probe.py bf16 gc 
 import os, sys, time, gc
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.dont_write_bytecode = True
 import torch
+from skghoi_amd import runtime as _rt; _rt.configure()      # hardware-queue setting, before the first GPU use
 import bench
 from skghoi_amd import trainer
 dev = torch.device("cuda", 0)

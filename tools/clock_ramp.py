@@ -2,6 +2,7 @@
 import sys, time
 sys.path.insert(0, "."); sys.dont_write_bytecode = True
 import torch
+from skghoi_amd import runtime as _rt; _rt.configure()      # hardware-queue setting, before the first GPU use
 from skghoi_amd.engine import gemm, SplitWeights
 M, N, K = 51200, 1024, 1024
 g = torch.Generator().manual_seed(0)

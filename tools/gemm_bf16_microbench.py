@@ -2,6 +2,7 @@
 import sys
 sys.path.insert(0, "."); sys.dont_write_bytecode = True
 import torch
+from skghoi_amd import runtime as _rt; _rt.configure()      # hardware-queue setting, before the first GPU use
 from skghoi_amd.autograd import gemm_bf16
 g = torch.Generator().manual_seed(0)
 for M, N, K in [(51200, 1024, 1024), (102400, 1024, 1024), (10240, 1024, 12544), (4096, 4096, 4096), (8192, 8192, 8192)]:

@@ -2,6 +2,7 @@
 import sys
 sys.path.insert(0, "."); sys.dont_write_bytecode = True
 import torch
+from skghoi_amd import runtime as _rt; _rt.configure()      # hardware-queue setting, before the first GPU use
 from skghoi_amd import _capi
 from skghoi_amd.engine import gemm, gemm_group, SplitWeights
 M, N, K = (int(sys.argv[1]) if len(sys.argv) > 1 else 51200), 1024, 1024

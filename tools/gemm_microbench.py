@@ -4,6 +4,7 @@ the fp16x2 split-operand loop and prints its max deviation from the exact fp32 l
 import sys
 sys.path.insert(0, "."); sys.dont_write_bytecode = True
 import torch
+from skghoi_amd import runtime as _rt; _rt.configure()      # hardware-queue setting, before the first GPU use
 from skghoi_amd import _capi
 from skghoi_amd.engine import gemm, SplitWeights, _NullCtx
 

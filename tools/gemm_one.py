@@ -2,6 +2,7 @@
 import sys
 sys.path.insert(0, "."); sys.dont_write_bytecode = True
 import torch
+from skghoi_amd import runtime as _rt; _rt.configure()      # hardware-queue setting, before the first GPU use
 from skghoi_amd.engine import gemm
 M, N, K, epi, reps = [int(x) for x in sys.argv[1:6]]
 g = torch.Generator().manual_seed(0)

@@ -3,6 +3,7 @@ import sys
 sys.path.insert(0, "."); sys.dont_write_bytecode = True
 import os
 import torch
+from skghoi_amd import runtime as _rt; _rt.configure()      # hardware-queue setting, before the first GPU use
 from skghoi_amd.engine import gemm, SplitWeights
 a = [int(x) for x in sys.argv[1:6]]
 M, N, K, epi, reps = a + [51200, 1024, 1024, 1, 300][len(a):]

@@ -3,6 +3,7 @@ A) all aliased to row 0 (leading dimension 0: every load hits the same line): if
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.dont_write_bytecode = True
 import torch
+from skghoi_amd import runtime as _rt; _rt.configure()      # hardware-queue setting, before the first GPU use
 from skghoi_amd import gemmx
 
 

@@ -5,6 +5,7 @@ usage: gemmx_gpu_time.py [bf16|fp32] [kind ...]      prints a K sweep and the al
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.dont_write_bytecode = True
 import torch
+from skghoi_amd import runtime as _rt; _rt.configure()      # hardware-queue setting, before the first GPU use
 from skghoi_amd import gemmx
 
 

@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.dont_write_bytecode = True
 import torch
+from skghoi_amd import runtime as _rt; _rt.configure()      # hardware-queue setting, before the first GPU use
 from skghoi_amd import gemmx
 
 BF16 = len(sys.argv) > 1 and sys.argv[1] == "bf16"

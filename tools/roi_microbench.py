@@ -2,6 +2,7 @@
 import sys
 sys.path.insert(0, "."); sys.dont_write_bytecode = True
 import torch
+from skghoi_amd import runtime as _rt; _rt.configure()      # hardware-queue setting, before the first GPU use
 from skghoi_amd import synth
 from skghoi_amd.roi_pool import MultiScaleRoIAlign
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32

@@ -4,6 +4,7 @@ usage: train_cpu_probe.py [precision=bf16] [batch=4]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.dont_write_bytecode = True
 import torch
+from skghoi_amd import runtime as _rt; _rt.configure()      # hardware-queue setting, before the first GPU use
 import bench
 from skghoi_amd import synth, trainer
 

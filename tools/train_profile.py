@@ -2,6 +2,7 @@
 import cProfile, pstats, sys, time
 sys.path.insert(0, "."); sys.dont_write_bytecode = True
 import torch
+from skghoi_amd import runtime as _rt; _rt.configure()      # hardware-queue setting, before the first GPU use
 import bench
 from skghoi_amd import synth, trainer
 dev = torch.device("cuda", 0)

@@ -1,6 +1,7 @@
 import sys, time
 sys.path.insert(0, "."); sys.dont_write_bytecode = True
 import torch, bench
+from skghoi_amd import runtime as _rt; _rt.configure()      # hardware-queue setting, before the first GPU use
 from skghoi_amd import synth, trainer
 dev = torch.device("cuda", 0); B = 4
 head = bench.build_head(dev).train()
