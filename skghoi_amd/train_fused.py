@@ -21,7 +21,9 @@ Parameter gradients are returned to autograd as views of one gradient arena laid
 branches = 16 contiguous slices), so `loss.backward()`, DDP and the optimizer see the reference's 408 parameters.
 """
 import ctypes as C
+import os
 import threading
+import weakref
 from operator import attrgetter, is_ as _is
 
 import numpy as np
@@ -772,8 +774,6 @@ class TrainContext:
     live = None
 
     def __init__(self):
-        import os
-        import weakref
         self._h = None
         self.pid = os.getpid()
         self.pending = []             # what the deferred backward still reads (tensors the plan names)
@@ -785,7 +785,6 @@ class TrainContext:
         TrainContext.live.add(self)
 
     def handle(self):
-        import os
         if self._h is None or self.pid != os.getpid():          # (a forked child: the parent's worker does not exist here)
             self._h = _capi.lib().skg_context_create()
             self.pid = os.getpid()
@@ -818,13 +817,12 @@ class TrainContext:
     def stage_wait(self, s):
         _check(_capi.lib().skg_ctx_train_backward_stage_wait(self.handle(), s), "skg_train_backward_f32 (deferred, stage %d)" % s)
 
-    def close(self):
-        import os
+    def close(self, _getpid=os.getpid, _lib=_capi.lib):
         h, self._h = self._h, None
-        if h and self.pid == os.getpid():
+        if h and self.pid == _getpid():
             try:
-                _capi.lib().skg_context_destroy(h)
-            except Exception:
+                _lib().skg_context_destroy(h)
+            except Exception:                       # noqa: BLE001  (interpreter shutdown)
                 pass
 
     def __del__(self):

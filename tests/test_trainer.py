@@ -145,9 +145,11 @@ def _dp_equiv_worker(rank, world, port, ref_path, q):
     head.box_roi_pool = _offset_pool(full, ref["n0"] * rank)
     net = trainer.wrap_ddp(head, torch.device("cuda", 0))
     assert net is head and head.grad_exchange is not None
-    opt = trainer.build_optimizer(net, lr=1e-3)
+    opt = trainer.build_optimizer(net, lr=1e-4)
     feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
-    torch.manual_seed(7 + rank)
+    # the TransH tables feed fc_head / fc_tail (HEAD:884-885), so the step depends on the host RNG: this rank's generator
+    # starts where the un-sharded run's generator stood when it drew the tables of image `rank`
+    torch.set_rng_state(ref["rng_state"][rank])
     from skghoi_amd import train_fused
     staged = []
     orig = train_fused.TrainContext.stage_wait
@@ -158,17 +160,17 @@ def _dp_equiv_worker(rank, world, port, ref_path, q):
     finally:
         train_fused.TrainContext.stage_wait = orig
     torch.cuda.synchronize()
-    worst_g = worst_o = worst_w = 0.0
+    worst_g, worst_o, worst_w = (0.0, ""), (0.0, ""), (0.0, "")
     for name, p in head.named_parameters():
         g = p.grad.detach().cpu()
         w = ref["grads"][name]
         scale = max(float(w.abs().max()), 1e-6)
-        worst_g = max(worst_g, max(float((g - w).abs().max()) - 1e-9, 0.0) / scale)
+        worst_g = max(worst_g, (max(float((g - w).abs().max()) - 1e-9, 0.0) / scale, name))
         if name in ref["oracle"]:
             o = ref["oracle"][name]
             so = max(float(o.abs().max()), 1e-6)
-            worst_o = max(worst_o, max(float((g - o).abs().max()) - 1e-9, 0.0) / so)
-        worst_w = max(worst_w, float((p.detach().cpu() - ref["weights"][name]).abs().max()))
+            worst_o = max(worst_o, (max(float((g - o).abs().max()) - 1e-9, 0.0) / so, name))
+        worst_w = max(worst_w, (float((p.detach().cpu() - ref["weights"][name]).abs().max()), name))
     q.put((rank, losses, worst_g, worst_o, worst_w, staged, head.grad_exchange.collectives))
     dist.barrier()
     dist.destroy_process_group()
@@ -189,16 +191,25 @@ def test_two_ranks_through_the_hip_arena_equal_the_unsharded_step(tmp_path):
     case = cases.build_case("train_tiny")
     head = gpu_run.build_head(case)
     net = trainer.wrap_ddp(head, torch.device("cuda", 0))
-    opt = trainer.build_optimizer(net, lr=1e-3)
+    opt = trainer.build_optimizer(net, lr=1e-4)
     feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
     det, tg = gpu_run.to_cuda(case["detections"]), gpu_run.to_cuda(case["targets"])
     n0 = int(head.engine().preprocess(det[:1], tg[:1], True, True).sizes[0])      # rows of image 0 in the pooled cache
-    torch.manual_seed(7)
-    single, _ = trainer.train_step(net, opt, feats, det, case["shapes"], targets=tg)
+    head.engine().debug = True
+    torch.manual_seed(case["rng_seed"])
+    state0 = torch.get_rng_state()
+    single, results = trainer.train_step(net, opt, feats, det, case["shapes"], targets=tg)
     torch.cuda.synchronize()
+    # where the generator stood when image 1's tables were drawn: image 0's six table fills + randperm(#negatives) (HEAD:574-580,
+    # 939) -- replayed on a copy of the start state
+    from skghoi_amd import transh
+    n_pos0 = int(head._last_train["pos_scores"][0].numel())
+    pairs0 = int(results[0]["boxes_h"].shape[0])
+    torch.set_rng_state(state0)
+    transh.draw_train(case["cfg"]["K"], [pairs0 * case["cfg"]["K"] - n_pos0], [n_pos0])
+    state1 = torch.get_rng_state()
     want, _ = helpers.oracle_train_grads(case)
-    # the transH term has no gradient towards the head; hoi + interactiveness are what the ranks share
-    ref = dict(n0=n0, grads={n: p.grad.detach().cpu().clone() for n, p in head.named_parameters()},
+    ref = dict(n0=n0, rng_state=[state0, state1], grads={n: p.grad.detach().cpu().clone() for n, p in head.named_parameters()},
                weights={n: p.detach().cpu().clone() for n, p in head.named_parameters()},
                oracle={n: torch.from_numpy(np.ascontiguousarray(g)) for n, g in want.items()})
     path = str(tmp_path / "unsharded.pt")
@@ -214,9 +225,11 @@ def test_two_ranks_through_the_hip_arena_equal_the_unsharded_step(tmp_path):
         p.join(timeout=120)
         assert p.exitcode == 0
     for rank, losses, worst_g, worst_o, worst_w, staged, k in res:
-        assert worst_g <= 1e-5, (rank, worst_g)          # exchanged arena == un-sharded arena (fp32 summation order)
-        assert worst_o <= 1e-4, (rank, worst_o)          # ... == oracle autograd of the two-image batch
-        assert worst_w <= 1e-6, (rank, worst_w)          # the replicas took the un-sharded step
+        assert worst_g[0] <= 1e-5, (rank, worst_g, worst_o, worst_w)    # exchanged arena == un-sharded arena (summation order)
+        assert worst_o[0] <= 1e-4, (rank, worst_o)          # ... == oracle autograd of the two-image batch
+        # the replicas took the un-sharded step (the reference's lr, main:109; AdamW's first update lr * g / (|g| + eps) turns
+        # the summation-order noise of near-zero gradient entries into at most a few 1e-7 of weight)
+        assert worst_w[0] <= 1e-6, (rank, worst_w)
         assert staged == sorted(staged) and len(staged) == k and 2 <= k <= 12, (staged, k)    # one host wait per chunk
     # data-parallel normaliser: local sum / (all_reduce_sum(n_p) / world)  ->  the mean over ranks is the batch loss
     for key in ("hoi_loss", "interactiveness_loss"):
@@ -244,8 +257,24 @@ def test_two_trainers_on_two_host_threads_do_not_share_a_job_slot():
         net = trainer.wrap_ddp(head, torch.device("cuda", 0))
         return head, net, trainer.build_optimizer(net, lr=lr)
 
-    def steps(net, opt, stream, errs, tables):
+    # The TransH tables feed fc_head / fc_tail (HEAD:884-885) and come from the GLOBAL CPU generator: to compare concurrent
+    # with sequential runs every trainer gets a generator stream of its own -- the draw swaps the trainer's state in and out
+    # of the global generator under a lock.
+    from skghoi_amd import transh
+    lock = threading.Lock()
+    local = threading.local()
+    orig_draw = transh.draw_train
+
+    def draw(*a, **k):
+        with lock:
+            torch.set_rng_state(local.state)
+            out = orig_draw(*a, **k)
+            local.state = torch.get_rng_state()
+        return out
+
+    def steps(net, opt, stream, errs, seed):
         try:
+            local.state = torch.Generator().manual_seed(seed).get_state()
             with torch.cuda.stream(stream):
                 for _ in range(12):
                     trainer.train_step(net, opt, feats, det, case["shapes"], targets=tg, lazy=True)
@@ -253,28 +282,32 @@ def test_two_trainers_on_two_host_threads_do_not_share_a_job_slot():
         except Exception as e:                      # noqa: BLE001
             errs.append(e)
 
-    # the TransH draws consume the global CPU generator: they do not reach the weights, so two threads
-    # interleaving their draws still have to end with the sequential weights
-    seq = []
-    for lr in (1e-3, 3e-4):
-        head, net, opt = make(lr)
+    transh.draw_train = draw
+    try:
+        seq = []
+        for lr, seed in ((1e-3, 5), (3e-4, 6)):
+            head, net, opt = make(lr)
+            errs = []
+            steps(net, opt, torch.cuda.current_stream(), errs, seed)
+            assert not errs, errs
+            seq.append({k: v.detach().clone() for k, v in head.state_dict().items()})
+        pairs = [make(1e-3), make(3e-4)]
+        assert train_fused.context_for(pairs[0][0]) is not train_fused.context_for(pairs[1][0])
         errs = []
-        steps(net, opt, torch.cuda.current_stream(), errs, None)
-        assert not errs
-        seq.append({k: v.detach().clone() for k, v in head.state_dict().items()})
-    pairs = [make(1e-3), make(3e-4)]
-    assert train_fused.context_for(pairs[0][0]) is not train_fused.context_for(pairs[1][0])
-    errs = []
-    ths = [threading.Thread(target=steps, args=(net, opt, torch.cuda.Stream(), errs, None)) for _, net, opt in pairs]
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
+        ths = [threading.Thread(target=steps, args=(net, opt, torch.cuda.Stream(), errs, seed))
+               for (_, net, opt), seed in zip(pairs, (5, 6))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    finally:
+        transh.draw_train = orig_draw
     assert not errs, errs
     torch.cuda.synchronize()
     for (head, _, _), want in zip(pairs, seq):
         for k, v in head.state_dict().items():
             assert torch.equal(v, want[k]), k
+
 
 # ---------------------------------------------------------------------------------------------------- shell (CPU)
 def test_filter_flip_and_collate():
