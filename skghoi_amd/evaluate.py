@@ -64,11 +64,13 @@ class DetectionAPMeter:
     """pocket.utils.DetectionAPMeter(num_cls, num_gt=..., algorithm='11P'): per-class lists of (score, label),
     AP = mean over t in {0, 0.1, ..., 1} of max precision at recall >= t (float64)."""
 
-    def __init__(self, num_cls, num_gt, algorithm="11P"):
+    def __init__(self, num_cls, num_gt=None, algorithm="11P"):
         if algorithm not in ("11P", "AUC"):
             raise ValueError("unknown algorithm %s" % algorithm)
         self.num_cls = num_cls
-        self.num_gt = [int(v) for v in num_gt]
+        # num_gt=None (the training / validation meter of utils.py:208, 285): recall is taken over the positives among the
+        # logged detections of the class
+        self.num_gt = None if num_gt is None else [int(v) for v in num_gt]
         self.algorithm = algorithm
         self.reset()
 
@@ -109,8 +111,85 @@ class DetectionAPMeter:
         out = torch.zeros(self.num_cls, dtype=torch.float64)
         for c in range(self.num_cls):
             if self._scores[c]:
-                out[c] = self._ap(torch.cat(self._scores[c]), torch.cat(self._labels[c]), self.num_gt[c], self.algorithm)
+                lab = torch.cat(self._labels[c])
+                n_gt = int(lab.sum()) if self.num_gt is None else self.num_gt[c]
+                out[c] = self._ap(torch.cat(self._scores[c]), lab, n_gt, self.algorithm)
         return out
+
+
+class DeviceAPMeter:
+    """The training-mAP / validation meter of the reference's engine (utils.py:208, 229, 263-282: every iteration the
+    batch's (scores, prediction, labels) are moved to the host, all-gathered over the ranks and appended to a
+    DetectionAPMeter(num_classes, algorithm='11P') on rank 0) without the per-iteration host synchronisation and collective:
+    `append` keeps the batch's three DEVICE tensors (no copy, no sync: the step loop stays asynchronous); `eval()` -- called
+    once, at the end of an epoch -- gathers the ranks' logs in one padded all_gather, sorts on the device and computes the
+    per-class 11-point APs with skg_eval_ap11_f64 (float64), on every rank.  Same numbers as DetectionAPMeter over the same
+    detections; ties between equal scores of one class resolve by rank, then arrival order (the reference: iteration, then
+    rank).  num_gt=None like the reference's meters: recall over the positives among the logged detections."""
+
+    def __init__(self, num_cls, num_gt=None, device="cuda", group=None):
+        self.num_cls = int(num_cls)
+        self.num_gt = None if num_gt is None else [int(v) for v in num_gt]
+        self.device = torch.device(device)
+        self.group = group
+        self.reset()
+
+    def reset(self):
+        self._log = []
+
+    def append(self, scores, classes, labels):
+        if scores.numel():
+            self._log.append((scores.detach(), classes.detach(), labels.detach()))
+
+    def append_results(self, results):
+        """results: the head's per-image dicts of one batch with `labels` (training mode, or eval mode with targets)."""
+        res = [r for r in results if "labels" in r and r["scores"].numel()]
+        if res:
+            self.append(torch.cat([r["scores"] for r in res]), torch.cat([r["prediction"] for r in res]),
+                        torch.cat([r["labels"] for r in res]))
+
+    def __len__(self):
+        return sum(int(s.shape[0]) for s, _, _ in self._log)
+
+    def eval(self):
+        import torch.distributed as dist
+        from . import _capi
+        from .engine import _stream
+        dev = self.device
+        if self._log:
+            mine = torch.stack([torch.cat([s.to(dev).float() for s, _, _ in self._log]),
+                                torch.cat([c.to(dev).float() for _, c, _ in self._log]),
+                                torch.cat([l.to(dev).float() for _, _, l in self._log])], dim=1)      # [L, 3]
+        else:
+            mine = torch.zeros(0, 3, device=dev)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            from .dist import _all_gather_ragged
+            mine = torch.cat(_all_gather_ragged(mine.contiguous(), self.group))
+        ap = torch.zeros(self.num_cls, dtype=torch.float64, device=dev)
+        if mine.shape[0] == 0:
+            return ap.cpu()
+        if dev.type != "cuda":                                  # (CPU tensors: rehearsals over gloo) the host meter
+            m = DetectionAPMeter(self.num_cls, self.num_gt)
+            m.append(mine[:, 0], mine[:, 1].long(), mine[:, 2])
+            return m.eval()
+        scores, cls, labels = mine[:, 0].contiguous(), mine[:, 1].long(), mine[:, 2].contiguous()
+        if ((cls < 0) | (cls >= self.num_cls)).any():
+            raise IndexError("a logged prediction is outside [0, %d)" % self.num_cls)
+        o1 = torch.sort(scores, descending=True, stable=True).indices
+        o2 = torch.sort(cls[o1], stable=True).indices
+        order = o1[o2]
+        lab_sorted = labels[order].contiguous()
+        class_off = torch.zeros(self.num_cls + 1, dtype=torch.int64, device=dev)
+        class_off[1:] = torch.cumsum(torch.bincount(cls, minlength=self.num_cls), 0)
+        if self.num_gt is None:
+            num_gt = torch.zeros(self.num_cls, device=dev, dtype=torch.float64).index_add_(0, cls, labels.double()).long()
+        else:
+            num_gt = torch.as_tensor(self.num_gt, dtype=torch.int64, device=dev)
+        thr = torch.linspace(0, 1, 11, dtype=torch.float64).to(dev)
+        _capi.check(_capi.lib().skg_eval_ap11_f64(lab_sorted.data_ptr(), class_off.data_ptr(), num_gt.data_ptr(),
+                                                  self.num_cls, thr.data_ptr(), ap.data_ptr(), _stream()),
+                    "skg_eval_ap11_f64")
+        return ap.cpu()
 
 
 class HOIEvaluator:

@@ -609,6 +609,19 @@ def make_loader(dataset, batch_size: int = 4, num_workers: int = 0, world_size: 
                       pin_memory=True, sampler=sampler)
 
 
+def relocate_to_device(x, device):
+    """pocket.ops.relocate_to_cuda for any device: tensors inside lists / tuples / dicts are moved (non-blocking), everything
+    else -- image sizes, strings -- is returned as it is."""
+    if torch.is_tensor(x):
+        return x.to(device, non_blocking=True)
+    if isinstance(x, dict):
+        return type(x)((k, relocate_to_device(v, device)) for k, v in x.items())
+    if isinstance(x, (list, tuple)):
+        y = [relocate_to_device(v, device) for v in x]
+        return y if isinstance(x, list) else (tuple(y) if type(x) is tuple else type(x)(*y))
+    return x
+
+
 def _with_lookahead(loader, enabled=True):
     """(batch, next batch or None) pairs; the loader is advanced one batch ahead of the step (nothing else changes: same
     batches, same order)."""
@@ -646,9 +659,11 @@ class Trainer:
     expects (features, detections, image_shapes, targets) batches and calls `train_step`."""
 
     def __init__(self, net, optimizer, scheduler=None, train_loader=None, rank=0, cache_dir=None, step_fn=None,
-                 print_interval=0, lazy_losses=False):
+                 print_interval=0, lazy_losses=False, val_loader=None, num_classes=117, train_meter=None, device=None):
         self.net, self.optimizer, self.scheduler = net, optimizer, scheduler
         self.train_loader = train_loader
+        self.val_loader = val_loader
+        self.num_classes = num_classes
         self.rank = rank
         self.cache_dir = cache_dir
         self.print_interval = print_interval
@@ -663,6 +678,63 @@ class Trainer:
         self.step_fn = step_fn or (lambda n, o, b, nxt=None: train_step(n, o, *b[:-1], targets=b[-1], lazy=lazy_losses,
                                                                         prefetch=nxt))
         self.history = []
+        # the training-mAP meter of the reference's engine (utils.py:208, 229): on when there is a validation loader (the
+        # end-of-epoch report needs it) unless switched explicitly
+        self.device = device
+        self.train_meter = (val_loader is not None) if train_meter is None else bool(train_meter)
+        self.meter = None
+        self.last_report = None
+
+    # -- meters and validation (utils.py:208, 229-299)
+    def _meter_device(self):
+        if self.device is not None:
+            return torch.device(self.device)
+        p = next(self._module().parameters(), None)
+        return p.device if p is not None else torch.device("cpu")
+
+    def _new_meter(self):
+        from .evaluate import DeviceAPMeter
+        return DeviceAPMeter(self.num_classes, device=self._meter_device())
+
+    def log_results(self, results, meter):
+        """utils.py:263-282 (_synchronise_and_log_results) without its per-iteration host copy and all_gather: the batch's
+        (scores, prediction, labels) stay on the device in `meter`; the ranks' logs meet once, in meter.eval()."""
+        if results:
+            meter.append_results([r for r in results if isinstance(r, dict)])
+
+    @torch.no_grad()
+    def validate(self):
+        """utils.py:283-299: eval mode over the (sharded) validation loader -- batches carry their targets, so the head takes
+        its eval-with-targets pass and the results carry `labels` -- into a fresh 117-class 11-point meter; returns the
+        per-class APs (every rank holds them; the reference returns them on rank 0 only)."""
+        meter = self._new_meter()
+        dev = self._meter_device()
+        self.net.eval()
+        for batch in self.val_loader:
+            inputs = relocate_to_device(batch, dev)
+            results = self.net(*inputs)
+            self.log_results(results, meter)
+        return meter.eval()
+
+    def on_end_epoch(self):
+        """utils.py:232-249: training mAP off the epoch's meter, validation mAP, one report line on rank 0, meter reset."""
+        import time
+        t0 = time.perf_counter()
+        ap_train = self.meter.eval() if self.meter is not None else None
+        t1 = time.perf_counter()
+        ap_val = self.validate() if self.val_loader is not None else None
+        t2 = time.perf_counter()
+        self.last_report = dict(epoch=self.epoch, training_map=(None if ap_train is None else float(ap_train.mean())),
+                                validation_map=(None if ap_val is None else float(ap_val.mean())),
+                                evaluation_time_s=t1 - t0, total_time_s=t2 - t0)
+        if self.rank == 0 and (ap_train is not None or ap_val is not None):
+            fmt = lambda v: "n/a" if v is None else "%.4f" % v
+            print("Epoch: {} | training mAP: {}, evaluation time: {:.2f}s |validation mAP: {}, total time: {:.2f}s\n".format(
+                self.epoch, fmt(self.last_report["training_map"]), t1 - t0, fmt(self.last_report["validation_map"]),
+                t2 - t0))
+        if self.meter is not None:
+            self.meter.reset()
+        return self.last_report
 
     # -- checkpoints (main:85-93, pocket engines' save_checkpoint)
     def _module(self):
@@ -697,9 +769,13 @@ class Trainer:
         if hasattr(sampler, "set_epoch"):
             sampler.set_epoch(self.epoch)                   # pocket: reshuffle the shards every epoch
         self.net.train()
+        if self.train_meter and self.meter is None:
+            self.meter = self._new_meter()
         for batch, nxt in _with_lookahead(self.train_loader, self.lookahead):
-            losses, _ = self.step_fn(self.net, self.optimizer, batch, nxt) if self.lookahead else \
+            losses, results = self.step_fn(self.net, self.optimizer, batch, nxt) if self.lookahead else \
                 self.step_fn(self.net, self.optimizer, batch)
+            if self.meter is not None:
+                self.log_results(results, self.meter)
             self.iteration += 1
             self.history.append(losses)
             if self.print_interval and self.iteration % self.print_interval == 0:
@@ -710,6 +786,8 @@ class Trainer:
                                                          ", ".join("%s %.4f" % kv for kv in losses.items())))
         if self.lazy_losses:
             self.history = [h if all(isinstance(v, float) for v in h.values()) else read_losses(h) for h in self.history]
+        if self.meter is not None or self.val_loader is not None:
+            self.on_end_epoch()
         self.epoch += 1
         if self.scheduler is not None:
             self.scheduler.step()

@@ -1,6 +1,8 @@
 """world_size-2 `gloo` tests (CPU) of the N>1 path: image sharding, max-over-ranks timing, the fused 3-element loss
 normaliser all-reduce (replaces the reference's three barrier + all-reduce pairs, HEAD:167-172/194-199/223-228)."""
 import os
+
+import numpy as np
 import socket
 
 import pytest
@@ -248,3 +250,41 @@ def test_arena_gradient_exchange_equals_single_process_batch_gradients():
         assert calls[0] == 3 and len(calls) == 1 + k and 2 <= k <= 12, calls
         assert sum(calls[1:]) == total
         assert worst <= 1e-4, worst               # fp32 summation order, like the other gradient tests
+
+
+def _meter_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    from skghoi_amd import evaluate as ev
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rs = np.random.RandomState(5)
+    n = 600
+    sc = torch.tensor(np.round(rs.uniform(0, 1, n), 3), dtype=torch.float32)
+    cl = torch.tensor(rs.randint(0, 9, n)); lb = torch.tensor((rs.uniform(0, 1, n) < 0.25).astype(np.float32))
+    whole = ev.DetectionAPMeter(9); whole.append(sc, cl, lb)
+    m = ev.DeviceAPMeter(9, device="cpu")
+    lo, hi = (0, 250) if rank == 0 else (250, n)                 # ragged shards; rank order = global order
+    for a in range(lo, hi, 100):
+        m.append(sc[a:min(a + 100, hi)], cl[a:min(a + 100, hi)], lb[a:min(a + 100, hi)])
+    got = m.eval()                                               # ONE padded all_gather, every rank gets the APs
+    empty = ev.DeviceAPMeter(9, device="cpu") if rank == 1 else m
+    _ = empty.eval()                                             # a rank with an empty log still meets its peer
+    q.put((rank, torch.equal(got, whole.eval()), float(got.mean())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_training_meter_gathers_the_ranks_logs_once():
+    """utils.py:263-282 all-gathers every iteration's results; the asynchronous meter keeps each rank's log on its device and
+    gathers once in eval(): two gloo ranks with ragged shards reproduce the single meter over all detections."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_meter_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res) and res[0][2] == res[1][2] > 0

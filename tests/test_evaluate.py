@@ -176,3 +176,51 @@ def test_vcoco_pickle_is_consumable_the_way_vsrl_eval_reads_it(tmp_path):
     gt = [dict(image_id=4711, person_box=[12., 11., 108., 205.], role_box=[52., 58., 149., 161.])]
     assert VC.role_ap(dets, gt, "hold", 1) == pytest.approx(1.0)                # found at rank 1
     assert VC.role_ap(dets, gt, "cut", 2) == pytest.approx(0.0)                 # the cut detection is another pair
+
+
+def _meter_case(seed, n=400, ncls=7):
+    rs = np.random.RandomState(seed)
+    sc = torch.tensor(np.round(rs.uniform(0, 1, n), 2), dtype=torch.float32)          # two decimals: plenty of score ties
+    cl = torch.tensor(rs.randint(0, ncls, n)); cl[cl == 3] = 2                         # class 3 never predicted
+    lb = torch.tensor((rs.uniform(0, 1, n) < 0.3).astype(np.float32)); lb[cl == 5] = 0  # class 5 without a positive
+    return sc, cl, lb
+
+
+def test_training_meter_without_num_gt_matches_the_loop_oracle():
+    """The reference's training / validation meters carry no ground-truth counts (utils.py:208, 285): recall over the
+    positives among the logged detections.  Host meter and the asynchronous meter (CPU tensors here) against the oracle."""
+    sc, cl, lb = _meter_case(0)
+    host = ev.DetectionAPMeter(7)
+    dev = ev.DeviceAPMeter(7, device="cpu")
+    for lo in range(0, 400, 64):                                    # appended batch by batch, like the training loop
+        host.append(sc[lo:lo + 64], cl[lo:lo + 64], lb[lo:lo + 64]); dev.append(sc[lo:lo + 64], cl[lo:lo + 64], lb[lo:lo + 64])
+    a, b = host.eval(), dev.eval()
+    assert torch.equal(a, b) and len(dev) == 400
+    for c in range(7):
+        m = cl == c
+        want = EO.ap_11p(sc[m].double().numpy(), lb[m].double().numpy(), int(lb[m].sum())) if m.any() else 0.0
+        assert abs(float(a[c]) - want) < 1e-12, c
+    assert float(a[3]) == 0.0 and float(a[5]) == 0.0
+    dev.reset()
+    assert len(dev) == 0 and float(dev.eval().sum()) == 0.0
+    # results-dict form: what Trainer.log_results feeds it
+    res = [dict(scores=sc[:100], prediction=cl[:100], labels=lb[:100]), dict(scores=sc[:0], prediction=cl[:0], labels=lb[:0]),
+           dict(scores=sc[100:], prediction=cl[100:], labels=lb[100:]), dict(hoi_loss=torch.tensor(1.0))]
+    dev.append_results(res)
+    assert torch.equal(dev.eval(), a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2])
+def test_training_meter_on_the_device_matches_the_host_meter(seed):
+    sc, cl, lb = _meter_case(seed, n=3000, ncls=117)
+    host = ev.DetectionAPMeter(117)
+    dev = ev.DeviceAPMeter(117, device="cuda")
+    for lo in range(0, 3000, 500):
+        host.append(sc[lo:lo + 500], cl[lo:lo + 500], lb[lo:lo + 500])
+        dev.append(sc[lo:lo + 500].cuda(), cl[lo:lo + 500].cuda(), lb[lo:lo + 500].cuda())
+    assert torch.equal(host.eval(), dev.eval())
+    with_gt = [int(lb[cl == c].sum()) + 2 for c in range(117)]
+    h2 = ev.DetectionAPMeter(117, with_gt); h2.append(sc, cl, lb)
+    d2 = ev.DeviceAPMeter(117, with_gt, device="cuda"); d2.append(sc.cuda(), cl.cuda(), lb.cuda())
+    assert torch.equal(h2.eval(), d2.eval())

@@ -309,6 +309,64 @@ def test_two_trainers_on_two_host_threads_do_not_share_a_job_slot():
             assert torch.equal(v, want[k]), k
 
 
+
+@pytest.mark.gpu
+def test_training_speed_survives_a_validation_pass_with_the_default_queue_count():
+    """The reference validates between epochs in the SAME process (utils.py:232-249).  Round 3 recorded a slow scheduling
+    mode for the training step once a process had replayed a hipGraph; the product now sets nothing in the
+    environment by itself, so this runs a child with the runtime's DEFAULT hardware-queue count: 60 bf16 steps, a validation
+    pass (eval with targets at batch 4 + single-image forwards replaying a captured plan), 60 more steps -- the second
+    block's step time stays within 10 % of the first."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "SKG_HW_QUEUES")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "alternation_probe.py"), "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stderr.decode()[-2000:]
+    rec = json.loads(lines[-1])
+    print(rec)
+    assert rec["runtime"]["GPU_MAX_HW_QUEUES"] is None            # the runtime's default
+    assert rec["graph_plans"] >= 1 and 0.0 <= rec["validation_map"] <= 1.0
+    assert rec["ratio"] <= 1.10, rec
+
+
+@pytest.mark.gpu
+def test_trainer_epoch_with_validation_on_the_real_head(capsys):
+    """Trainer over batches of the head's own call shape with a validation loader: per-iteration results into the
+    asynchronous 117-class meter, the end-of-epoch report (training mAP, validation mAP), and validate() == a host
+    DetectionAPMeter over the same eval-with-targets forwards."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from collections import OrderedDict
+    import cases, gpu_run
+    from skghoi_amd import evaluate as ev
+    case = cases.build_case("train_tiny")
+    head = gpu_run.build_head(case)
+    feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
+    det, tg = gpu_run.to_cuda(case["detections"]), gpu_run.to_cuda(case["targets"])
+    batch = (feats, det, case["shapes"], tg)
+    net = trainer.wrap_ddp(head, torch.device("cuda", 0))
+    opt = trainer.build_optimizer(net, lr=1e-4)
+    torch.manual_seed(5)
+    tr = trainer.Trainer(net, opt, None, [batch] * 3, val_loader=[batch] * 2, num_classes=case["cfg"]["K"], lazy_losses=True)
+    tr(2)
+    out = capsys.readouterr().out
+    assert out.count("training mAP") == 2 and tr.iteration == 6 and head.training
+    rep = tr.last_report
+    assert 0.0 <= rep["training_map"] <= 1.0 and 0.0 <= rep["validation_map"] <= 1.0
+    torch.manual_seed(9)
+    ap = tr.validate()
+    m = ev.DetectionAPMeter(case["cfg"]["K"])
+    torch.manual_seed(9)
+    with torch.no_grad():
+        for b in [batch] * 2:
+            for r in head(*b):
+                m.append(r["scores"], r["prediction"], r["labels"])
+    assert torch.allclose(ap, m.eval(), atol=1e-12) and float(ap.sum()) > 0
+
 # ---------------------------------------------------------------------------------------------------- shell (CPU)
 def test_filter_flip_and_collate():
     det = dict(boxes=[[10., 5., 50., 40.], [0., 0., 20., 20.], [30., 10., 90., 70.], [5., 5., 9., 9.]],
@@ -445,6 +503,50 @@ def test_trainer_default_step_takes_four_tuple_batches_and_only_prefetches_devic
         dets = [dict(boxes=_OnDevice())]
         trainer.prefetch_batch(net, "features", dets, [(8, 8)], ["t"])
     assert net.prefetched == [(dets, [(8, 8)], ["t"])]
+
+
+class _ValNet(_HeadLike):
+    """_HeadLike whose forward also returns per-image result dicts with labels (training mode, or eval with targets)."""
+
+    def forward(self, *args):
+        out = super().forward(*args)
+        x, targets = args[0], args[-1]
+        x = torch.stack(list(x)) if isinstance(x, (list, tuple)) else x
+        logits = self.lin(x).detach()
+        res = [dict(scores=torch.sigmoid(l), prediction=torch.arange(2), labels=(torch.stack(list(targets))[i] > 0).float())
+               for i, l in enumerate(logits)]
+        return res + ([out[-1]] if self.training else [])
+
+
+def test_trainer_validates_and_reports_training_map_at_the_end_of_an_epoch(capsys):
+    """utils.py:232-299: per-iteration results into the 11-point training meter, at the end of the epoch the training mAP,
+    a validation pass in eval mode over the validation loader (batches with targets), one report line, meter reset; the
+    next epoch trains again (net back in training mode)."""
+    from skghoi_amd import evaluate as ev
+    net = _ValNet(2)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-2)
+    loader = trainer.make_loader(_ToyData(), batch_size=4, shuffle=False)
+    val = trainer.make_loader(_ToyData(), batch_size=4, shuffle=False)
+    tr = trainer.Trainer(net, opt, None, loader, val_loader=val, num_classes=2, device="cpu")
+    assert tr.train_meter
+    tr(2)
+    out = capsys.readouterr().out
+    assert out.count("training mAP") == 2 and "validation mAP" in out
+    rep = tr.last_report
+    assert rep["epoch"] == 1 and 0.0 <= rep["training_map"] <= 1.0 and 0.0 <= rep["validation_map"] <= 1.0
+    assert len(tr.meter) == 0 and tr.iteration == 6                 # reset after the report
+    # validate() on its own == a host meter over the same eval-mode forwards
+    ap = tr.validate()
+    assert not net.training
+    m = ev.DetectionAPMeter(2)
+    with torch.no_grad():
+        for batch in val:
+            for r in net(*batch):
+                m.append(r["scores"], r["prediction"], r["labels"])
+    assert torch.equal(ap, m.eval()) and float(ap.mean()) == pytest.approx(rep["validation_map"])
+    # relocate_to_device keeps the batch's structure
+    b = trainer.relocate_to_device(([torch.zeros(2)], [dict(boxes=torch.zeros(1, 4), n=3)], ((8, 8),), None), "cpu")
+    assert isinstance(b, tuple) and isinstance(b[1][0], dict) and b[1][0]["n"] == 3 and b[2] == ((8, 8),) and b[3] is None
 
 
 def test_wrap_ddp_single_process_switches_direct_gradients():
