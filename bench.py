@@ -778,7 +778,7 @@ def main():
         # RCCL / xGMI) -- every rank runs it; value = whole-job images/s over the max-over-ranks time
         _trainer.limit_host_threads(world)
         ks = 40
-        el_t, losses, inf = run_train(4, "bf16", ks, 10, device, rank, world, True, measure=(rank == 0))
+        el_t, losses, inf = run_train(4, "bf16", ks, 10, device, rank, world, True, measure=True)   # (every rank: the steps hold collectives)
         el_t = skd.max_over_ranks(el_t, device=device)
         ms = el_t / ks * 1e3
         rec = dict(ms_per_step=round(ms, 3), images_per_s=round(4 * world * ks / el_t, 2), batch_per_gpu=4, steps=ks,

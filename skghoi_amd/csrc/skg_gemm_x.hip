@@ -25,6 +25,7 @@
 // per quad serialises them behind s_waitcnt and runs at a fraction of the speed).  A ragged last tile, operands
 // without 16-byte alignment and row-contiguous operands whose extent is not a multiple of 4 take the generic loop.
 #include "skg_common.h"
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 
@@ -986,6 +987,363 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_
             }
 }
 
+// ================================================================================================ bf16 twins, direct to LDS
+// skg_gemmx_t16_kernel: the same products when BOTH operands come with their bf16 twins (skg_gemmx_desc.A16 / B16) -- what
+// the training plan hands over once its producer kernels and the optimizer write twins.  Nothing passes through VGPRs on the
+// way in: the operand tiles are staged by global_load_lds_dwordx4 straight into a ring of TNB LDS buffers (TNB - 1 tiles in
+// flight across the one barrier of a k-step, counted s_waitcnt vmcnt), there is no conversion and no ds_write in the loop,
+// and the k-step is 64 deep -- the loop the round-3 decomposition asked for (global loads, conversion + ds_write and
+// fragment reads + MFMAs of the register-staged loop ran one after the other: ~1000 cycles per 32 k for 256 of MFMA).
+//
+// LDS images (16 KiB per operand tile, lane-linear per wave instruction as the DMA requires; swizzles live on the SOURCE side):
+//   k-contiguous operand  : [128 rows][64 k] bf16, 128-byte rows; 16-byte slot s of row r holds k-piece s ^ ((r >> 1) & 7):
+//                           the ds_read_b128 of a fragment (32 rows, one k-piece) is conflict-free
+//   row-contiguous operand: [64 k][128 rows] bf16, 256-byte rows; slot s of k-row k holds the 8-row chunk
+//                           s ^ (((k & 3) << 2) | ((k >> 2) & 3)); fragments come out by ds_read_b64_tr_b16 (the hardware
+//                           transpose read: 16 lanes fetch a 4 k x 16 row block, each receives its row's 4 k) -- no operand
+//                           is ever transposed in registers or memory
+// A ragged last k-tile (K or the split slice not a multiple of 64) is filled through registers, zero beyond the end, into the
+// same images.  The bias gradient (row sums of A over k) is one more MFMA per A fragment against a fragment of ones in the
+// workgroups of column tile 0: the fp32 sum of the bf16-rounded operand -- what the reference's autocast backward sums
+// (grad_output is bf16 there).  Same tiles (128 x 128, 4 waves of 64 x 64), same split-K, same epilogues as above.
+#define TBK 64
+// TNB = LDS buffers of the ring (TNB - 1 tiles in flight per workgroup).  Measured (tools/t16_time.sh, profiles/r04_gemmx_t16_*):
+// 3 and 4 buffers at one workgroup per CU time the same -- the loop then runs at the L2 -> CU rate, ~1250 cycles per 64-k step
+// for the 32 KiB a 128 x 128 tile draws per step -- while 2 buffers at TWO workgroups per CU (64 KiB of LDS each) are as fast on
+// one tile per CU and 1.4x faster once a CU has several tiles (N = 4096: 76 -> 53 us; M = 102400: 523 -> 364 us): the other
+// workgroup's loads, and its epilogue, run under this one's MFMAs.
+#ifndef TNB
+#define TNB 2
+#endif
+#define TOPB (128 * TBK * 2)                 // bytes of one operand tile
+#define TBUFB (2 * TOPB)                     // A | B
+
+typedef short t16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int tswz_rc(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
+
+// Pins a wave-uniform pointer in SGPRs so that `base + per-lane 32-bit offset` selects the saddr + voffset form.
+__device__ __forceinline__ const char* t_uniform_ptr(const char* p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+
+struct TLoad { uint32_t o[4]; };             // per-lane byte offsets of the four 16-byte pieces a thread stages per tile
+
+template <bool KC>
+__device__ __forceinline__ void tprep(const XOperand& op, int row0, int tid, TLoad& L) {
+    const int w = tid >> 6, l = tid & 63;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (KC) {                            // chunk 4 w + i = rows 32 w + 8 i .. + 7; lane: row l >> 3, slot l & 7
+            const int r = 32 * w + 8 * i + (l >> 3);
+            const int q = (l & 7) ^ ((r >> 1) & 7);
+            L.o[i] = (uint32_t)((xoff(min(row0 + r, op.rows - 1), op.rshift, op.rstride, op.s_row) + 8 * q) * 2);
+        } else {                             // chunk 4 w + i = k-rows 16 w + 4 i .. + 3; lane: k-row l >> 4, slot l & 15
+            const int k = 16 * w + 4 * i + (l >> 4);
+            const int ch = (l & 15) ^ tswz_rc(k);
+            const int64_t ro = xoff(max(0, min(row0 + 8 * ch, op.rows - 8)), op.rshift, op.rstride, 1);
+            L.o[i] = (uint32_t)((ro + (int64_t)k * op.s_k) * 2);
+        }
+    }
+}
+
+// the four DMA instructions of one operand tile of this wave: 4 x 1 KiB, LDS destination wave-uniform
+template <bool KC>
+__device__ __forceinline__ void tissue(const XOperand& op, const uint16_t* base16, const TLoad& L, int k0, uint8_t* dst, int wu) {
+    const char* gb = t_uniform_ptr(reinterpret_cast<const char*>(base16) +
+                                     2 * xoff(k0, op.kshift, op.kstride, KC ? 1 : op.s_k));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + L.o[i]),
+                                         (__attribute__((address_space(3))) void*)(dst + (4 * wu + i) * 1024), 16, 0, 0);
+}
+
+// ragged tile through registers: the thread's four pieces, zero where k >= kend, into the image the DMA would have written
+template <bool KC>
+__device__ __forceinline__ void tfill(const XOperand& op, const uint16_t* base16, int row0, int k0, int kend, int tid,
+                                      uint8_t* dst) {
+    const int w = tid >> 6, l = tid & 63;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (KC) {
+            const int r = 32 * w + 8 * i + (l >> 3);
+            const int q = (l & 7) ^ ((r >> 1) & 7);
+            const int k = k0 + 8 * q;
+            const uint16_t* p = base16 + xoff(min(row0 + r, op.rows - 1), op.rshift, op.rstride, op.s_row) +
+                                xoff(k, op.kshift, op.kstride, 1);
+            if (k + 7 < kend) v = *reinterpret_cast<const uint4*>(p);
+            else if (k < kend) {
+                uint16_t e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = k + j < kend ? p[j] : (uint16_t)0;
+                v = make_uint4(e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16), e[4] | ((uint32_t)e[5] << 16),
+                               e[6] | ((uint32_t)e[7] << 16));
+            }
+        } else {
+            const int kl = 16 * w + 4 * i + (l >> 4);
+            const int ch = (l & 15) ^ tswz_rc(kl);
+            if (k0 + kl < kend)
+                v = *reinterpret_cast<const uint4*>(base16 + xoff(max(0, min(row0 + 8 * ch, op.rows - 8)), op.rshift, op.rstride, 1) +
+                                                    xoff(k0 + kl, op.kshift, op.kstride, op.s_k));
+        }
+        *reinterpret_cast<uint4*>(dst + (4 * w + i) * 1024 + l * 16) = v;
+    }
+}
+
+// ---- fragment reads.  Written as inline asm: for a C++ LDS read hipcc orders the access behind every LDS-DMA still in flight
+// (s_waitcnt vmcnt(0) in front of the first ds_read of the step -- seen in the ISA), which would drain the ring every step.
+// The asm reads are ordered by hand: the step's counted vmcnt + barrier before them, counted lgkmcnt waits (tied to the
+// fragment registers, so that the MFMAs cannot move above them) after.
+template <int OFF>
+__device__ __forceinline__ bf16x8 t_ds_b128(uint32_t addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ t16x4 t_ds_tr(uint32_t addr) {      // (EXEC is all ones here: no divergence around the k loop)
+    t16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
+// Per-lane LDS byte offsets of an operand's fragments inside its tile (loop invariant).
+//   k-contiguous : f[ks] = address of k-step ks for the first 32-row block; the second block is + 4096 (32 rows x 128 B)
+//   row-contig.  : f[2 t + j] = address of block t (32 rows), k half j (4 k) for k-step 0; k-step ks is + 4096 (16 k-rows x 256 B)
+struct TFrag { uint32_t f[4]; };
+template <bool KC>
+__device__ __forceinline__ void tfrag_prep(int rb, int lane, TFrag& F) {
+    if (KC) {
+        const int r = rb + (lane & 31), sw = (r >> 1) & 7, h = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) F.f[ks] = (uint32_t)(r * 128 + (((2 * ks + h) ^ sw) << 4));
+    } else {
+        // group g = lane >> 4 of 16 lanes reads the block k = 8 (g >> 1) + 4 j .. + 3, rows rb + 32 t + 16 (g & 1) .. + 15; lane
+        // 4 q + p of the group addresses k-row q, 8-byte piece p of the block's 32 bytes per k-row
+        const int g = lane >> 4, i = lane & 15, pq = i >> 2, pp = i & 3;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ch = ((rb + 32 * t + 16 * (g & 1)) >> 3) + (pp >> 1);
+                const int k = 8 * (g >> 1) + 4 * j + pq;
+                F.f[2 * t + j] = (uint32_t)(k * 256 + ((ch ^ tswz_rc(k)) << 4) + 8 * (pp & 1));
+            }
+    }
+}
+
+// both fragments (32-row blocks 0 and 1) of k-step KS
+template <bool KC, int KS>
+__device__ __forceinline__ void tfrag2(uint32_t base, const TFrag& F, bf16x8& f0, bf16x8& f1) {
+    if (KC) {
+        f0 = t_ds_b128<0>(base + F.f[KS]);
+        f1 = t_ds_b128<4096>(base + F.f[KS]);
+    } else {
+        const t16x4 a = t_ds_tr<4096 * KS>(base + F.f[0]), b = t_ds_tr<4096 * KS>(base + F.f[1]);
+        const t16x4 c = t_ds_tr<4096 * KS>(base + F.f[2]), d = t_ds_tr<4096 * KS>(base + F.f[3]);
+        f0 = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+        f1 = __builtin_shufflevector(c, d, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+// (the row-contiguous form above shuffles asm outputs: the halves are tied to the wait instead, see T_WAIT_RC)
+
+// One 64-deep k-step from the tile pair at LDS byte address `buf` (A at + 0, B at + TOPB).  Reads of k-step ks + 2 are issued
+// before the MFMAs of k-step ks: at most two k-steps of reads are outstanding (the LGKM counter holds 15), and the LDS pipe
+// works while the matrix pipe does.
+template <bool AK, bool BK_>
+__device__ __forceinline__ void tstep(uint32_t buf, const TFrag& FA, const TFrag& FB, f32x16 (&acc)[2][2], f32x16 (&rsa)[2],
+                                      bool rowsum) {
+    constexpr int NR = (AK ? 2 : 4) + (BK_ ? 2 : 4);          // LDS instructions per k-step
+    bf16x8 a0[4], a1[4], b0[4], b1[4];
+    const uint32_t ab = buf, bb = buf + TOPB;
+#define T_READ(KS) { tfrag2<AK, KS>(ab, FA, a0[KS], a1[KS]); tfrag2<BK_, KS>(bb, FB, b0[KS], b1[KS]); }
+#define T_WAIT(KS, LEFT)                                                                                                  \
+    {                                                                                                                     \
+        if (LEFT == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[KS]), "+v"(a1[KS]), "+v"(b0[KS]), "+v"(b1[KS]));     \
+        else if (NR == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0[KS]), "+v"(a1[KS]), "+v"(b0[KS]), "+v"(b1[KS])); \
+        else if (NR == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a0[KS]), "+v"(a1[KS]), "+v"(b0[KS]), "+v"(b1[KS])); \
+        else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a0[KS]), "+v"(a1[KS]), "+v"(b0[KS]), "+v"(b1[KS]));              \
+    }
+#define T_MFMA(KS)                                                                                                        \
+    {                                                                                                                     \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[KS], b0[KS], acc[0][0], 0, 0, 0);                          \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[KS], b1[KS], acc[0][1], 0, 0, 0);                          \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[KS], b0[KS], acc[1][0], 0, 0, 0);                          \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[KS], b1[KS], acc[1][1], 0, 0, 0);                          \
+        if (rowsum) {                                                                                                     \
+            const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};                         \
+            rsa[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[KS], ones, rsa[0], 0, 0, 0);                              \
+            rsa[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[KS], ones, rsa[1], 0, 0, 0);                              \
+        }                                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+    }
+    T_READ(0) T_READ(1)
+    T_WAIT(0, 1) T_READ(2) T_MFMA(0)
+    T_WAIT(1, 1) T_READ(3) T_MFMA(1)
+    T_WAIT(2, 1) T_MFMA(2)
+    T_WAIT(3, 0) T_MFMA(3)
+#undef T_READ
+#undef T_WAIT
+#undef T_MFMA
+}
+
+template <bool AK, bool BK_>
+__device__ __forceinline__ void tmain(const skg_gemmx_desc& d, const XOperand& A, const XOperand& B, const XCtx& c, int kt0,
+                                      int kt1, uint8_t* smem, f32x16 (&acc)[2][2], f32x16 (&rsa)[2]) {
+    const int tid = c.tid, lane = tid & 63;
+    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: the DMA's LDS base stays scalar
+    const bool rowsum = c.do_rowsum && c.wn == 0;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;   // LDS byte address of the ring
+    TLoad LA, LB;
+    tprep<AK>(A, c.m0, tid, LA);
+    tprep<BK_>(B, c.n0, tid, LB);
+    TFrag FA, FB;
+    tfrag_prep<AK>(c.wm * 64, lane, FA);
+    tfrag_prep<BK_>(c.wn * 64, lane, FB);
+    const int ktf = (c.kend == kt1 * TBK) ? kt1 : max(kt0, kt1 - 1);       // [kt0, ktf): whole tiles
+    const int nt = ktf - kt0;
+    const uint16_t* const a16 = d.A16;                     // (locals: no descriptor reloads inside the k loop)
+    const uint16_t* const b16 = d.B16;
+    auto issue = [&](int t, int buf) {
+        uint8_t* dst = smem + buf * TBUFB;
+        tissue<AK>(A, a16, LA, (kt0 + t) * TBK, dst, wu);
+        tissue<BK_>(B, b16, LB, (kt0 + t) * TBK, dst + TOPB, wu);
+    };
+    static_assert(TNB >= 2 && TNB <= 4, "the waits below count TNB - 1 tiles in flight");
+#pragma unroll
+    for (int t = 0; t < TNB - 1; ++t)
+        if (t < nt) issue(t, t);
+    int cur = 0;                                           // buffer of tile t; tile t + TNB - 1 goes to the one before it in the ring
+    for (int t = 0; t < nt; ++t) {
+        // tile t has landed once all but the newer tiles' DMA instructions of THIS wave (eight per tile) are done ...
+        const int ahead = nt - 1 - t;                      // tiles issued after tile t
+        if (TNB == 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (TNB >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... and every wave has passed this barrier; behind it nobody reads buffer (t - 1) % TNB any more, which is where
+        // tile t + TNB - 1 goes
+        asm volatile("s_barrier" ::: "memory");
+        const int prev = cur == 0 ? TNB - 1 : cur - 1;
+        if (t + TNB - 1 < nt) issue(t + TNB - 1, prev);
+        tstep<AK, BK_>(lds0 + cur * TBUFB, FA, FB, acc, rsa, rowsum);
+        cur = cur + 1 == TNB ? 0 : cur + 1;
+    }
+    if (kt1 > ktf) {                                       // the ragged last tile of the slice
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        uint8_t* dst = smem + cur * TBUFB;                 // (last read TNB steps ago)
+        tfill<AK>(A, d.A16, c.m0, ktf * TBK, c.kend, tid, dst);
+        tfill<BK_>(B, d.B16, c.n0, ktf * TBK, c.kend, tid, dst + TOPB);
+        __syncthreads();
+        tstep<AK, BK_>(lds0 + cur * TBUFB, FA, FB, acc, rsa, rowsum);
+    }
+    __syncthreads();                                       // the staged epilogue reuses the buffers
+}
+
+__global__ __launch_bounds__(256, TNB == 2 ? 2 : 1) void skg_gemmx_t16_kernel(const skg_gemmx_group g) {
+    constexpr int TSMEM = TNB * TBUFB > 4 * XEP_FLOATS ? TNB * TBUFB : 4 * XEP_FLOATS;     // ring, then the staged epilogue
+    __shared__ __attribute__((aligned(1024))) uint8_t smem[TSMEM];
+    int gi = 0;
+#pragma unroll
+    for (int t = 1; t < SKG_GEMMX_GROUP_MAX; ++t)
+        if (t < g.n && (int)blockIdx.x >= g.start[t]) gi = t;
+    const skg_gemmx_desc& d = g.d[gi];
+    const int vecbits = g.vec[gi];
+    const int S = d.split_k > 1 ? d.split_k : 1;
+    const int nbn = (d.N + XBN - 1) / XBN;
+    const XTileId tid3 = xtile_of(blockIdx.x - g.start[gi], g.start[gi + 1] - g.start[gi], (d.M + XBM - 1) / XBM, nbn, S, d.K);
+    const int slice = tid3.slice, tn = tid3.tn, tm = tid3.tm;
+    const int nkt = (d.K + TBK - 1) / TBK;
+    const int per = (nkt + S - 1) / S;
+#ifdef SKG_XPROBE_NOLOOP                                   // timing builds (tools/build_gemmx_variants.sh): what the k loop costs
+    const int kt0 = min(nkt, slice * per), kt1 = kt0;
+#else
+    const int kt0 = min(nkt, slice * per), kt1 = min(nkt, kt0 + per);
+#endif
+
+    XOperand A, B;
+    xoperands(d, vecbits, A, B);
+    XCtx c;
+    c.m0 = tm * XBM; c.n0 = tn * XBN; c.kend = min(d.K, kt1 * TBK);
+    c.tid = threadIdx.x;
+    const int lane = c.tid & 63, wave = c.tid >> 6;
+    c.wm = wave >> 1; c.wn = wave & 1; c.li = lane & 31; c.lk = lane >> 5;
+    c.do_rowsum = d.a_rowsum != nullptr && tn == 0;
+    const int m0 = c.m0, n0 = c.n0, wm = c.wm, wn = c.wn, li = c.li, lk = c.lk;
+
+    f32x16 acc[2][2], rsa[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        acc[0][0][e] = 0.f; acc[0][1][e] = 0.f; acc[1][0][e] = 0.f; acc[1][1][e] = 0.f; rsa[0][e] = 0.f; rsa[1][e] = 0.f;
+    }
+    if (d.a_sk == 1) {
+        if (d.b_sk == 1) tmain<true, true>(d, A, B, c, kt0, kt1, smem, acc, rsa);
+        else tmain<true, false>(d, A, B, c, kt0, kt1, smem, acc, rsa);
+    } else {
+        if (d.b_sk == 1) tmain<false, true>(d, A, B, c, kt0, kt1, smem, acc, rsa);
+        else tmain<false, false>(d, A, B, c, kt0, kt1, smem, acc, rsa);
+    }
+
+#ifdef SKG_XPROBE_NOEPI                                    // timing builds: what the epilogue costs
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
+    // ---- epilogue.  acc[mi][ni][4*gq + t] = row m0 + wm*64 + mi*32 + 8*gq + 4*lk + t, column n0 + wn*64 + ni*32 + li.
+    const bool split = S > 1;
+    const int64_t MN = (int64_t)d.M * d.N;
+    float* ws = split ? d.split_ws + (int64_t)slice * MN : nullptr;           // [S][M * N] then [S][M] row sums
+    if (c.do_rowsum && wn == 0 && li == 0) {               // every column of rsa holds the row sums: column 0's lanes write
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + mi * 32 + 8 * (e >> 2) + 4 * lk + (e & 3);
+                if (row >= d.M) continue;
+                if (split) d.split_ws[(int64_t)S * MN + (int64_t)slice * d.M + row] = rsa[mi][e];
+                else d.a_rowsum[row] = d.accumulate ? d.a_rowsum[row] + rsa[mi][e] : rsa[mi][e];
+            }
+    }
+    if (vecbits & 8) {
+        float* stage = reinterpret_cast<float*>(smem) + wave * XEP_WAVE;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        stage[(8 * gq + 4 * lk + t) * XEP_LD + ni * 32 + li] = acc[mi][ni][4 * gq + t];
+            xep_rows(d, g.f[gi], stage, lane, m0 + wm * 64 + mi * 32, n0 + wn * 64, ws);
+        }
+        return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = m0 + wm * 64 + mi * 32 + 8 * gq + 4 * lk + t;
+                if (row >= d.M) continue;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int col = n0 + wn * 64 + ni * 32 + li;
+                    if (col >= d.N) continue;
+                    float v = acc[mi][ni][4 * gq + t];
+                    if (split) { ws[(int64_t)row * d.N + col] = v; continue; }
+                    if (d.bias) v += d.bias[col];
+                    if (d.relu) v = fmaxf(v, 0.f);
+                    float* p = d.C + xoff(col, d.c_nshift, d.c_nstride, 1) + (int64_t)row * d.ldc;
+                    if (d.accumulate) v += *p;
+                    if (d.mask && !(d.mask[(int64_t)row * d.ldmask + col] > 0.f)) v = 0.f;
+                    *p = v;
+                    if (d.C16) d.C16[p - d.C] = (uint16_t)ypack(v, 0.f);
+                }
+            }
+}
+
 // Adds the split-K slices in slice order and applies the epilogue.  One thread per output element (coalesced along n).
 __global__ __launch_bounds__(256) void skg_gemmx_reduce_kernel(const skg_gemmx_group g) {
     int gi = 0;
@@ -1075,6 +1433,8 @@ static bool xfused_ptrs_ok(const skg_gemmx_fused& f) {
            skg_aligned16(f.res) && xmul4(f.ldp) && xmul4(f.ldq) && xmul4(f.ldc_raw) && xmul4(f.ldres);
 }
 
+static bool g_t16_enabled = getenv("SKG_GEMMX_T16") == nullptr || atoi(getenv("SKG_GEMMX_T16")) != 0;   // developer A/B switch
+
 static int skg_gemmx_launch(const skg_gemmx_desc* descs_host, int n, void* stream, bool bf16,
                             const skg_gemmx_fused* fused_host = nullptr) {
     if (!descs_host || n < 1 || n > SKG_GEMMX_GROUP_MAX) return SKG_E_ARG;
@@ -1130,7 +1490,15 @@ static int skg_gemmx_launch(const skg_gemmx_desc* descs_host, int n, void* strea
     }
     if (g.n == 0) return 0;
     for (int i = g.n; i <= SKG_GEMMX_GROUP_MAX; ++i) g.start[i] = (int)blocks;
-    if (bf16) hipLaunchKernelGGL(skg_gemmx_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    // every product of the launch with both twins, whole 8-row pieces and k blocks of whole tiles: the direct-to-LDS kernel
+    bool t16 = bf16 && g_t16_enabled;
+    for (int i = 0; i < g.n && t16; ++i) {
+        const skg_gemmx_desc& d = g.d[i];
+        t16 = (g.vec[i] & 48) == 48 && d.K > 0 && (d.a_sk == 1 || ((d.M & 7) == 0 && d.M >= 8)) &&
+              (d.b_sk == 1 || ((d.N & 7) == 0 && d.N >= 8)) && (d.b_kshift == 0 || d.b_kshift >= 6);
+    }
+    if (t16) hipLaunchKernelGGL(skg_gemmx_t16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    else if (bf16) hipLaunchKernelGGL(skg_gemmx_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(skg_gemmx_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     if (r.n) {
         for (int i = r.n; i <= SKG_GEMMX_GROUP_MAX; ++i) r.start[i] = (int)rblocks;

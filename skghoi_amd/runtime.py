@@ -34,6 +34,8 @@ def _hip_started():
 def configure(hw_queues=None):
     """Sets GPU_MAX_HW_QUEUES for this process unless the user exported it.  hw_queues: None -> SKG_HW_QUEUES from the
     environment, else DEFAULT_HW_QUEUES; 0 -> leave the runtime's default.  Returns the info() record."""
+    if hw_queues is None and _STATE["configured"]:
+        return info()                                   # (an application's explicit choice stands; libraries calling again change nothing)
     if hw_queues is None:
         env = os.environ.get("SKG_HW_QUEUES")
         hw_queues = int(env) if env not in (None, "") else DEFAULT_HW_QUEUES

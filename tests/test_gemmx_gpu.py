@@ -28,11 +28,11 @@ def _rnd(*shape, seed=0):
     return torch.randn(*shape, generator=g).cuda()
 
 
-def _close(got, want, what):
+def _close(got, want, what, tol=1e-5):
     want = want.to(torch.float64)
     err = (got.to(torch.float64) - want).abs().max().item()
     scale = max(want.abs().max().item(), 1e-30)
-    assert err <= 1e-5 * scale, "%s: err %.3e at scale %.3e" % (what, err, scale)
+    assert err <= tol * scale, "%s: err %.3e at scale %.3e" % (what, err, scale)
 
 
 def _blocked(W, blk=64):
@@ -115,9 +115,19 @@ def test_bf16_twins_change_nothing(kind, M, N, K, which, split):
 
     ref, ref16, refdb = build(False)
     got, got16, gotdb = build(True)
+    assert torch.equal(got16.view(torch.int16), got.to(torch.bfloat16).view(torch.int16)), "C16 is not the rounding of C"
+    if which == "AB":
+        # both twins: the direct-to-LDS kernel (64-deep k-steps: other split-K slice boundaries; the bias gradient sums the
+        # ROUNDED operand there).  Without split-K the MFMA sequence over k is the same: bit-identical products.
+        if split == 0 and K % 64 == 0:
+            assert torch.equal(got, ref), "C differs with both twins"
+        else:
+            _close(got, ref.double(), "C with both twins")
+        if refdb is not None:
+            _close(gotdb, refdb.double(), "db with both twins", tol=4e-3)     # (sum of bf16-rounded values: 2^-9 per element)
+        return
     assert torch.equal(got, ref), "C differs with twins (%s)" % which
     assert torch.equal(got16.view(torch.int16), ref16.view(torch.int16))
-    assert torch.equal(got16.view(torch.int16), got.to(torch.bfloat16).view(torch.int16)), "C16 is not the rounding of C"
     if refdb is not None:
         assert torch.equal(gotdb, refdb)
 
