@@ -547,6 +547,13 @@ typedef struct {
     const float* dlogits;                       /* backward in: [max(Mp, 1), ld_logits]                                  */
     float* dx0; float* dgfeat;                  /* backward out, optional: gradients of x0 / gfeat                       */
     skg_train_timer* timer;                     /* NULL, or: HIP events around every skg_gemmx launch of the plan          */
+    /* bf16 twins (bf16 = 1 only; all optional -- NULL: the products read and round the fp32 tensors).  ws16: twin of the
+     * workspace, ws_floats elements, element i twins ws[i]: the products' outputs and the per-row kernels' outputs are also
+     * stored rounded to bf16 (round to nearest even) there, and every product whose two operands have twins runs on the
+     * direct-to-LDS kernel (skg_gemmx_t16_kernel).  params16: twin of the parameter arena (params_floats elements), written
+     * by part 0 of the forward.  pf16: twin of pair_features.                                                          */
+    uint16_t* ws16; uint16_t* params16; uint16_t* pf16;
+    int64_t params_floats;
 } skg_train_plan;
 /* Floats of workspace the plan needs (activations kept for the backward, backward temporaries, split-K scratch);
  * < 0: rejected plan.  Only the sizes, bf16 and params (non-null) are read.                                              */
@@ -595,6 +602,8 @@ int skg_train_backward_join(void);
 skg_train_timer* skg_train_timer_create(int capacity);
 void skg_train_timer_destroy(skg_train_timer* timer);
 int skg_train_timer_read(skg_train_timer* timer, double* out3_host);
+/* dst[i] = bf16(src[i]), round to nearest even, n a multiple of 4: the twin of a whole fp32 buffer (the parameter arena). */
+int skg_twin_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 /* Arithmetic of the plan: 2 M N K summed over every dense product it issues (which = 0 forward, 1 backward, 2 both; the
  * backward is counted with dx0 / dgfeat requested).  For roofline records.                                              */
 double skg_train_flops(const skg_train_plan* plan_host, int which);

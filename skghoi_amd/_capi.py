@@ -69,7 +69,8 @@ class TrainPlan(C.Structure):
                                    "grid_pair", "grid_img", "pair_grid", "pair_h", "pair_o", "pair_img", "hum_of",
                                    "node_of")] + \
                [("ws", _vp), ("ws_floats", _i64), ("pair_features", _vp), ("logits", _vp), ("dlogits", _vp),
-                ("dx0", _vp), ("dgfeat", _vp), ("timer", _vp)]
+                ("dx0", _vp), ("dgfeat", _vp), ("timer", _vp), ("ws16", _vp), ("params16", _vp), ("pf16", _vp),
+                ("params_floats", _i64)]
 
 
 # numpy dtype of skg_image_meta (12 x 4 bytes)
@@ -149,6 +150,7 @@ PROTOTYPES = {
     "skg_train_backward_f32": (C.c_int, [C.POINTER(TrainPlan), C.c_int, C.c_int, _vp]),
     "skg_train_backward_async_f32": (C.c_int, [C.POINTER(TrainPlan), C.c_int, C.c_int, _vp]),
     "skg_train_backward_join": (C.c_int, []),
+    "skg_twin_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
     "skg_train_timer_create": (_vp, [C.c_int]),
     "skg_train_timer_destroy": (None, [_vp]),
     "skg_train_timer_read": (C.c_int, [_vp, C.POINTER(C.c_double)]),

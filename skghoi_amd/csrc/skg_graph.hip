@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void skg_graph_aggregate_kernel(
     const skg_image_meta* __restrict__ meta, const int32_t* __restrict__ hum_img, const int32_t* __restrict__ node_img,
     int sum_h, const float* __restrict__ T_os, const float* __restrict__ T_so, int64_t ldt, int cols,
     float* __restrict__ U, float* __restrict__ V, int64_t ldu, float* __restrict__ adj_out,
-    float* __restrict__ alpha_out, float* __restrict__ beta_out) {
+    float* __restrict__ alpha_out, float* __restrict__ beta_out, uint16_t* __restrict__ U16, uint16_t* __restrict__ V16) {
     __shared__ float sw[SKG_MAX_NODES];
     __shared__ float sred[4];
     const int tid = threadIdx.x;
@@ -64,6 +64,8 @@ __global__ __launch_bounds__(256) void skg_graph_aggregate_kernel(
 
     const float* T = to_human ? T_os : T_so;
     float* out = (to_human ? U : V) + (int64_t)dst * ldu;
+    uint16_t* out16 = to_human ? U16 : V16;
+    if (out16) out16 += (int64_t)dst * ldu;
     for (int c = tid * 4; c < cols; c += 1024) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* p = T + row0 * ldt + c;
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(256) void skg_graph_aggregate_kernel(
             acc.x += wt * v.x; acc.y += wt * v.y; acc.z += wt * v.z; acc.w += wt * v.w;
         }
         *reinterpret_cast<float4*>(out + c) = acc;
+        if (out16) skg_store_twin4(out16 + c, acc);
     }
 }
 
@@ -89,7 +92,7 @@ extern "C" int skg_graph_aggregate_f32(const float* dot_partial, int n_partial, 
         return SKG_E_ALIGN;
     hipLaunchKernelGGL(skg_graph_aggregate_kernel, dim3(sum_h + sum_n), dim3(256), 0, (hipStream_t)stream, dot_partial,
                        n_partial, partial_ld, adj_bias, meta, hum_img, node_img, sum_h, T_os, T_so, ldt, cols, U, V,
-                       ldu, adj_out, (float*)nullptr, (float*)nullptr);
+                       ldu, adj_out, (float*)nullptr, (float*)nullptr, (uint16_t*)nullptr, (uint16_t*)nullptr);
     return skg_launch_status();
 }
 
@@ -109,7 +112,7 @@ extern "C" int skg_graph_aggregate_train_f32(const float* dot_partial, int n_par
         return SKG_E_ALIGN;
     hipLaunchKernelGGL(skg_graph_aggregate_kernel, dim3(sum_h + sum_n), dim3(256), 0, (hipStream_t)stream, dot_partial,
                        n_partial, partial_ld, adj_bias, meta, hum_img, node_img, sum_h, T_os, T_so, ldt, cols, U, V,
-                       ldu, adj_out, alpha_out, beta_out);
+                       ldu, adj_out, alpha_out, beta_out, skg_twin(U), skg_twin(V));
     return skg_launch_status();
 }
 

@@ -174,15 +174,20 @@ __global__ __launch_bounds__(256) void skg_concat_entity_kernel(const float* __r
                                                                 const float* __restrict__ ent,
                                                                 const int32_t* __restrict__ ent_img,
                                                                 const int32_t* __restrict__ ent_row,
-                                                                float* __restrict__ out, int64_t out_ld) {
+                                                                float* __restrict__ out, int64_t out_ld,
+                                                                uint16_t* __restrict__ out16) {
     const int r = blockIdx.x;
     const float* src = enc + (int64_t)enc_row[r] * ld_enc;
     float* dst = out + (int64_t)r * out_ld;
     const int t = threadIdx.x;
-    reinterpret_cast<float4*>(dst)[t] = reinterpret_cast<const float4*>(src)[t];          // 256 x 4 = 1024 columns
+    const float4 v = reinterpret_cast<const float4*>(src)[t];
+    reinterpret_cast<float4*>(dst)[t] = v;                                                 // 256 x 4 = 1024 columns
+    if (out16) skg_store_twin4(out16 + (int64_t)r * out_ld + 4 * t, v);
     if (t < 64) {
         const float* e = ent + ((int64_t)ent_img[r] * SKG_TRANSH_ENT + ent_row[r]) * SKG_TRANSH_DIM;
-        dst[1024 + t] = (t < SKG_TRANSH_DIM) ? e[t] : 0.f;                                 // 1024..1087
+        const float x = (t < SKG_TRANSH_DIM) ? e[t] : 0.f;
+        dst[1024 + t] = x;                                                                 // 1024..1087
+        if (out16) out16[(int64_t)r * out_ld + 1024 + t] = (uint16_t)skg_pack_bf16(x, 0.f);
     }
 }
 
@@ -194,7 +199,7 @@ extern "C" int skg_concat_entity_f32(const float* enc, int64_t ld_enc, const int
     if (!enc || !enc_row || !ent || !ent_img || !ent_row || !out || out_ld < 1088) return SKG_E_ARG;
     if (!skg_aligned16(enc) || !skg_aligned16(out) || (ld_enc & 3) || (out_ld & 3)) return SKG_E_ALIGN;
     hipLaunchKernelGGL(skg_concat_entity_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, enc, ld_enc, enc_row,
-                       ent, ent_img, ent_row, out, out_ld);
+                       ent, ent_img, ent_row, out, out_ld, skg_twin(out));
     return skg_launch_status();
 }
 
@@ -206,12 +211,14 @@ __global__ __launch_bounds__(256) void skg_rows_mul_relu_kernel(const float* __r
                                                                 const float* __restrict__ mbias,
                                                                 const float* __restrict__ F,
                                                                 const int32_t* __restrict__ f_idx, int64_t ldf,
-                                                                int cols, float* __restrict__ out, int64_t ldo) {
+                                                                int cols, float* __restrict__ out, int64_t ldo,
+                                                                uint16_t* __restrict__ out16) {
     const int r = blockIdx.x;
     const float* p = P + (int64_t)(p_idx ? p_idx[r] : r) * ldp;
     const float* q = Q ? Q + (int64_t)(q_idx ? q_idx[r] : r) * ldq : nullptr;
     const float* f = F + (int64_t)(f_idx ? f_idx[r] : r) * ldf;
     float* o = out + (int64_t)r * ldo;
+    uint16_t* o16 = out16 ? out16 + (int64_t)r * ldo : nullptr;
     for (int c = threadIdx.x * 4; c < cols; c += 1024) {
         float4 m = *reinterpret_cast<const float4*>(p + c);
         if (q) {
@@ -223,8 +230,9 @@ __global__ __launch_bounds__(256) void skg_rows_mul_relu_kernel(const float* __r
             m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
         }
         const float4 v = *reinterpret_cast<const float4*>(f + c);
-        *reinterpret_cast<float4*>(o + c) = make_float4(fmaxf(m.x * v.x, 0.f), fmaxf(m.y * v.y, 0.f),
-                                                        fmaxf(m.z * v.z, 0.f), fmaxf(m.w * v.w, 0.f));
+        const float4 res = make_float4(fmaxf(m.x * v.x, 0.f), fmaxf(m.y * v.y, 0.f), fmaxf(m.z * v.z, 0.f), fmaxf(m.w * v.w, 0.f));
+        *reinterpret_cast<float4*>(o + c) = res;
+        if (o16) skg_store_twin4(o16 + c, res);
     }
 }
 
@@ -237,6 +245,7 @@ __global__ __launch_bounds__(256) void skg_rows_mul_relu_multi_kernel(const skg_
     const float* q = a.Q ? a.Q + (int64_t)(a.q_idx ? a.q_idx[r] : r) * a.ldq : nullptr;
     const float* f = a.F + (int64_t)(a.f_idx ? a.f_idx[r] : r) * a.ldf;
     float* o = a.out + (int64_t)r * a.ldo;
+    uint16_t* o16 = a.out16 ? a.out16 + (int64_t)r * a.ldo : nullptr;
     for (int c = threadIdx.x * 4; c < a.cols; c += 1024) {
         float4 m = *reinterpret_cast<const float4*>(p + c);
         if (q) {
@@ -248,8 +257,9 @@ __global__ __launch_bounds__(256) void skg_rows_mul_relu_multi_kernel(const skg_
             m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
         }
         const float4 v = *reinterpret_cast<const float4*>(f + c);
-        *reinterpret_cast<float4*>(o + c) = make_float4(fmaxf(m.x * v.x, 0.f), fmaxf(m.y * v.y, 0.f),
-                                                        fmaxf(m.z * v.z, 0.f), fmaxf(m.w * v.w, 0.f));
+        const float4 res = make_float4(fmaxf(m.x * v.x, 0.f), fmaxf(m.y * v.y, 0.f), fmaxf(m.z * v.z, 0.f), fmaxf(m.w * v.w, 0.f));
+        *reinterpret_cast<float4*>(o + c) = res;
+        if (o16) skg_store_twin4(o16 + c, res);
     }
 }
 
@@ -265,7 +275,8 @@ int skg_rows_mul_relu_multi(const skg_rows_mul_args* calls, int n, void* stream)
         if ((a.ldp & 3) || (a.ldf & 3) || (a.ldo & 3) || (a.Q && (a.ldq & 3))) return SKG_E_ALIGN;
         if (!skg_aligned16(a.P) || !skg_aligned16(a.F) || !skg_aligned16(a.out) || !skg_aligned16(a.Q) || !skg_aligned16(a.mbias))
             return SKG_E_ALIGN;
-        pk.a[m++] = a;
+        pk.a[m] = a;
+        pk.a[m++].out16 = skg_twin(a.out);
         rows = a.rows > rows ? a.rows : rows;
     }
     if (m == 0) return 0;
@@ -285,7 +296,7 @@ extern "C" int skg_rows_mul_relu_f32(const float* P, const int32_t* p_idx, int64
         (mbias && !skg_aligned16(mbias)))
         return SKG_E_ALIGN;
     hipLaunchKernelGGL(skg_rows_mul_relu_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, P, p_idx, ldp, Q,
-                       q_idx, ldq, mbias, F, f_idx, ldf, cols, out, ldo);
+                       q_idx, ldq, mbias, F, f_idx, ldf, cols, out, ldo, skg_twin(out));
     return skg_launch_status();
 }
 

@@ -44,7 +44,7 @@ __device__ __forceinline__ void skg_add_layernorm_row(const float* __restrict__ 
                                                       const float* __restrict__ b, int64_t ldb,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float eps, float* __restrict__ xsum, float* __restrict__ y,
-                                                      float* __restrict__ stats, int r) {
+                                                      float* __restrict__ stats, int r, uint16_t* __restrict__ y16) {
     __shared__ float sred[4];
     const int c = threadIdx.x * 4;
     const float4 va = *reinterpret_cast<const float4*>(a + (int64_t)r * lda + c);
@@ -57,8 +57,9 @@ __device__ __forceinline__ void skg_add_layernorm_row(const float* __restrict__ 
     const float4 g = *reinterpret_cast<const float4*>(gamma + c);
     const float4 bb = *reinterpret_cast<const float4*>(beta + c);
     *reinterpret_cast<float4*>(xsum + (int64_t)r * TR_COLS + c) = v;
-    *reinterpret_cast<float4*>(y + (int64_t)r * TR_COLS + c) =
-        make_float4(d.x * rstd * g.x + bb.x, d.y * rstd * g.y + bb.y, d.z * rstd * g.z + bb.z, d.w * rstd * g.w + bb.w);
+    const float4 yo = make_float4(d.x * rstd * g.x + bb.x, d.y * rstd * g.y + bb.y, d.z * rstd * g.z + bb.z, d.w * rstd * g.w + bb.w);
+    *reinterpret_cast<float4*>(y + (int64_t)r * TR_COLS + c) = yo;
+    if (y16) skg_store_twin4(y16 + (int64_t)r * TR_COLS + c, yo);
     if (threadIdx.x == 0) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
 }
 
@@ -67,15 +68,15 @@ __global__ __launch_bounds__(256) void skg_add_layernorm_kernel(const float* __r
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float eps,
                                                                 float* __restrict__ xsum, float* __restrict__ y,
-                                                                float* __restrict__ stats) {
-    skg_add_layernorm_row(a, lda, b, ldb, gamma, beta, eps, xsum, y, stats, (int)blockIdx.x);
+                                                                float* __restrict__ stats, uint16_t* __restrict__ y16) {
+    skg_add_layernorm_row(a, lda, b, ldb, gamma, beta, eps, xsum, y, stats, (int)blockIdx.x, y16);
 }
 
 struct skg_add_layernorm_pack { skg_add_layernorm_args a[SKG_MULTI_MAX]; };
 __global__ __launch_bounds__(256) void skg_add_layernorm_multi_kernel(const skg_add_layernorm_pack pk, float eps) {
     const skg_add_layernorm_args& a = pk.a[blockIdx.y];
     if ((int)blockIdx.x >= a.rows) return;                 // (uniform per workgroup)
-    skg_add_layernorm_row(a.a, a.lda, a.b, a.ldb, a.gamma, a.beta, eps, a.xsum, a.y, a.stats, (int)blockIdx.x);
+    skg_add_layernorm_row(a.a, a.lda, a.b, a.ldb, a.gamma, a.beta, eps, a.xsum, a.y, a.stats, (int)blockIdx.x, a.y16);
 }
 
 int skg_add_layernorm_multi(const skg_add_layernorm_args* calls, int n, float eps, void* stream) {
@@ -90,7 +91,8 @@ int skg_add_layernorm_multi(const skg_add_layernorm_args* calls, int n, float ep
         if ((a.lda & 3) || (a.ldb & 3) || !skg_aligned16(a.a) || !skg_aligned16(a.b) || !skg_aligned16(a.gamma) ||
             !skg_aligned16(a.beta) || !skg_aligned16(a.xsum) || !skg_aligned16(a.y))
             return SKG_E_ALIGN;
-        pk.a[m++] = a;
+        pk.a[m] = a;
+        pk.a[m++].y16 = skg_twin(a.y);
         rows = a.rows > rows ? a.rows : rows;
     }
     if (m == 0) return 0;
@@ -108,7 +110,7 @@ extern "C" int skg_add_layernorm_f32(const float* a, int64_t lda, const float* b
         !skg_aligned16(beta) || !skg_aligned16(xsum) || !skg_aligned16(y))
         return SKG_E_ALIGN;
     hipLaunchKernelGGL(skg_add_layernorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, gamma,
-                       beta, eps, xsum, y, stats);
+                       beta, eps, xsum, y, stats, skg_twin(y));
     return skg_launch_status();
 }
 
@@ -117,7 +119,7 @@ __device__ __forceinline__ void skg_layernorm_bwd_row(const float* __restrict__ 
                                                       const float* __restrict__ x, const float* __restrict__ stats,
                                                       const float* __restrict__ gamma, float* __restrict__ dx,
                                                       const float* __restrict__ relu_src, float* __restrict__ dx_masked,
-                                                      int r) {
+                                                      int r, uint16_t* __restrict__ dx16, uint16_t* __restrict__ dxm16) {
     __shared__ float sred[4];
     const int c = threadIdx.x * 4;
     const float mean = stats[2 * r], rstd = stats[2 * r + 1];
@@ -131,10 +133,12 @@ __device__ __forceinline__ void skg_layernorm_bwd_row(const float* __restrict__ 
     const float4 o = make_float4(rstd * (g.x - c1 - xh.x * c2), rstd * (g.y - c1 - xh.y * c2),
                                  rstd * (g.z - c1 - xh.z * c2), rstd * (g.w - c1 - xh.w * c2));
     *reinterpret_cast<float4*>(dx + (int64_t)r * TR_COLS + c) = o;
+    if (dx16) skg_store_twin4(dx16 + (int64_t)r * TR_COLS + c, o);
     if (dx_masked) {
         const float4 m = *reinterpret_cast<const float4*>(relu_src + (int64_t)r * TR_COLS + c);
-        *reinterpret_cast<float4*>(dx_masked + (int64_t)r * TR_COLS + c) =
-            make_float4(m.x > 0.f ? o.x : 0.f, m.y > 0.f ? o.y : 0.f, m.z > 0.f ? o.z : 0.f, m.w > 0.f ? o.w : 0.f);
+        const float4 om = make_float4(m.x > 0.f ? o.x : 0.f, m.y > 0.f ? o.y : 0.f, m.z > 0.f ? o.z : 0.f, m.w > 0.f ? o.w : 0.f);
+        *reinterpret_cast<float4*>(dx_masked + (int64_t)r * TR_COLS + c) = om;
+        if (dxm16) skg_store_twin4(dxm16 + (int64_t)r * TR_COLS + c, om);
     }
 }
 
@@ -144,8 +148,9 @@ __global__ __launch_bounds__(256) void skg_layernorm_bwd_kernel(const float* __r
                                                                 const float* __restrict__ gamma,
                                                                 float* __restrict__ dx,
                                                                 const float* __restrict__ relu_src,
-                                                                float* __restrict__ dx_masked) {
-    skg_layernorm_bwd_row(dy, lddy, x, stats, gamma, dx, relu_src, dx_masked, (int)blockIdx.x);
+                                                                float* __restrict__ dx_masked,
+                                                                uint16_t* __restrict__ dx16, uint16_t* __restrict__ dxm16) {
+    skg_layernorm_bwd_row(dy, lddy, x, stats, gamma, dx, relu_src, dx_masked, (int)blockIdx.x, dx16, dxm16);
 }
 
 // dgamma[c] = sum_r dy[r, c] * xhat[r, c],  dbeta[c] = sum_r dy[r, c]: one thread per column, rows in order.
@@ -185,7 +190,8 @@ struct skg_layernorm_bwd_pack { skg_layernorm_bwd_args a[SKG_MULTI_MAX]; };
 __global__ __launch_bounds__(256) void skg_layernorm_bwd_multi_kernel(const skg_layernorm_bwd_pack pk) {
     const skg_layernorm_bwd_args& a = pk.a[blockIdx.y];
     if ((int)blockIdx.x >= a.rows) return;                 // (uniform per workgroup)
-    skg_layernorm_bwd_row(a.dy, a.lddy, a.x, a.stats, a.gamma, a.dx, a.relu_src, a.dx_masked, (int)blockIdx.x);
+    skg_layernorm_bwd_row(a.dy, a.lddy, a.x, a.stats, a.gamma, a.dx, a.relu_src, a.dx_masked, (int)blockIdx.x, a.dx16,
+                          a.dx_masked16);
 }
 __global__ __launch_bounds__(256) void skg_layernorm_param_grad_multi_kernel(const skg_layernorm_bwd_pack pk) {
     const skg_layernorm_bwd_args& a = pk.a[blockIdx.y];
@@ -204,6 +210,8 @@ int skg_layernorm_bwd_multi(const skg_layernorm_bwd_args* calls, int n, void* st
             !skg_aligned16(a.relu_src) || !skg_aligned16(a.dx_masked))
             return SKG_E_ALIGN;
         pk.a[i] = a;
+        pk.a[i].dx16 = skg_twin(a.dx);
+        pk.a[i].dx_masked16 = a.dx_masked ? skg_twin(a.dx_masked) : nullptr;
         rows = a.rows > rows ? a.rows : rows;
     }
     if (rows)
@@ -222,7 +230,7 @@ extern "C" int skg_layernorm_bwd_f32(const float* dy, int64_t lddy, const float*
         return SKG_E_ALIGN;
     if (rows)
         hipLaunchKernelGGL(skg_layernorm_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, stats,
-                           gamma, dx, relu_src, dx_masked);
+                           gamma, dx, relu_src, dx_masked, skg_twin(dx), dx_masked ? skg_twin(dx_masked) : (uint16_t*)nullptr);
     hipLaunchKernelGGL(skg_layernorm_param_grad_kernel, dim3(TR_COLS / 64), dim3(256), 0, (hipStream_t)stream, dy, lddy,
                        x, stats, rows, dgamma, dbeta);
     return skg_launch_status();
@@ -237,7 +245,8 @@ __global__ __launch_bounds__(256) void skg_mul_bwd_kernel(float* __restrict__ g,
                                                           const int32_t* __restrict__ p_idx, int64_t ldp,
                                                           const float* __restrict__ Q, const int32_t* __restrict__ q_idx,
                                                           int64_t ldq, const float* __restrict__ mbias,
-                                                          float* __restrict__ dF, int64_t lddf, int accumulate) {
+                                                          float* __restrict__ dF, int64_t lddf, int accumulate,
+                                                          uint16_t* __restrict__ dF16) {
     const int r = blockIdx.x;
     const int c = threadIdx.x * 4;
     const int fi = f_idx ? f_idx[r] : r;
@@ -257,6 +266,7 @@ __global__ __launch_bounds__(256) void skg_mul_bwd_kernel(float* __restrict__ g,
     float4 o = make_float4(gv.x * m.x, gv.y * m.y, gv.z * m.z, gv.w * m.w);
     if (accumulate) { const float4 t = *dp; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
     *dp = o;
+    if (dF16) skg_store_twin4(dF16 + (int64_t)fi * lddf + c, o);
     *gp = make_float4(gv.x * fv.x, gv.y * fv.y, gv.z * fv.z, gv.w * fv.w);
 }
 
@@ -283,6 +293,7 @@ __global__ __launch_bounds__(256) void skg_mul_bwd_multi_kernel(const skg_mul_bw
     float4 o = make_float4(gv.x * m.x, gv.y * m.y, gv.z * m.z, gv.w * m.w);
     if (a.accumulate) { const float4 t = *dp; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
     *dp = o;
+    if (a.dF16) skg_store_twin4(a.dF16 + (int64_t)fi * a.lddf + c, o);
     *gp = make_float4(gv.x * fv.x, gv.y * fv.y, gv.z * fv.z, gv.w * fv.w);
 }
 
@@ -299,7 +310,8 @@ int skg_mul_bwd_multi(const skg_mul_bwd_args* calls, int n, void* stream) {
         if (!skg_aligned16(a.g) || !skg_aligned16(a.F) || !skg_aligned16(a.P) || !skg_aligned16(a.dF) || !skg_aligned16(a.Q) ||
             !skg_aligned16(a.mbias))
             return SKG_E_ALIGN;
-        pk.a[m++] = a;
+        pk.a[m] = a;
+        pk.a[m++].dF16 = skg_twin(a.dF);
         rows = a.rows > rows ? a.rows : rows;
     }
     if (m == 0) return 0;
@@ -318,7 +330,7 @@ extern "C" int skg_mul_bwd_f32(float* g, int64_t ldg, const float* F, const int3
         (mbias && !skg_aligned16(mbias)))
         return SKG_E_ALIGN;
     hipLaunchKernelGGL(skg_mul_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, g, ldg, F, f_idx, ldf, P, p_idx,
-                       ldp, Q, q_idx, ldq, mbias, dF, lddf, accumulate);
+                       ldp, Q, q_idx, ldq, mbias, dF, lddf, accumulate, skg_twin(dF));
     return skg_launch_status();
 }
 
@@ -334,10 +346,11 @@ __device__ __forceinline__ void skg_segment_sum_body(const float* __restrict__ s
                                                      const int32_t* __restrict__ hum_img,
                                                      const int32_t* __restrict__ node_img, int n_dst_h, int mode,
                                                      float* __restrict__ outH, float* __restrict__ outN, int accumulate,
-                                                     int blk) {
+                                                     int blk, uint16_t* __restrict__ outH16, uint16_t* __restrict__ outN16) {
     const bool to_h = blk < n_dst_h;
     const int dst = to_h ? blk : blk - n_dst_h;
     float* out = to_h ? outH : outN;
+    uint16_t* out16 = to_h ? outH16 : outN16;
     if (!out) return;
     const int a = mode == 2 ? dst : (to_h ? hum_img[dst] : node_img[dst]);
     const skg_image_meta mt = meta[a];
@@ -380,6 +393,7 @@ __device__ __forceinline__ void skg_segment_sum_body(const float* __restrict__ s
     float4* o = reinterpret_cast<float4*>(out + (int64_t)(mode == 2 ? mt.image : dst) * TR_COLS + c);
     if (accumulate) { const float4 t = *o; acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
     *o = acc;
+    if (out16) skg_store_twin4(out16 + (int64_t)(mode == 2 ? mt.image : dst) * TR_COLS + c, acc);
 }
 
 __global__ __launch_bounds__(256) void skg_segment_sum_kernel(const float* __restrict__ src, int64_t ld,
@@ -387,8 +401,9 @@ __global__ __launch_bounds__(256) void skg_segment_sum_kernel(const float* __res
                                                               const int32_t* __restrict__ hum_img,
                                                               const int32_t* __restrict__ node_img, int n_dst_h, int mode,
                                                               float* __restrict__ outH, float* __restrict__ outN,
-                                                              int accumulate) {
-    skg_segment_sum_body(src, ld, meta, hum_img, node_img, n_dst_h, mode, outH, outN, accumulate, (int)blockIdx.x);
+                                                              int accumulate, uint16_t* __restrict__ outH16,
+                                                              uint16_t* __restrict__ outN16) {
+    skg_segment_sum_body(src, ld, meta, hum_img, node_img, n_dst_h, mode, outH, outN, accumulate, (int)blockIdx.x, outH16, outN16);
 }
 
 struct skg_segment_sum_pack { skg_segment_sum_args a[SKG_MULTI_MAX]; };
@@ -397,7 +412,8 @@ __global__ __launch_bounds__(256) void skg_segment_sum_multi_kernel(const skg_se
                                                                     const int32_t* __restrict__ hum_img,
                                                                     const int32_t* __restrict__ node_img, int n_dst_h) {
     const skg_segment_sum_args& a = pk.a[blockIdx.y];
-    skg_segment_sum_body(a.src, a.ld, meta, hum_img, node_img, n_dst_h, a.mode, a.outH, a.outN, a.accumulate, (int)blockIdx.x);
+    skg_segment_sum_body(a.src, a.ld, meta, hum_img, node_img, n_dst_h, a.mode, a.outH, a.outN, a.accumulate, (int)blockIdx.x,
+                         a.outH16, a.outN16);
 }
 
 int skg_segment_sum_multi(const skg_segment_sum_args* calls, int n, const skg_image_meta* meta, const int32_t* hum_img,
@@ -411,6 +427,8 @@ int skg_segment_sum_multi(const skg_segment_sum_args* calls, int n, const skg_im
         if (a.mode < 0 || a.mode > 1 || !a.src || (!a.outH && !a.outN)) return SKG_E_ARG;
         if ((a.ld & 3) || !skg_aligned16(a.src) || !skg_aligned16(a.outH) || !skg_aligned16(a.outN)) return SKG_E_ALIGN;
         pk.a[i] = a;
+        pk.a[i].outH16 = a.outH ? skg_twin(a.outH) : nullptr;
+        pk.a[i].outN16 = a.outN ? skg_twin(a.outN) : nullptr;
     }
     hipLaunchKernelGGL(skg_segment_sum_multi_kernel, dim3(sum_h + sum_n, n), dim3(256), 0, (hipStream_t)stream, pk, meta,
                        hum_img, node_img, sum_h);
@@ -422,7 +440,8 @@ int skg_segment_sum_multi(const skg_segment_sum_args* calls, int n, const skg_im
 // owns one float4 column quad of its 64-column block and every 16th row, and the 16 row groups are added in fixed order.
 __global__ __launch_bounds__(256) void skg_segment_sum_image_kernel(const float* __restrict__ src, int64_t ld,
                                                                     const skg_image_meta* __restrict__ meta,
-                                                                    float* __restrict__ out, int accumulate) {
+                                                                    float* __restrict__ out, int accumulate,
+                                                                    uint16_t* __restrict__ out16) {
     __shared__ float4 red[16][16];
     const skg_image_meta mt = meta[blockIdx.x];
     const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
@@ -450,6 +469,7 @@ __global__ __launch_bounds__(256) void skg_segment_sum_image_kernel(const float*
         float4* o = reinterpret_cast<float4*>(out + (int64_t)mt.image * TR_COLS + c);
         if (accumulate) { const float4 t = *o; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
         *o = s;
+        if (out16) skg_store_twin4(out16 + (int64_t)mt.image * TR_COLS + c, s);
     }
 }
 
@@ -464,11 +484,12 @@ extern "C" int skg_segment_sum_f32(const float* src, int64_t ld, const skg_image
     if (mode == 2) {
         if (!outH) return SKG_E_ARG;
         hipLaunchKernelGGL(skg_segment_sum_image_kernel, dim3(n_active, TR_COLS / 64), dim3(256), 0, (hipStream_t)stream, src,
-                           ld, meta, outH, accumulate);
+                           ld, meta, outH, accumulate, skg_twin(outH));
         return skg_launch_status();
     }
     hipLaunchKernelGGL(skg_segment_sum_kernel, dim3(nh + nn), dim3(256), 0, (hipStream_t)stream, src, ld, meta, hum_img,
-                       node_img, nh, mode, outH, outN, accumulate);
+                       node_img, nh, mode, outH, outN, accumulate, outH ? skg_twin(outH) : (uint16_t*)nullptr,
+                       outN ? skg_twin(outN) : (uint16_t*)nullptr);
     return skg_launch_status();
 }
 
@@ -559,15 +580,17 @@ __global__ __launch_bounds__(256) void skg_adjacency_bwd_kernel(const float* __r
                                                                 const float* __restrict__ dadj_n,
                                                                 const float* __restrict__ w,
                                                                 const float* __restrict__ Wt, float* __restrict__ dadj,
-                                                                float* __restrict__ dWt) {
+                                                                float* __restrict__ dWt, uint16_t* __restrict__ dWt16) {
     const int r = blockIdx.x;
     const int c = threadIdx.x * 4;
     const float d = dadj_h[r] + dadj_n[r];
     if (threadIdx.x == 0) dadj[r] = d;
     const float4 wv = *reinterpret_cast<const float4*>(w + c);
     const float4 t = *reinterpret_cast<const float4*>(Wt + (int64_t)r * TR_COLS + c);
-    *reinterpret_cast<float4*>(dWt + (int64_t)r * TR_COLS + c) =
-        make_float4(t.x > 0.f ? d * wv.x : 0.f, t.y > 0.f ? d * wv.y : 0.f, t.z > 0.f ? d * wv.z : 0.f, t.w > 0.f ? d * wv.w : 0.f);
+    const float4 o = make_float4(t.x > 0.f ? d * wv.x : 0.f, t.y > 0.f ? d * wv.y : 0.f, t.z > 0.f ? d * wv.z : 0.f,
+                                 t.w > 0.f ? d * wv.w : 0.f);
+    *reinterpret_cast<float4*>(dWt + (int64_t)r * TR_COLS + c) = o;
+    if (dWt16) skg_store_twin4(dWt16 + (int64_t)r * TR_COLS + c, o);
 }
 
 extern "C" int skg_adjacency_bwd_f32(const float* dadj_h, const float* dadj_n, const float* w, const float* Wt, int rows,
@@ -577,7 +600,7 @@ extern "C" int skg_adjacency_bwd_f32(const float* dadj_h, const float* dadj_n, c
     if (!dadj_h || !dadj_n || !w || !Wt || !dadj || !dWt) return SKG_E_ARG;
     if (!skg_aligned16(w) || !skg_aligned16(Wt) || !skg_aligned16(dWt)) return SKG_E_ALIGN;
     hipLaunchKernelGGL(skg_adjacency_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dadj_h, dadj_n, w, Wt, dadj,
-                       dWt);
+                       dWt, skg_twin(dWt));
     return skg_launch_status();
 }
 
@@ -588,7 +611,7 @@ __global__ __launch_bounds__(256) void skg_entity_rows_bwd_kernel(const float* _
                                                                   const int32_t* __restrict__ hum_of,
                                                                   const int32_t* __restrict__ node_of, int sum_h,
                                                                   const float* __restrict__ enc,
-                                                                  float* __restrict__ d_enc) {
+                                                                  float* __restrict__ d_enc, uint16_t* __restrict__ d_enc16) {
     const int e = blockIdx.x;
     const int c = threadIdx.x * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -599,8 +622,9 @@ __global__ __launch_bounds__(256) void skg_entity_rows_bwd_kernel(const float* _
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     const float4 m = *reinterpret_cast<const float4*>(enc + (int64_t)e * TR_COLS + c);
-    *reinterpret_cast<float4*>(d_enc + (int64_t)e * TR_COLS + c) =
-        make_float4(m.x > 0.f ? acc.x : 0.f, m.y > 0.f ? acc.y : 0.f, m.z > 0.f ? acc.z : 0.f, m.w > 0.f ? acc.w : 0.f);
+    const float4 r4 = make_float4(m.x > 0.f ? acc.x : 0.f, m.y > 0.f ? acc.y : 0.f, m.z > 0.f ? acc.z : 0.f, m.w > 0.f ? acc.w : 0.f);
+    *reinterpret_cast<float4*>(d_enc + (int64_t)e * TR_COLS + c) = r4;
+    if (d_enc16) skg_store_twin4(d_enc16 + (int64_t)e * TR_COLS + c, r4);
 }
 
 extern "C" int skg_entity_rows_bwd_f32(const float* dX, int64_t ldx, const int32_t* hum_of, const int32_t* node_of,
@@ -610,7 +634,7 @@ extern "C" int skg_entity_rows_bwd_f32(const float* dX, int64_t ldx, const int32
     if (!dX || !hum_of || !node_of || !enc || !d_enc) return SKG_E_ARG;
     if ((ldx & 3) || !skg_aligned16(dX) || !skg_aligned16(enc) || !skg_aligned16(d_enc)) return SKG_E_ALIGN;
     hipLaunchKernelGGL(skg_entity_rows_bwd_kernel, dim3(n_enc), dim3(256), 0, (hipStream_t)stream, dX, ldx, hum_of, node_of,
-                       sum_h, enc, d_enc);
+                       sum_h, enc, d_enc, skg_twin(d_enc));
     return skg_launch_status();
 }
 

@@ -50,6 +50,33 @@ struct Ctx {
     float* scratch;              // split-K partials (one region, reused by consecutive launches of the stream)
     int rc;
     double flops;                // 2 M N K over every dense product issued (sizing pass: what the plan WILL issue)
+    const float* no_twin;        // workspace buffer whose twin nobody writes (dadj: produced next to dWt, one column wide)
+};
+
+// bf16 twin of a tensor the plan's products read or write, or NULL: activations in the workspace (twin workspace, same
+// offsets), the pair features, the parameter arena.  Caller-owned inputs (pooled features, spatial encodings) have none.
+static uint16_t* twin_of(const Ctx& c, const float* p) {
+    const skg_train_plan* P = c.P;
+    if (!P->ws16 || !p) return nullptr;
+    if (p >= P->ws && p < P->ws + P->ws_floats) return (c.no_twin && p == c.no_twin) ? nullptr : P->ws16 + (p - P->ws);
+    const int64_t npf = (int64_t)(P->Mp > 0 ? P->Mp : 1) * 2048;
+    if (P->pf16 && p >= P->pair_features && p < P->pair_features + npf) return P->pf16 + (p - P->pair_features);
+    if (P->params16 && p >= P->params && p < P->params + P->params_floats) return P->params16 + (p - P->params);
+    return nullptr;
+}
+
+// announces the twin ranges to the per-row kernels for the duration of one plan call (skg_common.h, skg_tls_twin)
+struct TwinScope {
+    skg_twin_map saved;
+    explicit TwinScope(const skg_train_plan* P) : saved(skg_tls_twin) {
+        skg_twin_map m = {{nullptr, nullptr}, {nullptr, nullptr}, {0, 0}};
+        if (P->bf16 && P->ws16) {
+            m.base[0] = P->ws; m.base16[0] = P->ws16; m.n[0] = P->ws_floats;
+            if (P->pf16) { m.base[1] = P->pair_features; m.base16[1] = P->pf16; m.n[1] = (int64_t)(P->Mp > 0 ? P->Mp : 1) * 2048; }
+        }
+        skg_tls_twin = m;
+    }
+    ~TwinScope() { skg_tls_twin = saved; }
 };
 
 // ---- skg_gemmx descriptor builders (skghoi_amd/gemmx.py: forward / input_grad / weight_grad)
@@ -134,9 +161,14 @@ static void launch(Ctx& c, skg_gemmx_desc* ops, int n) {
             skg_gemmx_desc& d = live[i0 + i];
             int sk = pick_split(d, bk);
             d.split_k = sk > 1 ? sk : 0;
+            if (bf16 && !c.dry) {
+                d.A16 = twin_of(c, d.A); d.B16 = twin_of(c, d.B);
+                uint16_t* c16 = twin_of(c, d.C);
+                d.C16 = (c16 && (d.C < c.P->params || d.C >= c.P->params + c.P->params_floats)) ? c16 : nullptr;
+            }
             if (sk > 1) {
                 int64_t need = (int64_t)sk * ((int64_t)d.M * d.N + d.M);
-                need = (need + 3) & ~(int64_t)3;
+                need = (need + 7) & ~(int64_t)7;
                 d.split_ws = c.scratch ? c.scratch + used : nullptr;
                 used += need;
             }
@@ -205,8 +237,8 @@ struct Ws {
 static void layout_ws(const skg_train_plan* P, float* base, Ws& w) {
     int64_t off = 0;
     auto take = [&](int64_t rows, int64_t cols) -> float* {
-        int64_t n = rows * cols; if (n < 4) n = 4;
-        n = (n + 3) & ~(int64_t)3;
+        int64_t n = rows * cols; if (n < 8) n = 8;
+        n = (n + 7) & ~(int64_t)7;                          // 32-byte steps: the bf16 twin of every buffer is 16-byte aligned
         float* p = base ? base + off : nullptr;
         off += n;
         return p;
@@ -269,6 +301,10 @@ static void forward(Ctx& c, const Ws& w, int part) {
     if (part == 0) {
         if (!c.dry)
             hipLaunchKernelGGL(b3sum_kernel, dim3(16), dim3(256), 0, c.stream, W.at(SKG_SEG_B3), w.b3sum);
+        // bf16 step: the twin of the whole parameter arena, once per step (whatever changed the parameters since the last
+        // step -- the optimizer, load_state_dict, a caller writing p.data -- the products read what the arena holds NOW)
+        if (P->bf16 && P->params16 && P->params_floats > 0)
+            CK(skg_twin_bf16(P->params, P->params16, P->params_floats & ~(int64_t)3, c.stream));
         // ---- box_head (HEAD:812), fc_1 of the global branch (HEAD:971), the first two spatial layers (HEAD:888)
         skg_gemmx_desc l1[2] = {FWD(x0, bh1_w, E1, W.at(SKG_SEG_BH1_B), true),
                                 FWD(sp48, sp0_w, s1, W.at(SKG_SEG_SP0_B), true, -1, 46)};
@@ -440,7 +476,9 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
         launch(c, l, 4);
         // ---- read-out fc_1 * fc_2 products: dF at the pairs' grid rows (self-pair rows stay zero), dm in place
         if (!c.dry) {
-            hipError_t e = hipMemsetAsync(w.dF, 0, sizeof(float) * (size_t)((w.dG1 - w.dF) + (int64_t)Bf * 1024), c.stream);
+            const size_t nz = (size_t)((w.dG1 - w.dF) + (int64_t)Bf * 1024);
+            hipError_t e = hipMemsetAsync(w.dF, 0, sizeof(float) * nz, c.stream);
+            if (e == hipSuccess && P->bf16 && P->ws16) e = hipMemsetAsync(P->ws16 + (w.dF - P->ws), 0, sizeof(uint16_t) * nz, c.stream);
             if (e != hipSuccess) { c.rc = (int)e; break; }
         }
         if (Mp > 0) {
@@ -574,7 +612,8 @@ int skg_train_forward_f32(const skg_train_plan* P, int part, void* stream) {
     if (part == 1 && (!P->ent || !P->logits || !P->pair_features)) return SKG_E_ARG;
     Ws w; layout_ws(P, P->ws, w);
     if (w.total > P->ws_floats) return SKG_E_LIMIT;
-    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0, 0.0};
+    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0, 0.0, w.dadj};
+    TwinScope twins(P);
     // bound the scratch: the sizing pass told the caller how much the largest launch needs
     Ctx d{P, nullptr, true, 0, nullptr, 0, 0.0};
     forward(d, w, part);
@@ -603,7 +642,8 @@ int skg_train_backward_f32(const skg_train_plan* P, int first_stage, int last_st
     int rc = validate_backward(P, first_stage, last_stage);
     if (rc) return rc;
     Ws w; layout_ws(P, P->ws, w);
-    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0, 0.0};
+    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0, 0.0, w.dadj};
+    TwinScope twins(P);
     backward(c, w, first_stage, last_stage);
     if (!c.rc) { hipError_t e = hipGetLastError(); if (e != hipSuccess) c.rc = (int)e; }
     return c.rc;

@@ -112,3 +112,25 @@ extern "C" int skg_adamw_f32(const skg_adamw_chunk* chunks, int n_chunks, double
                        (float)(lr / bias1), (float)(1.0 / sqrt(bias2)), (float)eps);
     return skg_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------ bf16 twins
+thread_local skg_twin_map skg_tls_twin = {{nullptr, nullptr}, {nullptr, nullptr}, {0, 0}};
+
+// dst[i] = bf16(src[i]) (round to nearest even): the twin of a whole fp32 buffer in one pass (the parameter arena of the
+// bf16 training step: 118 MB read, 59 MB written, ~30 us).
+__global__ __launch_bounds__(256) void skg_twin_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+        skg_store_twin4(dst + 4 * i, reinterpret_cast<const float4*>(src)[i]);
+}
+
+extern "C" int skg_twin_bf16(const float* src, uint16_t* dst, int64_t n, void* stream) {
+    if (n < 0 || (n & 3)) return SKG_E_ARG;
+    if (n == 0) return 0;
+    if (!src || !dst) return SKG_E_ARG;
+    if (!skg_aligned16(src) || (((uintptr_t)dst) & 7u)) return SKG_E_ALIGN;
+    const int64_t n4 = n / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(skg_twin_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n4);
+    return skg_launch_status();
+}

@@ -104,7 +104,7 @@ class Stacked:
             for name in group:
                 n = int(np.prod(shapes[name]))
                 seg[name] = (off, shapes[name])
-                off += (n + 3) // 4 * 4                        # every segment 16-byte aligned
+                off += (n + 7) // 8 * 8                        # every segment 32-byte aligned (its bf16 twin: 16 bytes)
             ends.append(off)
         assert set(seg) == set(shapes)
         self.seg, self.total, self.milestone_end = seg, off, ends
@@ -168,6 +168,13 @@ class Stacked:
         views = self.grad_views(ga)
         self._ga = (ga, views, self._holders(views))
         return ga, views
+
+    def twin(self):
+        """bf16 twin of the parameter arena (same element offsets), rewritten by the forward's first part every bf16 step."""
+        t = getattr(self, "_twin", None)
+        if t is None:
+            t = self._twin = torch.empty(self.total, device=self.device, dtype=torch.int16)
+        return t
 
     def persistent_grads(self):
         """(arena, views) kept for the life of this Stacked: the gradient home of `fused_step`, which OVERWRITES every
@@ -290,6 +297,7 @@ class TrainJob:
         # precision="bf16": every dense layer of the step (forward, dX, dW) rounds its operands to bf16 on the way to
         # the matrix core and accumulates in fp32 -- the reference under torch.autocast(bfloat16); tensors stay fp32.
         self.bf16 = head.precision == "bf16"
+        self.twins = getattr(head, "bf16_twins", True) and os.environ.get("SKG_BF16_TWINS", "1") != "0"
 
     def gx(self, ops):
         gemmx.launch(ops, bf16=self.bf16)
@@ -672,8 +680,20 @@ class NativeJob(TrainJob):
             _check(n, "skg_train_ws_floats")
         self.ws = torch.empty(n, device=dev, dtype=torch.float32)
         pl.ws, pl.ws_floats = self.ws.data_ptr(), n
+        self.ws16 = None
+        if self.bf16 and self.twins:
+            # bf16 twins: a second workspace with the same element offsets (every product output and per-row kernel output is
+            # also stored rounded there), the twin of the parameter arena (rewritten by part 0 every step) and of the pair
+            # features -- the products then read 2-byte operands straight into LDS (skg_gemmx_t16_kernel)
+            self.ws16 = torch.empty(n, device=dev, dtype=torch.int16)
+            pl.ws16 = self.ws16.data_ptr()
+            pl.params16 = st.twin().data_ptr()
+            pl.params_floats = st.total
         Mp1 = max(lay.sum_p, 1)
         self.PF = torch.empty(Mp1, 2048, device=dev, dtype=torch.float32)
+        if self.ws16 is not None:
+            self.PF16 = torch.empty(Mp1, 2048, device=dev, dtype=torch.int16)
+            pl.pf16 = self.PF16.data_ptr()
         self.logits_full = torch.zeros(Mp1, pl.ld_logits, device=dev, dtype=torch.float32)
         pl.pair_features, pl.logits = self.PF.data_ptr(), self.logits_full.data_ptr()
         _check(lib.skg_train_forward_f32(C.byref(pl), 0, _stream()), "skg_train_forward_f32[0]")
@@ -742,7 +762,7 @@ class NativeJob(TrainJob):
             _check(lib.skg_ctx_train_backward_async_f32(ctx.handle(), C.byref(pl), 0, n, stream, events),
                    "skg_train_backward_async_f32")
             # everything the plan names stays alive until the worker has enqueued the last launch
-            ctx.pending.append((self, self.S, self.ws, dlogits, ga, dx0, dgfeat))
+            ctx.pending.append((self, self.S, self.ws, self.ws16, dlogits, ga, dx0, dgfeat))
             if ex is not None:
                 ctx.exchange = (ex, list(st.milestone_end))
             self.S = None

@@ -354,7 +354,7 @@ def test_trainer_epoch_with_validation_on_the_real_head(capsys):
     tr = trainer.Trainer(net, opt, None, [batch] * 3, val_loader=[batch] * 2, num_classes=case["cfg"]["K"], lazy_losses=True)
     tr(2)
     out = capsys.readouterr().out
-    assert out.count("training mAP") == 2 and tr.iteration == 6 and head.training
+    assert out.count("training mAP") == 2 and tr.iteration == 6 and not head.training      # (validate() leaves eval mode, like the reference)
     rep = tr.last_report
     assert 0.0 <= rep["training_map"] <= 1.0 and 0.0 <= rep["validation_map"] <= 1.0
     torch.manual_seed(9)
