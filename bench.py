@@ -152,10 +152,17 @@ def run_train(B, precision, steps, warmup, device, rank, world, dist_on, prefetc
                for i, d in enumerate(cpu_dets)]
 
     class Pool(torch.nn.Module):
+        """box_roi_pool stand-in: the cached box features, resident in HBM, for however many boxes the head selected (GT boxes
+        are appended in training: the row count follows the head)."""
+        cache = {}
+
         def forward(self, features, boxes, image_shapes):
-            n = sum(len(b) for b in boxes)           # GT boxes are appended in training: size follows the head
-            reps = (n + pooled.shape[0] - 1) // pooled.shape[0]
-            return pooled.repeat(reps, 1, 1, 1)[:n]
+            n = sum(len(b) for b in boxes)
+            t = self.cache.get(n)
+            if t is None:
+                reps = (n + pooled.shape[0] - 1) // pooled.shape[0]
+                t = self.cache[n] = pooled.repeat(reps, 1, 1, 1)[:n].contiguous()
+            return t
 
     head.box_roi_pool = Pool()
     net = trainer.wrap_ddp(head, device, force_exchange=force_exchange)

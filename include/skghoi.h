@@ -52,6 +52,34 @@ typedef struct {
 } skg_image_meta;
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Host-side layout of a training batch in ONE call (no device work): from the per-image counts the preprocess kernel
+ * reports -- humans n_h[B], nodes n[B], scored cells L[B] (may be NULL) -- the skg_image_meta records of the active images
+ * and every small index table the step gathers through, written as int32 slices (each 16-byte aligned) into the caller's
+ * staging buffer buf_host (pinned memory: the step uploads it in one copy).  Replaces the per-image index bookkeeping of
+ * the reference's image loop (HEAD:822-982).  shapes_hw[2 b], [2 b + 1] = image height, width.  Slices (info->off / len,
+ * in int32 units): META (n_active x 12 = skg_image_meta), NODE_IMG / HUM_IMG (active-image index of every node / human),
+ * NODE_ENC_ROW / HUM_ENC_ROW (row of box_head's output; faithful_skip_offset != 0 reproduces the reference's offset bug on
+ * skipped images), NODE_ENT_ROW / HUM_ENT_ROW (TransH entity row: position y / human_idx), the three
+ * [human rows | node rows] tables of the fc_head | fc_tail gather (ENC_ROW_HN, IMG_HN, ENT_ROW_HN), HUM_OF / NODE_OF (inverse
+ * maps encoding row -> human / node row, -1 = none; max(sum_all, 1) entries), PAIR_IMG (batch index of every kept pair's
+ * image), GT_OFF (n_active + 1 prefix sums of gt_count over the active images; zeros when gt_count is NULL), ACTIVE (batch
+ * index of every active image).  zip_truncation != 0: at most sum(n) images are visited (HEAD:822 zips over the rows of
+ * box_features).  Returns 0 and fills info (sizes of the row spaces, info->ints = int32 words needed); when buf_host is
+ * NULL or cap_ints < info->ints nothing is written (sizing call).  info->index_error = 1 where the reference raises
+ * IndexError (more than 80 nodes, human_idx outside the 80-row TransH table: HEAD:570-572, 690).                        */
+enum { SKG_LAY_META = 0, SKG_LAY_NODE_IMG, SKG_LAY_HUM_IMG, SKG_LAY_NODE_ENC_ROW, SKG_LAY_HUM_ENC_ROW, SKG_LAY_NODE_ENT_ROW,
+       SKG_LAY_HUM_ENT_ROW, SKG_LAY_ENC_ROW_HN, SKG_LAY_IMG_HN, SKG_LAY_ENT_ROW_HN, SKG_LAY_HUM_OF, SKG_LAY_NODE_OF,
+       SKG_LAY_PAIR_IMG, SKG_LAY_GT_OFF, SKG_LAY_ACTIVE, SKG_LAY_SLICES };
+typedef struct {
+    int32_t B, n_visit, n_active, index_error;
+    int64_t sum_all, sum_n, sum_h, sum_g, sum_p, sum_l, ints;
+    int32_t off[SKG_LAY_SLICES], len[SKG_LAY_SLICES];
+} skg_layout_info;
+int skg_layout_pack_train(const int64_t* n_h_host, const int64_t* n_host, const int64_t* L_host, int B,
+                          const float* shapes_hw_host, int human_idx, int faithful_skip_offset, int zip_truncation,
+                          const int32_t* gt_count_host, int32_t* buf_host, int64_t cap_ints, skg_layout_info* info_host);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * InteractionHead.preprocess (HEAD:92-151): score >= thresh -> class-wise NMS (torchvision batched_nms, coordinate
  * trick, IoU > nms_thresh suppresses) -> descending score (ties: ascending input index) -> first max_human humans and
  * max_object others -> humans first.  One workgroup per image.

@@ -73,6 +73,17 @@ class TrainPlan(C.Structure):
                 ("params_floats", _i64)]
 
 
+LAYOUT_SLICES = ("meta", "node_img", "hum_img", "node_enc_row", "hum_enc_row", "node_ent_row", "hum_ent_row", "enc_row_hn",
+                 "img_hn", "ent_row_hn", "hum_of", "node_of", "pair_img", "gt_off", "active")       # SKG_LAY_* order
+
+
+class LayoutInfo(C.Structure):
+    """Mirror of skg_layout_info."""
+    _fields_ = [(n, _i32) for n in ("B", "n_visit", "n_active", "index_error")] + \
+               [(n, _i64) for n in ("sum_all", "sum_n", "sum_h", "sum_g", "sum_p", "sum_l", "ints")] + \
+               [("off", _i32 * len(LAYOUT_SLICES)), ("len", _i32 * len(LAYOUT_SLICES))]
+
+
 # numpy dtype of skg_image_meta (12 x 4 bytes)
 META_FIELDS = [("image", "i4"), ("n_h", "i4"), ("n", "i4"), ("box_off", "i4"), ("enc_off", "i4"), ("node_off", "i4"),
                ("hum_off", "i4"), ("grid_off", "i4"), ("pair_off", "i4"), ("out_off", "i4"), ("img_h", "f4"),
@@ -151,6 +162,8 @@ PROTOTYPES = {
     "skg_train_backward_async_f32": (C.c_int, [C.POINTER(TrainPlan), C.c_int, C.c_int, _vp]),
     "skg_train_backward_join": (C.c_int, []),
     "skg_twin_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "skg_layout_pack_train": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _i64,
+                                        C.POINTER(LayoutInfo)]),
     "skg_train_timer_create": (_vp, [C.c_int]),
     "skg_train_timer_destroy": (None, [_vp]),
     "skg_train_timer_read": (C.c_int, [_vp, C.POINTER(C.c_double)]),

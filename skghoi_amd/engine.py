@@ -516,6 +516,7 @@ class HeadEngine:
         self._cnt_event = None
         self._cnt_host_dev = None
         self.plan_epoch = 0
+        self._ck_events = None
         self.small_two_branches = os.environ.get("SKG_SMALL_ONE_BRANCH") != "1"    # captured plans: spatial chain beside the box_head chain
         self.small_batch_max = 8    # eval batches of up to this many images replay a captured hipGraph (skghoi_amd/small.py); 0: off
         self.small_batch_buckets = True   # single images share one plan per BUCKET of (humans, nodes) instead of one per shape
@@ -676,9 +677,26 @@ class HeadEngine:
         # counts [B,4] | parameter checksum partials (u64 x CHECKSUM_PARTIALS): one buffer, one D2H copy
         countx = torch.empty(4 * B + 2 * _capi.CHECKSUM_PARTIALS, dtype=torch.int32, device=dev)
         watch = None
+        side_done = None
         if check_weights and self._pw is not None and self._pw.device == dev and self._pw.watch.table is not None:
             watch = self._pw.watch
-            watch.enqueue(countx.data_ptr() + 16 * B)                      # rides on the one D2H copy below
+            if B <= self.small_batch_max:
+                # a few images: the forward is a chain of short kernels, and the 18 us checksum (118 MB read) in front of
+                # the selection kernel would be on its critical path.  It runs BESIDE the selection kernel on the process's
+                # side stream, ordered behind everything this stream holds now (an optimizer step enqueued a moment ago is
+                # seen); the one D2H copy below waits for both.
+                ev = self._ck_events
+                if ev is None or ev[2] != dev:
+                    ev = self._ck_events = (torch.cuda.Event(), torch.cuda.Event(), dev)
+                side = shared_side_stream(dev, 0, slot=0)
+                ev[0].record()
+                side.wait_event(ev[0])
+                with torch.cuda.stream(side):
+                    watch.enqueue(countx.data_ptr() + 16 * B)
+                    ev[1].record(side)
+                side_done = ev[1]
+            else:
+                watch.enqueue(countx.data_ptr() + 16 * B)                  # rides on the one D2H copy below
         prior_pow = 1.0 if training else 2.8                                    # HEAD:742
         if boxes.numel() == 0:
             boxes = torch.zeros(1, 4, device=dev); scores = torch.zeros(1, device=dev)
@@ -688,6 +706,8 @@ class HeadEngine:
                                            self.max_human, self.max_object, vt.nverbs.data_ptr(), vt.num_obj,
                                            prior_pow, index.data_ptr(), countx.data_ptr(), _stream()),
                     "skg_preprocess_f32")
+        if side_done is not None:
+            torch.cuda.current_stream(dev).wait_event(side_done)
         if defer:
             # the caller goes on with other host work while the kernel runs and comes back with pre_launch_end()
             return dict(pending=self._read_counts(countx, defer=True), countx=countx, watch=watch, B=B, dev=dev,

@@ -85,6 +85,51 @@ def build(n_h, n, L, image_shapes, human_idx, faithful_skip_offset=True, zip_tru
     return lay
 
 
+def build_train(n_h, n, L, image_shapes, human_idx, gt_count=None, faithful_skip_offset=True, zip_truncation=True, pin=True):
+    """build() + pack_int_arrays() + the training step's extra tables (hum_of, node_of, pair_img, gt_off) in ONE native
+    call (skg_layout_pack_train, csrc/skg_layout.cpp), written straight into a pinned staging tensor.  Returns (lay, buf,
+    offs): the BatchLayout (its arrays are views of `buf`), the int32 host tensor to upload in one copy, and the slices
+    {name: (offset, length)} inside it.  Same numbers as the numpy route (tests/test_capi_and_host.py)."""
+    import ctypes as C
+    import torch
+    lib = _capi.lib()
+    n_h = np.ascontiguousarray(n_h, dtype=np.int64); n = np.ascontiguousarray(n, dtype=np.int64)
+    B = len(n)
+    L = np.zeros(B, np.int64) if L is None else np.ascontiguousarray(L, dtype=np.int64)
+    shp = np.ascontiguousarray([(float(s_[0]), float(s_[1])) for s_ in image_shapes], dtype=np.float32).reshape(-1, 2)
+    if len(shp) < B:
+        raise IndexError("list index out of range")
+    gtc = None if gt_count is None else np.ascontiguousarray(gt_count, dtype=np.int32)
+    info = _capi.LayoutInfo()
+    # capacity: every table is bounded by a small multiple of the row spaces; a sizing call costs less than guessing wrong
+    args = (n_h.ctypes.data, n.ctypes.data, L.ctypes.data, B, shp.ctypes.data, int(human_idx), int(bool(faithful_skip_offset)),
+            int(bool(zip_truncation)), (gtc.ctypes.data if gtc is not None else None))
+    _capi.check(lib.skg_layout_pack_train(*args, None, 0, C.byref(info)), "skg_layout_pack_train")
+    if info.index_error:
+        raise IndexError("index out of range in self")
+    buf = torch.empty(int(info.ints), dtype=torch.int32, pin_memory=pin)
+    _capi.check(lib.skg_layout_pack_train(*args, buf.data_ptr(), buf.numel(), C.byref(info)), "skg_layout_pack_train")
+    host = buf.numpy()
+    offs = {name: (int(info.off[i]), int(info.len[i])) for i, name in enumerate(_capi.LAYOUT_SLICES)}
+    sl = lambda name: host[offs[name][0]:offs[name][0] + offs[name][1]]
+    lay = BatchLayout()
+    lay.B = B
+    lay.n_h, lay.n = n_h, n
+    lay.sum_all, lay.n_visit, lay.n_active = int(info.sum_all), int(info.n_visit), int(info.n_active)
+    lay.box_off = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    lay.skipped = (n_h == 0) | (n <= 1)
+    lay.active = sl("active").astype(np.int64)
+    lay.meta = sl("meta").view(META_DTYPE)
+    lay.sum_n, lay.sum_h, lay.sum_g, lay.sum_p, lay.sum_l = (int(info.sum_n), int(info.sum_h), int(info.sum_g),
+                                                             int(info.sum_p), int(info.sum_l))
+    for name in ("node_img", "hum_img", "node_enc_row", "hum_enc_row", "node_ent_row", "hum_ent_row"):
+        setattr(lay, name, sl(name))
+    an = lay.meta["n"].astype(np.int64); ah = lay.meta["n_h"].astype(np.int64)
+    lay.pairs_per_image = ah * (an - 1)
+    lay.cells_per_image = L[lay.active]
+    return lay, buf, offs
+
+
 def single(n_h, n, L, image_shape):
     """The layout of ONE active image (n_h >= 1, n >= 2) with what result extraction reads (the captured single-image
     plans build it per call: build() costs ~0.1 ms of numpy for the general case, a fifth of such a forward)."""

@@ -74,6 +74,8 @@ class SmallBatchRunner:
         self.epoch = engine.plan_epoch
         self.retired = []                  # dropped plans: destroyed only on an idle device, never next to a capture
         self.captures = self.evictions = 0
+        self._ent_stage = None             # one image's entity table, drawn ahead of the count synchronisation
+        self._predrawn = None              # generator state from before that draw, while the draw is still unclaimed
 
     def _retire(self, plans):
         self.retired.extend(plans)
@@ -245,7 +247,22 @@ class SmallBatchRunner:
     def forward(self, head, features, detections, image_shapes):
         """Returns the list of result dicts, or None when this batch has to take the eager path."""
         eng = self.eng
-        pre = eng.pre_launch(detections, None, False, False, check_weights=True)
+        predrawn = None
+        if len(detections) == 1:
+            # one image (the reference's evaluation mode): its TransH entity table (HEAD:574-580: ~4 000 normal draws from the
+            # global CPU generator, ~20 us) is drawn while the selection kernel runs, not after the counts have arrived with
+            # the GPU idle.  Same generator, same order -- unless the image turns out to have no pairs or the call leaves for
+            # the eager path: then the generator is put back and that path draws for itself.
+            st = eng.pre_launch(detections, None, False, False, check_weights=True, defer=True)
+            state = torch.get_rng_state()
+            if self._ent_stage is None:
+                self._ent_stage = torch.empty(1, _capi.TRANSH_ENT, _capi.TRANSH_DIM)
+            transh.draw_batch(eng.K, 1, need_relations=False, out=(self._ent_stage, None, None))
+            predrawn = state
+            pre = eng.pre_launch_end(st)
+        else:
+            pre = eng.pre_launch(detections, None, False, False, check_weights=True)
+        self._predrawn = predrawn
         dev = pre.device
         pw = eng.weights(dev, wsum=pre.wsum, walk=False)
         if not pw.fused_cls:
@@ -353,7 +370,12 @@ class SmallBatchRunner:
             p.meta_f32[:, 11] = [float(image_shapes[int(b)][1]) for b in act]
             Lt = int(L.sum())
         p.lt_host[0] = Lt
-        transh.draw_batch(eng.K, lay.n_active, need_relations=False, out=(p.ent_host, None, None))
+        if self._predrawn is not None and lay.n_active == 1:
+            p.ent_host[0].copy_(self._ent_stage[0])          # drawn beside the selection kernel (top of this function)
+            self._predrawn = None
+        else:
+            self._undo_predraw()
+            transh.draw_batch(eng.K, lay.n_active, need_relations=False, out=(p.ent_host, None, None))
         p.dyn_dev.copy_(p.dyn_host, non_blocking=True)
         if p.h2d_done is None:
             p.h2d_done = torch.cuda.Event()
@@ -383,8 +405,15 @@ class SmallBatchRunner:
         eng.last = dict(p.out, layout=call_lay, plan=p)
         return head._results(call_lay, r, dev)
 
+    def _undo_predraw(self):
+        """Puts the global CPU generator back where it stood before this call's early table draw."""
+        if self._predrawn is not None:
+            torch.set_rng_state(self._predrawn)
+            self._predrawn = None
+
     def _fallback(self, head, pre, features, image_shapes):
         """Batches without a single kept pair, or with injected non-Linear classifiers: the eager path, continuing from
         the preprocess that has already run."""
+        self._undo_predraw()
         self.eng.pre_pack(pre)
         return head._forward_eager(pre, features, image_shapes)

@@ -153,6 +153,7 @@ class Stacked:
             torch._foreach_copy_(self.dst, [p.detach() for p in self.src])
             for p, d in zip(self.src, self.dst):
                 p.data = d
+                p._skg_arena = self          # (the optimizer's plan: this parameter's storage is checked by the step's forward)
         self.adoptions += 1
 
     def grad_arena(self):
@@ -168,6 +169,15 @@ class Stacked:
         views = self.grad_views(ga)
         self._ga = (ga, views, self._holders(views))
         return ga, views
+
+    def scratch(self, name, n, dtype, dev):
+        """A buffer of at least n elements that lives with this arena and is handed out again to the next step (grown when a
+        step needs more).  Only for memory whose every use is ordered on the step's stream."""
+        pool = self.__dict__.setdefault("_scratch", {})
+        t = pool.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype or t.device != dev:
+            t = pool[name] = torch.empty(max(n, 1), device=dev, dtype=dtype)
+        return t
 
     def twin(self):
         """bf16 twin of the parameter arena (same element offsets), rewritten by the forward's first part every bf16 step."""
@@ -678,21 +688,25 @@ class NativeJob(TrainJob):
         n = int(lib.skg_train_ws_floats(C.byref(pl)))
         if n < 0:
             _check(n, "skg_train_ws_floats")
-        self.ws = torch.empty(n, device=dev, dtype=torch.float32)
+        # workspaces are kept by the parameter arena object and reused from step to step (steps follow each other on one
+        # stream: step i + 1's forward is ordered behind step i's backward, and the worker thread of step i has been joined)
+        keep = getattr(self, "reuse_ws", False)
+        alloc = st.scratch if keep else (lambda name, m, dt, d: torch.empty(max(m, 1), device=d, dtype=dt))
+        self.ws = alloc("ws", n, torch.float32, dev)
         pl.ws, pl.ws_floats = self.ws.data_ptr(), n
         self.ws16 = None
         if self.bf16 and self.twins:
             # bf16 twins: a second workspace with the same element offsets (every product output and per-row kernel output is
             # also stored rounded there), the twin of the parameter arena (rewritten by part 0 every step) and of the pair
             # features -- the products then read 2-byte operands straight into LDS (skg_gemmx_t16_kernel)
-            self.ws16 = torch.empty(n, device=dev, dtype=torch.int16)
+            self.ws16 = alloc("ws16", n, torch.int16, dev)
             pl.ws16 = self.ws16.data_ptr()
             pl.params16 = st.twin().data_ptr()
             pl.params_floats = st.total
         Mp1 = max(lay.sum_p, 1)
         self.PF = torch.empty(Mp1, 2048, device=dev, dtype=torch.float32)
         if self.ws16 is not None:
-            self.PF16 = torch.empty(Mp1, 2048, device=dev, dtype=torch.int16)
+            self.PF16 = alloc("pf16", Mp1 * 2048, torch.int16, dev)
             pl.pf16 = self.PF16.data_ptr()
         self.logits_full = torch.zeros(Mp1, pl.ld_logits, device=dev, dtype=torch.float32)
         pl.pair_features, pl.logits = self.PF.data_ptr(), self.logits_full.data_ptr()
@@ -956,7 +970,10 @@ def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None
     pre = eng.pre_pack(eng.pre_launch_end(launched))
     dev = pre.device
     stream = _stream()
-    lay = layout.build(pre.n_h, pre.n, pre.L, image_shapes, gh.human_idx, faithful_skip_offset=eng.faithful_skip_offset)
+    # ---- the batch layout and every index table of the step: one native call into a pinned block, one upload
+    gt_all = [int(t["boxes_h"].shape[0]) for t in targets]
+    lay, hbuf, offs = layout.build_train(pre.n_h, pre.n, pre.L, image_shapes, gh.human_idx, gt_count=gt_all,
+                                         faithful_skip_offset=eng.faithful_skip_offset)
     prep = Prepared()
     prep.pre, prep.lay, prep.inputs = pre, lay, (detections, image_shapes, targets)
     A = lay.n_active
@@ -966,25 +983,9 @@ def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None
     Mg, Mp, Mh, Mn, NA = lay.sum_g, lay.sum_p, lay.sum_h, lay.sum_n, lay.sum_all
     f32 = dict(device=dev, dtype=torch.float32)
     i32 = dict(device=dev, dtype=torch.int32)
-    # ---- every index array of the step in one upload
-    buf, offs = layout.pack_int_arrays(lay)
-    hum_of = np.full(max(NA, 1), -1, np.int32); node_of = np.full(max(NA, 1), -1, np.int32)
-    hum_of[lay.hum_enc_row] = np.arange(Mh, dtype=np.int32)
-    node_of[lay.node_enc_row] = np.arange(Mn, dtype=np.int32)
-    pair_img = np.repeat(lay.meta["image"].astype(np.int32), lay.pairs_per_image)
     act_imgs = [int(b) for b in lay.active]
-    gt_cnt = [int(targets[b]["boxes_h"].shape[0]) for b in act_imgs]
-    gt_off_h = np.zeros(A + 1, np.int32); gt_off_h[1:] = np.cumsum(gt_cnt)
-    extra = [("hum_of", hum_of), ("node_of", node_of), ("pair_img", pair_img), ("gt_off", gt_off_h)]
-    cur = len(buf)
-    parts = [buf]
-    for name, arr in extra:
-        pad = (-cur) % 4
-        if pad:
-            parts.append(np.zeros(pad, np.int32)); cur += pad
-        offs[name] = (cur, len(arr))
-        parts.append(arr.astype(np.int32)); cur += len(arr)
-    ibuf = torch.from_numpy(np.concatenate(parts)).to(dev, non_blocking=True)
+    gt_off_h = hbuf.numpy()[offs["gt_off"][0]:offs["gt_off"][0] + offs["gt_off"][1]]
+    ibuf = hbuf.to(dev, non_blocking=True)
     isl = lambda name: ibuf[offs[name][0]:offs[name][0] + offs[name][1]]
     meta = isl("meta")
     # ---- pairs + spatial encoding, GT association (HEAD:847-868, 703-719): ahead of the dense part because the
@@ -1059,7 +1060,7 @@ def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None
     prep.pos_s, prep.neg_s, prep.mpart = pos_s[:M_pos], neg_s[:M_pos], mpart
     prep.cross = (pre.boxes, pre.scores, pre.labels, ibuf, grid, keep, sp48, labels_all, prep.ent, prep.rel, prep.nrm,
                   samp_d, gt_h, gt_o, gt_l, npos_d, scores_all, tr, sws)
-    prep.keep = (ent_h, rel_h, nrm_h, sh, npos_h)                   # pinned staging: alive until the copies have run
+    prep.keep = (ent_h, rel_h, nrm_h, sh, npos_h, hbuf)             # pinned staging: alive until the copies have run
     return prep
 
 
@@ -1070,6 +1071,7 @@ class TrainRun:
     def __init__(self, head, eng, features, image_shapes):
         self.head, self.eng, self.features, self.image_shapes = head, eng, features, image_shapes
         self.job = None
+        self.reuse_ws = False        # fused_step: the backward follows the forward at once -> the arena's persistent workspaces
 
     def start(self, prep):
         head, eng, pre, lay = self.head, self.eng, prep.pre, prep.lay
@@ -1085,6 +1087,8 @@ class TrainRun:
         isl = job.isl
         job.pair_img, job.hum_of, job.node_of = isl("pair_img"), isl("hum_of"), isl("node_of")
         job.labels = prep.labels
+        # (a differentiable RoI pooling in front hands the step to autograd: its backward may come after another forward)
+        job.reuse_ws = self.reuse_ws and not box_features.requires_grad
         self.gfeat = torch.nn.functional.adaptive_avg_pool2d(self.features["3"].float(), 1).flatten(start_dim=1)  # HEAD:811
         with torch.no_grad():
             job.forward_a(box_features, self.gfeat)
@@ -1171,6 +1175,7 @@ def fused_step(head, eng, features, detections, image_shapes, targets, prep=None
     if any(getattr(t, "requires_grad", False) for t in features.values()):
         return None, prep
     run = TrainRun(head, eng, features, image_shapes)
+    run.reuse_ws = True
     # measurement (bench.py): HIP events on the step's stream at the phase boundaries -- f0 forward begins, b0 backward
     # begins (= forward + losses done), b1 behind the backward's last launch, o1 behind the optimizer (trainer.train_step)
     spans = head.__dict__.get("_train_spans")

@@ -442,7 +442,16 @@ class SkgAdamW(CachedFusedAdamW):
         pl = self._plans.get(gi)
         params, exp_avgs, exp_avg_sqs, steps = c[1], c[2], c[3], c[4]
         if pl is not None and pl["lists"] is c:
-            if not pl["ok"] or pl["pbase"] == [p.data_ptr() for p in params]:     # .data re-pointed: rebuild
+            if not pl["ok"]:
+                return pl
+            # .data re-pointed -> rebuild.  Parameters that live in a head's parameter ARENA (train_fused.Stacked marks them)
+            # were checked against it, all 408, by this step's forward -- which re-adopts them if anything moved -- so here
+            # only the arena's own identity is left to check (its first and last parameter); everything else is compared
+            # pointer by pointer.
+            free, probe, base = pl["free"], pl["probe"], pl["pbase"]
+            if all(params[i].data_ptr() == base[i] for i in probe) and \
+                    (not free or [params[i].data_ptr() for i in free] == [base[i] for i in free]) and \
+                    all(getattr(params[i], "_skg_arena", None) is not None for i in probe):
                 return pl
         ok = all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params) and \
             all(t.dtype == torch.float32 and t.is_contiguous() for t in exp_avgs + exp_avg_sqs) and \
@@ -479,8 +488,15 @@ class SkgAdamW(CachedFusedAdamW):
         tab["count"] = cnt
         dev = params[0].device
         nb = tab.nbytes
+        managed = [i for i, p_ in enumerate(params) if getattr(p_, "_skg_arena", None) is not None]
+        free = [i for i, p_ in enumerate(params) if getattr(p_, "_skg_arena", None) is None]
+        arenas = {}
+        for i in managed:                                   # first and last parameter of every arena
+            a = arenas.setdefault(id(params[i]._skg_arena), [i, i])
+            a[1] = i
+        probe = sorted({i for a in arenas.values() for i in a})
         pl = dict(lists=c, ok=True, tab=tab, tix=tix, byte=byte, host_step=int(st[0]), dev=dev, numel=numel,
-                  pbase=[p.data_ptr() for p in params],
+                  pbase=[p.data_ptr() for p in params], free=free, probe=probe,
                   flat_step=flat_step,
                   pinned=[torch.empty(nb, dtype=torch.uint8, pin_memory=True) for _ in range(2)],
                   events=[None, None], dtab=torch.empty(nb, dtype=torch.uint8, device=dev), flip=0)

@@ -321,3 +321,51 @@ def test_copies_and_pickles_of_the_head_drop_runtime_caches():
     blob = pickle.dumps(head)
     back = pickle.loads(blob)
     assert back._engine is None and set(back.state_dict()) == set(head.state_dict())
+
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("faithful", [True, False])
+def test_native_training_layout_equals_the_numpy_route(seed, faithful):
+    """skg_layout_pack_train (one native call into the staging block) against layout.build + pack_int_arrays + the step's
+    extra tables built with numpy: skipped images (no human, a single node), the reference's offset bug on them (Q9), the zip
+    truncation of HEAD:822, ragged ground-truth counts."""
+    import numpy as np
+    from skghoi_amd import layout
+    rs = np.random.RandomState(seed)
+    B = int(rs.randint(1, 7))
+    n_h = rs.randint(0, 5, B); n_o = rs.randint(0, 6, B)
+    n = n_h + n_o
+    if seed == 3:
+        n[:] = 0; n_h[:] = 0; n[0] = 2; n_h[0] = 1                  # sum(n) < B: the zip truncation visits two images only
+    L = rs.randint(0, 50, B)
+    shapes = [(float(rs.randint(300, 900)), float(rs.randint(300, 900))) for _ in range(B)]
+    gt = rs.randint(0, 4, B)
+    want = layout.build(n_h, n, L, shapes, 49, faithful_skip_offset=faithful)
+    wbuf, woffs = layout.pack_int_arrays(want)
+    lay, buf, offs = layout.build_train(n_h, n, L, shapes, 49, gt_count=gt, faithful_skip_offset=faithful, pin=False)
+    host = buf.numpy()
+    for k in ("B", "sum_all", "n_visit", "n_active", "sum_n", "sum_h", "sum_g", "sum_p", "sum_l"):
+        assert getattr(lay, k) == getattr(want, k), k
+    for k in ("active", "skipped", "box_off", "pairs_per_image", "cells_per_image", "node_img", "hum_img", "node_enc_row",
+              "hum_enc_row", "node_ent_row", "hum_ent_row"):
+        assert np.array_equal(getattr(lay, k), getattr(want, k)), k
+    assert lay.meta.tobytes() == want.meta.tobytes()
+    for k, (o, l) in woffs.items():                                  # every slice of the numpy pack, bit for bit
+        o2, l2 = offs[k]
+        assert l2 == l and o2 % 4 == 0 and np.array_equal(host[o2:o2 + l2], wbuf[o:o + l]), k
+    NA, Mh, Mn = max(want.sum_all, 1), want.sum_h, want.sum_n
+    hum_of = np.full(NA, -1, np.int32); node_of = np.full(NA, -1, np.int32)
+    hum_of[want.hum_enc_row] = np.arange(Mh, dtype=np.int32); node_of[want.node_enc_row] = np.arange(Mn, dtype=np.int32)
+    sl = lambda k: host[offs[k][0]:offs[k][0] + offs[k][1]]
+    assert np.array_equal(sl("hum_of"), hum_of) and np.array_equal(sl("node_of"), node_of)
+    assert np.array_equal(sl("pair_img"), np.repeat(want.meta["image"].astype(np.int32), want.pairs_per_image))
+    gt_off = np.zeros(want.n_active + 1, np.int32); gt_off[1:] = np.cumsum(gt[want.active])
+    assert np.array_equal(sl("gt_off"), gt_off)
+
+
+def test_native_training_layout_raises_like_the_reference_on_too_many_nodes():
+    from skghoi_amd import layout
+    with pytest.raises(IndexError):
+        layout.build_train([1], [81], None, [(10., 10.)], 49, pin=False)
+    with pytest.raises(IndexError):
+        layout.build_train([1], [3], None, [(10., 10.)], 80, pin=False)
