@@ -605,18 +605,23 @@ void skg_context_destroy(skg_context* ctx);       /* waits for a job in flight, 
 /* skg_train_backward_f32 issued from the context's worker thread (one job at a time per context; the plan is copied, the
  * worker selects the caller's current device): returns at once -- 0, SKG_E_* for a plan / stage range / workspace that
  * skg_train_backward_f32 would reject (checked HERE, before the job is queued), SKG_E_LIMIT while a job is pending.
- * stage_events_host: NULL, or last_stage - first_stage hipEvent_t handles (entries may be NULL): the worker records
- * events[s - first_stage] on `stream` right behind stage s.  skg_ctx_train_backward_stage_wait(ctx, s) blocks until stage s
- * has been enqueued (and its event recorded) and returns 0, or the job's error if it ended before reaching s: a
- * data-parallel caller then orders the collective of the gradient-arena prefix stage s completed behind that event, while
- * the worker keeps issuing the later stages (reference: DistributedDataParallel's bucket all-reduces behind autograd,
- * utils.py:202-205).  skg_ctx_train_backward_join blocks until every launch of the job has been enqueued and returns what
+ * stage_mask: bit s set = the worker records the context's OWN event for stage s on `stream` right behind that stage (created
+ * without timing and with DEVICE-scope release: an event of the default, system-scope kind writes the L2 back and invalidates
+ * it at every record -- a dozen of those inside a backward cost +0.15 ms of 0.8).  skg_ctx_train_backward_stage_wait(ctx, s)
+ * blocks the HOST until stage s has been enqueued (and its event, if any, recorded) and returns 0, or the job's error if it
+ * ended before reaching s; skg_ctx_stream_wait_stage(ctx, s, other_stream) then makes `other_stream` wait for stage s on the
+ * DEVICE: a data-parallel caller orders the collective of the gradient-arena prefix stage s completed behind it, while the
+ * worker keeps issuing the later stages (reference: DistributedDataParallel's bucket all-reduces behind autograd,
+ * utils.py:202-205).  stage_events_host: NULL, or last_stage - first_stage caller-owned hipEvent_t handles (entries may be
+ * NULL) recorded behind their stages as well (measurement: a timing event behind the last stage).
+ * skg_ctx_train_backward_join blocks until every launch of the job has been enqueued and returns what
  * skg_train_backward_f32 returned (0 when no job was pending).  Between submit and join the caller may enqueue work on
  * OTHER streams and do host work; it must not enqueue anything ordered after the gradients on `stream`, nor release a
  * buffer the plan names.  For step loops bound by their own host thread (a Python trainer at batch 4: ~0.2 ms of launch
  * calls).                                                                                                              */
 int skg_ctx_train_backward_async_f32(skg_context* ctx, const skg_train_plan* plan_host, int first_stage, int last_stage,
-                                     void* stream, void* const* stage_events_host);
+                                     void* stream, void* const* stage_events_host, uint32_t stage_mask);
+int skg_ctx_stream_wait_stage(skg_context* ctx, int stage, void* waiting_stream);
 int skg_ctx_train_backward_stage_wait(skg_context* ctx, int stage);
 int skg_ctx_train_backward_join(skg_context* ctx);
 /* The same on the default context, without stage events. */

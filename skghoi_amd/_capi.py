@@ -169,7 +169,8 @@ PROTOTYPES = {
     "skg_train_timer_read": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "skg_context_create": (_vp, []),
     "skg_context_destroy": (None, [_vp]),
-    "skg_ctx_train_backward_async_f32": (C.c_int, [_vp, C.POINTER(TrainPlan), C.c_int, C.c_int, _vp, _vp]),
+    "skg_ctx_train_backward_async_f32": (C.c_int, [_vp, C.POINTER(TrainPlan), C.c_int, C.c_int, _vp, _vp, C.c_uint32]),
+    "skg_ctx_stream_wait_stage": (C.c_int, [_vp, C.c_int, _vp]),
     "skg_ctx_train_backward_stage_wait": (C.c_int, [_vp, C.c_int]),
     "skg_ctx_train_backward_join": (C.c_int, [_vp]),
     "skg_train_ws_offset": (C.c_int64, [C.POINTER(TrainPlan), C.c_int]),

@@ -669,7 +669,10 @@ struct skg_context {
     int first = 0, last = 0, device = 0, rc = 0;
     int issued = 0;                      // stages [first, issued) of the current / last job are on the stream
     void* stream = nullptr;
-    hipEvent_t events[SKG_TRAIN_BWD_STAGES];
+    hipEvent_t events[SKG_TRAIN_BWD_STAGES];       // caller's events (measurement), by stage - first
+    hipEvent_t own[SKG_TRAIN_BWD_STAGES];          // the context's own stage events: no timing, DEVICE-scope release
+    uint32_t own_mask = 0;                         // stages (absolute) behind which own[stage] is recorded
+    bool own_made = false;
     bool with_events = false;
     void loop() {
         for (;;) {
@@ -683,12 +686,18 @@ struct skg_context {
                 lk.lock();
                 issued = last;
             } else {
-                for (int s = first; s < last && !r; ++s) {
-                    r = skg_train_backward_f32(&plan, s, s + 1, stream);
-                    if (!r && events[s - first]) r = (int)hipEventRecord(events[s - first], (hipStream_t)stream);
+                // runs of stages up to the next stage that somebody waits for: one plan call per run, one event behind it
+                int s = first;
+                while (s < last && !r) {
+                    int e = s;
+                    while (e + 1 < last && !events[e - first] && !((own_mask >> e) & 1u)) ++e;
+                    r = skg_train_backward_f32(&plan, s, e + 1, stream);
+                    if (!r && events[e - first]) r = (int)hipEventRecord(events[e - first], (hipStream_t)stream);
+                    if (!r && ((own_mask >> e) & 1u)) r = (int)hipEventRecord(own[e], (hipStream_t)stream);
                     if (r) break;
-                    lk.lock(); issued = s + 1; lk.unlock();
+                    lk.lock(); issued = e + 1; lk.unlock();
                     cv.notify_all();
+                    s = e + 1;
                 }
                 lk.lock();
             }
@@ -729,11 +738,13 @@ void skg_context_destroy(skg_context* c) {
     }
     c->cv.notify_all();
     if (c->started && c->worker.joinable()) c->worker.join();
+    if (c->own_made)
+        for (int s = 0; s < SKG_TRAIN_BWD_STAGES; ++s) (void)hipEventDestroy(c->own[s]);
     delete c;
 }
 
 int skg_ctx_train_backward_async_f32(skg_context* ctx, const skg_train_plan* P, int first_stage, int last_stage,
-                                     void* stream, void* const* stage_events_host) {
+                                     void* stream, void* const* stage_events_host, uint32_t stage_mask) {
     int rc = validate_backward(P, first_stage, last_stage);    // rejected here, at submit -- not at the join
     if (rc) return rc;
     skg_context* a = ctx_or_default(ctx);
@@ -742,9 +753,22 @@ int skg_ctx_train_backward_async_f32(skg_context* ctx, const skg_train_plan* P, 
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
+    if (stage_mask && !a->own_made) {
+        // DEVICE-scope release: the default (system scope) writes the L2 back and invalidates it at every record -- a dozen
+        // of those inside a backward cost its kernels their L2-resident operands (measured: +0.15 ms on a 0.8 ms backward)
+        for (int s = 0; s < SKG_TRAIN_BWD_STAGES; ++s) {
+            e = hipEventCreateWithFlags(&a->own[s], hipEventDisableTiming | hipEventReleaseToDevice);
+            if (e != hipSuccess) {
+                for (int t = 0; t < s; ++t) (void)hipEventDestroy(a->own[t]);
+                return (int)e;
+            }
+        }
+        a->own_made = true;
+    }
+    a->own_mask = stage_mask;
     a->plan = *P; a->first = first_stage; a->last = last_stage; a->stream = stream; a->device = dev; a->rc = 0;
     a->issued = first_stage;
-    a->with_events = stage_events_host != nullptr;
+    a->with_events = stage_events_host != nullptr || stage_mask != 0;
     for (int s = 0; s < SKG_TRAIN_BWD_STAGES; ++s)
         a->events[s] = (stage_events_host && s < last_stage - first_stage) ? (hipEvent_t)stage_events_host[s] : nullptr;
     a->pending = true;
@@ -766,6 +790,16 @@ int skg_ctx_train_backward_stage_wait(skg_context* ctx, int stage) {
     return a->rc ? a->rc : SKG_E_ARG;                          // the job ended without reaching that stage
 }
 
+int skg_ctx_stream_wait_stage(skg_context* ctx, int stage, void* waiting_stream) {
+    skg_context* a = ctx_or_default(ctx);
+    if (stage < 0 || stage >= SKG_TRAIN_BWD_STAGES) return SKG_E_ARG;
+    std::unique_lock<std::mutex> lk(a->m);
+    if (!a->own_made || !((a->own_mask >> stage) & 1u) || a->issued <= stage) return SKG_E_ARG;
+    hipEvent_t ev = a->own[stage];
+    lk.unlock();
+    return (int)hipStreamWaitEvent((hipStream_t)waiting_stream, ev, 0);
+}
+
 int skg_ctx_train_backward_join(skg_context* ctx) {
     skg_context* a = ctx_or_default(ctx);
     std::unique_lock<std::mutex> lk(a->m);
@@ -776,7 +810,7 @@ int skg_ctx_train_backward_join(skg_context* ctx) {
 }
 
 int skg_train_backward_async_f32(const skg_train_plan* P, int first_stage, int last_stage, void* stream) {
-    return skg_ctx_train_backward_async_f32(nullptr, P, first_stage, last_stage, stream, nullptr);
+    return skg_ctx_train_backward_async_f32(nullptr, P, first_stage, last_stage, stream, nullptr, 0u);
 }
 
 int skg_train_backward_join(void) { return skg_ctx_train_backward_join(nullptr); }

@@ -762,18 +762,16 @@ class NativeJob(TrainJob):
             ctx = context_for(self.head)
             ctx.join()
             ctx.owner = threading.get_ident()
-            events = None
+            events, mask = None, 0
             if ex is not None:
                 ex.begin(ga)
-                events = ex.stage_events(self.dev, n, timing=span is not None)
-                if span is not None:
-                    span["b1"] = ex.stage_event(n - 1)
-            elif span is not None:
+                mask = ex.stage_mask(st.milestone_end)       # stages that complete an arena chunk: the context's own events
+            if span is not None:
                 span["b1"] = torch.cuda.Event(enable_timing=True)
                 span["b1"].record()                              # (torch creates the HIP event at its first record)
                 events = (C.c_void_p * n)()
                 events[n - 1] = span["b1"].cuda_event
-            _check(lib.skg_ctx_train_backward_async_f32(ctx.handle(), C.byref(pl), 0, n, stream, events),
+            _check(lib.skg_ctx_train_backward_async_f32(ctx.handle(), C.byref(pl), 0, n, stream, events, mask),
                    "skg_train_backward_async_f32")
             # everything the plan names stays alive until the worker has enqueued the last launch
             ctx.pending.append((self, self.S, self.ws, self.ws16, dlogits, ga, dx0, dgfeat))
@@ -848,8 +846,13 @@ class TrainContext:
         if ex is not None:
             ex.finish()
 
-    def stage_wait(self, s):
-        _check(_capi.lib().skg_ctx_train_backward_stage_wait(self.handle(), s), "skg_train_backward_f32 (deferred, stage %d)" % s)
+    def stage_wait(self, s, stream=None):
+        """Blocks (without the GIL) until the worker has issued stage s; with `stream`: also orders that stream behind the
+        stage on the device (the context's own event, recorded by the worker)."""
+        lib = _capi.lib()
+        _check(lib.skg_ctx_train_backward_stage_wait(self.handle(), s), "skg_train_backward_f32 (deferred, stage %d)" % s)
+        if stream is not None:
+            _check(lib.skg_ctx_stream_wait_stage(self.handle(), s, stream.cuda_stream), "skg_ctx_stream_wait_stage(%d)" % s)
 
     def close(self, _getpid=os.getpid, _lib=_capi.lib):
         h, self._h = self._h, None
@@ -1132,6 +1135,12 @@ class TrainRun:
             norm = skd.start_normalisers(counts, True, force=force).get().contiguous()     # ONE fused 3-element all-reduce
         _check(lib.skg_loss_finish_f32(partial.data_ptr(), rows, mpart.data_ptr(), A, M_pos, 1.0, _ptr(norm),
                                        losses.data_ptr(), job.loss_scale.data_ptr(), None, stream), "skg_loss_finish_f32")
+        ex = getattr(head, "grad_exchange", None)
+        if ex is not None and norm is not None:
+            # data parallel: the exchange SUMS the ranks' gradient arenas; with this rank's share of the mean folded into the
+            # scale of its logit gradients (two floats) the sum IS the mean -- no averaging pass over the 118 MB arena
+            job.loss_scale.mul_(1.0 / ex.world)
+            ex.prescaled = True
         self.pos_s, self.neg_s = prep.pos_s, prep.neg_s
         return losses
 

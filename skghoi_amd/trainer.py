@@ -142,8 +142,8 @@ class ArenaExchange:
         self.collectives = 0                  # arena collectives of the last step
         self.timing = False
         self.last_ms = None                   # with timing: (device time the step's stream waited for the exchange, ms)
-        self._stage_events = None             # one HIP event per backward stage (the library's worker records them)
         self._xstream = None                  # stream the collectives are issued on: ordered behind ONE stage event each
+        self.prescaled = False                # this step's gradients already carry the 1 / world of the mean
 
     # -- driven by NativeJob.backward
     def begin(self, ga):
@@ -152,43 +152,46 @@ class ArenaExchange:
 
     def on_stage(self, s, ga, end, last=False):
         if end - self.done >= self.min_chunk or (last and end > self.done):
-            self.works.append(dist.all_reduce(ga[self.done:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if _PROBE != "nocoll":           # (developer probe: the staged backward without its collectives)
+                self.works.append(dist.all_reduce(ga[self.done:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.done = end
             self.collectives += 1
 
-    def stage_events(self, dev, n, timing=False):
-        """ctypes array of `n` hipEvent_t handles for skg_ctx_train_backward_async_f32 (reused from step to step; with
-        timing -- a measurement run reads them afterwards -- fresh, timing-enabled events every step)."""
-        import ctypes
-        if timing or self._stage_events is None or len(self._stage_events[0]) != n or self._stage_events[2]:
-            evs = [torch.cuda.Event(enable_timing=timing) for _ in range(n)]
-            for e in evs:
-                e.record()                    # (torch creates the HIP event at its first record)
-            arr = (ctypes.c_void_p * n)(*[e.cuda_event for e in evs])
-            self._stage_events = (evs, arr, timing)
-        return self._stage_events[1]
+    def chunk_stages(self, ends):
+        """[(stage, end)]: the stages of the backward behind which an arena chunk goes out (prefixes coalesced to min_chunk)."""
+        out, done, n = [], 0, len(ends)
+        for s_, end in enumerate(ends):
+            last = s_ == n - 1
+            if end - done >= self.min_chunk or (last and end > done):
+                out.append((s_, end))
+                done = end
+        return out
 
-    def stage_event(self, s):
-        return self._stage_events[0][s]
+    def stage_mask(self, ends):
+        """Bit mask of chunk_stages() for skg_ctx_train_backward_async_f32: the worker records the context's own (device-
+        scope) event behind exactly these stages."""
+        m = 0
+        for s_, _ in self.chunk_stages(ends):
+            m |= 1 << s_
+        return m
 
     def drive(self, ctx, ends):
         """The backward was handed to the library's worker thread in ONE call (train_fused.NativeJob.backward, defer=True).
         For every arena chunk: wait (on the host, without the GIL) until the worker has issued the stage that completes the
         chunk, order the exchange stream behind THAT stage's event -- not behind whatever else the worker has put on the
-        step's stream since -- and start the collective there.  The chunk boundaries are those of `on_stage`."""
-        ga, evs = self.ga, self._stage_events[0]
+        step's stream since -- and start the collective there."""
+        ga = self.ga
         if self._xstream is None:
             from .engine import shared_side_stream
             self._xstream = shared_side_stream(ga.device, 0, slot=1)
         xs = self._xstream
+        if _PROBE == "mainstream":           # (developer probe: collectives on the step's own stream, behind whatever it holds)
+            xs = torch.cuda.current_stream(ga.device)
         n = len(ends)
-        for s_, end in enumerate(ends):
-            last = s_ == n - 1
-            if end - self.done >= self.min_chunk or (last and end > self.done):
-                ctx.stage_wait(s_)
-                xs.wait_event(evs[s_])
-                with torch.cuda.stream(xs):
-                    self.on_stage(s_, ga, end, last=last)
+        for s_, end in self.chunk_stages(ends):
+            ctx.stage_wait(s_, xs)
+            with torch.cuda.stream(xs):
+                self.on_stage(s_, ga, end, last=(s_ == n - 1))
 
     def finish(self):
         """Orders the step's stream behind every chunk and forms the average."""
@@ -201,7 +204,9 @@ class ArenaExchange:
             ev0.record()
         for w in self.works:
             w.wait()
-        ga.mul_(1.0 / self.world)
+        if not self.prescaled:               # (the fused step folds 1 / world into its logit gradients: train_fused.TrainRun.tail)
+            ga.mul_(1.0 / self.world)
+        self.prescaled = False
         if ev0 is not None:
             ev1.record()
             self._events = (ev0, ev1)
@@ -234,7 +239,11 @@ class ArenaExchange:
             for p, v in zip(st.src, views):
                 if p.grad is not None:
                     v.copy_(p.grad)
+        # this rank's share of the mean goes in before the sum, like its peers' (whose fused step folded 1 / world into
+        # their logit gradients): every rank then ends with the same sum
+        ga.mul_(1.0 / self.world)
         self.begin(ga)
+        self.prescaled = True
         for s_, end in enumerate(st.milestone_end):
             self.on_stage(s_, ga, end, last=(s_ == len(st.milestone_end) - 1))
         self.finish()
@@ -242,6 +251,10 @@ class ArenaExchange:
             if p.requires_grad:
                 p.grad = v
         self.ran = False
+
+
+import os as _os
+_PROBE = _os.environ.get("SKG_DP_PROBE", "")
 
 
 def exchanges(module: nn.Module):

@@ -153,7 +153,7 @@ def _dp_equiv_worker(rank, world, port, ref_path, q):
     from skghoi_amd import train_fused
     staged = []
     orig = train_fused.TrainContext.stage_wait
-    train_fused.TrainContext.stage_wait = lambda self, s: (staged.append(s), orig(self, s))[1]
+    train_fused.TrainContext.stage_wait = lambda self, s, stream=None: (staged.append(s), orig(self, s, stream))[1]
     try:
         losses, _ = trainer.train_step(net, opt, feats, gpu_run.to_cuda(case["detections"]), case["shapes"],
                                        targets=gpu_run.to_cuda(case["targets"]))
