@@ -53,6 +53,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef SKG_XNST
 #define SKG_XNST 4                      // register stages of the split-operand loop (tiles in flight)
 #endif
+#ifndef SKG_NB4
+#define SKG_NB4 3                       // buffers of the direct-to-LDS latency loop's ring (MODE 4, 32 KiB each)
+#endif
 #define LDS_LD (BK + 4)                 // + 4 dwords of padding: conflict-free ds_read_b128 at strides 20 and 36
 #define A_TILE (BM * LDS_LD)
 #define B_TILE (BN * LDS_LD)
@@ -94,8 +97,8 @@ __device__ __forceinline__ const char* skg_uniform_ptr(const char* p) {
 // MODE = main loop: 0 register-staged fp32 MFMA, 1 DMA-staged fp32 MFMA, 2 fp16x2-split operands on the fp16 MFMA.
 template <int EPI_T, int MODE, int T>
 __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_id, float* smem) {
-    static_assert(MODE == 1 || MODE == 3 || T == 2, "only the DMA-staged and the latency loop have a 64 x 64 variant");
-    static_assert(MODE != 3 || T == 1, "the latency loop is a 64 x 64 tile");
+    static_assert(MODE == 1 || MODE == 3 || MODE == 4 || T == 2, "only the DMA-staged and the latency loops have a 64 x 64 variant");
+    static_assert((MODE != 3 && MODE != 4) || T == 1, "the latency loops are 64 x 64 tiles");
     constexpr bool GLDS = MODE == 1;
     const int Kmap = d.K;
     constexpr int TBM = 64 * T, TBN = 64 * T;
@@ -336,6 +339,112 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
             step3(S0{}, st + 1);
         }
         if (st < s_end) step3(S1{}, st);
+    } else if constexpr (MODE == 4) {
+        // ---- latency loop, staged straight into LDS (round 4): the 64 x 64 x 64 steps of MODE 3 without its VGPR stage.  MODE 3
+        // loads a step's 32 KiB into registers, writes them to ONE LDS buffer between two barriers and only then multiplies:
+        // at one workgroup per CU (a single image: 208 workgroups) global loads, LDS writes, fragment reads and MFMAs of a
+        // step run one after the other -- 1.6-1.9 us per step for 0.93 us of MFMA (profiles/r04_b1_eval_timeline.txt).  Here
+        // global_load_lds_dwordx4 fills a ring of SKG_NB4 buffers (tiles t + 1 .. in flight across ONE barrier per step,
+        // counted s_waitcnt vmcnt), nothing is converted or re-written, and the fragment reads are inline asm with counted
+        // lgkmcnt waits (for a C++ LDS read hipcc waits vmcnt(0) on every DMA in flight: the ring would drain every step).
+        // LDS image of an operand tile: [64 rows][64 k] fp32, 256-byte rows; the 16-byte slot s of row r holds k-quad
+        // s ^ (r & 15) -- the swizzle lives on the per-lane SOURCE address (the DMA's destination is lane-linear) and makes the
+        // ds_read_b128 of a fragment (32 rows, one k-quad) conflict-free.  Same k order inside a step as MODE 3 (k-quad
+        // 2 ks + lh, element j = MFMA j): bit-identical sums.  Needs K % 64 == 0 and no row gather (host: skg_gemm_f32).
+        constexpr int BK4 = 64, NB4 = SKG_NB4, OPB = 64 * BK4 * 4, BUFB = 2 * OPB;
+        static_assert(NB4 == 2 || NB4 == 3, "the waits below count NB4 - 1 tiles in flight");
+        const int wu = __builtin_amdgcn_readfirstlane(wid);     // provably wave-uniform: the DMA's LDS base stays scalar
+        uint32_t oa[4], ow[4];                                  // per-lane byte offsets of the four 16-byte pieces per operand
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 16 * wid + 4 * i + (lane >> 4);       // wave-instruction i covers rows 16 wid + 4 i .. + 3
+            const int q = (lane & 15) ^ (r & 15);
+            const int ar = m0 + r < d.M ? r : 0, wrw = n0 + r < d.N ? r : 0;      // rows past M / N: a valid row, never stored
+            oa[i] = (uint32_t)(((int64_t)ar * d.lda + 4 * q) * 4);
+            ow[i] = (uint32_t)(((int64_t)wrw * d.ldw + 4 * q) * 4);
+        }
+        const char* a_base = reinterpret_cast<const char*>(d.A + (int64_t)m0 * d.lda);
+        const char* w_base = reinterpret_cast<const char*>(d.W + (int64_t)n0 * d.ldw);
+        int s_begin = 0, s_end = d.K / BK4;
+        if (d.split_k > 1) {
+            const int per = (s_end + d.split_k - 1) / d.split_k;
+            s_begin = split_slice * per < s_end ? split_slice * per : s_end;
+            s_end = s_begin + per < s_end ? s_begin + per : s_end;
+        }
+        const int nt = s_end - s_begin;
+        char* ring = reinterpret_cast<char*>(smem);
+        auto issue = [&](int t, int buf) {
+            const char* ab = skg_uniform_ptr(a_base + (int64_t)(s_begin + t) * BK4 * 4);
+            const char* wb = skg_uniform_ptr(w_base + (int64_t)(s_begin + t) * BK4 * 4);
+            char* dst = ring + buf * BUFB + (4 * wu) * 1024;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + oa[i]),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + ow[i]),
+                                                 (__attribute__((address_space(3))) void*)(dst + OPB + i * 1024), 16, 0, 0);
+            }
+        };
+        // fragment addresses inside a buffer: row (wr | wc) * 32 + li, k-quad (2 ks + lh) ^ (row & 15)
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+        uint32_t fa[8], fb[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int ra_ = wr * 32 + li, rb_ = wc * 32 + li;
+            fa[ks] = (uint32_t)(ra_ * 256 + (((2 * ks + lh) ^ (ra_ & 15)) << 4));
+            fb[ks] = (uint32_t)(OPB + rb_ * 256 + (((2 * ks + lh) ^ (rb_ & 15)) << 4));
+        }
+        auto step4 = [&](uint32_t buf) {
+            f32x4 a4[8], b4[8];
+#define S4_READ(KS)                                                                                                   \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(a4[KS]) : "v"(buf + fa[KS]));                                  \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(b4[KS]) : "v"(buf + fb[KS]));
+#define S4_MFMA(KS)                                                                                                   \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[KS].x, b4[KS].x, acc[0][0], 0, 0, 0);                \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[KS].y, b4[KS].y, acc[0][0], 0, 0, 0);                \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[KS].z, b4[KS].z, acc[0][0], 0, 0, 0);                \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[KS].w, b4[KS].w, acc[0][0], 0, 0, 0);
+            // eight k-quads per step; the reads of quads ks + 4 .. are issued while quads ks .. multiply (the LGKM counter
+            // holds 15: at most 8 + 6 reads are outstanding)
+            S4_READ(0) S4_READ(1) S4_READ(2) S4_READ(3)
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a4[0]), "+v"(b4[0]));
+            S4_READ(4)
+            S4_MFMA(0)
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a4[1]), "+v"(b4[1]));
+            S4_READ(5)
+            S4_MFMA(1)
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a4[2]), "+v"(b4[2]));
+            S4_READ(6)
+            S4_MFMA(2)
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a4[3]), "+v"(b4[3]));
+            S4_READ(7)
+            S4_MFMA(3)
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a4[4]), "+v"(b4[4]));
+            S4_MFMA(4)
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a4[5]), "+v"(b4[5]));
+            S4_MFMA(5)
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a4[6]), "+v"(b4[6]));
+            S4_MFMA(6)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a4[7]), "+v"(b4[7]));
+            S4_MFMA(7)
+#undef S4_READ
+#undef S4_MFMA
+        };
+#pragma unroll
+        for (int t = 0; t < NB4 - 1; ++t)
+            if (t < nt) issue(t, t);
+        int cur = 0;
+        for (int t = 0; t < nt; ++t) {
+            const int ahead = nt - 1 - t;                       // tiles issued after tile t (eight DMA instructions each)
+            if (NB4 == 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");             // tile t landed for everybody; nobody reads buffer cur - 1 any more
+            const int prev = cur == 0 ? NB4 - 1 : cur - 1;
+            if (t + NB4 - 1 < nt) issue(t + NB4 - 1, prev);
+            step4(lds0 + cur * BUFB);
+            cur = cur + 1 == NB4 ? 0 : cur + 1;
+        }
+        __syncthreads();                                        // the epilogue's transposition reuses the ring
     } else if constexpr (MODE == 2) {
         // ---- fp32-grade result from the fp16 matrix pipe (3 MFMA passes instead of the 8 of the fp32 MFMA per 16 k).
         // Every operand value x is carried as h + m with h = fp16(x), m = fp16(x - h): 22 significant bits, i.e.
@@ -831,9 +940,10 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
 }
 
 #define SKG_SMEM3 (2 * 64 * 68)              // latency loop: one 64 x 64(+4) tile per operand (34 KB)
+#define SKG_SMEM4 (SKG_NB4 * 2 * 64 * 64)
 template <int EPI, int MODE, int T>
-__global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_kernel(const skg_gemm_desc d) {
-    __shared__ __attribute__((aligned(16))) float smem[MODE == 3 ? SKG_SMEM3 : (T == 2 ? 2 * (A_TILE + B_TILE) : 4 * 32 * 36)];
+__global__ __launch_bounds__(256, (MODE == 4 && SKG_NB4 > 2) ? 1 : SKG_MINW) void skg_gemm_kernel(const skg_gemm_desc d) {
+    __shared__ __attribute__((aligned(1024))) float smem[MODE == 4 ? SKG_SMEM4 : MODE == 3 ? SKG_SMEM3 : (T == 2 ? 2 * (A_TILE + B_TILE) : 4 * 32 * 36)];
     skg_gemm_tile<EPI, MODE, T>(d, blockIdx.x, smem);
 }
 
@@ -875,6 +985,15 @@ __global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_group_small_kernel(con
     for (int t = 1; t < SKG_GEMM_GROUP_MAX; ++t)
         if (t < g.n && (int)blockIdx.x >= g.start[t]) k = t;
     skg_gemm_tile<-1, 1, 1>(g.d[k], blockIdx.x - g.start[k], smem);
+}
+
+__global__ __launch_bounds__(256, SKG_NB4 > 2 ? 1 : SKG_MINW) void skg_gemm_group_direct_kernel(const skg_gemm_group_args g) {
+    __shared__ __attribute__((aligned(1024))) float smem[SKG_SMEM4];
+    int k = 0;
+#pragma unroll
+    for (int t = 1; t < SKG_GEMM_GROUP_MAX; ++t)
+        if (t < g.n && (int)blockIdx.x >= g.start[t]) k = t;
+    skg_gemm_tile<-1, 4, 1>(g.d[k], blockIdx.x - g.start[k], smem);
 }
 
 __global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_group_latency_kernel(const skg_gemm_group_args g) {
@@ -1003,13 +1122,18 @@ extern "C" int skg_row_exponents_f32(const float* A, int64_t lda, const int32_t*
     return skg_launch_status();
 }
 
-// Which 64 x 64 loop the small launches take: 3 = latency loop (64 k per step, register staged), 1 = DMA-staged 16-k
-// steps.  A developer switch for A/B measurements (tools/small_batch_loop.py); both give bit-identical results only
+// Which 64 x 64 loop the small launches take: 4 = latency loop staged straight into LDS (64 k per step; needs K % 64 == 0,
+// otherwise 3), 3 = latency loop (64 k per step, register staged), 1 = DMA-staged 16-k steps.  A developer switch for A/B measurements (tools/small_batch_loop.py); both give bit-identical results only
 // with themselves (the summation order over k differs).
+// Round 4, measured on the single-image forward (profiles/r04_b1_eval_timeline_direct_lds_loop.txt): the direct-to-LDS loop (4)
+// is NOT faster than the register-staged one (3) -- single launches of 208 workgroups 24-30 us against 25-32, the 624-workgroup
+// group 76 against 64 us (its 96 KiB ring leaves one workgroup per CU), B = 1 0.517 against 0.498 ms.  A step of this tile is
+// a chain of 32 dependent fp32 MFMAs (0.93 us) plus a ~0.4 us bubble at the barrier whatever stages the tile: the launch is
+// bound by that chain at one wave per SIMD, not by the staging.  Mode 3 stays the default; 4 is selectable.
 static int g_small_mode = 3;
 extern "C" int skg_gemm_small_mode(int mode) {
     const int old = g_small_mode;
-    if (mode == 1 || mode == 3) g_small_mode = mode;
+    if (mode == 1 || mode == 3 || mode == 4) g_small_mode = mode;
     return old;
 }
 
@@ -1156,7 +1280,10 @@ extern "C" int skg_gemm_group_f32(const skg_gemm_desc* descs_host, int n, void* 
     }
     if (g.n == 0) return 0;
     for (int i = g.n; i <= SKG_GEMM_GROUP_MAX; ++i) g.start[i] = (int)blocks;
-    if (small && g_small_mode == 3) hipLaunchKernelGGL(skg_gemm_group_latency_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    bool direct = small && g_small_mode == 4;               // every member with whole 64-k steps: the direct-to-LDS loop
+    for (int i = 0; i < g.n && direct; ++i) direct = (g.d[i].K % 64) == 0;
+    if (direct) hipLaunchKernelGGL(skg_gemm_group_direct_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    else if (small && g_small_mode >= 3) hipLaunchKernelGGL(skg_gemm_group_latency_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     else if (small) hipLaunchKernelGGL(skg_gemm_group_small_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     else if (split) hipLaunchKernelGGL(skg_gemm_group_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(skg_gemm_group_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
@@ -1188,7 +1315,8 @@ extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
     hipStream_t s = (hipStream_t)stream;
 #define SKG_LAUNCH(E)                                                                              \
     if (split) hipLaunchKernelGGL((skg_gemm_kernel<E, 2, 2>), grid, block, 0, s, d);               \
-    else if (glds && T == 1 && g_small_mode == 3) hipLaunchKernelGGL((skg_gemm_kernel<E, 3, 1>), grid, block, 0, s, d); \
+    else if (glds && T == 1 && g_small_mode == 4 && (d.K % 64) == 0) hipLaunchKernelGGL((skg_gemm_kernel<E, 4, 1>), grid, block, 0, s, d); \
+    else if (glds && T == 1 && g_small_mode >= 3) hipLaunchKernelGGL((skg_gemm_kernel<E, 3, 1>), grid, block, 0, s, d); \
     else if (glds && T == 1) hipLaunchKernelGGL((skg_gemm_kernel<E, 1, 1>), grid, block, 0, s, d); \
     else if (glds) hipLaunchKernelGGL((skg_gemm_kernel<E, 1, 2>), grid, block, 0, s, d);           \
     else hipLaunchKernelGGL((skg_gemm_kernel<E, 0, 2>), grid, block, 0, s, d);

@@ -1245,6 +1245,9 @@ __device__ __forceinline__ void tmain(const skg_gemmx_desc& d, const XOperand& A
 __global__ __launch_bounds__(256, TNB == 2 ? 2 : 1) void skg_gemmx_t16_kernel(const skg_gemmx_group g) {
     constexpr int TSMEM = TNB * TBUFB > 4 * XEP_FLOATS ? TNB * TBUFB : 4 * XEP_FLOATS;     // ring, then the staged epilogue
     __shared__ __attribute__((aligned(1024))) uint8_t smem[TSMEM];
+#ifdef SKG_XPROBE_STAMPS                                    // timing builds: wall-clock stamps (100 MHz) of the workgroup's phases
+    const uint64_t stamp0 = wall_clock64();
+#endif
     int gi = 0;
 #pragma unroll
     for (int t = 1; t < SKG_GEMMX_GROUP_MAX; ++t)
@@ -1286,6 +1289,9 @@ __global__ __launch_bounds__(256, TNB == 2 ? 2 : 1) void skg_gemmx_t16_kernel(co
         else tmain<false, false>(d, A, B, c, kt0, kt1, smem, acc, rsa);
     }
 
+#ifdef SKG_XPROBE_STAMPS
+    const uint64_t stamp1 = wall_clock64();
+#endif
 #ifdef SKG_XPROBE_NOEPI                                    // timing builds: what the epilogue costs
     if (acc[0][0][0] != 12345.678f) return;
 #endif
@@ -1317,6 +1323,13 @@ __global__ __launch_bounds__(256, TNB == 2 ? 2 : 1) void skg_gemmx_t16_kernel(co
                         stage[(8 * gq + 4 * lk + t) * XEP_LD + ni * 32 + li] = acc[mi][ni][4 * gq + t];
             xep_rows(d, g.f[gi], stage, lane, m0 + wm * 64 + mi * 32, n0 + wn * 64, ws);
         }
+#ifdef SKG_XPROBE_STAMPS                                   // (split_ws of an unsplit product doubles as the stamp buffer: 4 x u64 per workgroup)
+        if (!split && d.split_ws && c.tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            uint64_t* o = reinterpret_cast<uint64_t*>(d.split_ws) + 4 * (uint64_t)blockIdx.x;
+            o[0] = stamp0; o[1] = stamp1; o[2] = wall_clock64(); o[3] = __smid();
+        }
+#endif
         return;
     }
 #pragma unroll
