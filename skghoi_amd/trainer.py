@@ -130,9 +130,10 @@ class ArenaExchange:
     at least `min_chunk` floats; the 12.8 M-float box_head.1 gradient closes the backward and is the tail that cannot
     overlap).  Gradients are averaged (sum, then 1 / world folded into ONE scaling pass: gloo has no AVG).
 
-    Ranks whose batch took the generic path (no image with pairs: nothing ran through the fused node) still have to
-    meet their peers in the same collectives: `after_backward` sends their parameter gradients (zeros where a parameter
-    has none -- DDP's find_unused_parameters semantics) through the same chunk sequence."""
+    A rank whose step did not run through the fused node (the Python-issued launch plan, an unsupported configuration on
+    that rank) still has to meet its peers in the same collectives: `after_backward` sends its parameter gradients (zeros
+    where a parameter has none -- DDP's find_unused_parameters semantics) through the same chunk sequence.  (A batch without
+    a single pair cannot complete a step on either side: the reference's torch.cat over its empty score lists raises.)"""
 
     def __init__(self, head, group=None, min_chunk=1 << 21):
         self.head, self.group, self.min_chunk = head, group, int(min_chunk)

@@ -367,6 +367,77 @@ def test_trainer_epoch_with_validation_on_the_real_head(capsys):
                 m.append(r["scores"], r["prediction"], r["labels"])
     assert torch.allclose(ap, m.eval(), atol=1e-12) and float(ap.sum()) > 0
 
+
+def _remainder_worker(rank, world, port, q):
+    """One rank of test_ddp_remainder_beside_the_arena_exchange: the head inside a module with one more trainable parameter
+    (DistributedDataParallel owns it); rank r trains on image r."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from collections import OrderedDict
+    import cases, gpu_run
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    case = cases.build_case("train_tiny")
+    case = dict(case)
+    for k in ("detections", "targets", "shapes"):
+        case[k] = case[k][rank:rank + 1]
+    case["feat3"] = case["feat3"][rank:rank + 1]
+    head = gpu_run.build_head(case)
+    head.distributed = True
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.scale = nn.Parameter(torch.ones(1))           # stands in for a detector that trains with the head
+            self.interaction_head = head
+
+        def forward(self, feats, det, shapes, targets):
+            return self.interaction_head(OrderedDict((k, v * self.scale) for k, v in feats.items()), det, shapes, targets)
+
+    net = Net().cuda()
+    ddp = trainer.wrap_ddp(net, torch.device("cuda", 0))
+    assert isinstance(ddp, nn.parallel.DistributedDataParallel)
+    ex = head.grad_exchange
+    assert ex is not None and ex.group is not None              # the arena's own process group beside DDP's
+    opt = trainer.build_optimizer(ddp, lr=1e-4)
+    feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
+    det = gpu_run.to_cuda(case["detections"]); tg = gpu_run.to_cuda(case["targets"])
+    torch.manual_seed(3 + rank)
+    losses, _ = trainer.train_step(ddp, opt, feats, det, case["shapes"], targets=tg)
+    torch.cuda.synchronize()
+    vec = torch.cat([p.detach().flatten()[:64].cpu() for p in net.parameters()])
+    q.put((rank, losses, vec.numpy(), float(net.scale.detach()), ex.collectives))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_ddp_remainder_beside_the_arena_exchange():
+    """Round-3 advisor finding: with a DistributedDataParallel remainder (a detector that trains with the head) the arena
+    exchange gets a process group of its own, so that its collectives can never interleave with DDP's buckets on one
+    communicator.  (The advisor's other half -- a rank whose batch has no pair at all -- cannot complete a step on either
+    side: the reference's torch.cat over its empty score lists raises there, HEAD:230, and so does this head.)  Two ranks on one
+    GPU (gloo), one image each, the features scaled by a trainable parameter outside the head: the step goes through autograd
+    (the features require grad), the arena leaves from inside the backward on its own group, DDP reduces the remainder; both
+    replicas end with the same weights, head and remainder."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_remainder_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=150) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, l0, v0, s0, k0), (r1, l1, v1, s1, k1) = res
+    assert np.array_equal(v0, v1) and s0 == s1 and s0 != 1.0          # same step everywhere; the remainder trained too
+    assert k0 == k1 and k0 >= 2
+    assert all(np.isfinite(v) for v in l0.values()) and all(np.isfinite(v) for v in l1.values())
+
 # ---------------------------------------------------------------------------------------------------- shell (CPU)
 def test_filter_flip_and_collate():
     det = dict(boxes=[[10., 5., 50., 40.], [0., 0., 20., 20.], [30., 10., 90., 70.], [5., 5., 9., 9.]],
