@@ -1377,320 +1377,9 @@ __global__ __launch_bounds__(256, TNB == 2 ? 2 : 1) void skg_gemmx_t16_kernel(co
             }
 }
 
-// ================================================================================================ exact fp32, direct to LDS
-// skg_gemmx_d32_kernel: the exact-fp32 products (v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain) with the staging of
-// skg_gemmx_t16_kernel: tiles go from global memory straight into a ring of two LDS buffers (global_load_lds_dwordx4, two
-// workgroups per CU), one barrier per 32-deep k-step, no VGPR stage, no ds_write.  The register-staged loop above holds 58-62 %
-// MFMA duty at one wave per SIMD (M = 3200: loads, LDS writes, fragment reads and MFMAs of a 16-k step one after the other);
-// here a step is 64 MFMAs per wave (4096 cycles) behind 32 KiB of DMA that was issued a step earlier.
-// A 128 x 32 fp32 tile has the byte geometry of the 128 x 64 bf16 tile:
-//   k-contiguous operand  : [128 rows][32 k], 128-byte rows; 16-byte slot s of row r holds k-quad s ^ ((r >> 1) & 7); a fragment
-//                           read is one ds_read_b128 = the four k of FOUR consecutive MFMA steps
-//   row-contiguous operand: [32 k][128 rows], 512-byte k-rows; the 4-row piece p of k-row k sits at piece p ^ (((k >> 2) & 1) << 3)
-//                           (the two lane halves of an MFMA read k and k + 4: 2 KiB apart, the same banks without it); a fragment
-//                           read is one conflict-free ds_read_b32 per MFMA step -- no transposition anywhere
-// k assignment inside a step (both layouts, so that any pair of operands agrees): MFMA step 4 s + j takes k = 8 s + 4 h + j from
-// lane half h.  The bias gradient (row sums of A) is one more MFMA per A fragment against 1.0f: fp32, exact products.
-#define DBK 32
-#define DNB 2
-#define DOPB (128 * DBK * 4)
-#define DBUFB (2 * DOPB)
-
-struct DLoad { uint32_t o[4]; };
-
-template <bool KC>
-__device__ __forceinline__ void dprep(const XOperand& op, int row0, int tid, DLoad& L) {
-    const int w = tid >> 6, l = tid & 63;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (KC) {                            // wave instruction i: rows 32 w + 8 i .. + 7; lane: row l >> 3, slot l & 7
-            const int r = 32 * w + 8 * i + (l >> 3);
-            const int q = (l & 7) ^ ((r >> 1) & 7);
-            L.o[i] = (uint32_t)((xoff(min(row0 + r, op.rows - 1), op.rshift, op.rstride, op.s_row) + 4 * q) * 4);
-        } else {                             // wave instruction i: k-rows 8 w + 2 i, + 1; lane: k-row l >> 5, piece l & 31
-            const int k = 8 * w + 2 * i + (l >> 5);
-            const int sp = (l & 31) ^ (((k >> 2) & 1) << 3);
-            const int64_t ro = xoff(max(0, min(row0 + 4 * sp, op.rows - 4)), op.rshift, op.rstride, 1);
-            L.o[i] = (uint32_t)((ro + (int64_t)k * op.s_k) * 4);
-        }
-    }
-}
-
-template <bool KC>
-__device__ __forceinline__ void dissue(const XOperand& op, const DLoad& L, int k0, uint8_t* dst, int wu) {
-    const char* gb = t_uniform_ptr(reinterpret_cast<const char*>(op.base) + 4 * xoff(k0, op.kshift, op.kstride, KC ? 1 : op.s_k));
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + L.o[i]),
-                                         (__attribute__((address_space(3))) void*)(dst + (4 * wu + i) * 1024), 16, 0, 0);
-}
-
-// ragged tile through registers: the thread's four pieces, zero where k >= kend, into the image the DMA would have written
-template <bool KC>
-__device__ __forceinline__ void dfill(const XOperand& op, int row0, int k0, int kend, int tid, uint8_t* dst) {
-    const int w = tid >> 6, l = tid & 63;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float4 v = xzero4();
-        if (KC) {
-            const int r = 32 * w + 8 * i + (l >> 3);
-            const int q = (l & 7) ^ ((r >> 1) & 7);
-            const int k = k0 + 4 * q;
-            if (k < kend)
-                v = xquad(op.base + xoff(min(row0 + r, op.rows - 1), op.rshift, op.rstride, op.s_row) +
-                          xoff(k, op.kshift, op.kstride, 1), k, kend, true);
-        } else {
-            const int kl = 8 * w + 2 * i + (l >> 5);
-            const int sp = (l & 31) ^ (((kl >> 2) & 1) << 3);
-            if (k0 + kl < kend)
-                v = xld4(op.base + xoff(max(0, min(row0 + 4 * sp, op.rows - 4)), op.rshift, op.rstride, 1) +
-                         xoff(k0 + kl, op.kshift, op.kstride, op.s_k));
-        }
-        *reinterpret_cast<float4*>(dst + (4 * w + i) * 1024 + l * 16) = v;
-    }
-}
-
-// Per-lane LDS byte offsets of an operand's fragments inside its tile (loop invariant).
-//   k-contiguous : f[s] = k-quad 2 s + h of the first 32-row block; the second block is + 4096
-//   row-contig.  : f[0], f[1] = the lane's dword in k-row 4 h of the first / second block; MFMA step 4 s + j is + (8 s + j) * 512
-struct DFrag { uint32_t f[4]; };
-template <bool KC>
-__device__ __forceinline__ void dfrag_prep(int rb, int lane, DFrag& F) {
-    const int li = lane & 31, h = lane >> 5;
-    if (KC) {
-        const int r = rb + li, sw = (r >> 1) & 7;
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) F.f[s_] = (uint32_t)(r * 128 + (((2 * s_ + h) ^ sw) << 4));
-    } else {
-        F.f[0] = (uint32_t)(h * 2048 + ((rb + li) ^ (h << 5)) * 4);
-        F.f[1] = (uint32_t)(h * 2048 + ((rb + 32 + li) ^ (h << 5)) * 4);
-        F.f[2] = F.f[3] = 0;
-    }
-}
-
-template <int OFF>
-__device__ __forceinline__ float d_ds_b32(uint32_t addr) {
-    float v;
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-template <int OFF>
-__device__ __forceinline__ f32x4 d_ds_b128(uint32_t addr) {
-    f32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-
-// The fragments of one group of four MFMA steps (k = 8 S .. 8 S + 7 over the two lane halves), both 32-row blocks, exactly as
-// the asm reads deliver them: nothing may touch these registers (not even a copy) before the counted wait that ties them.
-template <bool KC> struct DGroup;
-template <> struct DGroup<true> {
-    f32x4 q[2];
-    __device__ __forceinline__ float at(int t, int j) const { return q[t][j]; }
-};
-template <> struct DGroup<false> {
-    float a[2][4];
-    __device__ __forceinline__ float at(int t, int j) const { return a[t][j]; }
-};
-template <int S>
-__device__ __forceinline__ void dread(uint32_t base, const DFrag& F, DGroup<true>& G) {
-    G.q[0] = d_ds_b128<0>(base + F.f[S]);
-    G.q[1] = d_ds_b128<4096>(base + F.f[S]);
-}
-template <int S>
-__device__ __forceinline__ void dread(uint32_t base, const DFrag& F, DGroup<false>& G) {
-    G.a[0][0] = d_ds_b32<(8 * S + 0) * 512>(base + F.f[0]); G.a[0][1] = d_ds_b32<(8 * S + 1) * 512>(base + F.f[0]);
-    G.a[0][2] = d_ds_b32<(8 * S + 2) * 512>(base + F.f[0]); G.a[0][3] = d_ds_b32<(8 * S + 3) * 512>(base + F.f[0]);
-    G.a[1][0] = d_ds_b32<(8 * S + 0) * 512>(base + F.f[1]); G.a[1][1] = d_ds_b32<(8 * S + 1) * 512>(base + F.f[1]);
-    G.a[1][2] = d_ds_b32<(8 * S + 2) * 512>(base + F.f[1]); G.a[1][3] = d_ds_b32<(8 * S + 3) * 512>(base + F.f[1]);
-}
-// `WAIT` with the group's registers as read-write operands: the MFMAs (and any copy the compiler wants) come after it
-template <int LEFT>
-__device__ __forceinline__ void dtie(DGroup<true>& G) {
-    if (LEFT < 0) asm volatile("" : "+v"(G.q[0]), "+v"(G.q[1]));
-    else if (LEFT == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(G.q[0]), "+v"(G.q[1]));
-    else if (LEFT == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(G.q[0]), "+v"(G.q[1]));
-    else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(G.q[0]), "+v"(G.q[1]));
-}
-template <int LEFT>
-__device__ __forceinline__ void dtie(DGroup<false>& G) {
-#define D_TIE8 "+v"(G.a[0][0]), "+v"(G.a[0][1]), "+v"(G.a[0][2]), "+v"(G.a[0][3]), "+v"(G.a[1][0]), "+v"(G.a[1][1]),          \
-               "+v"(G.a[1][2]), "+v"(G.a[1][3])
-    if (LEFT < 0) asm volatile("" : D_TIE8);
-    else if (LEFT == 0) asm volatile("s_waitcnt lgkmcnt(0)" : D_TIE8);
-    else if (LEFT == 2) asm volatile("s_waitcnt lgkmcnt(2)" : D_TIE8);
-    else asm volatile("s_waitcnt lgkmcnt(8)" : D_TIE8);
-#undef D_TIE8
-}
-
-template <bool AK, bool BK_>
-__device__ __forceinline__ void dstep(uint32_t buf, const DFrag& FA, const DFrag& FB, f32x16 (&acc)[2][2], f32x16 (&rsa)[2],
-                                      bool rowsum) {
-    constexpr int NA = AK ? 2 : 8;                         // LDS instructions of one group of A fragments
-    const uint32_t ab = buf, bb = buf + DOPB;
-    DGroup<AK> a0, a1;                                     // groups s (even) and s + 1 (odd), double-buffered
-    DGroup<BK_> b0, b1;
-#define D_MFMA(GA, GB)                                                                                                    \
-    {                                                                                                                     \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                   \
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(GA.at(0, j), GB.at(0, j), acc[0][0], 0, 0, 0);               \
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(GA.at(0, j), GB.at(1, j), acc[0][1], 0, 0, 0);               \
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(GA.at(1, j), GB.at(0, j), acc[1][0], 0, 0, 0);               \
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(GA.at(1, j), GB.at(1, j), acc[1][1], 0, 0, 0);               \
-            if (rowsum) {                                                                                                 \
-                rsa[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(GA.at(0, j), 1.0f, rsa[0], 0, 0, 0);                        \
-                rsa[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(GA.at(1, j), 1.0f, rsa[1], 0, 0, 0);                        \
-            }                                                                                                             \
-        }                                                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                                \
-    }
-    // order of issue: A(s), B(s), A(s + 1) | wait for group s with A(s + 1) outstanding | B(s + 1), the 16 MFMAs of group s
-    dread<0>(ab, FA, a0); dread<0>(bb, FB, b0);
-    dread<1>(ab, FA, a1);
-    dtie<NA>(a0); dtie<-1>(b0); dread<1>(bb, FB, b1); D_MFMA(a0, b0)
-    dread<2>(ab, FA, a0);
-    dtie<NA>(a1); dtie<-1>(b1); dread<2>(bb, FB, b0); D_MFMA(a1, b1)
-    dread<3>(ab, FA, a1);
-    dtie<NA>(a0); dtie<-1>(b0); dread<3>(bb, FB, b1); D_MFMA(a0, b0)
-    dtie<0>(a1); dtie<-1>(b1); D_MFMA(a1, b1)
-#undef D_MFMA
-}
-
-template <bool AK, bool BK_>
-__device__ __forceinline__ void dmain(const XOperand& A, const XOperand& B, const XCtx& c, int kt0, int kt1, uint8_t* smem,
-                                      f32x16 (&acc)[2][2], f32x16 (&rsa)[2]) {
-    const int tid = c.tid, lane = tid & 63;
-    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool rowsum = c.do_rowsum && c.wn == 0;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
-    DLoad LA, LB;
-    dprep<AK>(A, c.m0, tid, LA);
-    dprep<BK_>(B, c.n0, tid, LB);
-    DFrag FA, FB;
-    dfrag_prep<AK>(c.wm * 64, lane, FA);
-    dfrag_prep<BK_>(c.wn * 64, lane, FB);
-    const int ktf = (c.kend == kt1 * DBK) ? kt1 : max(kt0, kt1 - 1);       // [kt0, ktf): whole tiles
-    const int nt = ktf - kt0;
-    auto issue = [&](int t, int buf) {
-        uint8_t* dst = smem + buf * DBUFB;
-        dissue<AK>(A, LA, (kt0 + t) * DBK, dst, wu);
-        dissue<BK_>(B, LB, (kt0 + t) * DBK, dst + DOPB, wu);
-    };
-    static_assert(DNB == 2, "the waits below leave no tile in flight across the barrier");
-    if (nt > 0) issue(0, 0);
-    int cur = 0;
-    for (int t = 0; t < nt; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile t has landed ...
-        asm volatile("s_barrier" ::: "memory");            // ... everybody's has; nobody reads the other buffer any more
-        if (t + 1 < nt) issue(t + 1, cur ^ 1);
-        dstep<AK, BK_>(lds0 + cur * DBUFB, FA, FB, acc, rsa, rowsum);
-        cur ^= 1;
-    }
-    if (kt1 > ktf) {                                       // the ragged last tile of the slice
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        uint8_t* dst = smem + cur * DBUFB;
-        dfill<AK>(A, c.m0, ktf * DBK, c.kend, tid, dst);
-        dfill<BK_>(B, c.n0, ktf * DBK, c.kend, tid, dst + DOPB);
-        __syncthreads();
-        dstep<AK, BK_>(lds0 + cur * DBUFB, FA, FB, acc, rsa, rowsum);
-    }
-    __syncthreads();                                       // the staged epilogue reuses the buffers
-}
-
-__global__ __launch_bounds__(256, 2) void skg_gemmx_d32_kernel(const skg_gemmx_group g) {
-    constexpr int DSMEM = DNB * DBUFB > 4 * XEP_FLOATS ? DNB * DBUFB : 4 * XEP_FLOATS;
-    __shared__ __attribute__((aligned(1024))) uint8_t smem[DSMEM];
-    int gi = 0;
-#pragma unroll
-    for (int t = 1; t < SKG_GEMMX_GROUP_MAX; ++t)
-        if (t < g.n && (int)blockIdx.x >= g.start[t]) gi = t;
-    const skg_gemmx_desc& d = g.d[gi];
-    const int vecbits = g.vec[gi];
-    const int S = d.split_k > 1 ? d.split_k : 1;
-    const int nbn = (d.N + XBN - 1) / XBN;
-    const XTileId tid3 = xtile_of(blockIdx.x - g.start[gi], g.start[gi + 1] - g.start[gi], (d.M + XBM - 1) / XBM, nbn, S, d.K);
-    const int slice = tid3.slice, tn = tid3.tn, tm = tid3.tm;
-    const int nkt = (d.K + DBK - 1) / DBK;
-    const int per = (nkt + S - 1) / S;
-    const int kt0 = min(nkt, slice * per), kt1 = min(nkt, kt0 + per);
-
-    XOperand A, B;
-    xoperands(d, vecbits, A, B);
-    XCtx c;
-    c.m0 = tm * XBM; c.n0 = tn * XBN; c.kend = min(d.K, kt1 * DBK);
-    c.tid = threadIdx.x;
-    const int lane = c.tid & 63, wave = c.tid >> 6;
-    c.wm = wave >> 1; c.wn = wave & 1; c.li = lane & 31; c.lk = lane >> 5;
-    c.do_rowsum = d.a_rowsum != nullptr && tn == 0;
-    const int m0 = c.m0, n0 = c.n0, wm = c.wm, wn = c.wn, li = c.li, lk = c.lk;
-
-    f32x16 acc[2][2], rsa[2];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        acc[0][0][e] = 0.f; acc[0][1][e] = 0.f; acc[1][0][e] = 0.f; acc[1][1][e] = 0.f; rsa[0][e] = 0.f; rsa[1][e] = 0.f;
-    }
-    if (d.a_sk == 1) {
-        if (d.b_sk == 1) dmain<true, true>(A, B, c, kt0, kt1, smem, acc, rsa);
-        else dmain<true, false>(A, B, c, kt0, kt1, smem, acc, rsa);
-    } else {
-        if (d.b_sk == 1) dmain<false, true>(A, B, c, kt0, kt1, smem, acc, rsa);
-        else dmain<false, false>(A, B, c, kt0, kt1, smem, acc, rsa);
-    }
-
-    // ---- epilogue.  acc[mi][ni][4*gq + t] = row m0 + wm*64 + mi*32 + 8*gq + 4*lk + t, column n0 + wn*64 + ni*32 + li.
-    const bool split = S > 1;
-    const int64_t MN = (int64_t)d.M * d.N;
-    float* ws = split ? d.split_ws + (int64_t)slice * MN : nullptr;           // [S][M * N] then [S][M] row sums
-    if (c.do_rowsum && wn == 0 && li == 0) {               // every column of rsa holds the row sums: column 0's lanes write
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * 64 + mi * 32 + 8 * (e >> 2) + 4 * lk + (e & 3);
-                if (row >= d.M) continue;
-                if (split) d.split_ws[(int64_t)S * MN + (int64_t)slice * d.M + row] = rsa[mi][e];
-                else d.a_rowsum[row] = d.accumulate ? d.a_rowsum[row] + rsa[mi][e] : rsa[mi][e];
-            }
-    }
-    if (vecbits & 8) {
-        float* stage = reinterpret_cast<float*>(smem) + wave * XEP_WAVE;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        stage[(8 * gq + 4 * lk + t) * XEP_LD + ni * 32 + li] = acc[mi][ni][4 * gq + t];
-            xep_rows(d, g.f[gi], stage, lane, m0 + wm * 64 + mi * 32, n0 + wn * 64, ws);
-        }
-        return;
-    }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int row = m0 + wm * 64 + mi * 32 + 8 * gq + 4 * lk + t;
-                if (row >= d.M) continue;
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int col = n0 + wn * 64 + ni * 32 + li;
-                    if (col >= d.N) continue;
-                    float v = acc[mi][ni][4 * gq + t];
-                    if (split) { ws[(int64_t)row * d.N + col] = v; continue; }
-                    if (d.bias) v += d.bias[col];
-                    if (d.relu) v = fmaxf(v, 0.f);
-                    float* p = d.C + xoff(col, d.c_nshift, d.c_nstride, 1) + (int64_t)row * d.ldc;
-                    if (d.accumulate) v += *p;
-                    if (d.mask && !(d.mask[(int64_t)row * d.ldmask + col] > 0.f)) v = 0.f;
-                    *p = v;
-                    if (d.C16) d.C16[p - d.C] = (uint16_t)ypack(v, 0.f);
-                }
-            }
-}
+// (An exact-fp32 twin of this kernel -- skg_gemmx_d32_kernel: 32-deep k-steps, ds_read_b128 / ds_read_b32 fragments -- was built,
+// tested on every layout and measured in round 4: not faster than skg_gemmx_kernel, dW 1.3-1.6x slower.  The register-staged fp32
+// loop is not staging-bound.  Removed again; the record is profiles/r04_fp32_direct_lds_experiment.txt.)
 
 // Adds the split-K slices in slice order and applies the epilogue.  One thread per output element (coalesced along n).
 __global__ __launch_bounds__(256) void skg_gemmx_reduce_kernel(const skg_gemmx_group g) {
@@ -1781,7 +1470,6 @@ static bool xfused_ptrs_ok(const skg_gemmx_fused& f) {
            skg_aligned16(f.res) && xmul4(f.ldp) && xmul4(f.ldq) && xmul4(f.ldc_raw) && xmul4(f.ldres);
 }
 
-static bool g_d32_enabled = getenv("SKG_GEMMX_D32") == nullptr || atoi(getenv("SKG_GEMMX_D32")) != 0;   // developer A/B switch
 static bool g_t16_enabled = getenv("SKG_GEMMX_T16") == nullptr || atoi(getenv("SKG_GEMMX_T16")) != 0;   // developer A/B switch
 
 static int skg_gemmx_launch(const skg_gemmx_desc* descs_host, int n, void* stream, bool bf16,
@@ -1846,16 +1534,7 @@ static int skg_gemmx_launch(const skg_gemmx_desc* descs_host, int n, void* strea
         t16 = (g.vec[i] & 48) == 48 && d.K > 0 && (d.a_sk == 1 || ((d.M & 7) == 0 && d.M >= 8)) &&
               (d.b_sk == 1 || ((d.N & 7) == 0 && d.N >= 8)) && (d.b_kshift == 0 || d.b_kshift >= 6);
     }
-    // exact fp32: every product with 16-byte loads on both operands, whole 4-row pieces and k blocks of whole tiles: the
-    // direct-to-LDS loop
-    bool d32 = !bf16 && g_d32_enabled;
-    for (int i = 0; i < g.n && d32; ++i) {
-        const skg_gemmx_desc& d = g.d[i];
-        d32 = (g.vec[i] & 3) == 3 && d.K > 0 && (d.a_sk == 1 || ((d.M & 3) == 0 && d.M >= 4)) &&
-              (d.b_sk == 1 || ((d.N & 3) == 0 && d.N >= 4)) && (d.b_kshift == 0 || d.b_kshift >= 5);
-    }
     if (t16) hipLaunchKernelGGL(skg_gemmx_t16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
-    else if (d32) hipLaunchKernelGGL(skg_gemmx_d32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     else if (bf16) hipLaunchKernelGGL(skg_gemmx_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(skg_gemmx_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     if (r.n) {
