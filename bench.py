@@ -205,14 +205,19 @@ def run_train(B, precision, steps, warmup, device, rank, world, dist_on, prefetc
         for _ in range(5):
             trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=nxt)
             waits.append(exs[0].read_timing())
+        native = exs[0].native is not None
         info["grad_exchange"] = dict(collectives_per_step=exs[0].collectives + 1,
                                      exposed_wait_ms=round(float(np.median(waits)), 4),
                                      arena_mb=round(exs[0].ga.numel() * 4 / 2 ** 20, 1),
-                                     note="1 fused normaliser all-reduce + the gradient arena in chunks, each ordered behind "
-                                          "the event of the backward stage that completes it (the backward itself is ONE call "
-                                          "issued by the library's worker thread; skghoi_amd.trainer.ArenaExchange.drive); "
-                                          "exposed_wait = device time the step's stream waited for the chunks after its "
-                                          "last backward kernel + the averaging pass, median of 5 untimed steps")
+                                     route=("libskghoi_hip's own RCCL communicator: ncclAllReduce per chunk issued by the "
+                                            "backward's worker thread (include/skghoi.h skg_comm, "
+                                            "skg_ctx_train_backward_exchange_f32)") if native else
+                                           "torch.distributed all_reduce per chunk from the Python thread (ArenaExchange.drive)",
+                                     note="1 fused normaliser all-reduce (issued while the batch is prepared) + the gradient "
+                                          "arena in chunks, each ordered behind the event of the backward stage that completes "
+                                          "it (the backward itself is ONE call issued by the library's worker thread); "
+                                          "exposed_wait = device time between the backward's last kernel and the end of the "
+                                          "last chunk's collective, median of 5 untimed steps")
         exs[0].timing = False
     if measure:
         lib = _capi.lib()

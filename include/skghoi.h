@@ -20,10 +20,12 @@
 extern "C" {
 #endif
 
-#define SKG_ABI_VERSION 12
+#define SKG_ABI_VERSION 14
 #define SKG_E_ARG   (-1)   /* null pointer / negative size / unsupported shape            */
 #define SKG_E_ALIGN (-2)   /* pointer or leading dimension not 16-byte aligned            */
 #define SKG_E_LIMIT (-3)   /* exceeds a compiled-in limit (boxes per image, verbs, ...)   */
+#define SKG_E_UNSUPPORTED (-4) /* an optional run-time dependency is absent (RCCL)        */
+#define SKG_E_COMM  (-5)   /* an RCCL call failed: skg_comm_last_error() has the text     */
 
 #define SKG_MAX_DET_PER_IMAGE 1024   /* candidates per image the preprocess kernel accepts */
 #define SKG_MAX_NODES         160    /* max_human + max_object                             */
@@ -453,13 +455,26 @@ int skg_hoi_loss_f32(const float* logits, int64_t ldl, int K, const skg_image_me
                      const float* labels, float* cell_labels, float* unary, float* partial, float* dlogits,
                      void* stream);
 
+/* Data parallel: the three per-rank normaliser counts {#non-zero labels among the scored cells, #pairs with a label, the same
+ * again} (HEAD:167-172, 194-199, 223-228 before their all_reduce) from the PREPARED batch -- associated labels [sumP, K],
+ * kept pairs, detections (prior of the human != 0 -> the verbs of the object's class are scored, HEAD:747-760) -- so the
+ * all-reduce can start with the preparation and skg_loss_finish_f32 is called once, with norm_in.  counts [3] is
+ * overwritten.  Equal to skg_loss_finish_f32's counts_out for the same batch.                                           */
+int skg_count_positives_f32(const float* labels, int K, const float* det_scores, const int64_t* det_labels,
+                            const skg_image_meta* meta, int n_active, const int64_t* x_keep, const int64_t* y_keep,
+                            const int32_t* verb_off, const int32_t* verb_list, int num_obj_classes, float prior_pow,
+                            float* counts, void* stream);
+
 /* The three loss scalars from the partial sums the loss and sampling kernels leave (HEAD:162-177, 190-205, 228-234):
  * sums = column sums of partial [rows, 4]; n_p = norm_in [3] (data parallel: all_reduce_sum(counts) / world, HEAD:167-172)
  * or, when NULL, {sums[2], sums[3], sums[3]};  losses = {sums[0] / n_p[0], sums[1] / n_p[1], (sum(mpart[0..n_img)) /
- * max(m_pos, 1) + margin) / n_p[2]};  scale = {1 / n_p[0], 1 / n_p[1]};  counts_out (optional) = {sums[2], sums[3],
- * sums[3]} -- a data-parallel caller asks for the counts first (losses = NULL), all-reduces them and calls again.       */
+ * max(m_pos, 1) + margin) / n_p[2]};  scale = {1 / n_p[0], 1 / n_p[1]} * grad_share -- the factor on the logit
+ * gradients; grad_share = 1 / world makes the ranks' gradient SUM their mean (utils.py:202-205 averages), 1 otherwise;
+ * counts_out (optional) = {sums[2], sums[3], sums[3]} -- a data-parallel caller without prepared counts
+ * (skg_count_positives_f32) asks for them first (losses = NULL), all-reduces them and calls again.                      */
 int skg_loss_finish_f32(const float* partial, int rows, const float* mpart, int n_img, int64_t m_pos, float margin,
-                        const float* norm_in, float* losses, float* scale, float* counts_out, void* stream);
+                        float grad_share, const float* norm_in, float* losses, float* scale, float* counts_out,
+                        void* stream);
 /* out[r, c] = dl[r, c] * (c < K ? scale[0] * g0[0] : scale[1] * g1[0]): the gradient of the summed losses w.r.t. the
  * logits from skg_hoi_loss_f32's d(sum)/d(logits), the normalisers and the upstream gradients of the two focal terms.  */
 int skg_scale_dlogits_f32(const float* dl, int64_t ld, int rows, int K, const float* scale, const float* g0,
@@ -624,6 +639,47 @@ int skg_ctx_train_backward_async_f32(skg_context* ctx, const skg_train_plan* pla
 int skg_ctx_stream_wait_stage(skg_context* ctx, int stage, void* waiting_stream);
 int skg_ctx_train_backward_stage_wait(skg_context* ctx, int stage);
 int skg_ctx_train_backward_join(skg_context* ctx);
+/* ---- data parallel: the gradient exchange inside the worker's backward (replaces utils.py:202-205, DistributedDataParallel's
+ * bucketed NCCL all-reduce, for the head's gradient arena).  skg_comm is an RCCL communicator OF THIS LIBRARY -- RCCL is
+ * bound at run time (skg_comm_load: dlopen of `librccl_path`, else of the librccl the process already has; SKG_E_UNSUPPORTED
+ * when there is none) -- with a stream of its own.  Bootstrap like any NCCL program: rank 0 draws skg_comm_unique_id
+ * (SKG_COMM_ID_BYTES bytes), the caller carries it to every rank (its process group's broadcast), every rank calls
+ * skg_comm_create(id, rank, world) with ITS device current (collective: returns on all ranks or on none).
+ * skg_ctx_train_backward_exchange_f32 = skg_ctx_train_backward_async_f32 whose worker, behind every stage ex->stage[i], orders
+ * the communicator's stream behind that stage's device-scope event and all-reduces (sum, in place, fp32) arena[ex->end[i-1],
+ * ex->end[i]) there, and behind the last stage orders `stream` behind the last collective: at the join the gradients on
+ * `stream` are the ranks' SUM (the caller folded 1 / world into its logit gradients).  Chunks in ascending stage order.
+ * skg_comm_all_reduce_chunks_f32: the same chunk sequence behind `stream`'s current tail, for a rank whose step did not take
+ * the staged route (its peers' collectives must be met one for one).  skg_comm_exposed_ms: device time between
+ * `after_event` (a recorded timing event, e.g. behind the backward's last launch) and the end of the step's last collective,
+ * clipped at 0 (blocks until both have happened).  skg_comm_all_reduce_begin_f32 / _end: ONE further collective outside
+ * the chunk sequence (the loss normalisers of the next batch, HEAD:167-172) -- begin orders the communicator's stream behind
+ * `stream`'s tail and all-reduces p[0, n) there, end orders the stream it is given behind that collective; one pair
+ * outstanding at a time.  Every rank must issue the communicator's collectives in the same order: callers keep them on
+ * one host thread at a time (the worker between submit and join, the submitting thread otherwise).                      */
+typedef struct skg_comm skg_comm;
+#define SKG_COMM_ID_BYTES 128
+typedef struct skg_exchange {
+    skg_comm* comm;
+    float* arena;                              /* the gradient arena (plan.grads) */
+    int32_t n_chunks;
+    int32_t stage[SKG_TRAIN_BWD_STAGES];       /* stage that completes chunk i (ascending) */
+    int64_t end[SKG_TRAIN_BWD_STAGES];         /* chunk i = arena[end[i - 1], end[i]) floats */
+} skg_exchange;
+int skg_comm_load(const char* librccl_path);
+int skg_comm_unique_id(void* id_out);
+int skg_comm_create(const void* id, int rank, int world, skg_comm** out);
+void skg_comm_destroy(skg_comm* comm);
+int skg_comm_world(const skg_comm* comm);
+int skg_comm_rank(const skg_comm* comm);
+int64_t skg_comm_collectives(const skg_comm* comm);                /* all-reduces issued since creation */
+const char* skg_comm_last_error(void);                             /* text of this thread's last SKG_E_COMM / _UNSUPPORTED */
+int skg_comm_all_reduce_chunks_f32(skg_comm* comm, float* arena, const int64_t* ends_host, int n_chunks, void* stream);
+int skg_comm_exposed_ms(skg_comm* comm, void* after_event, float* ms_out);
+int skg_comm_all_reduce_begin_f32(skg_comm* comm, float* p, int64_t n, void* stream);
+int skg_comm_all_reduce_end(skg_comm* comm, void* stream);
+int skg_ctx_train_backward_exchange_f32(skg_context* ctx, const skg_train_plan* plan_host, int first_stage, int last_stage,
+                                        void* stream, void* const* stage_events_host, const skg_exchange* ex_host);
 /* The same on the default context, without stage events. */
 int skg_train_backward_async_f32(const skg_train_plan* plan_host, int first_stage, int last_stage, void* stream);
 int skg_train_backward_join(void);

@@ -12,7 +12,7 @@ MAX_NODES = 160
 SPATIAL_LD = 48
 TRANSH_DIM = 50
 TRANSH_ENT = 80
-ABI_VERSION = 12
+ABI_VERSION = 14
 GEMM_GROUP_MAX = 4
 CHECKSUM_PARTIALS = 1024
 LOSS_CHUNKS = 64
@@ -58,6 +58,13 @@ TRAIN_SEGS = ("W1_0", "W1_1", "W1_2", "W1_3", "b1_0", "b1_1", "b1_2", "b1_3", "W
               "b2", "clsW", "clsb", "nh_w", "nh_b", "no_w", "no_b", "adj_w", "adj_b", "sp0_w", "sp0_b", "sp2_w", "sp2_b",
               "sp4_w", "sp4_b", "fh_w", "fh_b", "ft_w", "ft_b", "bh3_w", "bh3_b", "bh1_w", "bh1_b")    # SKG_SEG_* order
 TRAIN_BWD_STAGES = 12
+COMM_ID_BYTES = 128
+
+
+class Exchange(C.Structure):
+    """Mirror of skg_exchange: the arena chunks a staged backward all-reduces itself over an skg_comm."""
+    _fields_ = [("comm", C.c_void_p), ("arena", C.c_void_p), ("n_chunks", C.c_int32),
+                ("stage", C.c_int32 * TRAIN_BWD_STAGES), ("end", C.c_int64 * TRAIN_BWD_STAGES)]
 
 
 class TrainPlan(C.Structure):
@@ -154,7 +161,8 @@ PROTOTYPES = {
     "skg_transh_sample_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _f32, _vp, _vp, _vp, _vp, _vp,
                                         _vp]),
     "skg_hoi_loss_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "skg_loss_finish_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "skg_count_positives_f32": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _f32, _vp, _vp]),
+    "skg_loss_finish_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i64, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "skg_scale_dlogits_f32": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "skg_train_ws_floats": (C.c_int64, [C.POINTER(TrainPlan)]),
     "skg_train_forward_f32": (C.c_int, [C.POINTER(TrainPlan), C.c_int, _vp]),
@@ -170,6 +178,19 @@ PROTOTYPES = {
     "skg_context_create": (_vp, []),
     "skg_context_destroy": (None, [_vp]),
     "skg_ctx_train_backward_async_f32": (C.c_int, [_vp, C.POINTER(TrainPlan), C.c_int, C.c_int, _vp, _vp, C.c_uint32]),
+    "skg_ctx_train_backward_exchange_f32": (C.c_int, [_vp, C.POINTER(TrainPlan), C.c_int, C.c_int, _vp, _vp, C.POINTER(Exchange)]),
+    "skg_comm_load": (C.c_int, [C.c_char_p]),
+    "skg_comm_unique_id": (C.c_int, [_vp]),
+    "skg_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "skg_comm_destroy": (None, [_vp]),
+    "skg_comm_world": (C.c_int, [_vp]),
+    "skg_comm_rank": (C.c_int, [_vp]),
+    "skg_comm_collectives": (_i64, [_vp]),
+    "skg_comm_last_error": (C.c_char_p, []),
+    "skg_comm_all_reduce_chunks_f32": (C.c_int, [_vp, _vp, C.POINTER(_i64), C.c_int, _vp]),
+    "skg_comm_all_reduce_begin_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "skg_comm_all_reduce_end": (C.c_int, [_vp, _vp]),
+    "skg_comm_exposed_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "skg_ctx_stream_wait_stage": (C.c_int, [_vp, C.c_int, _vp]),
     "skg_ctx_train_backward_stage_wait": (C.c_int, [_vp, C.c_int]),
     "skg_ctx_train_backward_join": (C.c_int, [_vp]),
@@ -210,9 +231,13 @@ def lib():
 
 
 _ERR = {-1: "SKG_E_ARG (bad argument)", -2: "SKG_E_ALIGN (pointer / leading dimension not 16-byte aligned)",
-        -3: "SKG_E_LIMIT (compiled-in limit exceeded)"}
+        -3: "SKG_E_LIMIT (compiled-in limit exceeded)", -4: "SKG_E_UNSUPPORTED (RCCL not available in this process)",
+        -5: "SKG_E_COMM (an RCCL call failed)"}
 
 
 def check(rc, what):
     if rc != 0:
-        raise SkgError("%s failed: %s" % (what, _ERR.get(rc, "hipError_t %d" % rc)))
+        detail = ""
+        if rc in (-4, -5):
+            detail = " -- " + (lib().skg_comm_last_error() or b"").decode(errors="replace")
+        raise SkgError("%s failed: %s%s" % (what, _ERR.get(rc, "hipError_t %d" % rc), detail))

@@ -280,6 +280,8 @@ class _Prefetch:
                 return True
             except StopIteration as end:
                 self.prep = end.value
+                if self.prep.norm is not None:
+                    self.prep.norm.get()                 # data parallel: the side stream, not the step's, waits for the n_p all-reduce
                 self.prep.ready = torch.cuda.Event()
                 self.prep.ready.record(self.stream)
                 self.done = True

@@ -116,3 +116,9 @@ struct skg_layernorm_bwd_args {
     uint16_t* dx16; uint16_t* dx_masked16;   // filled by the launcher from the twin map
 };
 int skg_layernorm_bwd_multi(const skg_layernorm_bwd_args* calls, int n, void* stream);
+
+// ---- skg_comm.cpp: what the backward's worker thread calls between stages (data parallel).  skg_comm_chunk: the exchange
+// stream waits for `after` (a recorded event, or NULL), then all-reduces p[0, n) in place (sum, fp32) there;
+// skg_comm_close_step: `stream` ordered behind every collective issued so far.
+int skg_comm_chunk(skg_comm* c, hipEvent_t after, float* p, int64_t n);
+int skg_comm_close_step(skg_comm* c, hipStream_t stream);

@@ -727,6 +727,56 @@ extern "C" int skg_hoi_loss_f32(const float* logits, int64_t ldl, int K, const s
     return skg_launch_status();
 }
 
+// The three per-rank normaliser counts of the loss terms from what the PREPARATION of a batch knows (HEAD:162-172, 190-199,
+// 219-228: n_p = #non-zero labels among the scored cells / #pairs with any label, twice): they depend on the detections, the
+// verb table and the associated labels, not on the logits, so a data-parallel trainer forms them -- and starts their
+// all-reduce -- while the batch is being prepared instead of between the two halves of the loss.  A wave per kept pair;
+// the counts are small integers, exact in fp32 whatever the order of the atomic adds.
+__global__ __launch_bounds__(256) void skg_count_positives_kernel(
+    const float* __restrict__ labels, int K, const float* __restrict__ det_scores, const int64_t* __restrict__ det_labels,
+    const skg_image_meta* __restrict__ meta, const int64_t* __restrict__ x_keep, const int64_t* __restrict__ y_keep,
+    const int32_t* __restrict__ verb_off, const int32_t* __restrict__ verb_list, int num_obj_classes, float prior_pow,
+    float* __restrict__ counts) {
+    __shared__ float sred[4];
+    const skg_image_meta mt = meta[blockIdx.x];
+    const int P = mt.n_h * (mt.n - 1);
+    const int lane = threadIdx.x & 63;
+    float n1 = 0.f, n2 = 0.f;
+    for (int pl = blockIdx.y * 4 + (threadIdx.x >> 6); pl < P; pl += 4 * gridDim.y) {
+        const int64_t p = (int64_t)mt.pair_off + pl;
+        const int bh = mt.box_off + (int)x_keep[p];
+        const int64_t lab = det_labels[mt.box_off + (int)y_keep[p]];
+        const int cls = (int)lab;
+        const int nv = (lab >= 0 && lab < num_obj_classes && powf(det_scores[bh], prior_pow) != 0.f)
+                           ? verb_off[cls + 1] - verb_off[cls] : 0;                 // the pair's scored cells (skg_pair_cells)
+        float ys = 0.f, c1 = 0.f;
+        for (int v = lane; v < K; v += 64) ys += labels[p * K + v];
+        for (int t = lane; t < nv; t += 64) c1 += labels[p * K + verb_list[verb_off[cls] + t]] != 0.f ? 1.f : 0.f;
+        ys = skg_wave_sum(ys);
+        c1 = skg_wave_sum(c1);
+        if (lane == 0) { n1 += c1; if (ys != 0.f) n2 += 1.f; }
+    }
+    n1 = skg_block_sum256(n1, sred);
+    n2 = skg_block_sum256(n2, sred);
+    if (threadIdx.x == 0 && (n1 != 0.f || n2 != 0.f)) {
+        atomicAdd(counts, n1); atomicAdd(counts + 1, n2); atomicAdd(counts + 2, n2);
+    }
+}
+
+extern "C" int skg_count_positives_f32(const float* labels, int K, const float* det_scores, const int64_t* det_labels,
+                                       const skg_image_meta* meta, int n_active, const int64_t* x_keep,
+                                       const int64_t* y_keep, const int32_t* verb_off, const int32_t* verb_list,
+                                       int num_obj_classes, float prior_pow, float* counts, void* stream) {
+    if (n_active < 0 || K <= 0 || num_obj_classes <= 0 || !counts) return SKG_E_ARG;
+    hipError_t e = hipMemsetAsync(counts, 0, 3 * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    if (n_active == 0) return 0;
+    if (!labels || !det_scores || !det_labels || !meta || !x_keep || !y_keep || !verb_off || !verb_list) return SKG_E_ARG;
+    hipLaunchKernelGGL(skg_count_positives_kernel, dim3(n_active, 16), dim3(256), 0, (hipStream_t)stream, labels, K,
+                       det_scores, det_labels, meta, x_keep, y_keep, verb_off, verb_list, num_obj_classes, prior_pow, counts);
+    return skg_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------ TransH pos / neg sampling
 // HEAD:936-963 + the intended MarginLoss (HEAD:207-235; heads/NegativeSampling.py:52-56, heads/MarginLoss.py:28-36):
 // per image the TransH scores of the positive cells (labels != 0, row-major over (pair, verb)) and of as many sampled
@@ -851,7 +901,8 @@ extern "C" int skg_transh_sample_f32(const float* labels, const float* scores, i
 // One wavefront; fixed summation order (deterministic).
 __global__ __launch_bounds__(64) void skg_loss_finish_kernel(const float* __restrict__ partial, int rows,
                                                              const float* __restrict__ mpart, int n_img, float m_pos,
-                                                             float margin, const float* __restrict__ norm_in,
+                                                             float margin, float grad_share,
+                                                             const float* __restrict__ norm_in,
                                                              float* __restrict__ losses, float* __restrict__ scale,
                                                              float* __restrict__ counts_out) {
     const int lane = threadIdx.x;
@@ -870,17 +921,17 @@ __global__ __launch_bounds__(64) void skg_loss_finish_kernel(const float* __rest
             const float n0 = norm_in ? norm_in[0] : s2, n1 = norm_in ? norm_in[1] : s3, n2 = norm_in ? norm_in[2] : s3;
             losses[0] = s0 / n0; losses[1] = s1 / n1;
             losses[2] = (sm / (m_pos > 1.f ? m_pos : 1.f) + margin) / n2;
-            scale[0] = 1.f / n0; scale[1] = 1.f / n1;
+            scale[0] = (1.f / n0) * grad_share; scale[1] = (1.f / n1) * grad_share;
         }
     }
 }
 
 extern "C" int skg_loss_finish_f32(const float* partial, int rows, const float* mpart, int n_img, int64_t m_pos,
-                                   float margin, const float* norm_in, float* losses, float* scale, float* counts_out,
-                                   void* stream) {
+                                   float margin, float grad_share, const float* norm_in, float* losses, float* scale,
+                                   float* counts_out, void* stream) {
     if (rows < 0 || n_img < 0 || !partial || !mpart || (!losses && !counts_out) || (losses && !scale)) return SKG_E_ARG;
     hipLaunchKernelGGL(skg_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, rows, mpart, n_img,
-                       (float)m_pos, margin, norm_in, losses, scale, counts_out);
+                       (float)m_pos, margin, grad_share, norm_in, losses, scale, counts_out);
     return skg_launch_status();
 }
 

@@ -674,6 +674,15 @@ struct skg_context {
     uint32_t own_mask = 0;                         // stages (absolute) behind which own[stage] is recorded
     bool own_made = false;
     bool with_events = false;
+    skg_exchange ex = {};                          // data parallel: the arena chunks this job all-reduces itself (ex.comm != NULL)
+    // the collective of the chunk that stage e completes, behind the stage's own event (recorded just before)
+    int exchange_after(int e) {
+        if (!ex.comm) return 0;
+        for (int i = 0; i < ex.n_chunks; ++i)
+            if (ex.stage[i] == e)
+                return skg_comm_chunk(ex.comm, own[e], ex.arena + (i ? ex.end[i - 1] : 0), ex.end[i] - (i ? ex.end[i - 1] : 0));
+        return 0;
+    }
     void loop() {
         for (;;) {
             std::unique_lock<std::mutex> lk(m);
@@ -694,11 +703,13 @@ struct skg_context {
                     r = skg_train_backward_f32(&plan, s, e + 1, stream);
                     if (!r && events[e - first]) r = (int)hipEventRecord(events[e - first], (hipStream_t)stream);
                     if (!r && ((own_mask >> e) & 1u)) r = (int)hipEventRecord(own[e], (hipStream_t)stream);
+                    if (!r) r = exchange_after(e);
                     if (r) break;
                     lk.lock(); issued = e + 1; lk.unlock();
                     cv.notify_all();
                     s = e + 1;
                 }
+                if (!r && ex.comm) r = skg_comm_close_step(ex.comm, (hipStream_t)stream);     // `stream` behind the last collective
                 lk.lock();
             }
             rc = r; pending = false;
@@ -743,10 +754,20 @@ void skg_context_destroy(skg_context* c) {
     delete c;
 }
 
-int skg_ctx_train_backward_async_f32(skg_context* ctx, const skg_train_plan* P, int first_stage, int last_stage,
-                                     void* stream, void* const* stage_events_host, uint32_t stage_mask) {
+static int submit_backward(skg_context* ctx, const skg_train_plan* P, int first_stage, int last_stage, void* stream,
+                           void* const* stage_events_host, uint32_t stage_mask, const skg_exchange* ex) {
     int rc = validate_backward(P, first_stage, last_stage);    // rejected here, at submit -- not at the join
     if (rc) return rc;
+    if (ex) {
+        if (!ex->comm || !ex->arena || ex->n_chunks < 1 || ex->n_chunks > SKG_TRAIN_BWD_STAGES) return SKG_E_ARG;
+        stage_mask = 0;
+        for (int i = 0; i < ex->n_chunks; ++i) {
+            if (ex->stage[i] < first_stage || ex->stage[i] >= last_stage || (i && ex->stage[i] <= ex->stage[i - 1]) ||
+                ex->end[i] < (i ? ex->end[i - 1] : 0))
+                return SKG_E_ARG;
+            stage_mask |= 1u << ex->stage[i];
+        }
+    }
     skg_context* a = ctx_or_default(ctx);
     std::unique_lock<std::mutex> lk(a->m);
     if (a->pending || a->quit) return SKG_E_LIMIT;             // one job at a time per context: join first
@@ -766,6 +787,7 @@ int skg_ctx_train_backward_async_f32(skg_context* ctx, const skg_train_plan* P, 
         a->own_made = true;
     }
     a->own_mask = stage_mask;
+    if (ex) a->ex = *ex; else memset(&a->ex, 0, sizeof(a->ex));
     a->plan = *P; a->first = first_stage; a->last = last_stage; a->stream = stream; a->device = dev; a->rc = 0;
     a->issued = first_stage;
     a->with_events = stage_events_host != nullptr || stage_mask != 0;
@@ -780,6 +802,17 @@ int skg_ctx_train_backward_async_f32(skg_context* ctx, const skg_train_plan* P, 
     lk.unlock();
     a->cv.notify_all();
     return 0;
+}
+
+int skg_ctx_train_backward_async_f32(skg_context* ctx, const skg_train_plan* P, int first_stage, int last_stage,
+                                     void* stream, void* const* stage_events_host, uint32_t stage_mask) {
+    return submit_backward(ctx, P, first_stage, last_stage, stream, stage_events_host, stage_mask, nullptr);
+}
+
+int skg_ctx_train_backward_exchange_f32(skg_context* ctx, const skg_train_plan* P, int first_stage, int last_stage,
+                                        void* stream, void* const* stage_events_host, const skg_exchange* ex) {
+    if (!ex) return SKG_E_ARG;
+    return submit_backward(ctx, P, first_stage, last_stage, stream, stage_events_host, 0u, ex);
 }
 
 int skg_ctx_train_backward_stage_wait(skg_context* ctx, int stage) {

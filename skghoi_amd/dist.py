@@ -95,6 +95,43 @@ class Normalisers:
         return self._out
 
 
+class PreparedNormalisers:
+    """The fused `n_p` all-reduce of a PREPARED training batch (skghoi_amd.train_fused.prepare_steps): float32 device
+    counts [3] (integer-valued, exact), summed in place over the ranks from the stream the preparation runs on, as soon as
+    the label association is enqueued.  get() -> the same tensor divided by the world size (HEAD:167-172: all_reduce,
+    then n_p / world_size in float32), ordered behind the collective on the stream get() is called on -- the preparation's
+    side stream when the batch was prefetched (`finish()`), the step's stream otherwise."""
+
+    def __init__(self, counts, group=None, force=False, native=None):
+        self.vals, self.work, self.world, self._done, self.native = counts, None, 1, False, None
+        if native is not None:
+            # the trainer's gradient exchange runs on the HIP library's own RCCL communicator (trainer.NativeComm): this
+            # collective joins it there -- ONE communicator, one issue order on every rank [chunks of step i, this]
+            from . import _capi
+            self.world, self.native = native.world, native
+            _capi.check(_capi.lib().skg_comm_all_reduce_begin_f32(native.handle, counts.data_ptr(), counts.numel(),
+                                                                  torch.cuda.current_stream(counts.device).cuda_stream),
+                        "skg_comm_all_reduce_begin_f32")
+        elif dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
+            self.world = dist.get_world_size(group)
+            self.work = dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+    def get(self):
+        if not self._done:
+            if self.native is not None:
+                from . import _capi
+                _capi.check(_capi.lib().skg_comm_all_reduce_end(self.native.handle,
+                                                                torch.cuda.current_stream(self.vals.device).cuda_stream),
+                            "skg_comm_all_reduce_end")
+            if self.work is not None:
+                self.work.wait()
+                self.work = None
+            if self.world > 1:
+                self.vals.div_(self.world)
+            self._done = True
+        return self.vals
+
+
 def start_normalisers(counts, distributed=True, group=None, force=False):
     """counts: device (or CPU, for gloo) tensor of the three per-rank normaliser counts {#positive scored cells,
     #positive pairs, #positive pairs}.  Starts ONE 3-element all-reduce (async) when a process group with more than

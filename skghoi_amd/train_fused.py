@@ -763,19 +763,34 @@ class NativeJob(TrainJob):
             ctx.join()
             ctx.owner = threading.get_ident()
             events, mask = None, 0
+            native = ex is not None and ex.native is not None
             if ex is not None:
                 ex.begin(ga)
                 mask = ex.stage_mask(st.milestone_end)       # stages that complete an arena chunk: the context's own events
+            after = None
             if span is not None:
-                span["b1"] = torch.cuda.Event(enable_timing=True)
-                span["b1"].record()                              # (torch creates the HIP event at its first record)
+                after = span["b1"] = torch.cuda.Event(enable_timing=True)
+            elif native and ex.timing:
+                after = torch.cuda.Event(enable_timing=True)     # (bench.py: exposed wait = this event -> the last collective)
+            if after is not None:
+                after.record()                                   # (torch creates the HIP event at its first record)
                 events = (C.c_void_p * n)()
-                events[n - 1] = span["b1"].cuda_event
-            _check(lib.skg_ctx_train_backward_async_f32(ctx.handle(), C.byref(pl), 0, n, stream, events, mask),
-                   "skg_train_backward_async_f32")
+                events[n - 1] = after.cuda_event
+            if native:
+                # the library's own RCCL communicator: the WORKER all-reduces every arena chunk behind the stage that
+                # completes it and orders this stream behind the last collective -- nothing left to drive from here
+                ex._after = after
+                xd = ex.native_exchange(ga, st.milestone_end)
+                _check(lib.skg_ctx_train_backward_exchange_f32(ctx.handle(), C.byref(pl), 0, n, stream, events, C.byref(xd)),
+                       "skg_ctx_train_backward_exchange_f32")
+            else:
+                _check(lib.skg_ctx_train_backward_async_f32(ctx.handle(), C.byref(pl), 0, n, stream, events, mask),
+                       "skg_train_backward_async_f32")
             # everything the plan names stays alive until the worker has enqueued the last launch
             ctx.pending.append((self, self.S, self.ws, self.ws16, dlogits, ga, dx0, dgfeat))
-            if ex is not None:
+            if native:
+                ctx.driven = ex                                  # finish() at the join: bookkeeping only
+            elif ex is not None:
                 ctx.exchange = (ex, list(st.milestone_end))
             self.S = None
             self.ws = None
@@ -786,9 +801,13 @@ class NativeJob(TrainJob):
             # data parallel on the autograd route (a trainable detector in front of the head): the stages are issued from
             # this thread, and after every stage the gradient-arena prefix that stage completed goes out to the peers
             ex.begin(ga)
-            for s_ in range(n):
-                _check(lib.skg_train_backward_f32(C.byref(pl), s_, s_ + 1, stream), "skg_train_backward_f32[%d]" % s_)
-                ex.on_stage(s_, ga, st.milestone_end[s_], last=(s_ == n - 1))
+            if ex.native is not None:
+                _check(lib.skg_train_backward_f32(C.byref(pl), 0, n, stream), "skg_train_backward_f32")
+                ex.native_all_reduce(ga, st.milestone_end)       # the same chunk sequence as the peers' staged route
+            else:
+                for s_ in range(n):
+                    _check(lib.skg_train_backward_f32(C.byref(pl), s_, s_ + 1, stream), "skg_train_backward_f32[%d]" % s_)
+                    ex.on_stage(s_, ga, st.milestone_end[s_], last=(s_ == n - 1))
             ex.finish()
         out = []
         for p in self.params:
@@ -930,6 +949,7 @@ class Prepared:
     negative permutations drawn from the host RNG, all uploaded.  Made inline by the forward -- or ahead of time, for the
     NEXT batch, on a side stream while the GPU is busy with the current step (InteractionHead.prefetch_train)."""
     empty = False
+    norm = None           # data parallel: dist.PreparedNormalisers, the n_p all-reduce started by the preparation
     ready = None          # event behind the preparation's device work when it ran on a side stream
     cross = ()            # tensors allocated on the side stream and consumed on the step's stream
 
@@ -965,6 +985,7 @@ def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None
     before_sync(prep): called right before the second one (the inline forward enqueues the table-independent part of the
     dense forward there, so that the GPU works while the host waits and draws)."""
     from . import transh
+    from . import dist as skd
     lib = _capi.lib()
     gh = head.box_pair_head
     K = head.num_classes
@@ -1020,6 +1041,21 @@ def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None
     prep.arrays = dict(grid_h=grid_h, grid_o=grid_o, grid_pair=grid_pair, grid_img=grid_img, pair_grid=pair_grid,
                        pair_h=pair_h, pair_o=pair_o, x_keep=x_keep[:Mp], y_keep=y_keep[:Mp], sp48=sp48)
     prep.labels = labels_all
+    # data parallel: the three n_p normalisers (HEAD:167-172, 194-199, 223-228) depend on labels and detections, not on the
+    # logits -- counted here and all-reduced by the second half of the preparation (ONE 3-element collective), a whole
+    # forward ahead of the loss that divides by them; round 3 formed them inside the loss, with the collective between its
+    # two halves on the step's stream
+    prep.norm = None
+    counts = None
+    force = getattr(head, "force_collectives", False)
+    if head.distributed and skd.dist.is_available() and skd.dist.is_initialized() and \
+            (skd.dist.get_world_size() > 1 or force):
+        vt = eng.verbs(dev)
+        counts = torch.empty(3, **f32)
+        _check(lib.skg_count_positives_f32(labels_all.data_ptr(), K, pre.scores.data_ptr(), pre.labels.data_ptr(),
+                                           meta.data_ptr(), A, x_keep.data_ptr(), y_keep.data_ptr(), vt.off.data_ptr(),
+                                           vt.flat.data_ptr(), vt.num_obj, 1.0, counts.data_ptr(), stream),
+               "skg_count_positives_f32")
     # the positive counts travel to the host behind the association kernel
     npos_h = torch.empty(A, dtype=torch.int32, pin_memory=True)
     npos_h.copy_(npos_d, non_blocking=True)
@@ -1027,6 +1063,13 @@ def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None
     if before_sync is not None:
         before_sync(prep)
     yield 2
+    if counts is not None:
+        # the collective leaves from HERE, not from the first half: a prefetching trainer runs the first half while the
+        # current step's gradient chunks are still going out, this half behind its optimizer -- every rank, whichever route
+        # its current batch took, issues [chunks of step i, normalisers of batch i + 1] in that order on the one communicator
+        ex = getattr(head, "grad_exchange", None)
+        prep.norm = skd.PreparedNormalisers(counts, group=getattr(ex, "group", None), force=force,
+                                            native=getattr(ex, "native", None))
     # host RNG in the reference's order: per image six TransH draws (HEAD:574-580), then randperm(#negatives) (HEAD:939).
     npos_ev.synchronize()                                           # the step's second host synchronisation
     n_pos = npos_h.tolist()
@@ -1063,6 +1106,8 @@ def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None
     prep.pos_s, prep.neg_s, prep.mpart = pos_s[:M_pos], neg_s[:M_pos], mpart
     prep.cross = (pre.boxes, pre.scores, pre.labels, ibuf, grid, keep, sp48, labels_all, prep.ent, prep.rel, prep.nrm,
                   samp_d, gt_h, gt_o, gt_l, npos_d, scores_all, tr, sws)
+    if prep.norm is not None:
+        prep.cross += (prep.norm.vals,)
     prep.keep = (ent_h, rel_h, nrm_h, sh, npos_h, hbuf)             # pinned staging: alive until the copies have run
     return prep
 
@@ -1127,20 +1172,24 @@ class TrainRun:
         # (force_collectives: a process group of ONE rank still runs its collectives -- bench.py times the data-parallel
         #  route on a single GPU that way)
         force = getattr(head, "force_collectives", False)
-        if head.distributed and skd.dist.is_available() and skd.dist.is_initialized() and \
+        if prep.norm is not None:
+            norm = prep.norm.get()                                      # all-reduced since the preparation: no wait left here
+        elif head.distributed and skd.dist.is_available() and skd.dist.is_initialized() and \
                 (skd.dist.get_world_size() > 1 or force):
             counts = torch.empty(3, **f32)
             _check(lib.skg_loss_finish_f32(partial.data_ptr(), rows, mpart.data_ptr(), A, M_pos, 1.0, None, None, None,
                                            counts.data_ptr(), stream), "skg_loss_finish_f32")
             norm = skd.start_normalisers(counts, True, force=force).get().contiguous()     # ONE fused 3-element all-reduce
-        _check(lib.skg_loss_finish_f32(partial.data_ptr(), rows, mpart.data_ptr(), A, M_pos, 1.0, _ptr(norm),
-                                       losses.data_ptr(), job.loss_scale.data_ptr(), None, stream), "skg_loss_finish_f32")
         ex = getattr(head, "grad_exchange", None)
+        share = 1.0
         if ex is not None and norm is not None:
             # data parallel: the exchange SUMS the ranks' gradient arenas; with this rank's share of the mean folded into the
-            # scale of its logit gradients (two floats) the sum IS the mean -- no averaging pass over the 118 MB arena
-            job.loss_scale.mul_(1.0 / ex.world)
+            # scale of its logit gradients (two floats, inside the same kernel) the sum IS the mean -- no averaging pass over
+            # the 118 MB arena
+            share = 1.0 / ex.world
             ex.prescaled = True
+        _check(lib.skg_loss_finish_f32(partial.data_ptr(), rows, mpart.data_ptr(), A, M_pos, 1.0, share, _ptr(norm),
+                                       losses.data_ptr(), job.loss_scale.data_ptr(), None, stream), "skg_loss_finish_f32")
         self.pos_s, self.neg_s = prep.pos_s, prep.neg_s
         return losses
 

@@ -117,6 +117,80 @@ def _interaction_heads(module: nn.Module):
     return [m for m in module.modules() if isinstance(m, InteractionHead)]
 
 
+class NativeComm:
+    """An skg_comm (include/skghoi.h): the HIP library's own RCCL communicator + stream for the gradient exchange, over the
+    ranks of a torch.distributed process group whose backend is RCCL ("nccl").  `create` is COLLECTIVE over that group and
+    agrees on the outcome: every rank gets a communicator or every rank gets None (and keeps torch.distributed's
+    collectives) -- RCCL absent on some rank, ncclCommInitRank refused (two ranks on one GPU), SKG_NATIVE_RCCL=0."""
+
+    def __init__(self, handle, world, rank):
+        self.handle, self.world, self.rank = handle, world, rank
+
+    @staticmethod
+    def _agree(device, group, *flags):
+        """AND of each flag over the ranks of the group."""
+        t = torch.tensor([1 if f else 0 for f in flags], device=device, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        out = [bool(v) for v in t.tolist()]
+        return out[0] if len(out) == 1 else out
+
+    @classmethod
+    def create(cls, device, group=None):
+        import ctypes as C
+        import os
+        import warnings
+        from . import _capi
+        if os.environ.get("SKG_NATIVE_RCCL", "1") == "0" or dist.get_backend(group) != "nccl" or device.type != "cuda":
+            return None
+        lib = _capi.lib()
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        loaded = lib.skg_comm_load(path.encode() if os.path.exists(path) else None) == 0
+        if not cls._agree(device, group, loaded):
+            return None
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        ident = torch.zeros(_capi.COMM_ID_BYTES + 1, dtype=torch.uint8, device=device)      # id | "id is valid"
+        if rank == 0:
+            buf = (C.c_char * _capi.COMM_ID_BYTES)()
+            if lib.skg_comm_unique_id(buf) == 0:
+                ident = torch.cat([torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8),
+                                   torch.ones(1, dtype=torch.uint8)]).to(device)
+        dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        raw = bytes(ident.cpu().tolist())
+        h = C.c_void_p()
+        res = {}
+        if raw[-1] == 1:
+            # ncclCommInitRank is collective: a rank that never arrives would park its peers inside it for good.  It runs on
+            # a helper thread with a deadline; a rank that misses it reports so, everybody falls back, and the stuck
+            # communicator is left alone (never destroyed: its peers may still be inside the call).
+            import threading
+
+            def init():
+                with torch.cuda.device(device):
+                    res["rc"] = lib.skg_comm_create(raw[:_capi.COMM_ID_BYTES], rank, world, C.byref(h))
+                    res["err"] = (lib.skg_comm_last_error() or b"").decode(errors="replace")
+            t = threading.Thread(target=init, daemon=True)
+            t.start()
+            t.join(float(os.environ.get("SKG_NATIVE_RCCL_TIMEOUT", "120")))
+        rc = res.get("rc", -1)
+        in_time = raw[-1] != 1 or "rc" in res
+        ok, all_in_time = cls._agree(device, group, rc == 0, in_time)
+        if not ok:
+            if rc == 0 and all_in_time:
+                lib.skg_comm_destroy(h)
+            if rank == 0:
+                warnings.warn("skghoi_amd: the library's own RCCL communicator could not be created on every rank (%s); the "
+                              "gradient exchange stays on torch.distributed"
+                              % (res.get("err") or ("no answer within the deadline" if not in_time else "a peer failed")))
+            return None
+        return cls(h, world, rank)
+
+    def close(self):
+        h, self.handle = self.handle, None
+        if h:
+            from . import _capi
+            _capi.lib().skg_comm_destroy(h)
+
+
 class ArenaExchange:
     """Gradient exchange of the fused training step over its flat gradient ARENA (skghoi_amd/train_fused.py, Stacked).
 
@@ -135,8 +209,11 @@ class ArenaExchange:
     where a parameter has none -- DDP's find_unused_parameters semantics) through the same chunk sequence.  (A batch without
     a single pair cannot complete a step on either side: the reference's torch.cat over its empty score lists raises.)"""
 
-    def __init__(self, head, group=None, min_chunk=1 << 21):
-        self.head, self.group, self.min_chunk = head, group, int(min_chunk)
+    def __init__(self, head, group=None, min_chunk=1 << 22, native=None):
+        self.head, self.group, self.min_chunk = head, group, int(_os.environ.get("SKG_DP_MIN_CHUNK") or min_chunk)
+        self.n_stages = 12                    # (_capi.TRAIN_BWD_STAGES: the arena's milestones)
+        self.native = native                  # NativeComm: the library's worker thread issues the collectives itself
+        self._after = None                    # with timing on the native route: event behind the backward's last launch
         self.world = dist.get_world_size(group)
         self.works, self.done, self.ga = [], 0, None
         self.ran = False
@@ -151,8 +228,16 @@ class ArenaExchange:
         self.works, self.done, self.ga, self.collectives = [], 0, ga, 0
         self.ran = True
 
+    def _goes_out(self, s, pending, last):
+        """Whether the arena prefix pending behind stage s leaves as a chunk: coalesced to min_chunk floats (every chunk costs
+        the backward one event -- a ~12 us bubble on its queue, measured at world size 1: 6 / 4 / 2 chunks -> +0.08 / +0.05 /
+        +0.03 ms); the stage before the last sends what it has from a quarter of that on, so that the tail nobody can overlap
+        -- the 12.8 M-float box_head.1 gradient of the last stage -- is not made longer; the last stage sends the rest."""
+        return pending >= self.min_chunk or (s == self.n_stages - 2 and pending >= self.min_chunk // 4) or \
+            (last and pending > 0)
+
     def on_stage(self, s, ga, end, last=False):
-        if end - self.done >= self.min_chunk or (last and end > self.done):
+        if self._goes_out(s, end - self.done, last):
             if _PROBE != "nocoll":           # (developer probe: the staged backward without its collectives)
                 self.works.append(dist.all_reduce(ga[self.done:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.done = end
@@ -163,7 +248,7 @@ class ArenaExchange:
         out, done, n = [], 0, len(ends)
         for s_, end in enumerate(ends):
             last = s_ == n - 1
-            if end - done >= self.min_chunk or (last and end > done):
+            if self._goes_out(s_, end - done, last):
                 out.append((s_, end))
                 done = end
         return out
@@ -175,6 +260,35 @@ class ArenaExchange:
         for s_, _ in self.chunk_stages(ends):
             m |= 1 << s_
         return m
+
+    def native_exchange(self, ga, ends):
+        """skg_exchange of this step for skg_ctx_train_backward_exchange_f32: the chunk table of chunk_stages(), the arena
+        padding behind the last milestone included in the last chunk (as finish() sends it on the torch route)."""
+        from . import _capi
+        ex = _capi.Exchange()
+        chunks = self.chunk_stages(ends)
+        ex.comm, ex.arena, ex.n_chunks = self.native.handle, ga.data_ptr(), len(chunks)
+        for i, (s_, end) in enumerate(chunks):
+            ex.stage[i], ex.end[i] = s_, end
+        ex.end[len(chunks) - 1] = max(int(ex.end[len(chunks) - 1]), ga.numel())
+        self.done = ga.numel()
+        self.collectives = len(chunks)
+        return ex
+
+    def native_all_reduce(self, ga, ends):
+        """The step's chunk sequence on the library's communicator from THIS thread, behind the current stream's tail (a rank
+        off the staged route meets its peers' collectives one for one); the current stream is ordered behind the last."""
+        import ctypes as C
+        from . import _capi
+        chunks = self.chunk_stages(ends)
+        arr = (C.c_int64 * len(chunks))(*[int(e) for _, e in chunks])
+        arr[len(chunks) - 1] = max(int(arr[len(chunks) - 1]), ga.numel())
+        _capi.check(_capi.lib().skg_comm_all_reduce_chunks_f32(self.native.handle, ga.data_ptr(), arr, len(chunks),
+                                                               torch.cuda.current_stream(ga.device).cuda_stream),
+                    "skg_comm_all_reduce_chunks_f32")
+        self.done = ga.numel()
+        self.collectives = len(chunks)
+        self._after = None
 
     def drive(self, ctx, ends):
         """The backward was handed to the library's worker thread in ONE call (train_fused.NativeJob.backward, defer=True).
@@ -197,6 +311,12 @@ class ArenaExchange:
     def finish(self):
         """Orders the step's stream behind every chunk and forms the average."""
         ga = self.ga
+        if self.native is not None and not self.works and self.done >= ga.numel():
+            # the worker thread issued the collectives and ordered the step's stream behind the last one
+            if not self.prescaled:
+                ga.mul_(1.0 / self.world)
+            self.prescaled = False
+            return
         if self.done < ga.numel():                              # (arena padding at the very end)
             self.on_stage(-1, ga, ga.numel(), last=True)
         ev0 = ev1 = None
@@ -214,6 +334,14 @@ class ArenaExchange:
         self.works = []
 
     def read_timing(self):
+        if self.native is not None and self._after is not None:
+            import ctypes as C
+            from . import _capi
+            ms = C.c_float()
+            _capi.check(_capi.lib().skg_comm_exposed_ms(self.native.handle, self._after.cuda_event, C.byref(ms)),
+                        "skg_comm_exposed_ms")
+            self.last_ms = float(ms.value)
+            return self.last_ms
         ev = getattr(self, "_events", None)
         if ev is None:
             return None
@@ -245,8 +373,11 @@ class ArenaExchange:
         ga.mul_(1.0 / self.world)
         self.begin(ga)
         self.prescaled = True
-        for s_, end in enumerate(st.milestone_end):
-            self.on_stage(s_, ga, end, last=(s_ == len(st.milestone_end) - 1))
+        if self.native is not None:
+            self.native_all_reduce(ga, st.milestone_end)
+        else:
+            for s_, end in enumerate(st.milestone_end):
+                self.on_stage(s_, ga, end, last=(s_ == len(st.milestone_end) - 1))
         self.finish()
         for p, v in zip(st.src, views):
             if p.requires_grad:
@@ -305,6 +436,10 @@ def wrap_ddp(module: nn.Module, device=None, force_exchange=False):
     # issues them in after_backward(), i.e. AFTER DDP's bucket all-reduces, its peers from inside the backward, BEFORE --
     # on one communicator that order mismatch hangs or mixes buffers; two communicators are independent.
     group = dist.new_group() if (rest and fused and dist.get_world_size() > 1) else None
+    # The head alone is trained (BASELINE config 4: cached detections): its exchange runs on a communicator of the HIP
+    # library's own, issued by the backward's worker thread (NativeComm; collective, all ranks agree or all decline).  With a
+    # DDP remainder two host threads would feed two communicators at once -- kept on torch.distributed, one issue order.
+    native = NativeComm.create(next(fused[0].parameters()).device, group) if (fused and not rest) else None
     for h in fused:
         dev = next(h.parameters()).device
         h.grad_mode = "direct"
@@ -312,7 +447,9 @@ def wrap_ddp(module: nn.Module, device=None, force_exchange=False):
         if not st.aliased():
             st.adopt()
         dist.broadcast(st.buf, 0, group=group)              # DDP's constructor broadcast: rank 0's parameters everywhere
-        h.grad_exchange = ArenaExchange(h, group=group)
+        h.grad_exchange = ArenaExchange(h, group=group, native=native)
+        if force_exchange:
+            h.force_collectives = True                      # (a world of one rank still runs the normaliser collective)
     if not rest or dist.get_world_size() == 1:
         return module
     if ignore:
@@ -394,6 +531,13 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
         if not lazy and torch.isnan(loss_dict["hoi_loss"]):
             raise ValueError(f"The HOI loss is NaN")
         look_ahead()
+        advanced = False
+        if fused_ran and ahead[0] is not None and exchanges(net):
+            # data parallel: handing out the chunks blocks this thread until the worker has enqueued the backward's last stage
+            # (~0.4 ms) -- the look-ahead's first half (counts read, pairs + association launched) goes in front of that wait,
+            # not behind it, or the next batch's preparation and this step's optimizer both start late
+            ahead[0].advance()
+            advanced = True
         if fused_ran:
             _drive_exchanges()           # data parallel: the arena chunks go out behind the stages the worker is issuing
         if any(v.requires_grad for v in loss_dict.values()):
@@ -403,7 +547,7 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
                 optimizer.zero_grad(set_to_none=True)
             total = sum(loss for loss in loss_dict.values())
             total.backward()
-        if ahead[0] is not None:
+        if ahead[0] is not None and not advanced:
             ahead[0].advance()           # counts read (ready by now), pairs + association launched
         for ex in exchanges(net):        # data parallel: a rank whose batch bypassed the fused node joins its peers here
             ex.after_backward()

@@ -238,6 +238,44 @@ def test_two_ranks_through_the_hip_arena_equal_the_unsharded_step(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["train_tiny", "train_skips"])
+def test_normaliser_counts_of_the_prepared_batch_equal_the_loss_kernels(name):
+    """skg_count_positives_f32 (what a data-parallel rank all-reduces while the batch is still being prepared) against the
+    counts the loss kernels form from the logits' side (skg_loss_finish_f32 counts_out) and against the definition on the
+    step's own results: #non-zero labels among the scored cells, #pairs with any label (HEAD:167-172, 194-199, 223-228)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from collections import OrderedDict
+    import cases, gpu_run
+    from skghoi_amd import _capi, train_fused
+    case = cases.build_case(name)
+    head = gpu_run.build_head(case).train()
+    head.box_roi_pool = gpu_run.CachedPool(case)
+    eng = head.engine()
+    det, tg = gpu_run.to_cuda(case["detections"]), gpu_run.to_cuda(case["targets"])
+    torch.manual_seed(3)
+    prep = train_fused.prepare_train(head, eng, det, case["shapes"], tg)
+    assert not prep.empty and prep.norm is None                      # (single process: nothing to all-reduce)
+    lib = _capi.lib()
+    vt = eng.verbs(prep.pre.device)
+    K = head.num_classes
+    counts = torch.full((3,), -1.0, device="cuda")
+    _capi.check(lib.skg_count_positives_f32(
+        prep.labels.data_ptr(), K, prep.pre.scores.data_ptr(), prep.pre.labels.data_ptr(), prep.meta.data_ptr(),
+        prep.lay.n_active, prep.arrays["x_keep"].data_ptr(), prep.arrays["y_keep"].data_ptr(), vt.off.data_ptr(),
+        vt.flat.data_ptr(), vt.num_obj, 1.0, counts.data_ptr(), torch.cuda.current_stream().cuda_stream),
+        "skg_count_positives_f32")
+    # the step itself on the same batch: cell labels of the scored cells per image, label rows per pair
+    feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
+    torch.manual_seed(3)
+    out = head(feats, det, case["shapes"], tg)
+    n1 = sum(int((r["labels"] != 0).sum()) for r in out[:-1])
+    n2 = int((prep.labels[:prep.lay.sum_p].sum(dim=1) != 0).sum())
+    assert counts.tolist() == [float(n1), float(n2), float(n2)]
+    assert n1 > 0 and n2 > 0
+
+
+@pytest.mark.gpu
 def test_two_trainers_on_two_host_threads_do_not_share_a_job_slot():
     """no global state behind the C ABI.  Each head owns a skg_context (worker thread + job slot); two
     trainers stepping concurrently from two Python threads end with the weights of the same trainers run one after the
@@ -366,6 +404,88 @@ def test_trainer_epoch_with_validation_on_the_real_head(capsys):
             for r in head(*b):
                 m.append(r["scores"], r["prediction"], r["labels"])
     assert torch.allclose(ap, m.eval(), atol=1e-12) and float(ap.sum()) > 0
+
+
+def _native_comm_worker(port, ref_path, q):
+    """test_gradient_exchange_on_the_librarys_own_rccl_communicator: an RCCL process group of ONE rank, two training steps with
+    look-ahead through the data-parallel route."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from collections import OrderedDict
+    import cases, gpu_run
+    from skghoi_amd import _capi
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    ref = torch.load(ref_path)
+    case = cases.build_case("train_tiny")
+    head = gpu_run.build_head(case)
+    head.box_roi_pool = gpu_run.CachedPool(case)
+    head.distributed = True
+    net = trainer.wrap_ddp(head, torch.device("cuda", 0), force_exchange=True)
+    ex = head.grad_exchange
+    native = ex is not None and ex.native is not None
+    opt = trainer.build_optimizer(net, lr=1e-4)
+    feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
+    det, tg = gpu_run.to_cuda(case["detections"]), gpu_run.to_cuda(case["targets"])
+    batch = (feats, det, case["shapes"], tg)
+    torch.manual_seed(11)
+    lib = _capi.lib()
+    before = int(lib.skg_comm_collectives(ex.native.handle)) if native else -1
+    ex.timing = True
+    losses = []
+    for i in range(2):
+        l, _ = trainer.train_step(net, opt, *batch[:3], targets=tg, lazy=True, prefetch=batch if i == 0 else None)
+        losses.append(trainer.read_losses(l))
+    wait_ms = ex.read_timing()
+    torch.cuda.synchronize()
+    issued = int(lib.skg_comm_collectives(ex.native.handle)) - before if native else -1
+    worst = max(float((p.detach().cpu() - ref["weights"][n]).abs().max()) for n, p in head.named_parameters())
+    q.put(dict(native=native, losses=losses, worst=worst, issued=issued, chunks=ex.collectives, wait_ms=wait_ms,
+               same_losses=losses == ref["losses"]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_gradient_exchange_on_the_librarys_own_rccl_communicator(tmp_path):
+    """The data-parallel step with its collectives issued by the library itself (include/skghoi.h: skg_comm, RCCL bound at
+    run time; skg_ctx_train_backward_exchange_f32) in an RCCL world of ONE rank -- the only world a one-GPU box can hold --
+    against the same two steps without any exchange: the handshake gives every rank a communicator, the worker thread issues
+    one all-reduce per arena chunk (+ one for the prepared normalisers of each batch, on the same communicator), and with a
+    single rank sum = identity, so losses and weights must be the single-process ones bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.multiprocessing as mp
+    from collections import OrderedDict
+    import cases, gpu_run
+    case = cases.build_case("train_tiny")
+    head = gpu_run.build_head(case)
+    head.box_roi_pool = gpu_run.CachedPool(case)
+    net = trainer.wrap_ddp(head, torch.device("cuda", 0))
+    opt = trainer.build_optimizer(net, lr=1e-4)
+    feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
+    det, tg = gpu_run.to_cuda(case["detections"]), gpu_run.to_cuda(case["targets"])
+    batch = (feats, det, case["shapes"], tg)
+    torch.manual_seed(11)
+    losses = []
+    for i in range(2):
+        l, _ = trainer.train_step(net, opt, *batch[:3], targets=tg, lazy=True, prefetch=batch if i == 0 else None)
+        losses.append(trainer.read_losses(l))
+    torch.cuda.synchronize()
+    path = str(tmp_path / "single.pt")
+    torch.save(dict(losses=losses, weights={n: p.detach().cpu().clone() for n, p in head.named_parameters()}), path)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_native_comm_worker, args=(_free_port(), path, q))
+    p.start()
+    rec = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert rec["native"], rec
+    assert rec["same_losses"] and rec["worst"] == 0.0, rec
+    assert 2 <= rec["chunks"] <= 12 and rec["issued"] == 2 * rec["chunks"] + 2, rec     # chunks of two steps + two normaliser all-reduces
+    assert rec["wait_ms"] is not None and 0.0 <= rec["wait_ms"] < 5.0, rec
 
 
 def _remainder_worker(rank, world, port, q):

@@ -12,5 +12,6 @@ tot = 0
 for r in seg:
     d = int(r['End_Timestamp']) - int(r['Start_Timestamp']); tot += d
     n = r['Kernel_Name'].split('(')[0][-44:]
-    print("%8.1f %7.1f  grid %-8s %s" % ((int(r['Start_Timestamp']) - t0) / 1e3, d / 1e3, r.get('Grid_Size_X', r.get('Grid_Size', '')), n))
+    print("%8.1f %7.1f  q%-2s s%-2s grid %-8s %s" % ((int(r['Start_Timestamp']) - t0) / 1e3, d / 1e3, r.get('Queue_Id', '?'), r.get('Stream_Id', '?'),
+                                                 r.get('Grid_Size_X', r.get('Grid_Size', '')), n))
 print(len(seg), 'launches, busy %.1f us, span %.1f us' % (tot / 1e3, (int(seg[-1]['End_Timestamp']) - t0) / 1e3))
