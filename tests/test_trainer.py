@@ -488,6 +488,49 @@ def test_gradient_exchange_on_the_librarys_own_rccl_communicator(tmp_path):
     assert rec["wait_ms"] is not None and 0.0 <= rec["wait_ms"] < 5.0, rec
 
 
+def _declined_comm_worker(rank, world, port, q):
+    """test_two_ranks_on_one_device_agree_to_decline_the_librarys_communicator: the handshake of NativeComm.create with a
+    communicator RCCL must refuse (two ranks on one device)."""
+    import time
+    import warnings
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["SKG_NATIVE_RCCL_TIMEOUT"] = "60"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    real = dist.get_backend
+    dist.get_backend = lambda group=None: "nccl"            # (the group is gloo: only the handshake's own traffic runs over it)
+    t0 = time.time()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        comm = trainer.NativeComm.create(torch.device("cuda", 0), None)
+    dist.get_backend = real
+    q.put((rank, comm is None, time.time() - t0, [str(x.message) for x in w]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_device_agree_to_decline_the_librarys_communicator():
+    """NativeComm.create is collective and must end the same way on every rank.  Two ranks on ONE GPU: the unique id travels
+    from rank 0 over the process group, both ranks call ncclCommInitRank (on a helper thread, with a deadline), RCCL refuses
+    the duplicate device, the ranks agree on the failure and both keep the torch.distributed route -- nobody hangs, nobody
+    ends up alone with a communicator."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_declined_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=200) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(declined for _, declined, _, _ in res), res
+    assert any("torch.distributed" in m for m in res[0][3]), res       # rank 0 says why
+
+
 def _remainder_worker(rank, world, port, q):
     """One rank of test_ddp_remainder_beside_the_arena_exchange: the head inside a module with one more trainable parameter
     (DistributedDataParallel owns it); rank r trains on image r."""
