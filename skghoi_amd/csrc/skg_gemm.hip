@@ -65,20 +65,37 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // measured) is what the launch costs, not L2 reuse.
 #define SKG_DIRECT_MAP_TILES 1024
 // g = N-tiles per group (W slice <= 2 MiB), NG = number of groups rounded up to a power of two.
-__host__ __device__ __forceinline__ void skg_gemm_map(int nbn, int K, int T, int& g, int& NG) {
+#ifndef SKG_LOCKSTEP_MAP
+#define SKG_LOCKSTEP_MAP 1
+#endif
+// K so long that not even ONE tile's W slice fits (box_head layer 1: K = 12544, 6.4 MB per 128 columns): nothing stays
+// resident, but tiles that run SIDE BY SIDE on an XCD and walk K together share every k-slice they have in common.  The
+// direct map deals the N-tiles of one row panel to eight different XCDs -- each reads the whole A from HBM (7.5x the
+// algorithmic bytes, measured) --; the lockstep map gives an XCD whole row panels: its 32 CUs hold four panels x all
+// N-tiles (up to 8), each A k-slice is fetched once per XCD and reused by the panel's N-tiles, each W k-slice by the four
+// panels.  Returns false for the direct map.
+__host__ __device__ __forceinline__ bool skg_gemm_use_map(int64_t nbm, int nbn, int K, int T, int& g, int& NG) {
     g = (8192 / T) / (K > 0 ? K : 1);                    // tiles of 64*T columns whose W slice fits in ~2 MiB
+    const bool lockstep = SKG_LOCKSTEP_MAP && g < 1 && nbn <= 8;
+    if (lockstep) g = nbn;
     if (g < 1) g = 1;
     if (g > nbn) g = nbn;
     const int ng = (nbn + g - 1) / g;
     NG = 1;
     while (NG < ng) NG <<= 1;
+    if (NG >= 8) return false;
+    const int64_t tiles = nbm * nbn;
+    if (lockstep) {                                       // worth it at any grid size, unless the rounding to whole groups
+        const int64_t mapped = 8LL * g * ((nbm + 8 / NG - 1) / (8 / NG));       // adds more than 1/8 of idle workgroups
+        return mapped * 8 <= tiles * 9;
+    }
+    return tiles > SKG_DIRECT_MAP_TILES;
 }
 
 __host__ __device__ __forceinline__ int64_t skg_gemm_blocks(int M, int N, int K, int T) {
     const int64_t nbm = (M + 64 * T - 1) / (64 * T), nbn = (N + 64 * T - 1) / (64 * T);
     int g, NG;
-    skg_gemm_map((int)nbn, K, T, g, NG);
-    if (NG >= 8 || nbm * nbn <= SKG_DIRECT_MAP_TILES) return nbm * nbn;
+    if (!skg_gemm_use_map(nbm, (int)nbn, K, T, g, NG)) return nbm * nbn;
     const int XG = 8 / NG;
     return 8LL * g * ((nbm + XG - 1) / XG);
 }
@@ -97,8 +114,8 @@ __device__ __forceinline__ const char* skg_uniform_ptr(const char* p) {
 // MODE = main loop: 0 register-staged fp32 MFMA, 1 DMA-staged fp32 MFMA, 2 fp16x2-split operands on the fp16 MFMA.
 template <int EPI_T, int MODE, int T>
 __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_id, float* smem) {
-    static_assert(MODE == 1 || MODE == 3 || MODE == 4 || T == 2, "only the DMA-staged and the latency loops have a 64 x 64 variant");
-    static_assert((MODE != 3 && MODE != 4) || T == 1, "the latency loops are 64 x 64 tiles");
+    static_assert(MODE == 1 || MODE == 3 || MODE == 4 || MODE == 5 || T == 2, "only the DMA-staged and the latency loops have a 64 x 64 variant");
+    static_assert((MODE != 3 && MODE != 4 && MODE != 5) || T == 1, "the latency loops are 64 x 64 tiles");
     constexpr bool GLDS = MODE == 1;
     const int Kmap = d.K;
     constexpr int TBM = 64 * T, TBN = 64 * T;
@@ -117,7 +134,7 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
     }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid = tid >> 6;
+    const int wid = (tid >> 6) & 3;              // (MODE 5: eight waves, two per 32 x 32 sub-tile -- wave w and w + 4)
     const int wr = wid >> 1, wc = wid & 1;
     const int li = lane & 31, lh = lane >> 5;
 
@@ -131,8 +148,7 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
     int bm, bn;
     {
         int g, NG;
-        skg_gemm_map(nbn, Kmap, T, g, NG);
-        if (NG >= 8 || (int64_t)nbm * nbn <= SKG_DIRECT_MAP_TILES) {
+        if (!skg_gemm_use_map(nbm, nbn, Kmap, T, g, NG)) {
             bn = block_id % nbn;
             bm = block_id / nbn;
         } else {
@@ -244,7 +260,7 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
     };
     if constexpr (MODE == 0) {
         loop_exact();
-    } else if constexpr (MODE == 3) {
+    } else if constexpr (MODE == 3 || MODE == 5) {
         // ---- latency loop for a FEW images (64 x 64 tile, 64 k per step, exact fp32 MFMA).  At one to a handful of
         // graphs a launch has a few hundred workgroups at most: every workgroup walks its K range alone, and what a
         // step costs is one memory round trip (~1 us) whatever it computes.  The 16-k steps of the throughput loops make
@@ -252,22 +268,32 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
         // sixteen round trips, each hidden behind 32 MFMAs per wave (0.85 us) -- the loads of step t+1 are in flight in
         // registers while step t computes.  One LDS buffer, rows padded to 68 dwords (conflict-free ds_read_b128),
         // two barriers per step; gathers, K % 4 and split-K as in the register-staged loop.
+        // MODE 5 (round 4): the same loop on EIGHT waves.  A single image leaves each CU ONE workgroup -- one wave per SIMD,
+        // whose 32 dependent MFMAs of a step wait for its own fragment reads, LDS stores and barriers: 55-60 % MFMA duty
+        // measured, 25-32 us for K = 1024 where the MFMA chain alone is 13.6 us.  Here waves w and w + 4 share a 32 x 32
+        // sub-tile and split every 64-k step between them (k-quads 0-3 | 4-7 of each row): two independent accumulation
+        // chains per SIMD, half the staging work per thread; the upper waves hand their accumulators over through LDS
+        // after the last step (sum = lower + upper, a fixed order) and retire before the epilogue.
         constexpr int BK3 = 64, LD3 = BK3 + 4;
+        constexpr int NW3 = MODE == 5 ? 8 : 4;       // waves of the workgroup
+        constexpr int RP3 = NW3 * 4;                 // rows per staging pass
+        constexpr int NP3 = 64 / RP3;                // passes
+        const int kh = MODE == 5 ? (tid >> 8) : 0;   // k half this wave multiplies
         float* a_s3 = smem;
         float* b_s3 = smem + 64 * LD3;
-        const int lr = tid >> 4;                     // 16 rows per pass, 4 passes
+        const int lr = tid >> 4;                     // RP3 rows per pass
         const int lc = (tid & 15) * 4;               // k quad inside the 64-k step
-        const float* pa[4];
-        const float* pw[4];
-        bool va[4], vw[4];
+        const float* pa[NP3];
+        const float* pw[NP3];
+        bool va[NP3], vw[NP3];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = m0 + lr + 16 * i;
+        for (int i = 0; i < NP3; ++i) {
+            const int r = m0 + lr + RP3 * i;
             int src = -1;
             if (r < d.M) src = d.a_rows ? d.a_rows[r] : r;
             va[i] = src >= 0;
             pa[i] = d.A + (int64_t)(va[i] ? src : 0) * d.lda;
-            const int c = n0 + lr + 16 * i;
+            const int c = n0 + lr + RP3 * i;
             vw[i] = c < d.N;
             pw[i] = d.W + (int64_t)(vw[i] ? c : 0) * d.ldw;
         }
@@ -280,27 +306,33 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
         // Two register stages: the loads of step st + 2 are issued while step st is multiplied, so a tile has two steps
         // (~1 us each: 32 MFMAs of 64 cycles per wave) to arrive.  With one stage the round trip to L2 / HBM stuck out of
         // every step by ~0.7 us (2 us per step measured at one image).
-        float4 ra[2][4], rw[2][4];
+        float4 ra[2][NP3], rw[2][NP3];
         auto gload3 = [&](auto S, int st) {
             constexpr int sg = decltype(S)::value;
+#ifdef SKG_K3_NOLOAD                                  // (timing builds, tools/gemm_k3_knockout.sh: results are wrong)
+            if (st > s_begin + 2) return;
+#endif
             const int k = st * BK3 + lc;
             const int kk = (k < d.K) ? k : 0;        // clamped, masked when written to LDS (K % 4 == 0: whole quads)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NP3; ++i) {
                 ra[sg][i] = *reinterpret_cast<const float4*>(pa[i] + kk);
                 rw[sg][i] = *reinterpret_cast<const float4*>(pw[i] + kk);
             }
         };
         auto lstore3 = [&](auto S, int st) {
             constexpr int sg = decltype(S)::value;
+#ifdef SKG_K3_NOSTORE
+            if (st > s_begin) return;
+#endif
             const bool kin = st * BK3 + lc < d.K;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NP3; ++i) {
                 const bool ma = kin && va[i], mw = kin && vw[i];
                 const float4 x = ra[sg][i], w = rw[sg][i];
-                *reinterpret_cast<float4*>(a_s3 + (lr + 16 * i) * LD3 + lc) =
+                *reinterpret_cast<float4*>(a_s3 + (lr + RP3 * i) * LD3 + lc) =
                     make_float4(ma ? x.x : 0.f, ma ? x.y : 0.f, ma ? x.z : 0.f, ma ? x.w : 0.f);
-                *reinterpret_cast<float4*>(b_s3 + (lr + 16 * i) * LD3 + lc) =
+                *reinterpret_cast<float4*>(b_s3 + (lr + RP3 * i) * LD3 + lc) =
                     make_float4(mw ? w.x : 0.f, mw ? w.y : 0.f, mw ? w.z : 0.f, mw ? w.w : 0.f);
             }
         };
@@ -315,22 +347,30 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
         __syncthreads();
         // one step: tile st is in LDS, tile st + 1 in stage NX, tile st + 2 in flight into the other stage
         auto step3 = [&](auto NX, int st) {
-            const float* ap = a_s3 + (wr * 32 + li) * LD3 + 4 * lh;
-            const float* bp = b_s3 + (wc * 32 + li) * LD3 + 4 * lh;
+            const float* ap = a_s3 + (wr * 32 + li) * LD3 + 4 * lh + (MODE == 5 ? kh * (BK3 / 2) : 0);
+            const float* bp = b_s3 + (wc * 32 + li) * LD3 + 4 * lh + (MODE == 5 ? kh * (BK3 / 2) : 0);
 #pragma unroll
-            for (int ks = 0; ks < BK3 / 8; ++ks) {
+            for (int ks = 0; ks < BK3 / 8 / (MODE == 5 ? 2 : 1); ++ks) {
                 const float4 a4 = *reinterpret_cast<const float4*>(ap + ks * 8);
                 const float4 b4 = *reinterpret_cast<const float4*>(bp + ks * 8);
+#ifdef SKG_K3_NOMFMA
+                acc[0][0][ks] += a4.x * b4.x + a4.y * b4.y + a4.z * b4.z + a4.w * b4.w;
+#else
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[0][0], 0, 0, 0);
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[0][0], 0, 0, 0);
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[0][0], 0, 0, 0);
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[0][0], 0, 0, 0);
+#endif
             }
+#ifndef SKG_K3_NOBAR
             __syncthreads();                          // every wave is done reading this step's tile
+#endif
             if (st + 1 < s_end) {
                 lstore3(NX, st + 1);
                 gload3(NX, st + 3);
+#ifndef SKG_K3_NOBAR
                 __syncthreads();
+#endif
             }
         };
         int st = s_begin;
@@ -339,6 +379,21 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
             step3(S0{}, st + 1);
         }
         if (st < s_end) step3(S1{}, st);
+        if constexpr (MODE == 5) {
+            // upper k-halves -> LDS -> added to the lower ones; the upper waves retire (a finished wave leaves the workgroup's
+            // barrier count: the epilogue's barriers are among waves 0-3)
+            float* red = smem + ((tid >> 6) & 3) * (16 * 64) + lane;
+            __syncthreads();
+            if (kh) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[r * 64] = acc[0][0][r];
+            }
+            __syncthreads();
+            if (kh) return;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] += red[r * 64];
+            __syncthreads();                          // (the epilogue's transposition reuses this memory)
+        }
     } else if constexpr (MODE == 4) {
         // ---- latency loop, staged straight into LDS (round 4): the 64 x 64 x 64 steps of MODE 3 without its VGPR stage.  MODE 3
         // loads a step's 32 KiB into registers, writes them to ONE LDS buffer between two barriers and only then multiplies:
@@ -942,8 +997,8 @@ __device__ __forceinline__ void skg_gemm_tile(const skg_gemm_desc& d, int block_
 #define SKG_SMEM3 (2 * 64 * 68)              // latency loop: one 64 x 64(+4) tile per operand (34 KB)
 #define SKG_SMEM4 (SKG_NB4 * 2 * 64 * 64)
 template <int EPI, int MODE, int T>
-__global__ __launch_bounds__(256, (MODE == 4 && SKG_NB4 > 2) ? 1 : SKG_MINW) void skg_gemm_kernel(const skg_gemm_desc d) {
-    __shared__ __attribute__((aligned(1024))) float smem[MODE == 4 ? SKG_SMEM4 : MODE == 3 ? SKG_SMEM3 : (T == 2 ? 2 * (A_TILE + B_TILE) : 4 * 32 * 36)];
+__global__ __launch_bounds__(MODE == 5 ? 512 : 256, (MODE == 5 || (MODE == 4 && SKG_NB4 > 2)) ? 1 : SKG_MINW) void skg_gemm_kernel(const skg_gemm_desc d) {
+    __shared__ __attribute__((aligned(1024))) float smem[MODE == 4 ? SKG_SMEM4 : (MODE == 3 || MODE == 5) ? SKG_SMEM3 : (T == 2 ? 2 * (A_TILE + B_TILE) : 4 * 32 * 36)];
     skg_gemm_tile<EPI, MODE, T>(d, blockIdx.x, smem);
 }
 
@@ -1003,6 +1058,15 @@ __global__ __launch_bounds__(256, SKG_MINW) void skg_gemm_group_latency_kernel(c
     for (int t = 1; t < SKG_GEMM_GROUP_MAX; ++t)
         if (t < g.n && (int)blockIdx.x >= g.start[t]) k = t;
     skg_gemm_tile<-1, 3, 1>(g.d[k], blockIdx.x - g.start[k], smem);
+}
+
+__global__ __launch_bounds__(512, 1) void skg_gemm_group_khalves_kernel(const skg_gemm_group_args g) {
+    __shared__ __attribute__((aligned(16))) float smem[SKG_SMEM3];
+    int k = 0;
+#pragma unroll
+    for (int t = 1; t < SKG_GEMM_GROUP_MAX; ++t)
+        if (t < g.n && (int)blockIdx.x >= g.start[t]) k = t;
+    skg_gemm_tile<-1, 5, 1>(g.d[k], blockIdx.x - g.start[k], smem);
 }
 
 // Split-K reduction: adds the slices in slice order (deterministic) and applies the plain epilogues.
@@ -1131,9 +1195,10 @@ extern "C" int skg_row_exponents_f32(const float* A, int64_t lda, const int32_t*
 // a chain of 32 dependent fp32 MFMAs (0.93 us) plus a ~0.4 us bubble at the barrier whatever stages the tile: the launch is
 // bound by that chain at one wave per SIMD, not by the staging.  Mode 3 stays the default; 4 is selectable.
 static int g_small_mode = 3;
+static int64_t g_khalves_blocks = getenv("SKG_KHALVES_BLOCKS") ? atoll(getenv("SKG_KHALVES_BLOCKS")) : 320;   // mode 6: launches up to this many workgroups take the eight-wave loop
 extern "C" int skg_gemm_small_mode(int mode) {
     const int old = g_small_mode;
-    if (mode == 1 || mode == 3 || mode == 4) g_small_mode = mode;
+    if (mode == 1 || mode == 3 || mode == 4 || mode == 5 || mode == 6) g_small_mode = mode;
     return old;
 }
 
@@ -1282,7 +1347,9 @@ extern "C" int skg_gemm_group_f32(const skg_gemm_desc* descs_host, int n, void* 
     for (int i = g.n; i <= SKG_GEMM_GROUP_MAX; ++i) g.start[i] = (int)blocks;
     bool direct = small && g_small_mode == 4;               // every member with whole 64-k steps: the direct-to-LDS loop
     for (int i = 0; i < g.n && direct; ++i) direct = (g.d[i].K % 64) == 0;
+    const bool halves = small && (g_small_mode == 5 || (g_small_mode == 6 && blocks <= g_khalves_blocks));
     if (direct) hipLaunchKernelGGL(skg_gemm_group_direct_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    else if (halves) hipLaunchKernelGGL(skg_gemm_group_khalves_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, g);
     else if (small && g_small_mode >= 3) hipLaunchKernelGGL(skg_gemm_group_latency_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     else if (small) hipLaunchKernelGGL(skg_gemm_group_small_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     else if (split) hipLaunchKernelGGL(skg_gemm_group_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
@@ -1316,6 +1383,7 @@ extern "C" int skg_gemm_f32(const skg_gemm_desc* dh, void* stream) {
 #define SKG_LAUNCH(E)                                                                              \
     if (split) hipLaunchKernelGGL((skg_gemm_kernel<E, 2, 2>), grid, block, 0, s, d);               \
     else if (glds && T == 1 && g_small_mode == 4 && (d.K % 64) == 0) hipLaunchKernelGGL((skg_gemm_kernel<E, 4, 1>), grid, block, 0, s, d); \
+    else if (glds && T == 1 && (g_small_mode == 5 || (g_small_mode == 6 && nblk <= g_khalves_blocks))) hipLaunchKernelGGL((skg_gemm_kernel<E, 5, 1>), grid, dim3(512), 0, s, d); \
     else if (glds && T == 1 && g_small_mode >= 3) hipLaunchKernelGGL((skg_gemm_kernel<E, 3, 1>), grid, block, 0, s, d); \
     else if (glds && T == 1) hipLaunchKernelGGL((skg_gemm_kernel<E, 1, 1>), grid, block, 0, s, d); \
     else if (glds) hipLaunchKernelGGL((skg_gemm_kernel<E, 1, 2>), grid, block, 0, s, d);           \

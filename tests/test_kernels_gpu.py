@@ -660,6 +660,55 @@ def test_direct_lds_latency_loop_matches_the_register_staged_one(M, N, K, S, dir
     assert torch.equal(got, want)
 
 
+@pytest.fixture
+def eight_wave_small_loop():
+    """skg_gemm_small_mode(5): every 64 x 64 launch takes the eight-wave latency loop (two k-halves per 32 x 32 sub-tile)."""
+    lib = _capi.lib()
+    old = lib.skg_gemm_small_mode(5)
+    yield
+    lib.skg_gemm_small_mode(old)
+
+
+@pytest.mark.parametrize("M,N,K,S", [(400, 1024, 1024, 0), (40, 1024, 12544, 16), (1, 1024, 256, 0), (513, 256, 128, 0),
+                                     (257, 1024, 1088, 0), (64, 64, 64, 2), (130, 118, 2048, 3), (300, 72, 192, 0),
+                                     (77, 1024, 36, 0)])
+def test_eight_wave_latency_loop(M, N, K, S, eight_wave_small_loop):
+    """MODE 5 (waves w and w + 4 multiply the two halves of every 64-k step, partial accumulators meet in LDS, the upper
+    waves retire before the epilogue) against fp64; untouched columns stay untouched; repeated runs are bit-identical."""
+    A = _rand(M, K, seed=1); W = _rand(N, K, seed=2) / np.sqrt(K); b = _rand(N, seed=3)
+    ref = torch.relu(A.double() @ W.double().t() + b.double()).float()
+
+    def run():
+        C = torch.full((M, N + 4), 7.0, device="cuda")
+        kw = dict(split_k=S, split_ws=torch.empty(S, M, N, device="cuda")) if S else {}
+        gemm(A, W, b, C, M, N, K, _capi.EPI_BIAS_RELU, ldc=N + 4, **kw)
+        torch.cuda.synchronize()
+        return C
+    got = run()
+    _close(got[:, :N], ref, 2e-5)
+    assert torch.all(got[:, N:] == 7.0)
+    assert torch.equal(got, run())
+
+
+def test_eight_wave_latency_loop_in_a_grouped_launch_with_fused_epilogues(eight_wave_small_loop):
+    K = 256
+    specs, refs, outs = [], [], []
+    for i, (M, N, epi) in enumerate([(70, 1024, _capi.EPI_BIAS), (300, 256, _capi.EPI_BIAS_RELU),
+                                     (129, 1024, _capi.EPI_BIAS_RES_RELU), (5, 118, _capi.EPI_BIAS)]):
+        A = _rand(M, K, seed=10 + i); W = _rand(N, K, seed=20 + i) / 16; b = _rand(N, seed=30 + i)
+        res = _rand(M, N, seed=40 + i)
+        C = torch.empty(M, N, device="cuda")
+        kw = dict(res=res, ldres=N) if epi == _capi.EPI_BIAS_RES_RELU else {}
+        specs.append(((A, W, b, C, M, N, K, epi), kw)); outs.append(C)
+        v = A.double() @ W.double().t() + b.double()
+        refs.append({_capi.EPI_BIAS: v, _capi.EPI_BIAS_RELU: torch.relu(v),
+                     _capi.EPI_BIAS_RES_RELU: res.double() + torch.relu(v)}[epi].float())
+    gemm_group(specs)
+    torch.cuda.synchronize()
+    for C, r in zip(outs, refs):
+        _close(C, r, 2e-5)
+
+
 def test_direct_lds_latency_loop_in_a_grouped_launch_with_fused_epilogues(direct_lds_small_loop):
     K = 256
     specs, refs, outs = [], [], []

@@ -7,5 +7,5 @@ mkdir -p ../../build/variants
 for spec in "$@"; do
   name=${spec%%=*}; flags=${spec#*=}
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include $flags -c skg_gemm.hip -o /tmp/skg_gemm_$name.o
-  hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/variants/lib_$name.so /tmp/skg_gemm_$name.o skg_preprocess.o skg_pairs.o skg_graph.o skg_post.o skg_roialign.o skg_gemm_bf16.o skg_transh_rng.o
+  hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o ../../build/variants/lib_$name.so /tmp/skg_gemm_$name.o $(ls *.o | grep -v '^skg_gemm\.o$')
 done
