@@ -21,7 +21,7 @@ from torch import nn, Tensor
 from torch.nn import Module
 
 from skghoi_amd import _capi
-from skghoi_amd.engine import HeadEngine
+from skghoi_amd.engine import HeadEngine, current_stream_of, on_device, on_stream
 
 __all__ = ["InteractionHead", "GraphHead", "MultiBranchFusion", "MessageMBF", "transH_head"]
 
@@ -274,7 +274,7 @@ class _Prefetch:
     def advance(self):
         if self.done:
             return False
-        with torch.cuda.device(self.dev), torch.cuda.stream(self.stream):
+        with on_device(self.dev), on_stream(self.stream):
             try:
                 next(self.gen)
                 return True
@@ -428,7 +428,7 @@ class InteractionHead(Module):
         for det in detections:
             if det["boxes"].device != dev:
                 raise _capi.SkgError("detections on %s but features on %s" % (det["boxes"].device, dev))
-        with torch.cuda.device(dev):           # kernels are enqueued on the current stream OF THE INPUTS' device
+        with on_device(dev):                   # kernels are enqueued on the current stream OF THE INPUTS' device
             return self._forward(features, detections, image_shapes, targets)
 
     def _forward(self, features, detections, image_shapes, targets):
@@ -474,7 +474,7 @@ class InteractionHead(Module):
 
     # ------------------------------------------------------------------------------------------ prefetch
     def prefetch_train(self, detections: List[dict], image_shapes: List[Tuple[int, int]], targets: List[dict],
-                       after=None) -> bool:
+                       after=None, arena=False) -> bool:
         """Prepares the NEXT training batch while the GPU is busy with the current step: detection selection (HEAD:92-151),
         pairs + spatial encoding, label association and the host RNG draws of the forward (TransH tables, negative
         permutations) run now, on a high-priority side stream; the next `forward(features, detections, image_shapes,
@@ -488,7 +488,11 @@ class InteractionHead(Module):
         in flight).  The inputs are marked as in use by the side stream (record_stream), so their memory is not recycled
         under the preparation.  The host RNG is consumed here, in the order the forward would: call it once per batch, in
         batch order, with no other consumer of the global generator in between.  Returns False (nothing done) when the head
-        is not in the fused training configuration."""
+        is not in the fused training configuration.
+        arena=True (trainer.train_step only): the batch's device tensors are carved out of a reusable block
+        (train_fused.PrepArena, three slots in rotation) instead of one allocation each; the caller MUST call
+        train_fused.release_prepared(head) on the step's stream once the step that consumed the batch has enqueued its last
+        kernel -- the slot is reused behind that point."""
         from skghoi_amd import train_fused
         if not (self.training and self.fused_training and train_fused.supported(self)) or not detections:
             return False
@@ -499,14 +503,25 @@ class InteractionHead(Module):
         side = self._prefetch_stream(dev)
         if after is None:
             after = torch.cuda.Event()
-            after.record(torch.cuda.current_stream(dev))
+            after.record(current_stream_of(dev))
         side.wait_event(after)
         for group in (detections, targets):
             for d in group:
                 for t in d.values():
                     if torch.is_tensor(t) and t.is_cuda:
                         t.record_stream(side)
-        h = _Prefetch(self, train_fused.prepare_steps(self, eng, detections, image_shapes, targets), dev,
+        slot = None
+        if arena:
+            ring = self.__dict__.get("_prep_slots")
+            if ring is None or ring[0].dev != dev:
+                ring = self.__dict__["_prep_slots"] = [train_fused.PrepArena(dev) for _ in range(3)]
+                self.__dict__["_prep_slot_next"] = 0
+            k = self.__dict__["_prep_slot_next"]
+            self.__dict__["_prep_slot_next"] = (k + 1) % len(ring)
+            slot = ring[k]
+            with on_device(dev), on_stream(side):
+                slot.begin(side, current_stream_of(dev))
+        h = _Prefetch(self, train_fused.prepare_steps(self, eng, detections, image_shapes, targets, arena=slot), dev,
                       side, (detections, image_shapes, targets))
         h.advance()                            # launches the detection-selection kernel; its counts are read later
         self._prefetched = h
@@ -526,7 +541,7 @@ class InteractionHead(Module):
         dev = features["3"].device
         if dev.type != "cuda":
             return None
-        with torch.cuda.device(dev):
+        with on_device(dev):
             out, prep = train_fused.fused_step(self, self.engine(), features, detections, image_shapes, targets,
                                                prep=self._take_prefetched(detections, image_shapes, targets),
                                                after_forward=after_forward, defer_backward=defer_backward)
@@ -554,6 +569,8 @@ class InteractionHead(Module):
         prep = prep.finish()
         d, s, t = prep.inputs
         if d is detections and t is targets and (s is image_shapes or list(s) == list(image_shapes)):
+            if prep.slot is not None:
+                self.__dict__["_prep_slot_in_use"] = prep.slot      # (released by the trainer: train_fused.release_prepared)
             return prep
         return None
 

@@ -42,7 +42,7 @@ import numpy as np
 import torch
 
 from . import _capi, layout, transh
-from .engine import Preprocessed, enqueue_row_exponents, gemm_desc, gemm_group, pick_split_k, _stream
+from .engine import Preprocessed, current_stream_of, enqueue_row_exponents, gemm_desc, gemm_group, pick_split_k, _stream
 
 META_WORDS = layout.META_DTYPE.itemsize // 4
 
@@ -379,7 +379,7 @@ class SmallBatchRunner:
         p.dyn_dev.copy_(p.dyn_host, non_blocking=True)
         if p.h2d_done is None:
             p.h2d_done = torch.cuda.Event()
-        p.h2d_done.record()
+        p.h2d_done.record(current_stream_of(dev))
         if p.graph is None:
             self._capture(p)
         p.graph.replay()

@@ -30,7 +30,7 @@ import numpy as np
 import torch
 
 from . import _capi, gemmx, layout
-from .engine import _ptr, _stream, gemm, gemm_desc
+from .engine import _ptr, _stream, current_stream_of, gemm, gemm_desc
 
 _grad_of = attrgetter("grad")
 MBF_NAMES = ("attention_head", "obj_to_sub", "sub_to_obj", "attention_head_g")      # order of the stacked fc_2 block
@@ -943,6 +943,73 @@ def supported(head):
             and head.box_pair_predictor.bias is not None and head.box_pair_suppressor.bias is not None)
 
 
+_ESIZE = {torch.float32: 4, torch.int32: 4, torch.int64: 8, torch.uint8: 1, torch.int16: 2, torch.float64: 8, torch.bool: 1}
+
+
+class PrepArena:
+    """One reusable block of device memory for everything a PREPARED batch owns (index tables, labels, TransH tables and
+    scores ...: ~17 tensors per step).  Allocated one by one they cost the step's host thread ~0.1 ms -- torch.empty, a
+    record_stream per tensor for the stream that consumes them, and at release one event per tensor from the allocator --
+    on a step whose host thread IS the bound (1.38 ms of host work per 1.40 ms batch-4 bf16 step, measured).  A slot is
+    bump-allocated by one preparation on the side stream, read by one training step on the step's stream, and reused two
+    batches later: the side stream first waits for `done`, the event trainer.train_step records on the step's stream once
+    the step that consumed the slot has enqueued its last kernel.  Only the trainer's look-ahead uses slots
+    (prefetch_train(..., arena=True)): it alone knows when a prepared batch is dead.  A request that does not fit falls
+    back to torch.empty (returned through `spill`, handled like any cross-stream tensor) and enlarges the next block."""
+    ALIGN = 256
+
+    def __init__(self, dev):
+        self.dev, self.buf, self.off, self.need, self.done, self.spill = dev, None, 0, 1 << 20, None, []
+        self.typed = {}                           # dtype -> the block viewed as that type
+
+    def begin(self, stream, consumer):
+        """Start of a preparation on `stream` (current); `consumer`: the stream the training step runs on."""
+        if self.done is not None:
+            stream.wait_event(self.done)
+        if self.buf is None or self.buf.numel() < self.need:
+            self.buf = torch.empty(int(self.need * 1.25) // self.ALIGN * self.ALIGN + self.ALIGN, dtype=torch.uint8,
+                                   device=self.dev)
+            self.buf.record_stream(consumer)          # once per block: whenever it is dropped, both streams are honoured
+            self.typed = {}
+        self.off, self.spill = 0, []
+
+    def take(self, shape, dtype):
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        n = 1
+        for v in shape:
+            n *= int(v)
+        nbytes = n * (_ESIZE.get(dtype) or torch.empty(0, dtype=dtype).element_size())
+        end = self.off + (nbytes + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        if end > self.buf.numel():
+            self.need = max(self.need, end * 2)
+            t = torch.empty(shape, dtype=dtype, device=self.dev)
+            self.spill.append(t)
+            self.off = end
+            return t
+        base = self.typed.get(dtype)
+        if base is None:
+            base = self.typed[dtype] = self.buf.view(dtype)
+        es = nbytes // n if n else 1
+        strides, acc = [], 1
+        for v in reversed(shape):
+            strides.append(acc)
+            acc *= int(v)
+        t = base.as_strided(shape, strides[::-1], self.off // es)
+        self.off = end
+        self.need = max(self.need, end)
+        return t
+
+
+def release_prepared(head):
+    """trainer.train_step, once the step's last kernel is enqueued: the arena slot of the batch this step consumed may be
+    reused behind everything the current stream holds now."""
+    slot = head.__dict__.pop("_prep_slot_in_use", None)
+    if slot is not None:
+        if slot.done is None:
+            slot.done = torch.cuda.Event()
+        slot.done.record(current_stream_of(slot.dev))
+
+
 class Prepared:
     """Everything of a training forward that depends on the BATCH but not on the weights: selected detections (NMS,
     top-k, GT boxes prepended), layout, pair / spatial arrays, label matrix, positive counts, the TransH tables and
@@ -950,6 +1017,7 @@ class Prepared:
     NEXT batch, on a side stream while the GPU is busy with the current step (InteractionHead.prefetch_train)."""
     empty = False
     norm = None           # data parallel: dist.PreparedNormalisers, the n_p all-reduce started by the preparation
+    slot = None           # PrepArena the batch's device tensors live in (the trainer's look-ahead), else None
     ready = None          # event behind the preparation's device work when it ran on a side stream
     cross = ()            # tensors allocated on the side stream and consumed on the step's stream
 
@@ -975,7 +1043,7 @@ def prepare_train(head, eng, detections, image_shapes, targets, before_sync=None
         return done.value
 
 
-def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None):
+def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None, arena=None):
     """The weight-independent part of InteractionHead.forward in training mode (HEAD:92-151 preprocess with GT boxes
     appended, HEAD:847-868 pairs + spatial encoding, HEAD:703-719 label association, the host RNG of HEAD:574-580 / 939,
     and the whole TransH term HEAD:207-235 / 936-963: its scores depend only on the step's throw-away embeddings).
@@ -983,7 +1051,9 @@ def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None
     association kernel.  A GENERATOR that yields right before each of them, so that a prefetching caller can do other host
     work (enqueue the current step's backward, then its optimizer) while the kernels run, and returns the Prepared batch.
     before_sync(prep): called right before the second one (the inline forward enqueues the table-independent part of the
-    dense forward there, so that the GPU works while the host waits and draws)."""
+    dense forward there, so that the GPU works while the host waits and draws).
+    arena: a PrepArena slot (already begun on the current stream) that holds the batch's device tensors instead of one
+    torch allocation each."""
     from . import transh
     from . import dist as skd
     lib = _capi.lib()
@@ -1009,30 +1079,50 @@ def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None
     i32 = dict(device=dev, dtype=torch.int32)
     act_imgs = [int(b) for b in lay.active]
     gt_off_h = hbuf.numpy()[offs["gt_off"][0]:offs["gt_off"][0] + offs["gt_off"][1]]
-    ibuf = hbuf.to(dev, non_blocking=True)
+    # device tensors of the batch: views of the arena slot when the trainer's look-ahead supplied one, else one allocation each
+    if arena is not None:
+        E = arena.take
+    else:
+        def E(shape, dtype):
+            return torch.empty(shape, dtype=dtype, device=dev)
+
+    def upload(h):                                                   # pinned host tensor -> device, asynchronously
+        d = E(tuple(h.shape), h.dtype)
+        d.copy_(h, non_blocking=True)
+        return d
+    ibuf = upload(hbuf)
     isl = lambda name: ibuf[offs[name][0]:offs[name][0] + offs[name][1]]
     meta = isl("meta")
     # ---- pairs + spatial encoding, GT association (HEAD:847-868, 703-719): ahead of the dense part because the
     # number of positives per image sizes the host RNG draws below
-    grid = torch.empty(4 * Mg + 3 * max(Mp, 1), **i32)
+    grid = E(4 * Mg + 3 * max(Mp, 1), torch.int32)
     grid_h, grid_o, grid_pair, grid_img = grid[:Mg], grid[Mg:2 * Mg], grid[2 * Mg:3 * Mg], grid[3 * Mg:4 * Mg]
     pair_grid, pair_h, pair_o = grid[4 * Mg:].view(3, max(Mp, 1)).unbind(0)
-    keep = torch.empty(2, max(Mp, 1), device=dev, dtype=torch.int64)
+    keep = E((2, max(Mp, 1)), torch.int64)
     x_keep, y_keep = keep[0], keep[1]
-    sp48 = torch.empty(Mg, _capi.SPATIAL_LD, **f32)
+    sp48 = E((Mg, _capi.SPATIAL_LD), torch.float32)
     _check(lib.skg_pairs_spatial_f32(pre.boxes.data_ptr(), meta.data_ptr(), A, grid_h.data_ptr(), grid_o.data_ptr(),
                                      grid_pair.data_ptr(), grid_img.data_ptr(), pair_grid.data_ptr(), x_keep.data_ptr(),
                                      y_keep.data_ptr(), pair_h.data_ptr(), pair_o.data_ptr(), sp48.data_ptr(), 1, stream),
            "skg_pairs_spatial_f32")
-    if gt_off_h[-1]:
+    n_gt = int(gt_off_h[-1])
+    own_gt = ()
+    if n_gt and arena is not None and all(targets[b]["boxes_h"].dtype == torch.float32 and
+                                          targets[b]["boxes_o"].dtype == torch.float32 and
+                                          targets[b]["labels"].dtype == torch.int64 for b in act_imgs):
+        gt_h = torch.cat([targets[b]["boxes_h"].reshape(-1, 4) for b in act_imgs], out=E((n_gt, 4), torch.float32))
+        gt_o = torch.cat([targets[b]["boxes_o"].reshape(-1, 4) for b in act_imgs], out=E((n_gt, 4), torch.float32))
+        gt_l = torch.cat([targets[b]["labels"].reshape(-1) for b in act_imgs], out=E(n_gt, torch.int64))
+    elif n_gt:
         gt_h = torch.cat([targets[b]["boxes_h"].reshape(-1, 4) for b in act_imgs]).float().contiguous()
         gt_o = torch.cat([targets[b]["boxes_o"].reshape(-1, 4) for b in act_imgs]).float().contiguous()
         gt_l = torch.cat([targets[b]["labels"].reshape(-1) for b in act_imgs]).long().contiguous()
+        own_gt = (gt_h, gt_o, gt_l)                                  # (allocations of their own even beside an arena slot)
     else:
-        gt_h = torch.zeros(1, 4, device=dev); gt_o = torch.zeros(1, 4, device=dev)
-        gt_l = torch.zeros(1, dtype=torch.int64, device=dev)
-    labels_all = torch.zeros(max(Mp, 1), K, **f32)
-    npos_d = torch.empty(A, **i32)
+        gt_h = E((1, 4), torch.float32).zero_(); gt_o = E((1, 4), torch.float32).zero_()
+        gt_l = E(1, torch.int64).zero_()
+    labels_all = E((max(Mp, 1), K), torch.float32).zero_()
+    npos_d = E(A, torch.int32)
     _check(lib.skg_associate_f32(pre.boxes.data_ptr(), meta.data_ptr(), A, x_keep.data_ptr(), y_keep.data_ptr(),
                                  gt_h.data_ptr(), gt_o.data_ptr(), gt_l.data_ptr(), isl("gt_off").data_ptr(), K,
                                  float(gh.fg_iou_thresh), labels_all.data_ptr(), npos_d.data_ptr(), stream),
@@ -1051,7 +1141,7 @@ def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None
     if head.distributed and skd.dist.is_available() and skd.dist.is_initialized() and \
             (skd.dist.get_world_size() > 1 or force):
         vt = eng.verbs(dev)
-        counts = torch.empty(3, **f32)
+        counts = E(3, torch.float32)
         _check(lib.skg_count_positives_f32(labels_all.data_ptr(), K, pre.scores.data_ptr(), pre.labels.data_ptr(),
                                            meta.data_ptr(), A, x_keep.data_ptr(), y_keep.data_ptr(), vt.off.data_ptr(),
                                            vt.flat.data_ptr(), vt.num_obj, 1.0, counts.data_ptr(), stream),
@@ -1059,7 +1149,7 @@ def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None
     # the positive counts travel to the host behind the association kernel
     npos_h = torch.empty(A, dtype=torch.int32, pin_memory=True)
     npos_h.copy_(npos_d, non_blocking=True)
-    npos_ev = torch.cuda.Event(); npos_ev.record()
+    npos_ev = torch.cuda.Event(); npos_ev.record(current_stream_of(dev))
     if before_sync is not None:
         before_sync(prep)
     yield 2
@@ -1076,12 +1166,12 @@ def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None
     ppi = [int(v) for v in lay.pairs_per_image]
     neg_cnt = [ppi[a] * K - n_pos[a] for a in range(A)]
     ent_h, rel_h, nrm_h, perm_h = transh.draw_train(K, neg_cnt, n_pos, pin=True)      # tables + randperm heads, natively
-    prep.ent = ent_h.to(dev, non_blocking=True); prep.rel = rel_h.to(dev, non_blocking=True)
-    prep.nrm = nrm_h.to(dev, non_blocking=True)
+    prep.ent = upload(ent_h); prep.rel = upload(rel_h)
+    prep.nrm = upload(nrm_h)
     pos_off_h = np.zeros(A + 1, np.int32); pos_off_h[1:] = np.cumsum(n_pos)
     M_pos = int(pos_off_h[-1])
     o_perm = (A + 1 + 1) // 2 * 2                                   # one staging block: pos_off | perm (int64, 8-byte aligned)
-    samp_d = torch.empty(o_perm + 2 * max(M_pos, 1), **i32)
+    samp_d = E(o_perm + 2 * max(M_pos, 1), torch.int32)
     sh = torch.empty(o_perm + 2 * max(M_pos, 1), dtype=torch.int32, pin_memory=True)
     sh[:A + 1] = torch.from_numpy(pos_off_h)
     sh[o_perm:o_perm + 2 * M_pos].view(torch.int64).copy_(perm_h)
@@ -1092,22 +1182,28 @@ def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None
     # ---- TransH term (HEAD:207-235, intended semantics): the scores of the positives and of as many sampled negatives per
     # image, and per image sum_i max(p_i - n_i, -margin).  Nothing here depends on the head's weights (the embeddings are
     # drawn fresh per image), so it belongs to the preparation -- off the step's critical path when prefetched.
-    scores_all = torch.empty(max(Mp, 1), K, **f32)
+    scores_all = E((max(Mp, 1), K), torch.float32)
     _check(lib.skg_transh_scores_f32(prep.ent.data_ptr(), prep.rel.data_ptr(), prep.nrm.data_ptr(), K, gh.human_idx,
                                      meta.data_ptr(), A, scores_all.data_ptr(), stream), "skg_transh_scores_f32")
-    tr = torch.empty(2 * max(M_pos, 1) + A, **f32)                   # pos scores | neg scores | margin partials
+    tr = E(2 * max(M_pos, 1) + A, torch.float32)                     # pos scores | neg scores | margin partials
     pos_s, neg_s, mpart = tr[:max(M_pos, 1)], tr[max(M_pos, 1):2 * max(M_pos, 1)], tr[2 * max(M_pos, 1):]
     max_pos = max(n_pos) if n_pos else 0
-    sws = torch.empty(int(lib.skg_transh_sample_ws_ints(A, max_pos)) + max(M_pos, 1), **i32)
+    sws = E(int(lib.skg_transh_sample_ws_ints(A, max_pos)) + max(M_pos, 1), torch.int32)
     _check(lib.skg_transh_sample_f32(labels_all.data_ptr(), scores_all.data_ptr(), K, meta.data_ptr(), A,
                                      prep.pos_off_d.data_ptr(), max_pos, prep.perm_d.data_ptr(), 1.0, sws.data_ptr(),
                                      sws.data_ptr() + 4 * (sws.numel() - max(M_pos, 1)), pos_s.data_ptr(),
                                      neg_s.data_ptr(), mpart.data_ptr(), stream), "skg_transh_sample_f32")
     prep.pos_s, prep.neg_s, prep.mpart = pos_s[:M_pos], neg_s[:M_pos], mpart
-    prep.cross = (pre.boxes, pre.scores, pre.labels, ibuf, grid, keep, sp48, labels_all, prep.ent, prep.rel, prep.nrm,
-                  samp_d, gt_h, gt_o, gt_l, npos_d, scores_all, tr, sws)
-    if prep.norm is not None:
-        prep.cross += (prep.norm.vals,)
+    if arena is not None:
+        # the slot's block is known to both streams; what is left to hand over one by one: the selection's outputs and
+        # whatever did not fit the block this time
+        prep.cross = (pre.boxes, pre.scores, pre.labels) + tuple(arena.spill) + own_gt
+        prep.slot = arena
+    else:
+        prep.cross = (pre.boxes, pre.scores, pre.labels, ibuf, grid, keep, sp48, labels_all, prep.ent, prep.rel, prep.nrm,
+                      samp_d, gt_h, gt_o, gt_l, npos_d, scores_all, tr, sws)
+        if prep.norm is not None:
+            prep.cross += (prep.norm.vals,)
     prep.keep = (ent_h, rel_h, nrm_h, sh, npos_h, hbuf)             # pinned staging: alive until the copies have run
     return prep
 
@@ -1251,7 +1347,7 @@ def fused_step(head, eng, features, detections, image_shapes, targets, prep=None
         if prep.empty:
             return None, prep
         if prep.ready is not None:
-            main = torch.cuda.current_stream()
+            main = current_stream_of(None)
             main.wait_event(prep.ready)
             for t in prep.cross:
                 t.record_stream(main)
@@ -1317,7 +1413,7 @@ def train_forward(head, eng, features, detections, image_shapes, targets, prep=N
         if prep.empty:
             return None, prep
         if prep.ready is not None:                     # made on the side stream: order it before this stream's use
-            main = torch.cuda.current_stream()
+            main = current_stream_of(None)
             main.wait_event(prep.ready)
             for t in prep.cross:
                 t.record_stream(main)

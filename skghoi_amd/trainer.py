@@ -463,12 +463,46 @@ def _join_backward():
     join_backward()
 
 
+def _release_prepared(net):
+    mod = net.module if isinstance(net, nn.parallel.DistributedDataParallel) else net
+    if "_prep_slot_in_use" in mod.__dict__:
+        from .train_fused import release_prepared
+        release_prepared(mod)
+
+
 def _drive_exchanges():
     from .train_fused import drive_exchanges
     drive_exchanges()
 
 
-def prefetch_batch(net, *batch, after=None):
+_ACCEPTS = {}
+_CUDA_HERE = []
+
+
+def _cuda_here():
+    """torch.cuda.is_available(), asked once (it re-reads the environment and counts devices on every call: ~4 us)."""
+    if not _CUDA_HERE:
+        _CUDA_HERE.append(bool(torch.cuda.is_available()))
+    return _CUDA_HERE[0]
+
+
+
+def _accepts(fn, name):
+    """Whether the (bound) method takes a keyword `name` -- asked once per function (a module other than the interaction
+    head may offer prefetch_train with the older signature)."""
+    f = getattr(fn, "__func__", fn)
+    key = (f, name)
+    if key not in _ACCEPTS:
+        import inspect
+        try:
+            ps = inspect.signature(f).parameters
+            _ACCEPTS[key] = name in ps or any(p.kind is p.VAR_KEYWORD for p in ps.values())
+        except (TypeError, ValueError):
+            _ACCEPTS[key] = False
+    return _ACCEPTS[key]
+
+
+def prefetch_batch(net, *batch, after=None, arena=False):
     """Hands the NEXT batch to the head for preparation on its side stream (InteractionHead.prefetch_train) while the GPU
     works on the step just enqueued; returns the handle of the preparation in progress (advance() / finish()) or None.
     Only when `net` IS the interaction head (training from cached detections / features) and the batch has the head's own
@@ -484,8 +518,12 @@ def prefetch_batch(net, *batch, after=None):
     if not isinstance(detections, (list, tuple)) or not detections or not isinstance(detections[0], dict) \
             or not torch.is_tensor(detections[0].get("boxes")) or not detections[0]["boxes"].is_cuda or targets is None:
         return None
-    return (fn(detections, image_shapes, targets, after=after) if after is not None
-            else fn(detections, image_shapes, targets)) or None
+    kw = {}
+    if after is not None:
+        kw["after"] = after
+    if arena and _accepts(fn, "arena"):
+        kw["arena"] = True
+    return fn(detections, image_shapes, targets, **kw) or None
 
 
 def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
@@ -509,15 +547,16 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
     # counts, positive counts) runs on the side stream while this thread enqueues the backward resp. the optimizer
     ahead = [None]
     entry = None
-    if prefetch is not None and torch.cuda.is_available():
+    if prefetch is not None and _cuda_here():
         # behind whatever produced the next batch (a loader's non-blocking uploads were enqueued before this call), in front
         # of this step's own kernels: what the side stream's preparation has to wait for, and no more
+        from .engine import current_stream_of
         entry = torch.cuda.Event()
-        entry.record()
+        entry.record(current_stream_of(None))
 
     def look_ahead():
         if prefetch is not None and ahead[0] is None:
-            ahead[0] = prefetch_batch(net, *prefetch, after=entry)                  # selection kernel launched
+            ahead[0] = prefetch_batch(net, *prefetch, after=entry, arena=True)      # selection kernel launched
     out = None
     fused = getattr(net, "fused_step", None)            # the bare interaction head: forward + backward without the autograd
     try:
@@ -555,6 +594,7 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
         # whatever happened above (the NaN guard, a failing look-ahead): a backward handed to the worker thread is joined
         # before this frame's tensors go away -- the plan names them
         _join_backward()                 # the backward's launches are all on the stream before the optimizer's
+        _release_prepared(net)           # ... and the arena slot of the batch this step consumed may be reused behind them
     optimizer.step()
     spans = getattr(net, "_train_spans", None)
     if spans and "o1" not in spans[-1]:
