@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SKG_ABI_VERSION 14
+#define SKG_ABI_VERSION 15
 #define SKG_E_ARG   (-1)   /* null pointer / negative size / unsupported shape            */
 #define SKG_E_ALIGN (-2)   /* pointer or leading dimension not 16-byte aligned            */
 #define SKG_E_LIMIT (-3)   /* exceeds a compiled-in limit (boxes per image, verbs, ...)   */
@@ -535,14 +535,16 @@ int skg_param_checksum(const skg_param_chunk* chunks, int n_chunks, uint64_t* ou
  * Per element, torch's decoupled rule:  p *= 1 - lr * weight_decay;  m += (g - m)(1 - beta1);
  * v = beta2 v + (1 - beta2) g^2;  p -= (lr / bias1) * m / (sqrt(v) / sqrt(bias2) + eps),  bias_k = 1 - beta_k^step
  * (bias1, bias2 are passed in: the step count lives on the host; the scalar
- * factors are formed in double and rounded once, like torch's).  HBM-bound: 28 bytes per parameter.               */
+ * factors are formed in double and rounded once, like torch's).  steps [n_steps] (optional): fp32 step counters of the
+ * optimizer state (torch keeps one tensor per parameter), each incremented by one in the same launch.  HBM-bound: 28 bytes
+ * per parameter.                                                                                                      */
 #define SKG_ADAMW_CHUNK 16384
 typedef struct {
     float* p; const float* g; float* m; float* v;
     uint32_t count, reserved;
 } skg_adamw_chunk;
 int skg_adamw_f32(const skg_adamw_chunk* chunks, int n_chunks, double lr, double beta1, double beta2, double eps,
-                  double weight_decay, double bias1, double bias2, void* stream);
+                  double weight_decay, double bias1, double bias2, float* steps, int n_steps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Native launch plan of the fused TRAINING step's dense part: GraphHead.forward in training mode (HEAD:769-993; the

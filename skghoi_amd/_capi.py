@@ -12,7 +12,7 @@ MAX_NODES = 160
 SPATIAL_LD = 48
 TRANSH_DIM = 50
 TRANSH_ENT = 80
-ABI_VERSION = 14
+ABI_VERSION = 15
 GEMM_GROUP_MAX = 4
 CHECKSUM_PARTIALS = 1024
 LOSS_CHUNKS = 64
@@ -120,7 +120,7 @@ PROTOTYPES = {
     "skg_gemm_group_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, _vp]),
     "skg_gemm_group_tile": (C.c_int, [C.POINTER(GemmDesc), C.c_int]),
     "skg_row_exponents_f32": (C.c_int, [_vp, C.c_int64, _vp, C.c_int, C.c_int, _vp, _vp]),
-    "skg_adamw_f32": (C.c_int, [_vp, C.c_int] + [C.c_double] * 7 + [_vp]),
+    "skg_adamw_f32": (C.c_int, [_vp, C.c_int] + [C.c_double] * 7 + [_vp, C.c_int, _vp]),
     "skg_gemm_small_mode": (C.c_int, [C.c_int]),
     "skg_gemm_small_tiles": (C.c_int, [C.c_int]),
     "skg_gemm_route_tiles": (C.c_int, [C.c_int]),

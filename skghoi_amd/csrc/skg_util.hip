@@ -74,7 +74,9 @@ __device__ __forceinline__ void skg_adamw_one(float& p, float g, float& m, float
 
 __global__ __launch_bounds__(256) void skg_adamw_kernel(const skg_adamw_chunk* __restrict__ chunks, float decay, float c1,
                                                         float beta2, float c2, float step_size, float inv_sqrt_b2,
-                                                        float eps) {
+                                                        float eps, float* __restrict__ steps, int n_steps) {
+    if (blockIdx.x == 0)                         // the optimizer state's per-parameter step counters (torch keeps them as tensors)
+        for (int i = threadIdx.x; i < n_steps; i += 256) steps[i] += 1.f;
     const skg_adamw_chunk c = chunks[blockIdx.x];
     const uint32_t n = c.count;
     const bool vec = ((((uintptr_t)c.p) | ((uintptr_t)c.g) | ((uintptr_t)c.m) | ((uintptr_t)c.v)) & 15u) == 0;
@@ -103,13 +105,13 @@ __global__ __launch_bounds__(256) void skg_adamw_kernel(const skg_adamw_chunk* _
 
 // The scalar factors are formed in double on the host and rounded once (1 - beta2 in float arithmetic is 1.3e-5 off).
 extern "C" int skg_adamw_f32(const skg_adamw_chunk* chunks, int n_chunks, double lr, double beta1, double beta2, double eps,
-                             double weight_decay, double bias1, double bias2, void* stream) {
-    if (n_chunks < 0 || (n_chunks > 0 && !chunks)) return SKG_E_ARG;
+                             double weight_decay, double bias1, double bias2, float* steps, int n_steps, void* stream) {
+    if (n_chunks < 0 || (n_chunks > 0 && !chunks) || n_steps < 0 || (n_steps > 0 && !steps)) return SKG_E_ARG;
     if (!(bias1 > 0.0) || !(bias2 > 0.0) || !(eps >= 0.0)) return SKG_E_ARG;
     if (n_chunks == 0) return 0;
     hipLaunchKernelGGL(skg_adamw_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, chunks,
                        (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                       (float)(lr / bias1), (float)(1.0 / sqrt(bias2)), (float)eps);
+                       (float)(lr / bias1), (float)(1.0 / sqrt(bias2)), (float)eps, steps, n_steps);
     return skg_launch_status();
 }
 

@@ -463,6 +463,23 @@ def _join_backward():
     join_backward()
 
 
+def _optimizer_step(optimizer):
+    """optimizer.step() -- for SkgAdamW without torch's per-call profiler wrapper (Optimizer.profile_hook_step: a
+    record_function scope + hook bookkeeping, ~35 us of a step whose host thread is the bound) when no step hooks are
+    registered; what the wrapper and the LR schedulers' call counter record is kept."""
+    from torch.optim import optimizer as _topt
+    if isinstance(optimizer, SkgAdamW) and not optimizer._optimizer_step_pre_hooks and \
+            not optimizer._optimizer_step_post_hooks and not _topt._global_optimizer_pre_hooks and \
+            not _topt._global_optimizer_post_hooks:
+        # (Optimizer.__init__ patched the class: step = profile_hook_step(step), marked `hooked`; one level down is the
+        #  @torch.no_grad-decorated method itself)
+        raw = getattr(SkgAdamW.step, "__wrapped__", None) if getattr(SkgAdamW.step, "hooked", False) else None
+        if raw is not None:
+            optimizer._opt_called = True                    # (lr_scheduler's "step() before optimizer.step()" check)
+            return raw(optimizer)
+    return optimizer.step()
+
+
 def _release_prepared(net):
     mod = net.module if isinstance(net, nn.parallel.DistributedDataParallel) else net
     if "_prep_slot_in_use" in mod.__dict__:
@@ -595,7 +612,7 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
         # before this frame's tensors go away -- the plan names them
         _join_backward()                 # the backward's launches are all on the stream before the optimizer's
         _release_prepared(net)           # ... and the arena slot of the batch this step consumed may be reused behind them
-    optimizer.step()
+    _optimizer_step(optimizer)
     spans = getattr(net, "_train_spans", None)
     if spans and "o1" not in spans[-1]:
         spans[-1]["o1"] = torch.cuda.Event(enable_timing=True)
@@ -653,6 +670,7 @@ class SkgAdamW(CachedFusedAdamW):
                 return pl
         ok = all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params) and \
             all(t.dtype == torch.float32 and t.is_contiguous() for t in exp_avgs + exp_avg_sqs) and \
+            all(s_.dtype == torch.float32 and s_.is_cuda for s_ in steps) and \
             len({p.device for p in params}) == 1
         if not ok:
             self._plans[gi] = dict(lists=c, ok=False)
@@ -751,10 +769,10 @@ class SkgAdamW(CachedFusedAdamW):
                 pl["grad_ptrs"] = ptrs
             t = pl["host_step"] + 1
             beta1, beta2 = group["betas"]
+            fs = pl["flat_step"]                             # the state's step tensors (one flat fp32 buffer): + 1 in the same launch
             _capi.check(lib.skg_adamw_f32(pl["dtab"].data_ptr(), len(tab), float(group["lr"]), float(beta1), float(beta2),
                                           float(group["eps"]), float(group["weight_decay"]), 1.0 - beta1 ** t,
-                                          1.0 - beta2 ** t, _stream()), "skg_adamw_f32")
-            pl["flat_step"].add_(1)
+                                          1.0 - beta2 ** t, fs.data_ptr(), fs.numel(), _stream()), "skg_adamw_f32")
             pl["host_step"] = t
         return None
 
