@@ -208,18 +208,41 @@ __global__ void b3bcast_kernel(const float* __restrict__ db3, float* __restrict_
     out[i] = db3[m * 1024 + col];
 }
 // out[c] = sum_r X[r, c] + sum_r Y[r, c]  (gradient of attention_head.fc_1's bias: added once per row of both uses)
-__global__ void colsum2_kernel(const float* __restrict__ X, int rx, const float* __restrict__ Y, int ry,
-                               float* __restrict__ out) {
-    __shared__ float red[4][64];
-    int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    int part = threadIdx.x >> 6;
-    float s = 0.f;
-    for (int r = part; r < rx; r += 4) s += X[(int64_t)r * 1024 + col];
-    float t = 0.f;
-    for (int r = part; r < ry; r += 4) t += Y[(int64_t)r * 1024 + col];
-    red[part][threadIdx.x & 63] = s + t;
+// (sixteen row groups per workgroup of 1024 threads: four groups walked ~80 node rows in 40 dependent round trips, 17 us)
+__global__ __launch_bounds__(1024) void colsum2_kernel(const float* __restrict__ X, int rx, const float* __restrict__ Y, int ry,
+                                                       float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, col = blockIdx.x * 64 + lane;
+    const int part = threadIdx.x >> 6;
+    float s = 0.f, t = 0.f;
+    for (int r = part; r < rx; r += 16) s += X[(int64_t)r * 1024 + col];
+    for (int r = part; r < ry; r += 16) t += Y[(int64_t)r * 1024 + col];
+    red[part][lane] = s + t;
     __syncthreads();
-    if (part == 0) out[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (part == 0) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) a += (red[q][lane] + red[q + 1][lane]) + (red[q + 2][lane] + red[q + 3][lane]);
+        out[col] = a;
+    }
+}
+
+// dF [Mg, 4096] = [attention | obj_to_sub | sub_to_obj | global]: the read-out writes blocks 0 and 3 at the rows of kept pairs;
+// the in-loop stage overwrites blocks 1 and 2 on every row and ADDS to block 0.  What has to be zero beforehand is therefore
+// blocks 0 and 3 of the grid rows WITHOUT a pair (the self pairs, grid_pair < 0: 20 of an image's 400 rows) -- this kernel --
+// not the whole 52 MB (+ 26 MB twin) a memset node cleared every step (15 us).  One workgroup per grid row.
+__global__ __launch_bounds__(256) void zero_selfpair_rows_kernel(float* __restrict__ dF, uint16_t* __restrict__ dF16,
+                                                                 const int32_t* __restrict__ grid_pair, int Mg) {
+    const int g = blockIdx.x;
+    if (grid_pair[g] >= 0) return;
+    const int c = threadIdx.x * 4;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(dF + (int64_t)g * 4096 + c) = z;
+    *reinterpret_cast<float4*>(dF + (int64_t)g * 4096 + 3072 + c) = z;
+    if (dF16) {
+        *reinterpret_cast<uint2*>(dF16 + (int64_t)g * 4096 + c) = make_uint2(0u, 0u);
+        *reinterpret_cast<uint2*>(dF16 + (int64_t)g * 4096 + 3072 + c) = make_uint2(0u, 0u);
+    }
 }
 
 // ---- workspace ---------------------------------------------------------------------------------------------------------
@@ -476,10 +499,21 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
         launch(c, l, 4);
         // ---- read-out fc_1 * fc_2 products: dF at the pairs' grid rows (self-pair rows stay zero), dm in place
         if (!c.dry) {
-            const size_t nz = (size_t)((w.dG1 - w.dF) + (int64_t)Bf * 1024);
-            hipError_t e = hipMemsetAsync(w.dF, 0, sizeof(float) * nz, c.stream);
-            if (e == hipSuccess && P->bf16 && P->ws16) e = hipMemsetAsync(P->ws16 + (w.dF - P->ws), 0, sizeof(uint16_t) * nz, c.stream);
-            if (e != hipSuccess) { c.rc = (int)e; break; }
+            uint16_t* dF16 = (P->bf16 && P->ws16) ? P->ws16 + (w.dF - P->ws) : nullptr;
+            if (Mp > 0) {
+                hipLaunchKernelGGL(zero_selfpair_rows_kernel, dim3(Mg), dim3(256), 0, c.stream, w.dF, dF16, P->grid_pair, Mg);
+                if (A < Bf) {          // images without a graph: their dG1 rows are not written by the segment sum below
+                    hipError_t e = hipMemsetAsync(w.dG1, 0, sizeof(float) * (size_t)Bf * 1024, c.stream);
+                    if (e == hipSuccess && dF16)
+                        e = hipMemsetAsync(P->ws16 + (w.dG1 - P->ws), 0, sizeof(uint16_t) * (size_t)Bf * 1024, c.stream);
+                    if (e != hipSuccess) { c.rc = (int)e; break; }
+                }
+            } else {
+                const size_t nz = (size_t)((w.dG1 - w.dF) + (int64_t)Bf * 1024);
+                hipError_t e = hipMemsetAsync(w.dF, 0, sizeof(float) * nz, c.stream);
+                if (e == hipSuccess && dF16) e = hipMemsetAsync(dF16, 0, sizeof(uint16_t) * nz, c.stream);
+                if (e != hipSuccess) { c.rc = (int)e; break; }
+            }
         }
         if (Mp > 0) {
             skg_mul_bwd_args m[2] = {       // (disjoint column blocks of dF: one launch)
@@ -539,7 +573,7 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
         }
         // the multiplier bias of attention_head's fc_1 is added once per row: its gradient is the sum over all rows
         if (!c.dry)
-            hipLaunchKernelGGL(colsum2_kernel, dim3(16), dim3(256), 0, c.stream, w.dA1h, Mh, w.dB1h, Mh, db1[ATT]);
+            hipLaunchKernelGGL(colsum2_kernel, dim3(16), dim3(1024), 0, c.stream, w.dA1h, Mh, w.dB1h, Mh, db1[ATT]);
     } break;
     case 6: {
         // ---- fc_2 of all four MBFs: ONE product for the input gradient (K = 4096), one for the weights
