@@ -182,13 +182,26 @@ class NativeComm:
                               "gradient exchange stays on torch.distributed"
                               % (res.get("err") or ("no answer within the deadline" if not in_time else "a peer failed")))
             return None
-        return cls(h, world, rank)
+        comm = cls(h, world, rank)
+        import atexit
+        import weakref
+        ref = weakref.ref(comm)
+        atexit.register(lambda: ref() is not None and ref().close())     # RCCL torn down before the HIP runtime is
+        return comm
 
     def close(self):
+        """Destroys the communicator (drains its stream first).  The trainer's backward must have been joined."""
         h, self.handle = self.handle, None
         if h:
-            from . import _capi
+            from . import _capi, train_fused
+            train_fused.join_backward(True)
             _capi.lib().skg_comm_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                   # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 class ArenaExchange:
