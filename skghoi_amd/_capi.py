@@ -12,7 +12,7 @@ MAX_NODES = 160
 SPATIAL_LD = 48
 TRANSH_DIM = 50
 TRANSH_ENT = 80
-ABI_VERSION = 15
+ABI_VERSION = 16
 GEMM_GROUP_MAX = 4
 CHECKSUM_PARTIALS = 1024
 LOSS_CHUNKS = 64
@@ -64,7 +64,11 @@ COMM_ID_BYTES = 128
 class Exchange(C.Structure):
     """Mirror of skg_exchange: the arena chunks a staged backward all-reduces itself over an skg_comm."""
     _fields_ = [("comm", C.c_void_p), ("arena", C.c_void_p), ("n_chunks", C.c_int32),
-                ("stage", C.c_int32 * TRAIN_BWD_STAGES), ("end", C.c_int64 * TRAIN_BWD_STAGES)]
+                ("stage", C.c_int32 * TRAIN_BWD_STAGES), ("end", C.c_int64 * TRAIN_BWD_STAGES),
+                # the optimizer inside the backward (adamw = NULL: none): AdamW table entries per chunk + skg_adamw_f32's factors
+                ("adamw", C.c_void_p), ("adamw_first", C.c_int32 * (TRAIN_BWD_STAGES + 1)), ("adamw_n_steps", C.c_int32),
+                ("adamw_steps", C.c_void_p)] + [(n, C.c_double) for n in ("lr", "beta1", "beta2", "eps", "weight_decay",
+                                                                          "bias1", "bias2")]
 
 
 class TrainPlan(C.Structure):
@@ -179,6 +183,7 @@ PROTOTYPES = {
     "skg_context_destroy": (None, [_vp]),
     "skg_ctx_train_backward_async_f32": (C.c_int, [_vp, C.POINTER(TrainPlan), C.c_int, C.c_int, _vp, _vp, C.c_uint32]),
     "skg_ctx_train_backward_exchange_f32": (C.c_int, [_vp, C.POINTER(TrainPlan), C.c_int, C.c_int, _vp, _vp, C.POINTER(Exchange)]),
+    "skg_sizeof_exchange": (C.c_int, []),
     "skg_comm_load": (C.c_int, [C.c_char_p]),
     "skg_comm_unique_id": (C.c_int, [_vp]),
     "skg_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
@@ -218,6 +223,8 @@ def lib():
         fn = getattr(l, name)
         fn.restype = res
         fn.argtypes = args
+    if l.skg_abi_version() == ABI_VERSION and l.skg_sizeof_exchange() != C.sizeof(Exchange):
+        raise SkgError("skg_exchange is %d bytes in libskghoi_hip.so, %d in the binding" % (l.skg_sizeof_exchange(), C.sizeof(Exchange)))
     if l.skg_abi_version() != ABI_VERSION:
         raise SkgError("libskghoi_hip.so ABI %d != binding ABI %d" % (l.skg_abi_version(), ABI_VERSION))
     if os.environ.get("SKG_SMALL_MODE"):                 # developer switch: 64 x 64 main loop of the small launches

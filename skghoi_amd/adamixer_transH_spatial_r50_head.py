@@ -527,15 +527,20 @@ class InteractionHead(Module):
         self._prefetched = h
         return h
 
-    def fused_step(self, features, detections, image_shapes, targets, after_forward=None, defer_backward=False):
+    def fused_step(self, features, detections, image_shapes, targets, after_forward=None, defer_backward=False,
+                   adamw=None):
         """Forward + backward of one training step without the autograd engine (skghoi_amd.train_fused.fused_step) for a
         trainer that owns the loop: gradients of the summed losses land in `p.grad` (overwritten, not accumulated).
         Returns the result list with the (detached) loss dict appended, or None when this call has to go through
         `forward` + `backward()` instead.
         defer_backward=True: the backward's launches may still be on their way to the stream when this returns (the
         library's worker thread issues them); the caller runs `skghoi_amd.train_fused.join_backward()` before it
-        enqueues anything behind the gradients (trainer.train_step does, in front of the optimizer)."""
+        enqueues anything behind the gradients (trainer.train_step does, in front of the optimizer).
+        adamw (with defer_backward): trainer.SkgAdamW.backward_slices -- when it yields slices for this step, the worker
+        thread also issues the optimizer's update chunk by chunk inside the backward; the slices then sit in
+        self._adamw_in_backward for the caller to acknowledge (SkgAdamW.backward_done) instead of calling step()."""
         from skghoi_amd import train_fused
+        self.__dict__.pop("_adamw_in_backward", None)
         if not (self.training and self.fused_training and train_fused.supported(self)) or targets is None:
             return None
         dev = features["3"].device
@@ -544,7 +549,7 @@ class InteractionHead(Module):
         with on_device(dev):
             out, prep = train_fused.fused_step(self, self.engine(), features, detections, image_shapes, targets,
                                                prep=self._take_prefetched(detections, image_shapes, targets),
-                                               after_forward=after_forward, defer_backward=defer_backward)
+                                               after_forward=after_forward, defer_backward=defer_backward, adamw=adamw)
             if out is None and prep is not None:
                 self._prefetched = _Ready(prep)       # prepared but not consumed here: the `forward` that follows takes it
         return out

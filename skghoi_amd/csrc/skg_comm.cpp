@@ -154,6 +154,8 @@ int skg_comm_chunk(skg_comm* c, hipEvent_t after, float* p, int64_t n) {
     return 0;
 }
 
+hipStream_t skg_comm_stream(skg_comm* c) { return c ? c->stream : nullptr; }
+
 int skg_comm_close_step(skg_comm* c, hipStream_t stream) {
     if (!c) return SKG_E_ARG;
     hipError_t e = hipEventRecord(c->done, c->stream);

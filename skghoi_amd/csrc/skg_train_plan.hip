@@ -708,14 +708,38 @@ struct skg_context {
     uint32_t own_mask = 0;                         // stages (absolute) behind which own[stage] is recorded
     bool own_made = false;
     bool with_events = false;
-    skg_exchange ex = {};                          // data parallel: the arena chunks this job all-reduces itself (ex.comm != NULL)
-    // the collective of the chunk that stage e completes, behind the stage's own event (recorded just before)
-    int exchange_after(int e) {
-        if (!ex.comm) return 0;
-        for (int i = 0; i < ex.n_chunks; ++i)
-            if (ex.stage[i] == e)
-                return skg_comm_chunk(ex.comm, own[e], ex.arena + (i ? ex.end[i - 1] : 0), ex.end[i] - (i ? ex.end[i - 1] : 0));
+    skg_exchange ex = {};                          // the arena chunks this job all-reduces (ex.comm) and / or updates (ex.adamw) itself
+    bool has_ex = false;
+    hipStream_t aux = nullptr;                     // single process + optimizer inside the backward: the updates' stream
+    hipEvent_t aux_done = nullptr;
+    // behind the stage that completes chunk i (its own event was recorded just before): the chunk's collective, then the
+    // optimizer's update of the chunk's parameters -- both on the exchange stream, concurrent with the stages still to run
+    int exchange_after(int e, hipStream_t stream) {
+        if (!has_ex) return 0;
+        for (int i = 0; i < ex.n_chunks; ++i) {
+            if (ex.stage[i] != e) continue;
+            int fi = 0;                                // the first chunk with table entries also bumps the step counters
+            while (ex.adamw && fi < ex.n_chunks - 1 && ex.adamw_first[fi + 1] <= ex.adamw_first[fi]) ++fi;
+            if (!ex.comm && i == ex.n_chunks - 1)      // no collective to wait for: the last update follows its stage in-stream
+                return skg_adamw_slice(ex.adamw, ex.adamw_first[i], ex.adamw_first[i + 1], ex, i == fi, stream);
+            hipStream_t xs = ex.comm ? skg_comm_stream(ex.comm) : aux;
+            int r = 0;
+            if (ex.comm)
+                r = skg_comm_chunk(ex.comm, own[e], ex.arena + (i ? ex.end[i - 1] : 0), ex.end[i] - (i ? ex.end[i - 1] : 0));
+            else
+                r = (int)hipStreamWaitEvent(xs, own[e], 0);
+            if (!r && ex.adamw) r = skg_adamw_slice(ex.adamw, ex.adamw_first[i], ex.adamw_first[i + 1], ex, i == fi, xs);
+            return r;
+        }
         return 0;
+    }
+    // `stream` behind everything the exchange stream holds for this job
+    int exchange_close(hipStream_t stream) {
+        if (!has_ex) return 0;
+        if (ex.comm) return skg_comm_close_step(ex.comm, stream);
+        hipError_t err = hipEventRecord(aux_done, aux);
+        if (err == hipSuccess) err = hipStreamWaitEvent(stream, aux_done, 0);
+        return (int)err;
     }
     void loop() {
         for (;;) {
@@ -737,13 +761,13 @@ struct skg_context {
                     r = skg_train_backward_f32(&plan, s, e + 1, stream);
                     if (!r && events[e - first]) r = (int)hipEventRecord(events[e - first], (hipStream_t)stream);
                     if (!r && ((own_mask >> e) & 1u)) r = (int)hipEventRecord(own[e], (hipStream_t)stream);
-                    if (!r) r = exchange_after(e);
+                    if (!r) r = exchange_after(e, (hipStream_t)stream);
                     if (r) break;
                     lk.lock(); issued = e + 1; lk.unlock();
                     cv.notify_all();
                     s = e + 1;
                 }
-                if (!r && ex.comm) r = skg_comm_close_step(ex.comm, (hipStream_t)stream);     // `stream` behind the last collective
+                if (!r) r = exchange_close((hipStream_t)stream);                 // `stream` behind the last collective / update
                 lk.lock();
             }
             rc = r; pending = false;
@@ -785,6 +809,8 @@ void skg_context_destroy(skg_context* c) {
     if (c->started && c->worker.joinable()) c->worker.join();
     if (c->own_made)
         for (int s = 0; s < SKG_TRAIN_BWD_STAGES; ++s) (void)hipEventDestroy(c->own[s]);
+    if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+    if (c->aux_done) (void)hipEventDestroy(c->aux_done);
     delete c;
 }
 
@@ -793,13 +819,20 @@ static int submit_backward(skg_context* ctx, const skg_train_plan* P, int first_
     int rc = validate_backward(P, first_stage, last_stage);    // rejected here, at submit -- not at the join
     if (rc) return rc;
     if (ex) {
-        if (!ex->comm || !ex->arena || ex->n_chunks < 1 || ex->n_chunks > SKG_TRAIN_BWD_STAGES) return SKG_E_ARG;
+        if ((!ex->comm && !ex->adamw) || !ex->arena || ex->n_chunks < 1 || ex->n_chunks > SKG_TRAIN_BWD_STAGES) return SKG_E_ARG;
+        if (ex->adamw) {
+            if (!(ex->bias1 > 0.0) || !(ex->bias2 > 0.0) || !(ex->eps >= 0.0) || ex->adamw_n_steps < 0 ||
+                (ex->adamw_n_steps > 0 && !ex->adamw_steps) || ex->adamw_first[0] < 0)
+                return SKG_E_ARG;
+            for (int i = 0; i < ex->n_chunks; ++i)
+                if (ex->adamw_first[i + 1] < ex->adamw_first[i]) return SKG_E_ARG;
+        }
         stage_mask = 0;
         for (int i = 0; i < ex->n_chunks; ++i) {
             if (ex->stage[i] < first_stage || ex->stage[i] >= last_stage || (i && ex->stage[i] <= ex->stage[i - 1]) ||
                 ex->end[i] < (i ? ex->end[i - 1] : 0))
                 return SKG_E_ARG;
-            stage_mask |= 1u << ex->stage[i];
+            if (ex->comm || i + 1 < ex->n_chunks) stage_mask |= 1u << ex->stage[i];      // (no event behind a chunk updated in-stream)
         }
     }
     skg_context* a = ctx_or_default(ctx);
@@ -821,10 +854,16 @@ static int submit_backward(skg_context* ctx, const skg_train_plan* P, int first_
         a->own_made = true;
     }
     a->own_mask = stage_mask;
+    a->has_ex = ex != nullptr;
     if (ex) a->ex = *ex; else memset(&a->ex, 0, sizeof(a->ex));
+    if (ex && !ex->comm && !a->aux) {
+        e = hipStreamCreateWithFlags(&a->aux, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&a->aux_done, hipEventDisableTiming);
+        if (e != hipSuccess) return (int)e;
+    }
     a->plan = *P; a->first = first_stage; a->last = last_stage; a->stream = stream; a->device = dev; a->rc = 0;
     a->issued = first_stage;
-    a->with_events = stage_events_host != nullptr || stage_mask != 0;
+    a->with_events = stage_events_host != nullptr || stage_mask != 0 || ex != nullptr;
     for (int s = 0; s < SKG_TRAIN_BWD_STAGES; ++s)
         a->events[s] = (stage_events_host && s < last_stage - first_stage) ? (hipEvent_t)stage_events_host[s] : nullptr;
     a->pending = true;
@@ -848,6 +887,8 @@ int skg_ctx_train_backward_exchange_f32(skg_context* ctx, const skg_train_plan* 
     if (!ex) return SKG_E_ARG;
     return submit_backward(ctx, P, first_stage, last_stage, stream, stage_events_host, 0u, ex);
 }
+
+int skg_sizeof_exchange(void) { return (int)sizeof(skg_exchange); }     // (bindings check their mirror of the struct)
 
 int skg_ctx_train_backward_stage_wait(skg_context* ctx, int stage) {
     skg_context* a = ctx_or_default(ctx);

@@ -115,6 +115,16 @@ extern "C" int skg_adamw_f32(const skg_adamw_chunk* chunks, int n_chunks, double
     return skg_launch_status();
 }
 
+// a slice of the chunk table with the same factors (the optimizer inside the backward, skg_exchange.adamw)
+int skg_adamw_slice(const skg_adamw_chunk* chunks, int first, int last, const skg_exchange& x, bool with_steps, hipStream_t stream) {
+    if (last <= first) return 0;
+    hipLaunchKernelGGL(skg_adamw_kernel, dim3((unsigned)(last - first)), dim3(256), 0, stream, chunks + first,
+                       (float)(1.0 - x.lr * x.weight_decay), (float)(1.0 - x.beta1), (float)x.beta2, (float)(1.0 - x.beta2),
+                       (float)(x.lr / x.bias1), (float)(1.0 / sqrt(x.bias2)), (float)x.eps,
+                       with_steps ? x.adamw_steps : (float*)nullptr, with_steps ? x.adamw_n_steps : 0);
+    return skg_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------ bf16 twins
 thread_local skg_twin_map skg_tls_twin = {{nullptr, nullptr}, {nullptr, nullptr}, {0, 0}};
 

@@ -735,7 +735,11 @@ class NativeJob(TrainJob):
                           adjacency=(lay.sum_g, 1))[which]
         return self.ws[off:off + rows * cols].view(rows, cols)
 
-    def backward(self, dlogits, need_dx0, need_dgfeat, arena=None, defer=False, span=None):
+    # single process: the stages behind which the optimizer inside the backward updates an arena chunk (two events on the
+    # backward's queue, ~12 us each; the last chunk -- box_head.1, 44 % of the parameters -- follows its stage in-stream)
+    ADAMW_STAGES = (6, 9)
+
+    def backward(self, dlogits, need_dx0, need_dgfeat, arena=None, defer=False, span=None, adamw=None):
         """defer=True (engine-free step): the launches are issued by the worker thread of the head's context
         (skg_ctx_train_backward_async_f32) while this thread goes on with host work; `join_backward()` must run before
         anything is enqueued behind the gradients.  span: a dict that receives "b1", a timing event the worker records behind
@@ -776,13 +780,34 @@ class NativeJob(TrainJob):
                 after.record()                                   # (torch creates the HIP event at its first record)
                 events = (C.c_void_p * n)()
                 events[n - 1] = after.cuda_event
+            xd = None
             if native:
                 # the library's own RCCL communicator: the WORKER all-reduces every arena chunk behind the stage that
                 # completes it and orders this stream behind the last collective -- nothing left to drive from here
                 ex._after = after
                 xd = ex.native_exchange(ga, st.milestone_end)
+            elif ex is None and adamw is not None:
+                xd = _capi.Exchange()                            # single process: chunks for the optimizer only
+                cs = [(s_, st.milestone_end[s_]) for s_ in self.ADAMW_STAGES] + [(n - 1, ga.numel())]
+                xd.comm, xd.arena, xd.n_chunks = None, ga.data_ptr(), len(cs)
+                for i, (s_, end) in enumerate(cs):
+                    xd.stage[i], xd.end[i] = s_, end
+            sl = None
+            if xd is not None and adamw is not None:
+                sl = adamw(st, ga, [(int(xd.stage[i]), int(xd.end[i])) for i in range(xd.n_chunks)])
+                if sl is not None:
+                    xd.adamw, xd.adamw_steps, xd.adamw_n_steps = sl["adamw"], sl["steps"], sl["n_steps"]
+                    for i, f in enumerate(sl["first"]):
+                        xd.adamw_first[i] = f
+                    for k in ("lr", "beta1", "beta2", "eps", "weight_decay", "bias1", "bias2"):
+                        setattr(xd, k, sl[k])
+                elif not native:
+                    xd = None
+            if xd is not None:
                 _check(lib.skg_ctx_train_backward_exchange_f32(ctx.handle(), C.byref(pl), 0, n, stream, events, C.byref(xd)),
                        "skg_ctx_train_backward_exchange_f32")
+                if sl is not None:
+                    self.head.__dict__["_adamw_in_backward"] = sl
             else:
                 _check(lib.skg_ctx_train_backward_async_f32(ctx.handle(), C.byref(pl), 0, n, stream, events, mask),
                        "skg_train_backward_async_f32")
@@ -1312,7 +1337,7 @@ class TrainRun:
 
 
 def fused_step(head, eng, features, detections, image_shapes, targets, prep=None, after_forward=None,
-               defer_backward=False):
+               defer_backward=False, adamw=None):
     """One whole forward + backward of the training step WITHOUT the autograd engine, for a trainer that owns the loop
     (skghoi_amd.trainer.train_step): the same kernels in the same order as `StepFn`, with the upstream gradient of the
     three summed losses (utils.py:221: their plain sum) fixed at one, the gradients written into a persistent arena whose
@@ -1378,7 +1403,8 @@ def fused_step(head, eng, features, detections, image_shapes, targets, prep=None
                                                  _stream()), "skg_scale_dlogits_f32")
         if sp is not None:
             sp["b0"].record()
-        job.backward(d, False, False, arena=(ga, views), defer=defer_backward, span=sp if defer_backward else None)
+        job.backward(d, False, False, arena=(ga, views), defer=defer_backward, span=sp if defer_backward else None,
+                     adamw=adamw if defer_backward else None)
         if sp is not None and "b1" not in sp:
             sp["b1"] = torch.cuda.Event(enable_timing=True); sp["b1"].record()
         ctx = context_for(head)

@@ -476,6 +476,18 @@ def _join_backward():
     join_backward()
 
 
+def _plain_step(optimizer):
+    """A SkgAdamW without step hooks whose update may be issued by the backward's worker thread (train_step) -- OPT-IN
+    (SKG_ADAMW_IN_BACKWARD=1).  Measured on one MI355X, batch-4 step: the update of the first 16.6 M parameters running
+    beside backward stages 7-11 costs those stages more (HBM / L2 traffic of a 0.5 GB stream under GEMMs that live on L2
+    hits, two more events on their queue) than the 0.07 ms it takes off the tail: bf16 1.27 -> 1.33 ms, fp32 2.48 -> 2.51,
+    data-parallel route at world size 1 1.35 -> 1.38.  Results are bit-identical either way (tests/test_trainer.py)."""
+    from torch.optim import optimizer as _topt
+    return isinstance(optimizer, SkgAdamW) and not optimizer._optimizer_step_pre_hooks and \
+        not optimizer._optimizer_step_post_hooks and not _topt._global_optimizer_pre_hooks and \
+        not _topt._global_optimizer_post_hooks and _os.environ.get("SKG_ADAMW_IN_BACKWARD", "0") == "1"
+
+
 def _optimizer_step(optimizer):
     """optimizer.step() -- for SkgAdamW without torch's per-call profiler wrapper (Optimizer.profile_hook_step: a
     record_function scope + hook bookkeeping, ~35 us of a step whose host thread is the bound) when no step hooks are
@@ -577,6 +589,7 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
     # counts, positive counts) runs on the side stream while this thread enqueues the backward resp. the optimizer
     ahead = [None]
     entry = None
+    updated = None
     if prefetch is not None and _cuda_here():
         # behind whatever produced the next batch (a loader's non-blocking uploads were enqueued before this call), in front
         # of this step's own kernels: what the side stream's preparation has to wait for, and no more
@@ -591,8 +604,15 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
     fused = getattr(net, "fused_step", None)            # the bare interaction head: forward + backward without the autograd
     try:
         if fused is not None and len(inputs) == 3:      # engine (gradients overwrite p.grad: nothing to zero beforehand)
-            out = fused(*inputs, targets, after_forward=look_ahead, defer_backward=True)
+            kw = {}
+            if lazy and _accepts(fused, "adamw") and _plain_step(optimizer):
+                # the optimizer inside the backward: the worker thread updates each arena chunk's parameters as soon as the
+                # chunk's gradients are final (and all-reduced), beside the stages still to run.  Only with lazy losses: the
+                # eager NaN guard below must be able to stop the step BEFORE any parameter moves.
+                kw["adamw"] = optimizer.backward_slices
+            out = fused(*inputs, targets, after_forward=look_ahead, defer_backward=True, **kw)
         fused_ran = out is not None
+        updated = fused_ran and net.__dict__.pop("_adamw_in_backward", None)
         if out is None:
             optimizer.zero_grad(set_to_none=True)
             out = net(*inputs, targets)
@@ -625,7 +645,12 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
         # before this frame's tensors go away -- the plan names them
         _join_backward()                 # the backward's launches are all on the stream before the optimizer's
         _release_prepared(net)           # ... and the arena slot of the batch this step consumed may be reused behind them
-    _optimizer_step(optimizer)
+        if updated is None and fused is not None:
+            updated = getattr(net, "__dict__", {}).pop("_adamw_in_backward", None)      # (fused() raised after the submit)
+        if updated:
+            optimizer.backward_done(updated)                 # (whatever else happened: the update IS on the stream)
+    if not updated:
+        _optimizer_step(optimizer)
     spans = getattr(net, "_train_spans", None)
     if spans and "o1" not in spans[-1]:
         spans[-1]["o1"] = torch.cuda.Event(enable_timing=True)
@@ -731,6 +756,65 @@ class SkgAdamW(CachedFusedAdamW):
                   events=[None, None], dtab=torch.empty(nb, dtype=torch.uint8, device=dev), flip=0)
         self._plans[gi] = pl
         return pl
+
+    # ---- the update inside the backward (include/skghoi.h, skg_exchange.adamw)
+    def backward_slices(self, st, ga, chunks):
+        """For a fused step whose gradients land in the arena `ga` of the parameter arena `st` (train_fused.Stacked) and
+        whose backward hands out the arena in `chunks` = [(stage, end in floats)]: the AdamW chunk table sorted by arena
+        offset, the table range of every chunk and this step's factors -- what the backward's worker thread needs to
+        update chunk i's parameters behind stage i (behind its all-reduce, data parallel) while the later stages still run.
+        None when this step has to go through step(): no state yet, several groups, parameters outside the arena, options
+        the one-launch kernel does not cover, step hooks.  The caller MUST call backward_done() once the backward has been
+        submitted with the slices."""
+        import numpy as np
+        if len(self.param_groups) != 1 or getattr(self, "grad_scale", None) is not None or \
+                getattr(self, "found_inf", None) is not None:
+            return None
+        group = self.param_groups[0]
+        if group.get("amsgrad") or group.get("maximize") or group.get("capturable") or group.get("differentiable") \
+                or not group.get("fused") or torch.is_tensor(group["lr"]) or not group["params"]:
+            return None
+        c = self._cached(0, group)
+        pl = self._plan(0, c) if c is not None else None
+        if pl is None or not pl["ok"] or pl["free"]:
+            return None
+        base, gbase = st.buf.data_ptr(), ga.data_ptr()
+        key = (id(st), base, gbase, tuple(chunks))
+        ov = pl.get("ov")
+        if ov is None or ov["key"] != key:
+            params, exp_avgs, exp_avg_sqs = c[1], c[2], c[3]
+            if any(getattr(p_, "_skg_arena", None) is not st for p_ in params):
+                return None
+            off = np.array([(p_.data_ptr() - base) // 4 for p_ in params], np.int64)
+            if off.min() < 0 or int((off + np.array([p_.numel() for p_ in params])).max()) > st.total:
+                return None
+            order = np.argsort(off, kind="stable")
+            rows, first, k = [], [0], 0
+            ends = [int(e) for _, e in chunks]
+            for i in order:
+                while k < len(ends) - 1 and off[i] >= ends[k]:
+                    first.append(len(rows)); k += 1
+                n, pp, mp, vp = params[i].numel(), params[i].data_ptr(), exp_avgs[i].data_ptr(), exp_avg_sqs[i].data_ptr()
+                gp = gbase + 4 * int(off[i])
+                for o in range(0, n, self.CHUNK):
+                    rows.append((pp + 4 * o, gp + 4 * o, mp + 4 * o, vp + 4 * o, min(self.CHUNK, n - o), 0))
+            while len(first) < len(ends):
+                first.append(len(rows))
+            first.append(len(rows))
+            tab = np.array(rows, dtype=SkgAdamW._DT)
+            dtab = torch.from_numpy(tab.view(np.uint8).copy()).to(pl["dev"])
+            ov = pl["ov"] = dict(key=key, dtab=dtab, first=first, rows=len(rows))
+        t = pl["host_step"] + 1
+        beta1, beta2 = group["betas"]
+        fs = pl["flat_step"]
+        return dict(plan=pl, adamw=ov["dtab"].data_ptr(), first=ov["first"], steps=fs.data_ptr(), n_steps=fs.numel(),
+                    lr=float(group["lr"]), beta1=float(beta1), beta2=float(beta2), eps=float(group["eps"]),
+                    weight_decay=float(group["weight_decay"]), bias1=1.0 - beta1 ** t, bias2=1.0 - beta2 ** t)
+
+    def backward_done(self, sl):
+        """The backward that carried `sl` (backward_slices) has been submitted: this step's update is on its way."""
+        sl["plan"]["host_step"] += 1
+        self._opt_called = True                              # (lr_scheduler's "step() before optimizer.step()" check)
 
     @torch.no_grad()
     def step(self, closure=None):

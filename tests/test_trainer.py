@@ -1017,6 +1017,64 @@ def test_worker_thread_backward_changes_nothing(precision):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_optimizer_inside_the_backward_changes_nothing(precision, monkeypatch):
+    """trainer.train_step with lazy losses lets the backward's worker thread issue the AdamW update chunk by chunk (arena
+    chunks behind stages 6 and 9 on a side stream, the rest behind the last stage: skg_exchange.adamw) instead of one launch
+    after the join.  Same kernel, same factors, every parameter exactly once per step: losses, weights and optimizer state
+    after five steps equal the run with the update after the join (SKG_ADAMW_IN_BACKWARD=0) bit for bit; the first two steps
+    of either run go through step() (the state is created, then the one-launch plan is made)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    import cases
+    import gpu_run
+    from collections import OrderedDict
+    case = cases.build_case("train_tiny")
+    case2 = cases.build_case("train_skips")
+    batches = []
+    for c in (case, case2, case, case2, case):
+        batches.append((OrderedDict((k, c["feat3"].cuda()) for k in "0123"), gpu_run.to_cuda(c["detections"]),
+                        c["shapes"], gpu_run.to_cuda(c["targets"]), c))
+
+    def run(inside):
+        monkeypatch.setenv("SKG_ADAMW_IN_BACKWARD", "1" if inside else "0")
+        head = gpu_run.build_head(case)
+        head.precision = precision
+        net = trainer.wrap_ddp(head, torch.device("cuda", 0))
+        opt = trainer.build_optimizer(net, lr=1e-3)
+        torch.manual_seed(7)
+        losses, took = [], 0
+        real = trainer.SkgAdamW.backward_done
+
+        def counted(self, sl):
+            nonlocal took
+            took += 1
+            return real(self, sl)
+        monkeypatch.setattr(trainer.SkgAdamW, "backward_done", counted)
+        for i, (f, d, s, t, c) in enumerate(batches):
+            head.box_roi_pool = gpu_run.CachedPool(c)
+            nxt = batches[i + 1][:4] if i + 1 < len(batches) else None
+            l, _ = trainer.train_step(net, opt, f, d, s, targets=t, lazy=True, prefetch=nxt)
+            losses.append(trainer.read_losses(l))
+        monkeypatch.setattr(trainer.SkgAdamW, "backward_done", real)
+        torch.cuda.synchronize()
+        return head, opt, losses, took
+
+    h0, o0, l0, n0 = run(False)
+    h1, o1, l1, n1 = run(True)
+    assert n0 == 0 and n1 >= 2, (n0, n1)                      # the later steps really took the in-backward route
+    assert l0 == l1
+    for (k, a), (_, b) in zip(h0.state_dict().items(), h1.state_dict().items()):
+        assert torch.equal(a, b), k
+    s0, s1 = o0.state_dict()["state"], o1.state_dict()["state"]
+    assert s0.keys() == s1.keys()
+    for k in s0:
+        for name in ("step", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(s0[k][name], s1[k][name]), (k, name)
+        assert float(s1[k]["step"]) == len(batches)
+
+
+@pytest.mark.gpu
 def test_training_in_the_arena_keeps_eval_and_checkpoints_consistent():
     """After training steps the 408 parameters are views of the flat arena the optimizer updates in place.  The eval engine
     must notice every update (its packed copies are rebuilt), a checkpoint written from the arena-backed module must load
