@@ -576,6 +576,7 @@ class HeadEngine:
         self.small_two_branches = os.environ.get("SKG_SMALL_ONE_BRANCH") != "1"    # captured plans: spatial chain beside the box_head chain
         self.small_batch_max = 8    # eval batches of up to this many images replay a captured hipGraph (skghoi_amd/small.py); 0: off
         self.small_batch_buckets = True   # single images share one plan per BUCKET of (humans, nodes) instead of one per shape
+        self.small_capture_after = 2      # an exact-shape plan is captured at the shape's 2nd sighting (eager until then; 1: at once)
         self._small = None
         self.last = None          # intermediates of the last graph pass (parity tests read them)
 

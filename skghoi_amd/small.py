@@ -30,7 +30,8 @@ garbage in the unused rows, which nothing reads: the pair kernel fills the index
 entries and zero features (skg_pairs_spatial_padded_f32).  A few dozen plans cover every shape; padded work costs
 at most (1.4)^2 of the rows.  Results equal the eager path's up to the summation order of split-K reductions (their
 factors follow the capacity), i.e. ~1e-7 relative; integer outputs are identical.  Batches of 2..8 images keep one plan per
-exact shape tuple.
+exact shape tuple, captured when the tuple is seen for the second time (engine.small_capture_after): the first call with a
+new tuple takes the eager path, so a stream whose tuples never repeat never pays a capture.
 
 Reference path replaced: heads/adamixer_transH_spatial_r50_head.py:341-429 (InteractionHead.forward, eval mode).
 """
@@ -70,6 +71,8 @@ class SmallBatchRunner:
         self.plans = OrderedDict()
         self.pool = None                   # graph memory pool shared by the plans (one forward at a time per engine)
         self.hits = self.misses = 0
+        self.deferred = 0                  # calls that took the eager path because their exact shape had not been seen often enough
+        self.sightings = OrderedDict()     # exact-shape keys seen but not captured yet -> count
         self.side = None                   # second stream of the plan bodies (second branch of the captured graphs)
         self.epoch = engine.plan_epoch
         self.retired = []                  # dropped plans: destroyed only on an idle device, never next to a capture
@@ -83,7 +86,7 @@ class SmallBatchRunner:
     def stats(self):
         n = self.hits + self.misses
         return dict(calls=n, hits=self.hits, misses=self.misses, hit_rate=(self.hits / n if n else None),
-                    captures=self.captures, evictions=self.evictions, plans=len(self.plans))
+                    captures=self.captures, evictions=self.evictions, plans=len(self.plans), deferred=self.deferred)
 
     def close(self):
         """Drops every plan through the idle-device path (engine replaced, head torn down, tests)."""
@@ -283,6 +286,20 @@ class SmallBatchRunner:
         key = shape_key + (tuple(feat3.shape[:2]), eng.precision, eng.gh.num_iter, eng.faithful_skip_offset,
                            eng.plan_epoch, dev.index)
         p = self.plans.get(key)
+        if p is None and not bucket and eng.small_capture_after > 1:
+            # exact-shape plans (batches of 2..8 images, single images without buckets): a capture costs 10-20 ms -- an eager
+            # forward 1-2 -- and pays only for a shape that comes back.  A stream of batches whose shape tuples never repeat
+            # (any real dataset at batch 4) would capture on EVERY call; so a shape is captured when it is seen for the
+            # `small_capture_after`-th time and served by the eager path until then.
+            seen = self.sightings.get(key, 0) + 1
+            if seen < eng.small_capture_after:
+                self.sightings[key] = seen
+                self.sightings.move_to_end(key)
+                while len(self.sightings) > 4096:
+                    self.sightings.popitem(last=False)
+                self.deferred += 1
+                return self._fallback(head, pre, features, image_shapes)
+            self.sightings.pop(key, None)
         call_lay = None
         if bucket:
             call_lay = layout.single(nh1, n1, int(pre.L[0]), image_shapes[0])

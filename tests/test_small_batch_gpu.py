@@ -18,11 +18,12 @@ pytestmark = pytest.mark.gpu
 SMALL_CASES = [c for c in cases.EVAL_CASES if c not in ("eval_targets", "many12")]
 
 
-def _run(head, case, seed, small, det=None, shapes=None, feat3=None, buckets=False):
+def _run(head, case, seed, small, det=None, shapes=None, feat3=None, buckets=False, capture_after=1):
     eng = head.engine()
     eng.debug = False
     eng.small_batch_max = 8 if small else 0
     eng.small_batch_buckets = buckets            # exact-shape plans are bit-identical to eager; bucket plans: see below
+    eng.small_capture_after = capture_after      # 1: capture at the first sighting (these tests count captures and replays)
     det = gpu_run.to_cuda(case["detections"]) if det is None else det
     feat3 = case["feat3"].cuda() if feat3 is None else feat3
     feats = OrderedDict((k, feat3) for k in "0123")
@@ -125,6 +126,23 @@ def test_small_path_reference_quirks_and_errors():
     head3 = gpu_run.build_head(only, reference_quirks=False).eval()
     got, _, _ = _run(head3, only, 3, small=True)
     assert len(got) == 1 and got[0]["boxes_h"].shape == (0, 4)
+
+
+def test_an_exact_shape_is_captured_at_its_second_sighting():
+    """The default for exact-shape plans (batches of 2..8 images): the first call with a shape tuple takes the eager path and
+    only notes the shape, the second captures, the third replays -- a stream whose shapes never repeat never pays a capture.
+    All three results are bit-identical to eager."""
+    case = cases.build_case("ragged3")
+    head = gpu_run.build_head(case).eval()
+    runner = None
+    for i, want_stats in enumerate([(1, 0, 0), (1, 1, 0), (1, 1, 1)]):
+        want, _, _ = _run(head, case, 20 + i, small=False)
+        got, _, _ = _run(head, case, 20 + i, small=True, capture_after=2)
+        _same(got, want)
+        runner = head.engine()._small
+        st = runner.stats()
+        assert (st["deferred"], st["misses"], st["hits"]) == want_stats, (i, st)
+    assert len(case["detections"]) >= 2 and not runner.sightings          # (a multi-image batch; the noted shape was consumed)
 
 
 def test_plans_are_dropped_when_weights_change():
