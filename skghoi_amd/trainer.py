@@ -140,10 +140,14 @@ class NativeComm:
         import os
         import warnings
         from . import _capi
-        if os.environ.get("SKG_NATIVE_RCCL", "1") == "0" or dist.get_backend(group) != "nccl" or device.type != "cuda":
+        # SKG_RCCL_LIB: the library to bind instead of PyTorch's librccl (another RCCL build -- or the blocking shared-memory
+        # stand-in of tests/fake_rccl, which lets two ranks on ONE GPU run this route end to end over a gloo group)
+        named = os.environ.get("SKG_RCCL_LIB")
+        if os.environ.get("SKG_NATIVE_RCCL", "1") == "0" or device.type != "cuda" or \
+                (dist.get_backend(group) != "nccl" and not named):
             return None
         lib = _capi.lib()
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        path = named or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         loaded = lib.skg_comm_load(path.encode() if os.path.exists(path) else None) == 0
         if not cls._agree(device, group, loaded):
             return None

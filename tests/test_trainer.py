@@ -122,7 +122,18 @@ def _offset_pool(case, first_row):
     return Pool()
 
 
-def _dp_equiv_worker(rank, world, port, ref_path, q):
+def _build_fake_rccl(tmp_path):
+    """tests/fake_rccl/fake_rccl.cpp -> a shared library with RCCL's entry points over POSIX shared memory (blocking, summed
+    in rank order, checks that every rank is in the same collective)."""
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "fake_rccl.cpp")
+    out = str(tmp_path / "libfake_rccl.so")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", out,
+                    "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-pthread", "-Wno-format-truncation"], check=True)
+    return out
+
+
+def _dp_equiv_worker(rank, world, port, ref_path, q, rccl_lib=None):
     """One rank of test_two_ranks_through_the_hip_arena_equal_the_unsharded_step: image `rank` of train_tiny through
     trainer.train_step (fused step, backward on the library's worker thread, arena chunks behind its stage events)."""
     import sys
@@ -131,6 +142,8 @@ def _dp_equiv_worker(rank, world, port, ref_path, q):
     from collections import OrderedDict
     import cases, gpu_run
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    if rccl_lib:
+        os.environ["SKG_RCCL_LIB"] = rccl_lib
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     ref = torch.load(ref_path)
@@ -145,6 +158,10 @@ def _dp_equiv_worker(rank, world, port, ref_path, q):
     head.box_roi_pool = _offset_pool(full, ref["n0"] * rank)
     net = trainer.wrap_ddp(head, torch.device("cuda", 0))
     assert net is head and head.grad_exchange is not None
+    native = head.grad_exchange.native
+    assert (native is not None) == bool(rccl_lib)
+    from skghoi_amd import _capi
+    issued0 = int(_capi.lib().skg_comm_collectives(native.handle)) if native else 0
     opt = trainer.build_optimizer(net, lr=1e-4)
     feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
     # the TransH tables feed fc_head / fc_tail (HEAD:884-885), so the step depends on the host RNG: this rank's generator
@@ -171,14 +188,22 @@ def _dp_equiv_worker(rank, world, port, ref_path, q):
             so = max(float(o.abs().max()), 1e-6)
             worst_o = max(worst_o, (max(float((g - o).abs().max()) - 1e-9, 0.0) / so, name))
         worst_w = max(worst_w, (float((p.detach().cpu() - ref["weights"][name]).abs().max()), name))
-    q.put((rank, losses, worst_g, worst_o, worst_w, staged, head.grad_exchange.collectives))
+    issued = int(_capi.lib().skg_comm_collectives(native.handle)) - issued0 if native else None
+    q.put((rank, losses, worst_g, worst_o, worst_w, staged, head.grad_exchange.collectives, issued))
     dist.barrier()
+    if native:
+        native.close()
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-def test_two_ranks_through_the_hip_arena_equal_the_unsharded_step(tmp_path):
-    """The data-parallel step as a rank of BASELINE config 4 runs it -- one image per rank, the HIP backward issued by the
+@pytest.mark.parametrize("transport", ["torch.distributed", "library"])
+def test_two_ranks_through_the_hip_arena_equal_the_unsharded_step(tmp_path, transport):
+    """transport = "library": the collectives are issued by libskghoi_hip's worker thread on its own communicator
+    (skg_comm, skg_ctx_train_backward_exchange_f32) -- bound, for this test, to tests/fake_rccl instead of RCCL, which
+    refuses two ranks on one device: everything of the route but RCCL's own ring runs, between two real ranks.
+
+    The data-parallel step as a rank of BASELINE config 4 runs it -- one image per rank, the HIP backward issued by the
     library's worker thread in one call, the gradient arena leaving chunk by chunk behind its stage events, the fused
     3-element normaliser all-reduce -- against the SAME two images as one batch in a single process: gradients of all 408
     parameters (after the exchange) and the weights after one AdamW step agree, and both agree with the oracle's autograd
@@ -217,20 +242,26 @@ def test_two_ranks_through_the_hip_arena_equal_the_unsharded_step(tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dp_equiv_worker, args=(r, 2, port, path, q)) for r in range(2)]
+    fake = _build_fake_rccl(tmp_path) if transport == "library" else None
+    procs = [ctx.Process(target=_dp_equiv_worker, args=(r, 2, port, path, q, fake)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    for rank, losses, worst_g, worst_o, worst_w, staged, k in res:
+    for rank, losses, worst_g, worst_o, worst_w, staged, k, issued in res:
         assert worst_g[0] <= 1e-5, (rank, worst_g, worst_o, worst_w)    # exchanged arena == un-sharded arena (summation order)
         assert worst_o[0] <= 1e-4, (rank, worst_o)          # ... == oracle autograd of the two-image batch
         # the replicas took the un-sharded step (the reference's lr, main:109; AdamW's first update lr * g / (|g| + eps) turns
         # the summation-order noise of near-zero gradient entries into at most a few 1e-7 of weight)
         assert worst_w[0] <= 1e-6, (rank, worst_w)
-        assert staged == sorted(staged) and len(staged) == k and 2 <= k <= 12, (staged, k)    # one host wait per chunk
+        if fake:
+            # the worker issued one all-reduce per arena chunk, the preparation one for the normalisers; nothing was driven
+            # from Python
+            assert staged == [] and 2 <= k <= 12 and issued == k + 1, (staged, k, issued)
+        else:
+            assert staged == sorted(staged) and len(staged) == k and 2 <= k <= 12, (staged, k)    # one host wait per chunk
     # data-parallel normaliser: local sum / (all_reduce_sum(n_p) / world)  ->  the mean over ranks is the batch loss
     for key in ("hoi_loss", "interactiveness_loss"):
         mean = 0.5 * (res[0][1][key] + res[1][1][key])
