@@ -603,7 +603,10 @@ class InteractionHead(Module):
         norm = []
         # the three n_p normalisers (HEAD:162-172, 190-199, 219-228) leave as ONE 3-element all-reduce as soon as the
         # labels exist, and come back as a device tensor when the loss scalars are formed: no barrier, no .item()
-        on_counts = (lambda c: norm.append(_skd.start_normalisers(c, self.distributed))) if with_losses else None
+        ex = getattr(self, "grad_exchange", None)       # (its communicator and group: the SAME collective as peers on the fused route)
+        on_counts = (lambda c: norm.append(_skd.start_normalisers(
+            c, self.distributed, group=getattr(ex, "group", None), force=getattr(self, "force_collectives", False),
+            native=getattr(ex, "native", None)))) if with_losses else None
         (feats, bh, bo, oc, labels, prior, pos, neg, he, te, re, rn), lay, P = graph_train(
             eng, self.box_pair_head, features["3"], image_shapes, box_features, pre, targets, on_counts=on_counts)
         if len(feats) == 0:

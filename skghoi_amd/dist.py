@@ -78,23 +78,6 @@ def gather_counts(value, device=None, group=None):
     return [int(o.item()) for o in out]
 
 
-class Normalisers:
-    """Handle of the in-flight fused `n_p` all-reduce.  `get()` -> float32 device tensor [3] = all_reduce_sum(counts) /
-    world_size (HEAD:167-172 per term), without a host synchronisation: waiting on the work object only orders the
-    collective's stream before the current one."""
-
-    def __init__(self, vals, work, world):
-        self.vals, self.work, self.world = vals, work, world
-        self._out = None
-
-    def get(self):
-        if self._out is None:
-            if self.work is not None:
-                self.work.wait()
-            self._out = (self.vals / self.world).to(torch.float32)
-        return self._out
-
-
 class PreparedNormalisers:
     """The fused `n_p` all-reduce of a PREPARED training batch (skghoi_amd.train_fused.prepare_steps): float32 device
     counts [3] (integer-valued, exact), summed in place over the ranks from the stream the preparation runs on, as soon as
@@ -102,8 +85,10 @@ class PreparedNormalisers:
     then n_p / world_size in float32), ordered behind the collective on the stream get() is called on -- the preparation's
     side stream when the batch was prefetched (`finish()`), the step's stream otherwise."""
 
-    def __init__(self, counts, group=None, force=False, native=None):
+    def __init__(self, counts, group=None, force=False, native=None, enabled=True):
         self.vals, self.work, self.world, self._done, self.native = counts, None, 1, False, None
+        if not enabled:
+            return
         if native is not None:
             # the trainer's gradient exchange runs on the HIP library's own RCCL communicator (trainer.NativeComm): this
             # collective joins it there -- ONE communicator, one issue order on every rank [chunks of step i, this]
@@ -132,16 +117,16 @@ class PreparedNormalisers:
         return self.vals
 
 
-def start_normalisers(counts, distributed=True, group=None, force=False):
+def start_normalisers(counts, distributed=True, group=None, force=False, native=None):
     """counts: device (or CPU, for gloo) tensor of the three per-rank normaliser counts {#positive scored cells,
     #positive pairs, #positive pairs}.  Starts ONE 3-element all-reduce (async) when a process group with more than
-    one rank is up and `distributed`; returns a Normalisers handle."""
-    vals = counts.to(torch.float64).reshape(3).clone()
-    work, world = None, 1
-    if distributed and dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
-        world = dist.get_world_size(group)
-        work = dist.all_reduce(vals, op=dist.ReduceOp.SUM, group=group, async_op=True)
-    return Normalisers(vals, work, world)
+    one rank is up and `distributed`; returns a handle whose get() is all_reduce_sum(counts) / world_size as float32 [3].
+    The SAME collective as the fused step's preparation issues (PreparedNormalisers: three fp32 words in place, on the
+    trainer's communicator): a rank whose batch takes this route -- the autograd path -- meets ranks on the fused route."""
+    vals = counts.to(torch.float32).reshape(3).clone()
+    if not distributed:
+        return PreparedNormalisers(vals, enabled=False)
+    return PreparedNormalisers(vals, group=group, force=force, native=native)
 
 
 def _all_gather_ragged(t, group=None):

@@ -1300,7 +1300,9 @@ class TrainRun:
             counts = torch.empty(3, **f32)
             _check(lib.skg_loss_finish_f32(partial.data_ptr(), rows, mpart.data_ptr(), A, M_pos, 1.0, None, None, None,
                                            counts.data_ptr(), stream), "skg_loss_finish_f32")
-            norm = skd.start_normalisers(counts, True, force=force).get().contiguous()     # ONE fused 3-element all-reduce
+            ex_ = getattr(head, "grad_exchange", None)
+            norm = skd.start_normalisers(counts, True, group=getattr(ex_, "group", None), force=force,
+                                         native=getattr(ex_, "native", None)).get().contiguous()     # ONE fused 3-element all-reduce
         ex = getattr(head, "grad_exchange", None)
         share = 1.0
         if ex is not None and norm is not None:

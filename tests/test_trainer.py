@@ -196,6 +196,91 @@ def _dp_equiv_worker(rank, world, port, ref_path, q, rccl_lib=None):
     dist.destroy_process_group()
 
 
+def _dp_steps_worker(rank, world, port, out_path, q, rccl_lib, adamw_inside):
+    """One rank of test_data_parallel_routes_take_the_same_steps: four training steps with look-ahead, image (rank + step) % 2
+    of train_tiny (every batch has pairs: one without raises, here as in the reference); the weights go to out_path."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from collections import OrderedDict
+    import cases, gpu_run
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["SKG_ADAMW_IN_BACKWARD"] = "1" if adamw_inside else "0"
+    if rccl_lib:
+        os.environ["SKG_RCCL_LIB"] = rccl_lib
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    batches = []
+    for step in range(4):
+        c = dict(cases.build_case("train_tiny"))
+        keep = (rank + step) % len(c["detections"])
+        for k in ("detections", "targets", "shapes"):
+            c[k] = c[k][keep:keep + 1]
+        c["feat3"] = c["feat3"][keep:keep + 1]
+        batches.append(c)
+    head = gpu_run.build_head(batches[0])
+    head.distributed = True
+    net = trainer.wrap_ddp(head, torch.device("cuda", 0))
+    ex = head.grad_exchange
+    assert (ex.native is not None) == bool(rccl_lib)
+    opt = trainer.build_optimizer(net, lr=1e-3)
+    torch.manual_seed(100 + rank)
+    inside = []
+    real = trainer.SkgAdamW.backward_done
+    trainer.SkgAdamW.backward_done = lambda self, sl: (inside.append(1), real(self, sl))[1]
+    feed = [(OrderedDict((k, c["feat3"].cuda()) for k in "0123"), gpu_run.to_cuda(c["detections"]), c["shapes"],
+             gpu_run.to_cuda(c["targets"])) for c in batches]
+    losses = []
+    for i, (f, d, s_, t) in enumerate(feed):
+        head.box_roi_pool = gpu_run.CachedPool(batches[i])
+        nxt = feed[i + 1] if i + 1 < len(feed) else None
+        l, _ = trainer.train_step(net, opt, f, d, s_, targets=t, lazy=True, prefetch=nxt)
+        losses.append(trainer.read_losses(l))
+    torch.cuda.synchronize()
+    torch.save({n: p.detach().cpu() for n, p in head.named_parameters()}, out_path)
+    q.put((rank, losses, len(inside)))
+    dist.barrier()
+    if ex.native is not None:
+        ex.native.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_data_parallel_routes_take_the_same_steps(tmp_path):
+    """Four data-parallel steps with look-ahead (two ranks on one GPU, different images per rank, the next batch's normaliser
+    all-reduce issued by its preparation): (a) collectives through torch.distributed from the Python thread, (b) issued by the
+    library's worker thread on its own communicator (the shared-memory stand-in for RCCL), (c) as (b) with the optimizer
+    inside the backward, each chunk's parameters updated right behind the chunk's all-reduce.  Every route leaves both
+    replicas with identical weights, and the three routes agree with each other: same losses, weights equal to 1e-6 relative
+    (the sums of two ranks commute; what differs is where the collectives are issued)."""
+    import torch.multiprocessing as mp
+    fake = _build_fake_rccl(tmp_path)
+    runs = {}
+    for tag, lib_, inside in (("torch", None, False), ("library", fake, False), ("library+adamw", fake, True)):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        paths = [str(tmp_path / ("%s_%d.pt" % (tag.replace("+", "_"), r))) for r in range(2)]
+        procs = [ctx.Process(target=_dp_steps_worker, args=(r, 2, port, paths[r], q, lib_, inside)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=150) for _ in range(2))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        w = [torch.load(pp) for pp in paths]
+        for n in w[0]:
+            assert torch.equal(w[0][n], w[1][n]), (tag, n)              # the replicas took the same step
+        runs[tag] = (w[0], [r[1] for r in res], [r[2] for r in res])
+    assert runs["library+adamw"][2] == [3, 3] and runs["library"][2] == [0, 0]      # (the first step creates the optimizer state: step())
+    base = runs["torch"]
+    for tag in ("library", "library+adamw"):
+        assert runs[tag][1] == base[1], tag                            # per-rank losses of every step
+        for n, a in base[0].items():
+            b = runs[tag][0][n]
+            assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max())), (tag, n)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("transport", ["torch.distributed", "library"])
 def test_two_ranks_through_the_hip_arena_equal_the_unsharded_step(tmp_path, transport):
