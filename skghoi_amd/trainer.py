@@ -386,8 +386,10 @@ class ArenaExchange:
                 if p.grad is not None:
                     v.copy_(p.grad)
         # this rank's share of the mean goes in before the sum, like its peers' (whose fused step folded 1 / world into
-        # their logit gradients): every rank then ends with the same sum
-        ga.mul_(1.0 / self.world)
+        # their logit gradients): every rank then ends with the same sum.  A step that left the fused node AFTER the shared
+        # loss tail (the Python-issued launch plan: train_fused.TrainRun.tail) already carries the share in its gradients.
+        if not self.prescaled:
+            ga.mul_(1.0 / self.world)
         self.begin(ga)
         self.prescaled = True
         if self.native is not None:

@@ -196,7 +196,7 @@ def _dp_equiv_worker(rank, world, port, ref_path, q, rccl_lib=None):
     dist.destroy_process_group()
 
 
-def _dp_steps_worker(rank, world, port, out_path, q, rccl_lib, adamw_inside):
+def _dp_steps_worker(rank, world, port, out_path, q, rccl_lib, adamw_inside, python_plan_rank=-1):
     """One rank of test_data_parallel_routes_take_the_same_steps: four training steps with look-ahead, image (rank + step) % 2
     of train_tiny (every batch has pairs: one without raises, here as in the reference); the weights go to out_path."""
     import sys
@@ -220,6 +220,8 @@ def _dp_steps_worker(rank, world, port, out_path, q, rccl_lib, adamw_inside):
         batches.append(c)
     head = gpu_run.build_head(batches[0])
     head.distributed = True
+    if rank == python_plan_rank:
+        head.train_plan = "python"       # this rank leaves the fused node: autograd route, launches issued from Python
     net = trainer.wrap_ddp(head, torch.device("cuda", 0))
     ex = head.grad_exchange
     assert (ex.native is not None) == bool(rccl_lib)
@@ -256,12 +258,13 @@ def test_data_parallel_routes_take_the_same_steps(tmp_path):
     import torch.multiprocessing as mp
     fake = _build_fake_rccl(tmp_path)
     runs = {}
-    for tag, lib_, inside in (("torch", None, False), ("library", fake, False), ("library+adamw", fake, True)):
+    for tag, lib_, inside, pyrank in (("torch", None, False, -1), ("library", fake, False, -1), ("library+adamw", fake, True, -1),
+                                      ("library, rank 1 off the fused node", fake, True, 1)):
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         port = _free_port()
-        paths = [str(tmp_path / ("%s_%d.pt" % (tag.replace("+", "_"), r))) for r in range(2)]
-        procs = [ctx.Process(target=_dp_steps_worker, args=(r, 2, port, paths[r], q, lib_, inside)) for r in range(2)]
+        paths = [str(tmp_path / ("run%d_%d.pt" % (len(runs), r))) for r in range(2)]
+        procs = [ctx.Process(target=_dp_steps_worker, args=(r, 2, port, paths[r], q, lib_, inside, pyrank)) for r in range(2)]
         for p in procs:
             p.start()
         res = sorted(q.get(timeout=150) for _ in range(2))
@@ -279,6 +282,18 @@ def test_data_parallel_routes_take_the_same_steps(tmp_path):
         for n, a in base[0].items():
             b = runs[tag][0][n]
             assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max())), (tag, n)
+    # a rank whose step leaves the fused node (here: the Python-issued launch plan) meets its peer's collectives one for one
+    # -- the normalisers from its autograd forward, the arena chunks after its backward -- and takes its optimizer step after
+    # the join while the peer updates inside the backward: replicas identical (asserted above), and the same training up to
+    # the summation order of the Python plan's three small reductions
+    mixed = runs["library, rank 1 off the fused node"]
+    assert mixed[2] == [3, 0]
+    for r in range(2):
+        for st_, (la, lb) in enumerate(zip(base[1][r], mixed[1][r])):
+            for k in la:
+                assert abs(la[k] - lb[k]) <= 2e-3 * max(1.0, abs(la[k])), (r, st_, k, base[1][r], mixed[1][r])
+    for n, a in base[0].items():
+        assert float((a - mixed[0][n]).abs().max()) <= 2e-4 * max(1.0, float(a.abs().max())), n
 
 
 @pytest.mark.gpu
