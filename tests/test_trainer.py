@@ -46,6 +46,18 @@ def test_host_cpu_share_and_thread_limit():
         torch.set_num_threads(before)
 
 
+def _gather(procs, q, n, timeout):
+    """n results from the workers' queue; whatever happens, no worker outlives the call (a rank stuck in a collective would
+    hold the GPU box until the run's own limit)."""
+    try:
+        return [q.get(timeout=timeout) for _ in range(n)]
+    except Exception:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        raise
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -94,7 +106,7 @@ def test_two_rank_ddp_train_step_on_one_gpu():
     procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    res = sorted(_gather(procs, q, 2, 300), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -259,7 +271,8 @@ def test_data_parallel_routes_take_the_same_steps(tmp_path):
     fake = _build_fake_rccl(tmp_path)
     runs = {}
     for tag, lib_, inside, pyrank in (("torch", None, False, -1), ("library", fake, False, -1), ("library+adamw", fake, True, -1),
-                                      ("library, rank 1 off the fused node", fake, True, 1)):
+                                      ("library, rank 1 off the fused node", fake, True, 1),
+                                      ("torch, rank 1 off the fused node", None, False, 1)):
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         port = _free_port()
@@ -267,10 +280,15 @@ def test_data_parallel_routes_take_the_same_steps(tmp_path):
         procs = [ctx.Process(target=_dp_steps_worker, args=(r, 2, port, paths[r], q, lib_, inside, pyrank)) for r in range(2)]
         for p in procs:
             p.start()
-        res = sorted(q.get(timeout=150) for _ in range(2))
-        for p in procs:
-            p.join(timeout=60)
-            assert p.exitcode == 0
+        try:
+            res = sorted(q.get(timeout=150) for _ in range(2))
+            for p in procs:
+                p.join(timeout=60)
+                assert p.exitcode == 0, tag
+        finally:
+            for p in procs:                                            # (a rank stuck in a collective must not outlive the test)
+                if p.is_alive():
+                    p.kill()
         w = [torch.load(pp) for pp in paths]
         for n in w[0]:
             assert torch.equal(w[0][n], w[1][n]), (tag, n)              # the replicas took the same step
@@ -286,14 +304,15 @@ def test_data_parallel_routes_take_the_same_steps(tmp_path):
     # -- the normalisers from its autograd forward, the arena chunks after its backward -- and takes its optimizer step after
     # the join while the peer updates inside the backward: replicas identical (asserted above), and the same training up to
     # the summation order of the Python plan's three small reductions
-    mixed = runs["library, rank 1 off the fused node"]
-    assert mixed[2] == [3, 0]
-    for r in range(2):
-        for st_, (la, lb) in enumerate(zip(base[1][r], mixed[1][r])):
-            for k in la:
-                assert abs(la[k] - lb[k]) <= 2e-3 * max(1.0, abs(la[k])), (r, st_, k, base[1][r], mixed[1][r])
-    for n, a in base[0].items():
-        assert float((a - mixed[0][n]).abs().max()) <= 2e-4 * max(1.0, float(a.abs().max())), n
+    assert runs["library, rank 1 off the fused node"][2] == [3, 0]
+    for tag in ("library, rank 1 off the fused node", "torch, rank 1 off the fused node"):
+        mixed = runs[tag]
+        for r in range(2):
+            for st_, (la, lb) in enumerate(zip(base[1][r], mixed[1][r])):
+                for k in la:
+                    assert abs(la[k] - lb[k]) <= 2e-3 * max(1.0, abs(la[k])), (tag, r, st_, k, base[1][r], mixed[1][r])
+        for n, a in base[0].items():
+            assert float((a - mixed[0][n]).abs().max()) <= 2e-4 * max(1.0, float(a.abs().max())), (tag, n)
 
 
 @pytest.mark.gpu
@@ -346,7 +365,7 @@ def test_two_ranks_through_the_hip_arena_equal_the_unsharded_step(tmp_path, tran
     procs = [ctx.Process(target=_dp_equiv_worker, args=(r, 2, port, path, q, fake)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    res = sorted(_gather(procs, q, 2, 300), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -610,7 +629,7 @@ def test_gradient_exchange_on_the_librarys_own_rccl_communicator(tmp_path):
     q = ctx.Queue()
     p = ctx.Process(target=_native_comm_worker, args=(_free_port(), path, q))
     p.start()
-    rec = q.get(timeout=240)
+    rec = _gather([p], q, 1, 240)[0]
     p.join(timeout=60)
     assert p.exitcode == 0
     assert rec["native"], rec
@@ -654,7 +673,7 @@ def test_two_ranks_on_one_device_agree_to_decline_the_librarys_communicator():
     procs = [ctx.Process(target=_declined_comm_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=200) for _ in range(2))
+    res = sorted(_gather(procs, q, 2, 200))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -723,7 +742,7 @@ def test_ddp_remainder_beside_the_arena_exchange():
     procs = [ctx.Process(target=_remainder_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=150) for _ in range(2)), key=lambda t: t[0])
+    res = sorted(_gather(procs, q, 2, 150), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
