@@ -360,6 +360,9 @@ def enqueue_row_exponents(d, device):
     return t
 
 
+_LONGK_SMALL_TILES = os.environ.get("SKG_LONGK_SMALL_TILES", "1") != "0"        # (developer A/B switch)
+
+
 def pick_split_k(M, N, K, target_blocks=1024):
     """Split-K factor for a plain layer whose M x N tile grid would leave most of the 256 CUs idle while each
     workgroup walks a long K (box_head: K = 12544).  Slices keep >= 16 k-tiles (256 k) each."""
@@ -370,6 +373,13 @@ def pick_split_k(M, N, K, target_blocks=1024):
         return int(max(1, min(-(-512 // blocks), K // 64, 64))) if K >= 512 else 1
     if blocks >= target_blocks or K < 2048:
         return 1
+    if M <= 512 and K >= 4096 and _LONGK_SMALL_TILES:
+        # a few images' box rows against K = 12544 (box_head layer 1 at 2 ... 8 images): 128-row tiles spend up to half their
+        # MFMAs on padding rows and ~50 slices of 16 k-steps each cost a launch of 784 workgroups 86 us at M = 160.  Fewer,
+        # longer slices keep the launch under the launcher's bounds for 64 x 64 tiles on the latency loop (fewer than 200 tiles
+        # of 128 x 128, slices included: csrc/skg_gemm.hip g_route_tiles / g_small_tiles) with ~3 workgroups per CU.
+        blocks64 = ((M + 63) // 64) * ((N + 63) // 64)
+        return int(max(1, min(199 // blocks, -(-768 // blocks64), K // 256, 64)))
     return int(max(1, min(-(-target_blocks // blocks), K // 256, 64)))
 
 
