@@ -411,8 +411,10 @@ def gemm(A, W, bias, C_out, M, N, K, epilogue, **kw):
 
 # Workgroups a small (64 x 64 tile) grouped launch aims for; split-K supplies them.  Two costs pull against each other at a
 # few images (measured on MI355X): every workgroup costs ~10 ns of dispatch, and every k-tile a workgroup walks costs ~1 us
-# (one HBM / L2 round trip behind a one-tile-deep prefetch).  ~512 workgroups of >= 4 k-tiles sit near the minimum.
-SMALL_GROUP_BLOCKS = 512
+# (one HBM / L2 round trip behind a one-tile-deep prefetch).  ~512 workgroups of >= 4 k-tiles sat near the minimum in round 2;
+# re-swept at the end of round 4 (64-k steps, two stages in flight): 320 / 384 / 448 / 512 -> single 20 x 20 image 0.483-0.488 /
+# 0.474-0.482 / 0.502-0.504 / 0.498-0.499 ms, batches of 2 and 4 level, a stream of mixed shapes level (0.46-0.47 either way).
+SMALL_GROUP_BLOCKS = int(os.environ.get("SKG_SMALL_GROUP_BLOCKS") or 384)     # (the env override: developer sweeps)
 
 
 def gemm_group(specs):
