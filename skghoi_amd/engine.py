@@ -360,6 +360,7 @@ def enqueue_row_exponents(d, device):
     return t
 
 
+_M64_TARGET = int(os.environ.get("SKG_SPLIT_M64_TARGET") or 512)                  # (developer sweeps)
 _LONGK_SMALL_TILES = os.environ.get("SKG_LONGK_SMALL_TILES", "1") != "0"        # (developer A/B switch)
 
 
@@ -370,7 +371,7 @@ def pick_split_k(M, N, K, target_blocks=1024):
     if M <= 64:
         # one tile high: the launcher takes 64 x 64 tiles (skg_gemm_tile_scale); slices of >= 4 k-tiles
         blocks = (N + 63) // 64
-        return int(max(1, min(-(-512 // blocks), K // 64, 64))) if K >= 512 else 1
+        return int(max(1, min(-(-_M64_TARGET // blocks), K // 64, 64))) if K >= 512 else 1
     if blocks >= target_blocks or K < 2048:
         return 1
     if M <= 512 and K >= 4096 and _LONGK_SMALL_TILES:
