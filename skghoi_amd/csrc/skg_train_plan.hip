@@ -126,12 +126,14 @@ static skg_gemmx_desc WG(const Mat& dz, const Mat& x, const Mat& dW, float* db, 
 // With the staged epilogue and the four-column reduce a workgroup costs less and a slice's round trip relatively more:
 // re-swept on the step, bf16 128 / 192 / 256 / 320 / 448 / 640 -> 1.503 / 1.489 / 1.486 / 1.555 / 1.546 / 1.61 ms,
 // fp32 300 / 500 / 750 / 1000 / 1400 -> 2.676 / 2.672 / 2.703 / 2.696 / 2.81 ms.
+// End of round 4 (direct-to-LDS kernel on most launches): bf16 64 / 96 / 128 / 160 / 208 / 256 / 320 -> 1.332 / 1.260 / 1.274 /
+// 1.258 / 1.279 (other box) / 1.265 / 1.378 ms; fp32 350 / 500 / 700 level (2.49 / 2.48 / 2.49).
 static int split_target(int bk) {
     static int t16 = 0, t32 = 0;
     if (!t16) {
         const char* a = getenv("SKG_SPLIT_TARGET_F32"); const char* b = getenv("SKG_SPLIT_TARGET_BF16");    // developer knobs
         t16 = a && atoi(a) > 0 ? atoi(a) : 500;
-        t32 = b && atoi(b) > 0 ? atoi(b) : 256;
+        t32 = b && atoi(b) > 0 ? atoi(b) : 160;
     }
     return bk == 16 ? t16 : t32;
 }
