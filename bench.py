@@ -790,18 +790,39 @@ def main():
         # RCCL / xGMI) -- every rank runs it; value = whole-job images/s over the max-over-ranks time
         _trainer.limit_host_threads(world)
         ks = 40
-        el_t, losses, inf = run_train(4, "bf16", ks, 10, device, rank, world, True, measure=True)   # (every rank: the steps hold collectives)
-        el_t = skd.max_over_ranks(el_t, device=device)
-        ms = el_t / ks * 1e3
-        rec = dict(ms_per_step=round(ms, 3), images_per_s=round(4 * world * ks / el_t, 2), batch_per_gpu=4, steps=ks,
-                   n_gpus=world, scaling="weak", losses={k: round(v, 6) for k, v in losses.items()},
-                   grad_exchange=inf.get("grad_exchange"), dist=dist_info(world))
-        rec["roofline"] = train_roofline("bf16", ms, inf)
-        if inf.get("phases_ms"):
-            rec["phases_ms"] = inf["phases_ms"]
-        out["train"] = dict(bf16=rec, note="data-parallel training step on every rank: fwd + bwd + AdamW at batch 4 per GPU, "
-                                           "gradient arena exchanged in chunks behind the backward + one fused normaliser "
-                                           "all-reduce (RCCL); ms_per_step = max over ranks; roofline of rank 0")
+        # This leg is the first code to move gradients between real GPUs (a one-GPU box cannot): whatever goes wrong in it
+        # must not cost the run its headline line.  An exception becomes an error record; a leg that does not come back within
+        # the deadline (a rank stuck in a collective) makes rank 0 print the line without it and every rank leave.
+        import threading
+        leg_done = threading.Event()
+        deadline = float(os.environ.get("SKG_BENCH_TRAIN_DEADLINE", "300"))
+
+        def bail():
+            if leg_done.wait(deadline):
+                return
+            out["train"] = dict(bf16=dict(error="the data-parallel training leg did not finish within %.0f s" % deadline))
+            out["runtime"] = runtime_info()
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        threading.Thread(target=bail, daemon=True).start()
+        try:
+            el_t, losses, inf = run_train(4, "bf16", ks, 10, device, rank, world, True, measure=True)   # (every rank: the steps hold collectives)
+            el_t = skd.max_over_ranks(el_t, device=device)
+            ms = el_t / ks * 1e3
+            rec = dict(ms_per_step=round(ms, 3), images_per_s=round(4 * world * ks / el_t, 2), batch_per_gpu=4, steps=ks,
+                       n_gpus=world, scaling="weak", losses={k: round(v, 6) for k, v in losses.items()},
+                       grad_exchange=inf.get("grad_exchange"), dist=dist_info(world))
+            rec["roofline"] = train_roofline("bf16", ms, inf)
+            if inf.get("phases_ms"):
+                rec["phases_ms"] = inf["phases_ms"]
+            out["train"] = dict(bf16=rec, note="data-parallel training step on every rank: fwd + bwd + AdamW at batch 4 per GPU, "
+                                               "gradient arena exchanged in chunks behind the backward + one fused normaliser "
+                                               "all-reduce (RCCL); ms_per_step = max over ranks; roofline of rank 0")
+        except Exception as e:                                   # noqa: BLE001
+            out["train"] = dict(bf16=dict(error=("%s: %s" % (type(e).__name__, e))[:600]))
+        finally:
+            leg_done.set()
         torch.set_num_threads(max(1, host_cpu_share() // world))
     out["runtime"] = runtime_info()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
