@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SKG_ABI_VERSION 16
+#define SKG_ABI_VERSION 17
 #define SKG_E_ARG   (-1)   /* null pointer / negative size / unsupported shape            */
 #define SKG_E_ALIGN (-2)   /* pointer or leading dimension not 16-byte aligned            */
 #define SKG_E_LIMIT (-3)   /* exceeds a compiled-in limit (boxes per image, verbs, ...)   */
@@ -364,8 +364,10 @@ int skg_associate_f32(const float* boxes, const skg_image_meta* meta, int n_acti
  *   mask (optional) [M, >= N], ldmask: C is zeroed where mask <= 0 -- the ReLU of the layer that produced the tensor C is
  *   the gradient of; applied AFTER the accumulation (the sum of all contributions is what the ReLU cuts)
  *   split_k > 1: slices of K by separate workgroups into split_ws (skg_gemmx_ws_floats(desc) floats), reduced in slice
- *   order by a second launch that applies the epilogue.
- * Up to SKG_GEMMX_GROUP_MAX independent products per call share ONE launch (plus one reduce launch if any is split). */
+ *   order -- by the last-arriving workgroup of every tile inside the same launch when split_ctr is given, else by a
+ *   second launch -- with the epilogue applied to the sum.
+ * Up to SKG_GEMMX_GROUP_MAX independent products per call share ONE launch (plus one reduce launch if any is split
+ * without counters). */
 typedef struct {
     const float* A; int64_t a_sm, a_sk;
     const float* B; int64_t b_sn, b_sk;
@@ -386,6 +388,13 @@ typedef struct {
     const uint16_t* A16;
     const uint16_t* B16;
     uint16_t* C16;
+    /* split_k > 1 only, optional: device array of ceil(M / 128) * ceil(N / 128) counters, ZERO before the first launch that
+     * names it.  With it the slices are reduced INSIDE the product launch: every slice's workgroup stores its partial tile to
+     * split_ws and arrives at the tile's counter; the last arriver adds the slices in slice order (the same additions in the
+     * same order as the reduce launch: results are bit-identical, whichever slice finishes last) and applies the epilogue.
+     * No second launch; the counters are zero again when the launch ends (they wrap), so one array serves every later
+     * launch of the same stream.  Launches that may run CONCURRENTLY need arrays of their own.                          */
+    uint32_t* split_ctr;
 } skg_gemmx_desc;
 #define SKG_GEMMX_GROUP_MAX 8
 int64_t skg_gemmx_ws_floats(const skg_gemmx_desc* desc_host);
@@ -599,6 +608,10 @@ typedef struct {
      * by part 0 of the forward.  pf16: twin of pair_features.                                                          */
     uint16_t* ws16; uint16_t* params16; uint16_t* pf16;
     int64_t params_floats;
+    /* optional: n_counters zeroed uint32 (zero before the first call that names them; every call leaves them zero): the
+     * plan's split-K products are then reduced inside their own launch (skg_gemmx_desc.split_ctr) instead of by a second
+     * launch each -- 16 launches less per batch-4 step.  Products whose tiles do not fit keep the reduce launch.       */
+    uint32_t* counters; int64_t n_counters;
 } skg_train_plan;
 /* Floats of workspace the plan needs (activations kept for the backward, backward temporaries, split-K scratch);
  * < 0: rejected plan.  Only the sizes, bf16 and params (non-null) are read.                                              */

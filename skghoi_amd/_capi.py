@@ -12,7 +12,7 @@ MAX_NODES = 160
 SPATIAL_LD = 48
 TRANSH_DIM = 50
 TRANSH_ENT = 80
-ABI_VERSION = 16
+ABI_VERSION = 17
 GEMM_GROUP_MAX = 4
 CHECKSUM_PARTIALS = 1024
 LOSS_CHUNKS = 64
@@ -40,7 +40,7 @@ class GemmXDesc(C.Structure):
                 ("C", _vp), ("ldc", _i64), ("c_nshift", _i32), ("accumulate", _i32), ("c_nstride", _i64),
                 ("M", _i32), ("N", _i32), ("K", _i32), ("relu", _i32), ("bias", _vp), ("mask", _vp), ("ldmask", _i64),
                 ("a_rowsum", _vp), ("split_k", _i32), ("reserved", _i32), ("split_ws", _vp),
-                ("A16", _vp), ("B16", _vp), ("C16", _vp)]
+                ("A16", _vp), ("B16", _vp), ("C16", _vp), ("split_ctr", _vp)]
 
 
 GEMMX_GROUP_MAX = 8
@@ -81,7 +81,7 @@ class TrainPlan(C.Structure):
                                    "node_of")] + \
                [("ws", _vp), ("ws_floats", _i64), ("pair_features", _vp), ("logits", _vp), ("dlogits", _vp),
                 ("dx0", _vp), ("dgfeat", _vp), ("timer", _vp), ("ws16", _vp), ("params16", _vp), ("pf16", _vp),
-                ("params_floats", _i64)]
+                ("params_floats", _i64), ("counters", _vp), ("n_counters", _i64)]
 
 
 LAYOUT_SLICES = ("meta", "node_img", "hum_img", "node_enc_row", "hum_enc_row", "node_ent_row", "hum_ent_row", "enc_row_hn",

@@ -180,7 +180,86 @@ __device__ __forceinline__ uint32_t ypack(float a, float b) {          // two fl
 #define XEP_WAVE (32 * XEP_LD)
 #define XEP_FLOATS (4 * XEP_WAVE)            // 36 KiB per workgroup
 
-// Rows [row0, row0 + 32) x columns [col0, col0 + 64) of the product from the wave's staged block.
+// ---- split-K reduced INSIDE the product launch (skg_gemmx_desc.split_ctr).  Every slice's workgroup stores its partial tile
+// (and partial row sums) to split_ws as before, then ARRIVES at the tile's counter: atomicInc wraps at S - 1, so the workgroup
+// that reads S - 1 is the last one and the counter is zero again for the next launch -- no reset pass, no second kernel.  The
+// last arriver adds the slices IN SLICE ORDER (its own from its registers at its position in that order: the same additions
+// in the same order as skg_gemmx_reduce_kernel, whichever slice happens to finish last -- deterministic, no float atomics) and
+// applies the epilogue.  Partials cross XCDs (private L2s): the stores are released and the reads acquired at device scope
+// (__threadfence = L2 write-back before the arrival, invalidate after it).  The tile order keeps a tile's slices adjacent
+// on one XCD (xtile_of), so the partials are normally still in that XCD's L2.
+struct XRed { const float* ws; int64_t MN; int S, slice; };
+
+// Arrival of one slice's workgroup at its tile's counter; true for the last one.  The hand-off is the counter form of the
+// inter-workgroup recipe (cdna_hip_programming.md, in-launch split-K): every wave drains its stores, the workgroup meets,
+// ONE lane releases at device scope (L2 write-back), waits for that, and only then adds; the last arriver acquires at device
+// scope before anybody of its workgroup loads a partial.  `flag`: a free word of the kernel's ONE LDS array (a second
+// __shared__ object beside a DMA-staged ring makes hipcc drain the ring in front of every k-step's first ds_read).
+__device__ __forceinline__ bool xsplit_last(uint32_t* ctr, int S, volatile uint32_t* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (kept: the compiler may drop the fence's own wait)
+        const uint32_t old = atomicInc(ctr, (uint32_t)(S - 1));
+        const bool last = old == (uint32_t)(S - 1);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    return *flag != 0u;
+}
+
+// Epilogue of four consecutive columns of one output row (16-byte accesses).
+__device__ __forceinline__ void xep_apply(const skg_gemmx_desc& d, const skg_gemmx_fused& f, float4 v, int row, int col,
+                                          int64_t coff, bool hb, const float4& bv, const float4& mb) {
+    if (hb) { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+    if (f.kind | (f.out_rows != nullptr)) {            // eval-path epilogues (skg_gemm_desc), uniform per product
+        const int orow = f.out_rows ? f.out_rows[row] : row;
+        if (f.kind == SKG_EPI_MUL_RELU) {
+            if (f.C_raw) *reinterpret_cast<float4*>(f.C_raw + (int64_t)row * f.ldc_raw + col) = v;
+            if (orow < 0) return;
+            float4 m = mb;
+            if (f.P) {
+                const float4 t = xld4(f.P + (int64_t)(f.p_idx ? f.p_idx[row] : row) * f.ldp + col);
+                m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
+            }
+            if (f.Q) {
+                const float4 t = xld4(f.Q + (int64_t)(f.q_idx ? f.q_idx[row] : row) * f.ldq + col);
+                m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
+            }
+            *reinterpret_cast<float4*>(d.C + coff + (int64_t)orow * d.ldc) =
+                make_float4(fmaxf(v.x * m.x, 0.f), fmaxf(v.y * m.y, 0.f), fmaxf(v.z * m.z, 0.f), fmaxf(v.w * m.w, 0.f));
+            return;
+        }
+        if (orow < 0) return;
+        if (d.relu || f.kind == SKG_EPI_BIAS_RES_RELU) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (f.kind == SKG_EPI_BIAS_RES_RELU) {
+            const float4 t = xld4(f.res + (int64_t)row * f.ldres + col);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        *reinterpret_cast<float4*>(d.C + coff + (int64_t)orow * d.ldc) = v;
+        return;
+    }
+    if (d.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    float* p = d.C + coff + (int64_t)row * d.ldc;
+    if (d.accumulate) { const float4 o = xld4(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+    if (d.mask) {                                      // accumulate first, mask last
+        const float4 m = xld4(d.mask + (int64_t)row * d.ldmask + col);
+        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+    }
+    *reinterpret_cast<float4*>(p) = v;
+    if (d.C16)                                         // the bf16 twin of what was just stored (next product's operand)
+        *reinterpret_cast<uint2*>(d.C16 + coff + (int64_t)row * d.ldc) = make_uint2(ypack(v.x, v.y), ypack(v.z, v.w));
+}
+
+// Rows [row0, row0 + 32) x columns [col0, col0 + 64) of the product from the wave's staged block.  ws: this slice's partial
+// tile goes there instead (split-K).
 __device__ __forceinline__ void xep_rows(const skg_gemmx_desc& d, const skg_gemmx_fused& f, const float* stage, int lane,
                                          int row0, int col0, float* ws) {
     const int c4 = 4 * (lane & 15), rr = lane >> 4, col = col0 + c4;
@@ -194,48 +273,102 @@ __device__ __forceinline__ void xep_rows(const skg_gemmx_desc& d, const skg_gemm
     for (int i = 0; i < 8; ++i) {
         const int row = row0 + 4 * i + rr;
         if (row >= d.M) continue;
-        float4 v = *reinterpret_cast<const float4*>(stage + (4 * i + rr) * XEP_LD + c4);
+        const float4 v = *reinterpret_cast<const float4*>(stage + (4 * i + rr) * XEP_LD + c4);
         if (ws) { *reinterpret_cast<float4*>(ws + (int64_t)row * d.N + col) = v; continue; }
-        if (hb) { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
-        if (f.kind | (f.out_rows != nullptr)) {            // eval-path epilogues (skg_gemm_desc), uniform per product
-            const int orow = f.out_rows ? f.out_rows[row] : row;
-            if (f.kind == SKG_EPI_MUL_RELU) {
-                if (f.C_raw) *reinterpret_cast<float4*>(f.C_raw + (int64_t)row * f.ldc_raw + col) = v;
-                if (orow < 0) continue;
-                float4 m = mb;
-                if (f.P) {
-                    const float4 t = xld4(f.P + (int64_t)(f.p_idx ? f.p_idx[row] : row) * f.ldp + col);
-                    m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
-                }
-                if (f.Q) {
-                    const float4 t = xld4(f.Q + (int64_t)(f.q_idx ? f.q_idx[row] : row) * f.ldq + col);
-                    m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
-                }
-                *reinterpret_cast<float4*>(d.C + coff + (int64_t)orow * d.ldc) =
-                    make_float4(fmaxf(v.x * m.x, 0.f), fmaxf(v.y * m.y, 0.f), fmaxf(v.z * m.z, 0.f), fmaxf(v.w * m.w, 0.f));
-                continue;
-            }
-            if (orow < 0) continue;
-            if (d.relu || f.kind == SKG_EPI_BIAS_RES_RELU) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            }
-            if (f.kind == SKG_EPI_BIAS_RES_RELU) {
-                const float4 t = xld4(f.res + (int64_t)row * f.ldres + col);
-                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-            }
-            *reinterpret_cast<float4*>(d.C + coff + (int64_t)orow * d.ldc) = v;
-            continue;
+        xep_apply(d, f, v, row, col, coff, hb, bv, mb);
+    }
+}
+
+// The same rows by the tile's LAST ARRIVER: every slice added in slice order, then the epilogue.  OWN: this workgroup's slice
+// (red.slice) comes from its staged block at its position in that order; otherwise it is read back like the others.  Loads
+// are unconditional (rows past M clamped, never stored) and two slices deep: sixteen 16-byte loads in flight per lane.
+template <bool OWN, int R>
+__device__ __forceinline__ void xep_reduce(const skg_gemmx_desc& d, const skg_gemmx_fused& f, const float* stage, int lane,
+                                           int row0, int col0, const XRed& red) {
+    static_assert(R == 4 || R == 8, "rows per lane and pass");
+    const int c4 = 4 * (lane & 15), rr = lane >> 4, col = col0 + c4;
+    if (col >= d.N) return;
+    const bool hb = d.bias != nullptr;
+    float4 bv = xzero4(), mb = xzero4();
+    if (hb) bv = xld4(d.bias + col);
+    if (f.kind == SKG_EPI_MUL_RELU && f.mbias) mb = xld4(f.mbias + col);
+    const int64_t coff = xoff(col, d.c_nshift, d.c_nstride, 1);
+#pragma unroll 1
+    for (int h = 0; h < 8 / R; ++h) {                      // (R = 4: two passes of four rows -- half the registers)
+        uint32_t ro[R];                                    // element offsets inside a slice (M * N < 2^31: checked on the host)
+        float4 sum[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            ro[i] = (uint32_t)min(row0 + 4 * (R * h + i) + rr, d.M - 1) * (uint32_t)d.N + (uint32_t)col;
+            sum[i] = xzero4();
         }
-        if (d.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        float* p = d.C + coff + (int64_t)row * d.ldc;
-        if (d.accumulate) { const float4 o = xld4(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        if (d.mask) {                                      // accumulate first, mask last
-            const float4 m = xld4(d.mask + (int64_t)row * d.ldmask + col);
-            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        auto add_slices = [&](int s0, int s1) {
+            int s = s0;
+            for (; s + 1 < s1; s += 2) {
+                const float* w0 = red.ws + (int64_t)s * red.MN;
+                const float* w1 = w0 + red.MN;
+                float4 q0[R], q1[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) { q0[i] = xld4(w0 + ro[i]); q1[i] = xld4(w1 + ro[i]); }
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    sum[i].x += q0[i].x; sum[i].y += q0[i].y; sum[i].z += q0[i].z; sum[i].w += q0[i].w;
+                    sum[i].x += q1[i].x; sum[i].y += q1[i].y; sum[i].z += q1[i].z; sum[i].w += q1[i].w;
+                }
+            }
+            if (s < s1) {
+                const float* w0 = red.ws + (int64_t)s * red.MN;
+                float4 q0[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) q0[i] = xld4(w0 + ro[i]);
+#pragma unroll
+                for (int i = 0; i < R; ++i) { sum[i].x += q0[i].x; sum[i].y += q0[i].y; sum[i].z += q0[i].z; sum[i].w += q0[i].w; }
+            }
+        };
+        if (OWN) {
+            add_slices(0, red.slice);
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const float4 q = *reinterpret_cast<const float4*>(stage + (4 * (R * h + i) + rr) * XEP_LD + c4);
+                sum[i].x += q.x; sum[i].y += q.y; sum[i].z += q.z; sum[i].w += q.w;
+            }
+            add_slices(red.slice + 1, red.S);
+        } else {
+            add_slices(0, red.S);
         }
-        *reinterpret_cast<float4*>(p) = v;
-        if (d.C16)                                         // the bf16 twin of what was just stored (next product's operand)
-            *reinterpret_cast<uint2*>(d.C16 + coff + (int64_t)row * d.ldc) = make_uint2(ypack(v.x, v.y), ypack(v.z, v.w));
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int row = row0 + 4 * (R * h + i) + rr;
+            if (row < d.M) xep_apply(d, f, sum[i], row, col, coff, hb, bv, mb);
+        }
+    }
+}
+
+// One output element of a split product from the slices in split_ws (slice order), with the epilogue: the element-wise
+// form of the reduction (products whose C does not admit 16-byte accesses), shared by the reduce kernel and the last arriver.
+__device__ __forceinline__ void xreduce_elem(const skg_gemmx_desc& d, int64_t MN, int row, int col) {
+    const int64_t i = (int64_t)row * d.N + col;
+    float v = 0.f;
+    for (int s = 0; s < d.split_k; ++s) v += d.split_ws[(int64_t)s * MN + i];
+    if (d.bias) v += d.bias[col];
+    if (d.relu) v = fmaxf(v, 0.f);
+    float* p = d.C + xoff(col, d.c_nshift, d.c_nstride, 1) + (int64_t)row * d.ldc;
+    if (d.accumulate) v += *p;
+    if (d.mask && !(d.mask[(int64_t)row * d.ldmask + col] > 0.f)) v = 0.f;      // accumulate first, mask last
+    *p = v;
+    if (d.C16) d.C16[p - d.C] = (uint16_t)ypack(v, 0.f);
+}
+// bias gradient of a split product: the slices' partial row sums, slice order
+__device__ __forceinline__ void xreduce_rowsum(const skg_gemmx_desc& d, int64_t MN, int row) {
+    float v = 0.f;
+    for (int s = 0; s < d.split_k; ++s) v += d.split_ws[(int64_t)d.split_k * MN + (int64_t)s * d.M + row];
+    d.a_rowsum[row] = d.accumulate ? d.a_rowsum[row] + v : v;
+}
+// what the last arriver of tile (m0, n0) does when the tile left through the element-wise epilogue
+__device__ __forceinline__ void xreduce_tile_elems(const skg_gemmx_desc& d, int64_t MN, int m0, int n0, int tid) {
+    for (int idx = tid; idx < XBM * XBN; idx += 256) {
+        const int row = m0 + (idx >> 7), col = n0 + (idx & 127);
+        if (row < d.M && col < d.N) xreduce_elem(d, MN, row, col);
     }
 }
 
@@ -387,7 +520,7 @@ __device__ __forceinline__ void xoperands(const skg_gemmx_desc& d, int vecbits, 
 
 __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group g) {
     static_assert(XEP_FLOATS >= 4 * XTILE, "the staged epilogue reuses the operand tiles' LDS");
-    __shared__ __attribute__((aligned(16))) float smem[XEP_FLOATS];     // A0 | B0 | A1 | B1, then the staged epilogue
+    __shared__ __attribute__((aligned(16))) float smem[XEP_FLOATS + 4]; // A0 | B0 | A1 | B1, then the staged epilogue (+ the arrival flag)
     int gi = 0;
 #pragma unroll
     for (int t = 1; t < SKG_GEMMX_GROUP_MAX; ++t)
@@ -434,6 +567,7 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
     const bool split = S > 1;
     const int64_t MN = (int64_t)d.M * d.N;
     float* ws = split ? d.split_ws + (int64_t)slice * MN : nullptr;           // [S][M * N] then [S][M] row sums
+    const bool inl = split && d.split_ctr != nullptr;      // reduced in this launch by the tile's last arriver
     if (c.do_rowsum && tid < XBM && m0 + tid < d.M) {
         if (split) d.split_ws[(int64_t)S * MN + (int64_t)slice * d.M + m0 + tid] = rsum;
         else d.a_rowsum[m0 + tid] = d.accumulate ? d.a_rowsum[m0 + tid] + rsum : rsum;
@@ -454,6 +588,15 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
                     }
             xep_rows(d, g.f[gi], stage, lane, m0 + wm * 64 + 32 * ps, n0 + wn * 64, ws);
         }
+        if (!inl || !xsplit_last(d.split_ctr + tm * nbn + tn, S, reinterpret_cast<uint32_t*>(smem + XEP_FLOATS))) return;
+        // the last slice of this tile to arrive: all slices in slice order + the epilogue
+        if (c.do_rowsum && tid < XBM && m0 + tid < d.M) xreduce_rowsum(d, MN, m0 + tid);
+        // (slice -1: this workgroup's own partial is read back like the others -- keeping the 64 accumulators alive across
+        //  the arrival would cost this kernel its third wave per SIMD: 164 -> 179 VGPRs)
+        const XRed red = {d.split_ws, MN, S, -1};
+#pragma unroll 1
+        for (int ps = 0; ps < 2; ++ps)
+            xep_reduce<false, 4>(d, g.f[gi], stage, lane, m0 + wm * 64 + 32 * ps, n0 + wn * 64, red);
         return;
     }
     const bool vecC = (vecbits >> 2) & 1;
@@ -505,6 +648,10 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
                     }
                 }
             }
+    if (inl && xsplit_last(d.split_ctr + tm * nbn + tn, S, reinterpret_cast<uint32_t*>(smem) + XEP_FLOATS)) {
+        if (c.do_rowsum && tid < XBM && m0 + tid < d.M) xreduce_rowsum(d, MN, m0 + tid);
+        xreduce_tile_elems(d, MN, m0, n0, tid);
+    }
 }
 
 // ================================================================================================ bf16 operands
@@ -884,7 +1031,7 @@ __device__ __forceinline__ void ymain(const XOperand& A, const XOperand& B, cons
 
 __global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_group g) {
     static_assert(2 * XEP_FLOATS >= 4 * YTILE, "the staged epilogue reuses the operand tiles' LDS");
-    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * XEP_FLOATS];  // A0 | B0 | A1 | B1, then the staged epilogue
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * XEP_FLOATS + 8];  // A0 | B0 | A1 | B1, then the staged epilogue (+ flag)
     int gi = 0;
 #pragma unroll
     for (int t = 1; t < SKG_GEMMX_GROUP_MAX; ++t)
@@ -936,6 +1083,7 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_
     const bool split = S > 1;
     const int64_t MN = (int64_t)d.M * d.N;
     float* ws = split ? d.split_ws + (int64_t)slice * MN : nullptr;           // [S][M * N] then [S][M] row sums
+    const bool inl = split && d.split_ctr != nullptr;      // reduced in this launch by the tile's last arriver
     if (c.do_rowsum) {                                     // uniform per workgroup; ymain left the partial sums in LDS
         if (tid < XBM && m0 + tid < d.M) {
             const float* part = reinterpret_cast<const float*>(smem);
@@ -959,6 +1107,22 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_
                     for (int ni = 0; ni < 2; ++ni)
                         stage[(8 * gq + 4 * lk + t) * XEP_LD + ni * 32 + li] = acc[mi][ni][4 * gq + t];
             xep_rows(d, g.f[gi], stage, lane, m0 + wm * 64 + mi * 32, n0 + wn * 64, ws);
+        }
+        if (inl && xsplit_last(d.split_ctr + tm * nbn + tn, S, reinterpret_cast<uint32_t*>(smem) + XEP_FLOATS)) {
+            // the last slice of this tile to arrive: all slices in slice order + the epilogue
+            if (c.do_rowsum && c.tid < XBM && m0 + c.tid < d.M) xreduce_rowsum(d, MN, m0 + c.tid);
+            const XRed red = {d.split_ws, MN, S, slice};
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            stage[(8 * gq + 4 * lk + t) * XEP_LD + ni * 32 + li] = acc[mi][ni][4 * gq + t];
+                xep_reduce<true, 8>(d, g.f[gi], stage, lane, m0 + wm * 64 + mi * 32, n0 + wn * 64, red);
+            }
         }
         return;
     }
@@ -985,6 +1149,10 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_
                     if (d.C16) d.C16[p - d.C] = (uint16_t)ypack(v, 0.f);
                 }
             }
+    if (inl && xsplit_last(d.split_ctr + tm * nbn + tn, S, reinterpret_cast<uint32_t*>(smem) + XEP_FLOATS)) {
+        if (c.do_rowsum && c.tid < XBM && m0 + c.tid < d.M) xreduce_rowsum(d, MN, m0 + c.tid);
+        xreduce_tile_elems(d, MN, m0, n0, c.tid);
+    }
 }
 
 // ================================================================================================ bf16 twins, direct to LDS
@@ -1263,7 +1431,7 @@ __device__ __forceinline__ void tmain(const skg_gemmx_desc& d, const XOperand& A
 }
 
 __global__ __launch_bounds__(256, TNB == 2 ? 2 : 1) void skg_gemmx_t16_kernel(const skg_gemmx_group g) {
-    constexpr int TSMEM = TNB * TBUFB > 4 * XEP_FLOATS ? TNB * TBUFB : 4 * XEP_FLOATS;     // ring, then the staged epilogue
+    constexpr int TSMEM = TNB * TBUFB > 4 * XEP_FLOATS + 16 ? TNB * TBUFB : 4 * XEP_FLOATS + 16;   // ring, then the staged epilogue + flag
     __shared__ __attribute__((aligned(1024))) uint8_t smem[TSMEM];
 #ifdef SKG_XPROBE_STAMPS                                    // timing builds: wall-clock stamps (100 MHz) of the workgroup's phases
     const uint64_t stamp0 = wall_clock64();
@@ -1319,6 +1487,7 @@ __global__ __launch_bounds__(256, TNB == 2 ? 2 : 1) void skg_gemmx_t16_kernel(co
     const bool split = S > 1;
     const int64_t MN = (int64_t)d.M * d.N;
     float* ws = split ? d.split_ws + (int64_t)slice * MN : nullptr;           // [S][M * N] then [S][M] row sums
+    const bool inl = split && d.split_ctr != nullptr;      // reduced in this launch by the tile's last arriver
     if (c.do_rowsum && wn == 0 && li == 0) {               // every column of rsa holds the row sums: column 0's lanes write
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -1342,6 +1511,22 @@ __global__ __launch_bounds__(256, TNB == 2 ? 2 : 1) void skg_gemmx_t16_kernel(co
                     for (int ni = 0; ni < 2; ++ni)
                         stage[(8 * gq + 4 * lk + t) * XEP_LD + ni * 32 + li] = acc[mi][ni][4 * gq + t];
             xep_rows(d, g.f[gi], stage, lane, m0 + wm * 64 + mi * 32, n0 + wn * 64, ws);
+        }
+        if (inl && xsplit_last(d.split_ctr + tm * nbn + tn, S, reinterpret_cast<uint32_t*>(smem) + XEP_FLOATS)) {
+            // the last slice of this tile to arrive: all slices in slice order + the epilogue
+            if (c.do_rowsum && c.tid < XBM && m0 + c.tid < d.M) xreduce_rowsum(d, MN, m0 + c.tid);
+            const XRed red = {d.split_ws, MN, S, slice};
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            stage[(8 * gq + 4 * lk + t) * XEP_LD + ni * 32 + li] = acc[mi][ni][4 * gq + t];
+                xep_reduce<true, 8>(d, g.f[gi], stage, lane, m0 + wm * 64 + mi * 32, n0 + wn * 64, red);
+            }
         }
 #ifdef SKG_XPROBE_STAMPS                                   // (split_ws of an unsplit product doubles as the stamp buffer: 4 x u64 per workgroup)
         if (!split && d.split_ws && c.tid == 0) {
@@ -1375,6 +1560,10 @@ __global__ __launch_bounds__(256, TNB == 2 ? 2 : 1) void skg_gemmx_t16_kernel(co
                     if (d.C16) d.C16[p - d.C] = (uint16_t)ypack(v, 0.f);
                 }
             }
+    if (inl && xsplit_last(d.split_ctr + tm * nbn + tn, S, reinterpret_cast<uint32_t*>(smem) + XEP_FLOATS)) {
+        if (c.do_rowsum && c.tid < XBM && m0 + c.tid < d.M) xreduce_rowsum(d, MN, m0 + c.tid);
+        xreduce_tile_elems(d, MN, m0, n0, c.tid);
+    }
 }
 
 // (An exact-fp32 twin of this kernel -- skg_gemmx_d32_kernel: 32-deep k-steps, ds_read_b128 / ds_read_b32 fragments -- was built,
@@ -1395,9 +1584,7 @@ __global__ __launch_bounds__(256) void skg_gemmx_reduce_kernel(const skg_gemmx_g
     if (w >= nmat) {                                       // bias gradient (row sums of A)
         const int64_t m = w - nmat;
         if (m >= d.M || !d.a_rowsum) return;
-        float v = 0.f;
-        for (int s = 0; s < d.split_k; ++s) v += d.split_ws[(int64_t)d.split_k * MN + (int64_t)s * d.M + m];
-        d.a_rowsum[m] = d.accumulate ? d.a_rowsum[m] + v : v;
+        xreduce_rowsum(d, MN, (int)m);
         return;
     }
     if (quads) {
@@ -1420,17 +1607,7 @@ __global__ __launch_bounds__(256) void skg_gemmx_reduce_kernel(const skg_gemmx_g
         if (d.C16) *reinterpret_cast<uint2*>(d.C16 + (p - d.C)) = make_uint2(ypack(v.x, v.y), ypack(v.z, v.w));
         return;
     }
-    const int64_t i = w;
-    float v = 0.f;
-    for (int s = 0; s < d.split_k; ++s) v += d.split_ws[(int64_t)s * MN + i];
-    const int row = (int)(i / d.N), col = (int)(i % d.N);
-    if (d.bias) v += d.bias[col];
-    if (d.relu) v = fmaxf(v, 0.f);
-    float* p = d.C + xoff(col, d.c_nshift, d.c_nstride, 1) + (int64_t)row * d.ldc;
-    if (d.accumulate) v += *p;
-    if (d.mask && !(d.mask[(int64_t)row * d.ldmask + col] > 0.f)) v = 0.f;      // accumulate first, mask last
-    *p = v;
-    if (d.C16) d.C16[p - d.C] = (uint16_t)ypack(v, 0.f);
+    xreduce_elem(d, MN, (int)(w / d.N), (int)(w % d.N));
 }
 
 static int skg_gemmx_validate(const skg_gemmx_desc& d) {
@@ -1446,6 +1623,7 @@ static int skg_gemmx_validate(const skg_gemmx_desc& d) {
     if (d.mask && d.ldmask < d.N) return SKG_E_ARG;
     if (d.split_k > 1 && (!d.split_ws || d.split_k > 256)) return SKG_E_ARG;
     if ((((uintptr_t)d.C16) & 1u) || (((uintptr_t)d.A16) & 1u) || (((uintptr_t)d.B16) & 1u)) return SKG_E_ALIGN;
+    if (((uintptr_t)d.split_ctr) & 3u) return SKG_E_ALIGN;
     return 0;
 }
 
@@ -1510,13 +1688,18 @@ static int skg_gemmx_launch(const skg_gemmx_desc* descs_host, int n, void* strea
             vec |= 32;
         if (fused_host && (fused_host[i].kind || fused_host[i].out_rows)) {
             // eval-path epilogues exist in the staged epilogue only, and not behind a split-K reduce
-            if (!(vec & 8) || S > 1 || d.c_nshift || d.accumulate || d.mask || d.C16 || !xfused_ptrs_ok(fused_host[i]))
+            if (!(vec & 8) || (S > 1 && !(d.split_ctr && (int64_t)d.M * d.N < (1LL << 31))) || d.c_nshift || d.accumulate || d.mask || d.C16 ||
+                !xfused_ptrs_ok(fused_host[i]))
                 return SKG_E_ARG;
             g.f[g.n] = fused_host[i];
         }
-        g.d[g.n] = d; g.vec[g.n] = vec; g.start[g.n] = (int)blocks; ++g.n;
+        g.d[g.n] = d; g.vec[g.n] = vec; g.start[g.n] = (int)blocks;
+        // (the last arriver addresses a slice with 32-bit element offsets)
+        const bool inlaunch = S > 1 && d.split_ctr && (int64_t)d.M * d.N < (1LL << 31);
+        if (!inlaunch) g.d[g.n].split_ctr = nullptr;
+        ++g.n;
         blocks += nb;
-        if (S > 1) {
+        if (S > 1 && !inlaunch) {                          // (with counters the slices are reduced inside the product launch)
             const int64_t MN = (int64_t)d.M * d.N;
             const int64_t total = ((vec & 8) ? MN / 4 : MN) + (d.a_rowsum ? d.M : 0);
             const int64_t nr = (total + 255) / 256;
@@ -1557,7 +1740,7 @@ int skg_gemmx_can_fuse(const skg_gemmx_desc* dp, const skg_gemmx_fused* f) {
     if (skg_gemmx_validate(d)) return 0;
     const bool staged = (d.N & 3) == 0 && skg_aligned16(d.C) && xmul4(d.ldc) && d.c_nshift == 0 && skg_aligned16(d.bias);
     if (!f || !(f->kind || f->out_rows)) return 1;
-    return staged && d.split_k <= 1 && !d.accumulate && !d.mask && xfused_ptrs_ok(*f);
+    return staged && (d.split_k <= 1 || d.split_ctr) && !d.accumulate && !d.mask && xfused_ptrs_ok(*f);
 }
 
 extern "C" int skg_gemmx_bf16(const skg_gemmx_desc* descs_host, int n, void* stream) {

@@ -158,11 +158,16 @@ static void launch(Ctx& c, skg_gemmx_desc* ops, int n) {
         if (ops[i].M > 0 && ops[i].N > 0) live[m++] = ops[i];
     for (int i0 = 0; i0 < m; i0 += SKG_GEMMX_GROUP_MAX) {
         int cnt = m - i0 < SKG_GEMMX_GROUP_MAX ? m - i0 : SKG_GEMMX_GROUP_MAX;
-        int64_t used = 0;
+        int64_t used = 0, used_ctr = 0;
         for (int i = 0; i < cnt; ++i) {
             skg_gemmx_desc& d = live[i0 + i];
             int sk = pick_split(d, bk);
             d.split_k = sk > 1 ? sk : 0;
+            d.split_ctr = nullptr;
+            if (sk > 1 && c.P->counters) {                 // reduced inside the product launch: one counter per tile
+                const int64_t tiles = (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128);
+                if (used_ctr + tiles <= c.P->n_counters) { d.split_ctr = c.P->counters + used_ctr; used_ctr += tiles; }
+            }
             if (bf16 && !c.dry) {
                 d.A16 = twin_of(c, d.A); d.B16 = twin_of(c, d.B);
                 uint16_t* c16 = twin_of(c, d.C);

@@ -106,16 +106,34 @@ def pick_split(op, blocks_so_far=0, target=None, bk=16):
     return int(max(1, min(int(target / tiles + 0.5), cap)))
 
 
-def launch(ops, bf16=False):
-    """Enqueues the products (one launch, plus one reduce launch when any of them is split along K).  bf16: operands
-    rounded to bf16 on the way to the matrix core (skg_gemmx_bf16), everything in memory stays fp32."""
+# Split products are reduced INSIDE their launch (skg_gemmx_desc.split_ctr: tile counters, zero when made, left zero by every
+# launch) unless INLAUNCH is False: then a second launch adds the slices.  Same additions in the same order either way.
+INLAUNCH = True
+_COUNTERS = {}
+N_COUNTERS = 1 << 14
+
+
+def counters(device):
+    """The tile counters of `device`'s launches through this module (one array: the launches of a step share one stream)."""
+    t = _COUNTERS.get(device)
+    if t is None:
+        t = _COUNTERS[device] = torch.zeros(N_COUNTERS, device=device, dtype=torch.int32)
+    return t
+
+
+def launch(ops, bf16=False, inlaunch=None):
+    """Enqueues the products (one launch; split products are reduced by their tiles' last workgroups, or -- inlaunch=False,
+    or more tiles than counters -- by one more launch).  bf16: operands rounded to bf16 on the way to the matrix core
+    (skg_gemmx_bf16), everything in memory stays fp32."""
     lib = _capi.lib()
+    inlaunch = INLAUNCH if inlaunch is None else inlaunch
     fn, name, bk = (lib.skg_gemmx_bf16, "skg_gemmx_bf16", 32) if bf16 else (lib.skg_gemmx_f32, "skg_gemmx_f32", 16)
     ops = [o for o in ops if o.M > 0 and o.N > 0]
     for i0 in range(0, len(ops), _capi.GEMMX_GROUP_MAX):
         chunk = ops[i0:i0 + _capi.GEMMX_GROUP_MAX]
         arr = (_capi.GemmXDesc * len(chunk))()
         keep = []
+        used = 0
         for d, o in zip(arr, chunk):
             d.A, d.a_sm, d.a_sk = o.A, o.a_sm, o.a_sk
             d.B, d.b_sn, d.b_sk = o.B, o.b_sn, o.b_sk
@@ -132,4 +150,8 @@ def launch(ops, bf16=False):
                 ws = torch.empty(sk * (o.M * o.N + o.M), device=dev, dtype=torch.float32)
                 keep.append(ws)
                 d.split_ws = ws.data_ptr()
+                tiles = ((o.M + 127) // 128) * ((o.N + 127) // 128)
+                if inlaunch and used + tiles <= N_COUNTERS:
+                    d.split_ctr = counters(dev).data_ptr() + 4 * used
+                    used += tiles
         _capi.check(fn(arr, len(chunk), _stream()), "%s[%d]" % (name, len(chunk)))

@@ -36,6 +36,9 @@ _grad_of = attrgetter("grad")
 MBF_NAMES = ("attention_head", "obj_to_sub", "sub_to_obj", "attention_head_g")      # order of the stacked fc_2 block
 ATT, OS, SO, GL = range(4)
 EPS_LN = 1e-5
+# split-K of the plan's products reduced inside the product launch (skg_gemmx_desc.split_ctr); SKG_INLAUNCH_REDUCE=0: the
+# second launch per split product (developer A/B switch; results are bit-identical either way)
+INLAUNCH_SPLIT_REDUCE = os.environ.get("SKG_INLAUNCH_REDUCE", "1") != "0"
 
 
 def _check(rc, what):
@@ -177,6 +180,14 @@ class Stacked:
         t = pool.get(name)
         if t is None or t.numel() < n or t.dtype != dtype or t.device != dev:
             t = pool[name] = torch.empty(max(n, 1), device=dev, dtype=dtype)
+        return t
+
+    def counters(self):
+        """Tile counters of the plan's split-K products (include/skghoi.h, skg_train_plan.counters): zero when made, and every
+        launch that uses them leaves them zero -- so ONE array serves every step of this arena's stream."""
+        t = getattr(self, "_ctr", None)
+        if t is None:
+            t = self._ctr = torch.zeros(1 << 14, device=self.device, dtype=torch.int32)
         return t
 
     def twin(self):
@@ -670,6 +681,9 @@ class NativeJob(TrainJob):
             setattr(pl, k, S[k].data_ptr())
         pl.pair_img, pl.hum_of, pl.node_of = self.pair_img.data_ptr(), self.hum_of.data_ptr(), self.node_of.data_ptr()
         pl.timer = self.head.__dict__.get("_train_timer")      # measurement aid (bench.py): events around every gemmx launch
+        if INLAUNCH_SPLIT_REDUCE:
+            ctr = st.counters()                                # split-K reduced inside the product launches (skg_gemmx_desc.split_ctr)
+            pl.counters, pl.n_counters = ctr.data_ptr(), ctr.numel()
         return pl
 
     def forward_a(self, x0, gfeat):

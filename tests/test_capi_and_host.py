@@ -55,7 +55,7 @@ def _header_struct_fields(hdr, name):
     out = []
     for stmt in body.split(";"):
         stmt = stmt.replace("typedef struct {", "").strip()
-        m = re.match(r"(?:const\s+)?(void|float|int32_t|int64_t|uint16_t)\s*(\*?)\s*(.+)$", stmt, flags=re.S)
+        m = re.match(r"(?:const\s+)?(void|float|int32_t|int64_t|uint16_t|uint32_t)\s*(\*?)\s*(.+)$", stmt, flags=re.S)
         if not m:
             continue
         base, star, rest = m.groups()

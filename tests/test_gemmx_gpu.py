@@ -18,6 +18,17 @@ def bf16(request):
     return request.param
 
 
+@pytest.fixture(autouse=True, params=[True, False], ids=["reduce-in-launch", "reduce-launch"])
+def split_reduction(request, monkeypatch):
+    """Every test of this file runs with both reductions of split products: by the tiles' last-arriving workgroups inside the
+    product launch (skg_gemmx_desc.split_ctr, the default) and by the second launch."""
+    monkeypatch.setattr(gemmx, "INLAUNCH", request.param)
+    yield
+    if request.param:
+        assert int(gemmx.counters(torch.device("cuda", torch.cuda.current_device())).abs().sum()) == 0, \
+            "a launch left its tile counters non-zero"
+
+
 def _q(t, bf16):
     """The operand as the matrix core sees it, in float64."""
     return (t.to(torch.bfloat16) if bf16 else t).double()
@@ -235,6 +246,74 @@ def test_many_small_products_one_call(bf16):
     gemmx.launch(ops, bf16=bf16)
     for o, w in zip(outs, wants):
         _close(o, w, "small product")
+
+
+@pytest.mark.parametrize("kernel", ["f32", "bf16", "t16"])
+@pytest.mark.parametrize("kind,M,N,K,split", [
+    ("fwd", 300, 256, 1024, 4), ("fwd", 3200, 1024, 1024, 2), ("fwd", 513, 72, 1030, 5), ("fwd", 131, 258, 640, 3),
+    ("dx", 300, 256, 1024, 8), ("dx", 130, 1024, 560, 3), ("dw", 3200, 256, 128, 7), ("dw", 3205, 1024, 48, 9),
+    ("dw", 1077, 120, 2048, 2), ("dwb", 700, 1024, 1024, 3)])
+def test_split_reduced_inside_the_launch_equals_the_reduce_launch_bit_for_bit(kernel, kind, M, N, K, split):
+    """The tiles' last arrivers add the slices in slice order -- the additions of skg_gemmx_reduce_kernel in the same order,
+    whichever slice finishes last: C, its bf16 twin and the bias gradient are bit-identical, on every kernel (exact fp32,
+    register-staged bf16, direct-to-LDS with both twins), staged and element-wise epilogues (N = 258: no 16-byte rows),
+    ragged tiles, accumulation + ReLU mask, branch-major C.  Run three times in a row: the counters wrap back to zero."""
+    bf = kernel != "f32"
+
+    def build(inlaunch, rep):
+        if kind == "fwd":
+            x, W, b = _rnd(M, K, seed=61), _rnd(N, K, seed=62), _rnd(N, seed=63)
+            out = torch.full((M, N), float("nan")).cuda()
+            op = gemmx.forward(x, W, out, bias=b, relu=True)
+            a, bb, db = x, W, None
+        elif kind == "dx":
+            dz, W, x = _rnd(M, N, seed=64), _rnd(N, K, seed=65), _rnd(M, K, seed=66)
+            out = _rnd(M, K, seed=67)
+            op = gemmx.input_grad(dz, W, out, mask=x, accumulate=True)
+            a, bb, db = dz, W, None
+        else:
+            dz, x = _rnd(M, N, seed=68), _rnd(M, K, seed=69)
+            db = _rnd(N, seed=70)
+            if kind == "dwb":
+                out = _rnd(K // 64, N, 64, seed=71)
+                op = gemmx.weight_grad(dz, x, out, db=db, accumulate=True, w_blocks=(6, N * 64))
+            else:
+                out = _rnd(N, K, seed=71)
+                op = gemmx.weight_grad(dz, x, out, db=db, accumulate=True)
+            a, bb = dz, x
+        op.split_k = split
+        c16 = torch.full(out.shape, float("nan"), dtype=torch.bfloat16).cuda()
+        op.C16 = c16
+        if kernel == "t16":
+            op.A16, op.B16 = _twin(a), _twin(bb)
+        gemmx.launch([op], bf16=bf, inlaunch=inlaunch)
+        return out, c16, db
+
+    ref = build(False, 0)
+    for rep in range(3):
+        got = build(True, rep)
+        assert torch.equal(got[0], ref[0]), "C differs (run %d)" % rep
+        assert torch.equal(got[1].view(torch.int16), ref[1].view(torch.int16)), "C16 differs"
+        if ref[2] is not None:
+            assert torch.equal(got[2], ref[2]), "bias gradient differs"
+
+
+def test_grouped_split_products_reduce_inside_one_launch(bf16):
+    """dX (ReLU mask) and dW (+ bias gradient) of a layer, both split, in ONE launch: each product has its own counters."""
+    rows, N_out, K_in = 900, 1024, 1088
+    dz = _rnd(rows, N_out, seed=81)
+    x, W, y_prev = _rnd(rows, K_in, seed=82), _rnd(N_out, K_in, seed=83) * 0.05, _rnd(rows, K_in, seed=84)
+    res = []
+    for inl in (False, True):
+        dx = torch.empty(rows, K_in).cuda(); dW = torch.empty(N_out, K_in).cuda(); db = torch.empty(N_out).cuda()
+        a, b = gemmx.input_grad(dz, W, dx, mask=y_prev), gemmx.weight_grad(dz, x, dW, db=db)
+        a.split_k, b.split_k = 4, 3
+        gemmx.launch([a, b], bf16=bf16, inlaunch=inl)
+        res.append((dx, dW, db))
+    for u, v in zip(*res):
+        assert torch.equal(u, v)
+    _close(res[1][0], (_q(dz, bf16) @ _q(W, bf16)) * (y_prev > 0), "grouped dx")
+    _close(res[1][1], _q(dz, bf16).t() @ _q(x, bf16), "grouped dW")
 
 
 def test_argument_validation():
