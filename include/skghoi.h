@@ -393,7 +393,9 @@ typedef struct {
      * split_ws and arrives at the tile's counter; the last arriver adds the slices in slice order (the same additions in the
      * same order as the reduce launch: results are bit-identical, whichever slice finishes last) and applies the epilogue.
      * No second launch; the counters are zero again when the launch ends (they wrap), so one array serves every later
-     * launch of the same stream.  Launches that may run CONCURRENTLY need arrays of their own.                          */
+     * launch of the same stream.  Launches that may run CONCURRENTLY need arrays of their own.  Honoured for products
+     * whose C / bias / mask / split_ws admit 16-byte accesses (N % 4 == 0, ...) and M * N < 2^29; others keep the
+     * second launch.                                                                                                  */
     uint32_t* split_ctr;
 } skg_gemmx_desc;
 #define SKG_GEMMX_GROUP_MAX 8

@@ -185,30 +185,35 @@ __device__ __forceinline__ uint32_t ypack(float a, float b) {          // two fl
 // that reads S - 1 is the last one and the counter is zero again for the next launch -- no reset pass, no second kernel.  The
 // last arriver adds the slices IN SLICE ORDER (its own from its registers at its position in that order: the same additions
 // in the same order as skg_gemmx_reduce_kernel, whichever slice happens to finish last -- deterministic, no float atomics) and
-// applies the epilogue.  Partials cross XCDs (private L2s): the stores are released and the reads acquired at device scope
-// (__threadfence = L2 write-back before the arrival, invalidate after it).  The tile order keeps a tile's slices adjacent
-// on one XCD (xtile_of), so the partials are normally still in that XCD's L2.
+// applies the epilogue.
+// Partials cross XCDs, whose L2s are private: they are stored WRITE-THROUGH (sc1, 16 bytes per lane) and read back with sc1
+// loads only -- the counter form of the inter-workgroup hand-off (cdna_hip_programming.md, Guideline 16 R1 / in-launch
+// split-K): every storing wave drains its stores, the workgroup meets, ONE lane adds to the counter, and the workgroup whose
+// add came last loads behind a barrier that lane joins.  The first version stored plainly and released with an agent-scope
+// fence (buffer_wbl2: the whole XCD's dirty L2 written back by each of ~20 workgroups per XCD): +40 us per launch, the batch-4
+// bf16 step 1.28 -> 1.91 ms.
 struct XRed { const float* ws; int64_t MN; int S, slice; };
+typedef unsigned int xu4s __attribute__((__vector_size__(16)));
+#define XSC1 16                              // aux bits of a buffer access: sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t xrsrc(const float* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void xst_sc1(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, const float4& v) {
+    const xu4s u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)byte_off, 0, XSC1);
+}
+__device__ __forceinline__ float4 xld_sc1(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    const xu4s u = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, XSC1);
+    return make_float4(__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3]));
+}
 
-// Arrival of one slice's workgroup at its tile's counter; true for the last one.  The hand-off is the counter form of the
-// inter-workgroup recipe (cdna_hip_programming.md, in-launch split-K): every wave drains its stores, the workgroup meets,
-// ONE lane releases at device scope (L2 write-back), waits for that, and only then adds; the last arriver acquires at device
-// scope before anybody of its workgroup loads a partial.  `flag`: a free word of the kernel's ONE LDS array (a second
-// __shared__ object beside a DMA-staged ring makes hipcc drain the ring in front of every k-step's first ds_read).
+// Arrival of one slice's workgroup at its tile's counter; true for the last one.  `flag`: a free word of the kernel's ONE
+// LDS array (a second __shared__ object beside a DMA-staged ring makes hipcc drain the ring in front of every k-step's
+// first ds_read).
 __device__ __forceinline__ bool xsplit_last(uint32_t* ctr, int S, volatile uint32_t* flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave: its write-through stores have left
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (kept: the compiler may drop the fence's own wait)
-        const uint32_t old = atomicInc(ctr, (uint32_t)(S - 1));
-        const bool last = old == (uint32_t)(S - 1);
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        *flag = last ? 1u : 0u;
-    }
+    if (threadIdx.x == 0) *flag = atomicInc(ctr, (uint32_t)(S - 1)) == (uint32_t)(S - 1) ? 1u : 0u;
     __syncthreads();
     return *flag != 0u;
 }
@@ -260,6 +265,7 @@ __device__ __forceinline__ void xep_apply(const skg_gemmx_desc& d, const skg_gem
 
 // Rows [row0, row0 + 32) x columns [col0, col0 + 64) of the product from the wave's staged block.  ws: this slice's partial
 // tile goes there instead (split-K).
+template <bool WT = false>                   // WT: the partial tile is stored write-through (reduced in this launch)
 __device__ __forceinline__ void xep_rows(const skg_gemmx_desc& d, const skg_gemmx_fused& f, const float* stage, int lane,
                                          int row0, int col0, float* ws) {
     const int c4 = 4 * (lane & 15), rr = lane >> 4, col = col0 + c4;
@@ -274,6 +280,7 @@ __device__ __forceinline__ void xep_rows(const skg_gemmx_desc& d, const skg_gemm
         const int row = row0 + 4 * i + rr;
         if (row >= d.M) continue;
         const float4 v = *reinterpret_cast<const float4*>(stage + (4 * i + rr) * XEP_LD + c4);
+        if (WT) { xst_sc1(xrsrc(ws), ((uint32_t)row * (uint32_t)d.N + (uint32_t)col) * 4u, v); continue; }
         if (ws) { *reinterpret_cast<float4*>(ws + (int64_t)row * d.N + col) = v; continue; }
         xep_apply(d, f, v, row, col, coff, hb, bv, mb);
     }
@@ -295,21 +302,21 @@ __device__ __forceinline__ void xep_reduce(const skg_gemmx_desc& d, const skg_ge
     const int64_t coff = xoff(col, d.c_nshift, d.c_nstride, 1);
 #pragma unroll 1
     for (int h = 0; h < 8 / R; ++h) {                      // (R = 4: two passes of four rows -- half the registers)
-        uint32_t ro[R];                                    // element offsets inside a slice (M * N < 2^31: checked on the host)
+        uint32_t ro[R];                                    // byte offsets inside a slice (M * N < 2^29: checked on the host)
         float4 sum[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            ro[i] = (uint32_t)min(row0 + 4 * (R * h + i) + rr, d.M - 1) * (uint32_t)d.N + (uint32_t)col;
+            ro[i] = ((uint32_t)min(row0 + 4 * (R * h + i) + rr, d.M - 1) * (uint32_t)d.N + (uint32_t)col) * 4u;
             sum[i] = xzero4();
         }
         auto add_slices = [&](int s0, int s1) {
             int s = s0;
             for (; s + 1 < s1; s += 2) {
-                const float* w0 = red.ws + (int64_t)s * red.MN;
-                const float* w1 = w0 + red.MN;
+                const __amdgpu_buffer_rsrc_t w0 = xrsrc(red.ws + (int64_t)s * red.MN);
+                const __amdgpu_buffer_rsrc_t w1 = xrsrc(red.ws + (int64_t)(s + 1) * red.MN);
                 float4 q0[R], q1[R];
 #pragma unroll
-                for (int i = 0; i < R; ++i) { q0[i] = xld4(w0 + ro[i]); q1[i] = xld4(w1 + ro[i]); }
+                for (int i = 0; i < R; ++i) { q0[i] = xld_sc1(w0, ro[i]); q1[i] = xld_sc1(w1, ro[i]); }
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
                     sum[i].x += q0[i].x; sum[i].y += q0[i].y; sum[i].z += q0[i].z; sum[i].w += q0[i].w;
@@ -317,10 +324,10 @@ __device__ __forceinline__ void xep_reduce(const skg_gemmx_desc& d, const skg_ge
                 }
             }
             if (s < s1) {
-                const float* w0 = red.ws + (int64_t)s * red.MN;
+                const __amdgpu_buffer_rsrc_t w0 = xrsrc(red.ws + (int64_t)s * red.MN);
                 float4 q0[R];
 #pragma unroll
-                for (int i = 0; i < R; ++i) q0[i] = xld4(w0 + ro[i]);
+                for (int i = 0; i < R; ++i) q0[i] = xld_sc1(w0, ro[i]);
 #pragma unroll
                 for (int i = 0; i < R; ++i) { sum[i].x += q0[i].x; sum[i].y += q0[i].y; sum[i].z += q0[i].z; sum[i].w += q0[i].w; }
             }
@@ -364,12 +371,17 @@ __device__ __forceinline__ void xreduce_rowsum(const skg_gemmx_desc& d, int64_t 
     for (int s = 0; s < d.split_k; ++s) v += d.split_ws[(int64_t)d.split_k * MN + (int64_t)s * d.M + row];
     d.a_rowsum[row] = d.accumulate ? d.a_rowsum[row] + v : v;
 }
-// what the last arriver of tile (m0, n0) does when the tile left through the element-wise epilogue
-__device__ __forceinline__ void xreduce_tile_elems(const skg_gemmx_desc& d, int64_t MN, int m0, int n0, int tid) {
-    for (int idx = tid; idx < XBM * XBN; idx += 256) {
-        const int row = m0 + (idx >> 7), col = n0 + (idx & 127);
-        if (row < d.M && col < d.N) xreduce_elem(d, MN, row, col);
-    }
+// the same by a tile's last arriver: the partial sums were stored write-through, and are read past the caches
+__device__ __forceinline__ void xreduce_rowsum_sc1(const skg_gemmx_desc& d, int64_t MN, int row) {
+    float v = 0.f;
+    for (int s = 0; s < d.split_k; ++s)
+        v += __hip_atomic_load(d.split_ws + (int64_t)d.split_k * MN + (int64_t)s * d.M + row, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    d.a_rowsum[row] = d.accumulate ? d.a_rowsum[row] + v : v;
+}
+__device__ __forceinline__ void xstore_rowsum_part(float* p, float v, bool wt) {
+    if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
 }
 
 // ================================================================================================ exact fp32
@@ -567,9 +579,9 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
     const bool split = S > 1;
     const int64_t MN = (int64_t)d.M * d.N;
     float* ws = split ? d.split_ws + (int64_t)slice * MN : nullptr;           // [S][M * N] then [S][M] row sums
-    const bool inl = split && d.split_ctr != nullptr;      // reduced in this launch by the tile's last arriver
+    const bool inl = split && d.split_ctr != nullptr;      // reduced in this launch by the tile's last arriver (staged epilogue only: the host checked)
     if (c.do_rowsum && tid < XBM && m0 + tid < d.M) {
-        if (split) d.split_ws[(int64_t)S * MN + (int64_t)slice * d.M + m0 + tid] = rsum;
+        if (split) xstore_rowsum_part(d.split_ws + (int64_t)S * MN + (int64_t)slice * d.M + m0 + tid, rsum, inl);
         else d.a_rowsum[m0 + tid] = d.accumulate ? d.a_rowsum[m0 + tid] + rsum : rsum;
     }
     if (vecbits & 8) {                                     // staged: the k loop ended on a barrier, LDS is free
@@ -586,11 +598,12 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
                         *reinterpret_cast<float2*>(stage + (2 * (8 * g2 + 4 * lk + t) + mb) * XEP_LD + 2 * li) =
                             make_float2(acc[mb][0][e], acc[mb][1][e]);
                     }
-            xep_rows(d, g.f[gi], stage, lane, m0 + wm * 64 + 32 * ps, n0 + wn * 64, ws);
+            if (inl) xep_rows<true>(d, g.f[gi], stage, lane, m0 + wm * 64 + 32 * ps, n0 + wn * 64, ws);
+            else xep_rows(d, g.f[gi], stage, lane, m0 + wm * 64 + 32 * ps, n0 + wn * 64, ws);
         }
         if (!inl || !xsplit_last(d.split_ctr + tm * nbn + tn, S, reinterpret_cast<uint32_t*>(smem + XEP_FLOATS))) return;
         // the last slice of this tile to arrive: all slices in slice order + the epilogue
-        if (c.do_rowsum && tid < XBM && m0 + tid < d.M) xreduce_rowsum(d, MN, m0 + tid);
+        if (c.do_rowsum && tid < XBM && m0 + tid < d.M) xreduce_rowsum_sc1(d, MN, m0 + tid);
         // (slice -1: this workgroup's own partial is read back like the others -- keeping the 64 accumulators alive across
         //  the arrival would cost this kernel its third wave per SIMD: 164 -> 179 VGPRs)
         const XRed red = {d.split_ws, MN, S, -1};
@@ -648,10 +661,6 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_kernel(const skg_gemmx_group
                     }
                 }
             }
-    if (inl && xsplit_last(d.split_ctr + tm * nbn + tn, S, reinterpret_cast<uint32_t*>(smem) + XEP_FLOATS)) {
-        if (c.do_rowsum && tid < XBM && m0 + tid < d.M) xreduce_rowsum(d, MN, m0 + tid);
-        xreduce_tile_elems(d, MN, m0, n0, tid);
-    }
 }
 
 // ================================================================================================ bf16 operands
@@ -1083,14 +1092,14 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_
     const bool split = S > 1;
     const int64_t MN = (int64_t)d.M * d.N;
     float* ws = split ? d.split_ws + (int64_t)slice * MN : nullptr;           // [S][M * N] then [S][M] row sums
-    const bool inl = split && d.split_ctr != nullptr;      // reduced in this launch by the tile's last arriver
+    const bool inl = split && d.split_ctr != nullptr;      // reduced in this launch by the tile's last arriver (staged epilogue only: the host checked)
     if (c.do_rowsum) {                                     // uniform per workgroup; ymain left the partial sums in LDS
         if (tid < XBM && m0 + tid < d.M) {
             const float* part = reinterpret_cast<const float*>(smem);
             float s = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) s += part[q * 128 + tid];
-            if (split) d.split_ws[(int64_t)S * MN + (int64_t)slice * d.M + m0 + tid] = s;
+            if (split) xstore_rowsum_part(d.split_ws + (int64_t)S * MN + (int64_t)slice * d.M + m0 + tid, s, inl);
             else d.a_rowsum[m0 + tid] = d.accumulate ? d.a_rowsum[m0 + tid] + s : s;
         }
         __syncthreads();                                   // read before the staged epilogue overwrites them
@@ -1106,11 +1115,12 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
                         stage[(8 * gq + 4 * lk + t) * XEP_LD + ni * 32 + li] = acc[mi][ni][4 * gq + t];
-            xep_rows(d, g.f[gi], stage, lane, m0 + wm * 64 + mi * 32, n0 + wn * 64, ws);
+            if (inl) xep_rows<true>(d, g.f[gi], stage, lane, m0 + wm * 64 + mi * 32, n0 + wn * 64, ws);
+            else xep_rows(d, g.f[gi], stage, lane, m0 + wm * 64 + mi * 32, n0 + wn * 64, ws);
         }
         if (inl && xsplit_last(d.split_ctr + tm * nbn + tn, S, reinterpret_cast<uint32_t*>(smem) + XEP_FLOATS)) {
             // the last slice of this tile to arrive: all slices in slice order + the epilogue
-            if (c.do_rowsum && c.tid < XBM && m0 + c.tid < d.M) xreduce_rowsum(d, MN, m0 + c.tid);
+            if (c.do_rowsum && c.tid < XBM && m0 + c.tid < d.M) xreduce_rowsum_sc1(d, MN, m0 + c.tid);
             const XRed red = {d.split_ws, MN, S, slice};
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
@@ -1149,10 +1159,6 @@ __global__ __launch_bounds__(256, 2) void skg_gemmx_bf16_kernel(const skg_gemmx_
                     if (d.C16) d.C16[p - d.C] = (uint16_t)ypack(v, 0.f);
                 }
             }
-    if (inl && xsplit_last(d.split_ctr + tm * nbn + tn, S, reinterpret_cast<uint32_t*>(smem) + XEP_FLOATS)) {
-        if (c.do_rowsum && c.tid < XBM && m0 + c.tid < d.M) xreduce_rowsum(d, MN, m0 + c.tid);
-        xreduce_tile_elems(d, MN, m0, n0, c.tid);
-    }
 }
 
 // ================================================================================================ bf16 twins, direct to LDS
@@ -1487,7 +1493,7 @@ __global__ __launch_bounds__(256, TNB == 2 ? 2 : 1) void skg_gemmx_t16_kernel(co
     const bool split = S > 1;
     const int64_t MN = (int64_t)d.M * d.N;
     float* ws = split ? d.split_ws + (int64_t)slice * MN : nullptr;           // [S][M * N] then [S][M] row sums
-    const bool inl = split && d.split_ctr != nullptr;      // reduced in this launch by the tile's last arriver
+    const bool inl = split && d.split_ctr != nullptr;      // reduced in this launch by the tile's last arriver (staged epilogue only: the host checked)
     if (c.do_rowsum && wn == 0 && li == 0) {               // every column of rsa holds the row sums: column 0's lanes write
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -1495,7 +1501,7 @@ __global__ __launch_bounds__(256, TNB == 2 ? 2 : 1) void skg_gemmx_t16_kernel(co
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * 64 + mi * 32 + 8 * (e >> 2) + 4 * lk + (e & 3);
                 if (row >= d.M) continue;
-                if (split) d.split_ws[(int64_t)S * MN + (int64_t)slice * d.M + row] = rsa[mi][e];
+                if (split) xstore_rowsum_part(d.split_ws + (int64_t)S * MN + (int64_t)slice * d.M + row, rsa[mi][e], inl);
                 else d.a_rowsum[row] = d.accumulate ? d.a_rowsum[row] + rsa[mi][e] : rsa[mi][e];
             }
     }
@@ -1510,11 +1516,12 @@ __global__ __launch_bounds__(256, TNB == 2 ? 2 : 1) void skg_gemmx_t16_kernel(co
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
                         stage[(8 * gq + 4 * lk + t) * XEP_LD + ni * 32 + li] = acc[mi][ni][4 * gq + t];
-            xep_rows(d, g.f[gi], stage, lane, m0 + wm * 64 + mi * 32, n0 + wn * 64, ws);
+            if (inl) xep_rows<true>(d, g.f[gi], stage, lane, m0 + wm * 64 + mi * 32, n0 + wn * 64, ws);
+            else xep_rows(d, g.f[gi], stage, lane, m0 + wm * 64 + mi * 32, n0 + wn * 64, ws);
         }
         if (inl && xsplit_last(d.split_ctr + tm * nbn + tn, S, reinterpret_cast<uint32_t*>(smem) + XEP_FLOATS)) {
             // the last slice of this tile to arrive: all slices in slice order + the epilogue
-            if (c.do_rowsum && c.tid < XBM && m0 + c.tid < d.M) xreduce_rowsum(d, MN, m0 + c.tid);
+            if (c.do_rowsum && c.tid < XBM && m0 + c.tid < d.M) xreduce_rowsum_sc1(d, MN, m0 + c.tid);
             const XRed red = {d.split_ws, MN, S, slice};
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
@@ -1560,10 +1567,6 @@ __global__ __launch_bounds__(256, TNB == 2 ? 2 : 1) void skg_gemmx_t16_kernel(co
                     if (d.C16) d.C16[p - d.C] = (uint16_t)ypack(v, 0.f);
                 }
             }
-    if (inl && xsplit_last(d.split_ctr + tm * nbn + tn, S, reinterpret_cast<uint32_t*>(smem) + XEP_FLOATS)) {
-        if (c.do_rowsum && c.tid < XBM && m0 + c.tid < d.M) xreduce_rowsum(d, MN, m0 + c.tid);
-        xreduce_tile_elems(d, MN, m0, n0, c.tid);
-    }
 }
 
 // (An exact-fp32 twin of this kernel -- skg_gemmx_d32_kernel: 32-deep k-steps, ds_read_b128 / ds_read_b32 fragments -- was built,
@@ -1688,14 +1691,14 @@ static int skg_gemmx_launch(const skg_gemmx_desc* descs_host, int n, void* strea
             vec |= 32;
         if (fused_host && (fused_host[i].kind || fused_host[i].out_rows)) {
             // eval-path epilogues exist in the staged epilogue only, and not behind a split-K reduce
-            if (!(vec & 8) || (S > 1 && !(d.split_ctr && (int64_t)d.M * d.N < (1LL << 31))) || d.c_nshift || d.accumulate || d.mask || d.C16 ||
+            if (!(vec & 8) || (S > 1 && !(d.split_ctr && (int64_t)d.M * d.N < (1LL << 29))) || d.c_nshift || d.accumulate || d.mask || d.C16 ||
                 !xfused_ptrs_ok(fused_host[i]))
                 return SKG_E_ARG;
             g.f[g.n] = fused_host[i];
         }
         g.d[g.n] = d; g.vec[g.n] = vec; g.start[g.n] = (int)blocks;
-        // (the last arriver addresses a slice with 32-bit element offsets)
-        const bool inlaunch = S > 1 && d.split_ctr && (int64_t)d.M * d.N < (1LL << 31);
+        // (16-byte write-through partials, addressed with 32-bit byte offsets inside a slice; anything else: the reduce launch)
+        const bool inlaunch = S > 1 && d.split_ctr && (vec & 8) && (int64_t)d.M * d.N < (1LL << 29);
         if (!inlaunch) g.d[g.n].split_ctr = nullptr;
         ++g.n;
         blocks += nb;
