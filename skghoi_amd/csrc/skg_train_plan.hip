@@ -144,6 +144,9 @@ static int pick_split(const skg_gemmx_desc& o, int bk) {
     int cap = kt * bk / 128; if (cap > 64) cap = 64;
     if (tiles == 0 || cap < 2) return 1;
     int sk = (int)((double)target / (double)tiles + 0.5);
+    static int smax = -1;
+    if (smax < 0) { const char* e = getenv("SKG_SPLIT_MAX"); smax = e && atoi(e) > 0 ? atoi(e) : 64; }    // developer knob
+    if (cap > smax) cap = smax;
     if (sk > cap) sk = cap;
     return sk < 1 ? 1 : sk;
 }

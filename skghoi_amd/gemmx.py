@@ -106,9 +106,11 @@ def pick_split(op, blocks_so_far=0, target=None, bk=16):
     return int(max(1, min(int(target / tiles + 0.5), cap)))
 
 
-# Split products are reduced INSIDE their launch (skg_gemmx_desc.split_ctr: tile counters, zero when made, left zero by every
-# launch) unless INLAUNCH is False: then a second launch adds the slices.  Same additions in the same order either way.
-INLAUNCH = True
+# INLAUNCH = True: split products are reduced INSIDE their launch (skg_gemmx_desc.split_ctr: tile counters, zero when made,
+# left zero by every launch) instead of by a second launch that adds the slices.  Same additions in the same order either way
+# (tests/test_gemmx_gpu.py runs every case both ways); measured slower on MI355X at the training shapes (train_fused.py,
+# INLAUNCH_SPLIT_REDUCE), hence off by default.
+INLAUNCH = False
 _COUNTERS = {}
 N_COUNTERS = 1 << 14
 

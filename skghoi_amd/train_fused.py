@@ -36,9 +36,13 @@ _grad_of = attrgetter("grad")
 MBF_NAMES = ("attention_head", "obj_to_sub", "sub_to_obj", "attention_head_g")      # order of the stacked fc_2 block
 ATT, OS, SO, GL = range(4)
 EPS_LN = 1e-5
-# split-K of the plan's products reduced inside the product launch (skg_gemmx_desc.split_ctr); SKG_INLAUNCH_REDUCE=0: the
-# second launch per split product (developer A/B switch; results are bit-identical either way)
-INLAUNCH_SPLIT_REDUCE = os.environ.get("SKG_INLAUNCH_REDUCE", "1") != "0"
+# SKG_INLAUNCH_REDUCE=1: split-K of the plan's products reduced inside the product launch (skg_gemmx_desc.split_ctr) instead
+# of by a second launch per split product.  Bit-identical results, 14 launches less per batch-4 step -- and SLOWER on MI355X
+# (round 5, profiles/r05_inlaunch_splitk_*): the tile's last arriver drains its write-through partials, takes the counter's
+# round trip and reads S slices at one workgroup's memory-level parallelism (10-17 us on top of the product's own time),
+# while the reduce launch it replaces costs ~5 us and back-to-back launches of one stream leave no gap between them:
+# bf16 step 1.26 -> 1.37 ms, fp32 2.47 -> 2.59.  Opt-in.
+INLAUNCH_SPLIT_REDUCE = os.environ.get("SKG_INLAUNCH_REDUCE", "0") == "1"
 
 
 def _check(rc, what):

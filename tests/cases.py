@@ -130,6 +130,19 @@ def build_case(name):
         # the live reference's autograd.
         imgs = _grid_images([(20, 20)] * 4, 256, 7, 49, 80, 1500)
         c.update(C=256, p=7, max_human=20, max_object=20, weight_seed=0, training=True, n_gt=4)
+    elif name == "train_vcoco":
+        # BASELINE config 5's TRAINING half: the V-COCO head (K = 24, human_idx = 1: main:73-76, cache.py:165-168) at full
+        # width -- the classifier block is 25 columns, every K-dependent shape of the step changes (logit leading dimension,
+        # dW of the classifier, the TransH relation tables, the split targets).  Gradient samples from the live reference.
+        cfg = VCOCO
+        imgs = _grid_images([(12, 10), (7, 13)], 256, 7, 1, 81, 1600)
+        c.update(C=256, p=7, weight_seed=0, training=True, n_gt=4)
+    elif name == "train_ragged_full":
+        # a ragged full-width training batch at the reference's DEFAULT caps (15 / 15): an image over both caps (17 humans
+        # + GT, 18 objects: truncation), a SKIPPED image in the middle (no human: the Q9 offset bug at C = 256, p = 7 --
+        # HEAD:829-839 -- shifts the pooled rows of everything behind it), a small one and a one-pair image.
+        imgs = _grid_images([(17, 18), (0, 5), (3, 9), (1, 1)], 256, 7, 49, 80, 1700)
+        c.update(C=256, p=7, weight_seed=0, training=True, n_gt=4)
     else:
         raise KeyError(name)
     c["cfg"] = cfg
@@ -145,12 +158,14 @@ def build_case(name):
 
 EVAL_CASES = ["tiny", "ragged3", "skips_eval", "nanbox", "vcoco", "nms", "iter1", "iter0", "full20", "full15x2",
               "eval_targets", "full20x3", "many8", "many12"]
-OUTPUT_ONLY = ["full20", "full15x2", "full20x3", "many8", "many12", "train_full20x4"]   # no bulky intermediates
 TRAIN_CASES = ["train_tiny", "train_skips"]
 FULL_TRAIN_CASE = "train_full20x4"        # full-size training step: losses / labels / samples + gradient samples
-GRAD_SAMPLES = 512                        # entries kept per parameter gradient in that fixture (evenly strided)
+# every full-width (C = 256, p = 7) training fixture: the uniform BASELINE shape, the V-COCO head, a ragged batch with a skip
+FULL_TRAIN_CASES = [FULL_TRAIN_CASE, "train_vcoco", "train_ragged_full"]
+OUTPUT_ONLY = ["full20", "full15x2", "full20x3", "many8", "many12"] + FULL_TRAIN_CASES   # no bulky intermediates
+GRAD_SAMPLES = 512                        # entries kept per parameter gradient in those fixtures (evenly strided)
 RAISING_CASES = ["skips_raise"]
-ALL_CASES = EVAL_CASES + TRAIN_CASES + [FULL_TRAIN_CASE]
+ALL_CASES = EVAL_CASES + TRAIN_CASES + FULL_TRAIN_CASES
 
 
 def grad_sample(flat_grad):

@@ -68,7 +68,7 @@ def run_reference(case):
     hooks = [gh.adjacency.register_forward_hook(lambda m, i, o: cap["adjacency"].append(o.detach().clone())),
              gh.norm_h.register_forward_hook(lambda m, i, o: cap["norm_h"].append(o.detach().clone())),
              gh.norm_o.register_forward_hook(lambda m, i, o: cap["norm_o"].append(o.detach().clone()))]
-    want_grads = case["name"] == cases.FULL_TRAIN_CASE     # gradient samples from the reference's own autograd
+    want_grads = case["name"] in cases.FULL_TRAIN_CASES    # gradient samples from the reference's own autograd
     try:
         with torch.set_grad_enabled(want_grads), StableTies():
             det = head.preprocess(case["detections"], case["targets"], append_gt=case["training"])

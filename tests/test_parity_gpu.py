@@ -328,11 +328,12 @@ def test_eval_with_targets_consumes_rng_like_reference():
         assert np.abs(got["res%d.scores" % b] - want["res%d.scores" % b]).max() <= 1e-5
 
 
-@pytest.fixture(scope="module")
-def full_train_oracle():
-    """CPU autograd of the oracle on the full-size training case (pinned to the live reference's autograd by
-    tests/test_oracle_golden.py::test_oracle_full_size_training_step_matches_reference_autograd)."""
-    case = cases.build_case(cases.FULL_TRAIN_CASE)
+@pytest.fixture(scope="module", params=cases.FULL_TRAIN_CASES)
+def full_train_oracle(request):
+    """CPU autograd of the oracle on a full-width training case (pinned to the live reference's autograd by
+    tests/test_oracle_golden.py::test_oracle_full_size_training_step_matches_reference_autograd): the uniform BASELINE batch,
+    the V-COCO head (K = 24, human_idx = 1) and a ragged batch at the default caps with a skipped image in the middle."""
+    case = cases.build_case(request.param)
     grads, losses = helpers.oracle_train_grads(case)
     return case, grads, losses
 
@@ -357,15 +358,16 @@ def test_full_size_training_step_matches_reference(full_train_oracle, grad_mode)
     norms (the reference's own autograd) and every entry against CPU autograd of the oracle, <= 1e-4 relative."""
     case, ograds, olosses = full_train_oracle
     flat, grads = _full_train_run(case, "fp32", grad_mode)
-    want = helpers.load_golden(cases.FULL_TRAIN_CASE)
+    want = helpers.load_golden(case["name"])
     helpers.compare_flat(flat, want, atol=LOGIT_TOL, rtol=1e-4, only_common=True, skip=(".ent", ".adjacency"))
     for k in ("hoi_loss", "interactiveness_loss", "transH_loss"):
         assert abs(float(flat[k]) - float(want[k])) <= 1e-5 * max(1.0, abs(float(want[k]))), k
-    assert int(want["n_results"]) == 4
-    for b in range(4):
+    pairs = {"train_full20x4": [780] * 4, "train_vcoco": [252, 133], "train_ragged_full": [435, 0, 33, 1]}[case["name"]]
+    assert int(want["n_results"]) == len(pairs)
+    for b, npair in enumerate(pairs):
         for k in ("index", "prediction", "labels", "unary_labels"):
             assert np.array_equal(flat["res%d.%s" % (b, k)], want["res%d.%s" % (b, k)]), (b, k)
-        assert flat["res%d.unary_labels" % b].shape == (780,)
+        assert flat["res%d.unary_labels" % b].shape == (npair,)
     assert set(grads) == set(ograds)
     worst = 0.0
     for k, w in ograds.items():
@@ -393,10 +395,10 @@ def test_full_size_bf16_training_step_tracks_the_reference(full_train_oracle):
     gradient direction kept (cosine > 0.97 per large tensor, > 0.99 on average, norm within 5 %)."""
     case, ograds, olosses = full_train_oracle
     flat, grads = _full_train_run(case, "bf16")
-    want = helpers.load_golden(cases.FULL_TRAIN_CASE)
+    want = helpers.load_golden(case["name"])
     for k in ("hoi_loss", "interactiveness_loss", "transH_loss"):
         assert abs(float(flat[k]) - float(want[k])) <= 2e-2 * max(abs(float(want[k])), 1e-3), k
-    for b in range(4):
+    for b in range(int(want["n_results"])):
         for k in ("index", "prediction", "labels", "unary_labels"):
             assert np.array_equal(flat["res%d.%s" % (b, k)], want["res%d.%s" % (b, k)]), (b, k)
     coss = []
@@ -445,7 +447,7 @@ def test_fused_step_sees_repointed_parameter_storage_and_refuses_a_second_backwa
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("name", ["train_tiny", "train_skips", cases.FULL_TRAIN_CASE])
+@pytest.mark.parametrize("name", ["train_tiny", "train_skips"] + cases.FULL_TRAIN_CASES)
 def test_native_training_plan_equals_the_python_issued_sequence(name, precision):
     """The native launch plan (skg_train_forward_f32 / skg_train_backward_f32: one C call per phase) against the same
     kernel sequence issued launch by launch from Python (head.train_plan = "python"): identical logits, losses and
