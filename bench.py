@@ -182,6 +182,8 @@ def run_train(B, precision, steps, warmup, device, rank, world, dist_on, prefetc
     if dist_on:
         torch.distributed.barrier()
         torch.cuda.synchronize()
+    from skghoi_amd import gemmx as _gemmx
+    _gemmx.path_counts(reset=True)
     t0 = time.perf_counter()
     for _ in range(steps):
         losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=nxt)
@@ -191,6 +193,9 @@ def run_train(B, precision, steps, warmup, device, rank, world, dist_on, prefetc
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     info = {}
+    pc = _gemmx.path_counts()
+    info["product_launches_per_step"] = dict(zip(("exact_fp32", "bf16_register_staged", "bf16_direct_to_lds"),
+                                                 (round(v / max(steps, 1), 2) for v in pc)))
     import ctypes
     from skghoi_amd import _capi
     pl = getattr(head, "_last_train_plan", None)

@@ -397,6 +397,12 @@ typedef struct {
      * whose C / bias / mask / split_ws admit 16-byte accesses (N % 4 == 0, ...) and M * N < 2^29; others keep the
      * second launch.                                                                                                  */
     uint32_t* split_ctr;
+    /* Leading dimension (elements) of A16 / B16 where the twin is a PADDED copy with a pitch of its own -- the stride that
+     * is not 1 (a_sm or a_sk; b_sn or b_sk) -- or 0: the fp32 array's.  For operands whose fp32 rows are not multiples of
+     * 16 bytes (a [1024, 1074] weight: twin rows of 1088 elements).  Only the direct-to-LDS kernel (both twins present)
+     * reads such a twin; not with blocked B.  A row-contiguous twin is read in 8-row pieces: its rows must be a multiple
+     * of 8 or its pitch >= rows rounded up to 8 (what lies past the end is read, never used for a stored output).      */
+    int64_t a16_ld, b16_ld;
 } skg_gemmx_desc;
 #define SKG_GEMMX_GROUP_MAX 8
 int64_t skg_gemmx_ws_floats(const skg_gemmx_desc* desc_host);
@@ -405,6 +411,10 @@ int skg_gemmx_f32(const skg_gemmx_desc* descs_host, int n, void* stream);
  * (v_mfma_f32_32x32x16_bf16); operands, results, bias gradient and epilogue stay fp32 in memory.  The dense layers of a
  * precision="bf16" training step (BASELINE config 3: the reference under torch.autocast(bfloat16)).                  */
 int skg_gemmx_bf16(const skg_gemmx_desc* descs_host, int n, void* stream);
+/* Statistics: launches since the last reset by main loop -- out3_host = {exact fp32, bf16 register-staged, bf16 direct-to-LDS
+ * (both twins)}; reset != 0 zeroes them.  For tests and profiles (which products of a step reach the direct-to-LDS kernel);
+ * nothing reads them back into a decision.                                                                            */
+void skg_gemmx_path_counts(int64_t* out3_host, int reset);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Non-GEMM stages of the fused TRAINING step (skg_train.hip): the forward pieces that keep what the backward needs and

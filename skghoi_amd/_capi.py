@@ -40,7 +40,8 @@ class GemmXDesc(C.Structure):
                 ("C", _vp), ("ldc", _i64), ("c_nshift", _i32), ("accumulate", _i32), ("c_nstride", _i64),
                 ("M", _i32), ("N", _i32), ("K", _i32), ("relu", _i32), ("bias", _vp), ("mask", _vp), ("ldmask", _i64),
                 ("a_rowsum", _vp), ("split_k", _i32), ("reserved", _i32), ("split_ws", _vp),
-                ("A16", _vp), ("B16", _vp), ("C16", _vp), ("split_ctr", _vp)]
+                ("A16", _vp), ("B16", _vp), ("C16", _vp), ("split_ctr", _vp),
+                ("a16_ld", _i64), ("b16_ld", _i64)]
 
 
 GEMMX_GROUP_MAX = 8
@@ -131,6 +132,7 @@ PROTOTYPES = {
     "skg_gemmx_ws_floats": (C.c_int64, [C.POINTER(GemmXDesc)]),
     "skg_gemmx_f32": (C.c_int, [C.POINTER(GemmXDesc), C.c_int, _vp]),
     "skg_gemmx_bf16": (C.c_int, [C.POINTER(GemmXDesc), C.c_int, _vp]),
+    "skg_gemmx_path_counts": (None, [C.POINTER(_i64), C.c_int]),
     "skg_gemm_bf16": (C.c_int, [C.POINTER(GemmBf16Desc), _vp]),
     "skg_transpose_bf16": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _vp, _i64, _vp]),
     "skg_transpose_f32": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _vp, _i64, _vp]),

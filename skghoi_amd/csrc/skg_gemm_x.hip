@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include <atomic>
 
 #define XBM 128
 #define XBN 128
@@ -63,6 +64,7 @@ struct XOperand {
     __amdgpu_buffer_rsrc_t rsrc; // buffer descriptor over the operand (fast loop)
     __amdgpu_buffer_rsrc_t rsrc16;   // ... over its bf16 twin (skg_gemmx_bf16 only)
     bool vec16;                  // the twin exists and may be read with 16-byte loads
+    int64_t s_row16, s_k16;      // the TWIN's strides (skg_gemmx_desc.a16_ld / b16_ld; normally those of the fp32 array)
 };
 
 struct XQ2 { float4 a, b; };
@@ -526,6 +528,8 @@ __device__ __forceinline__ void xoperands(const skg_gemmx_desc& d, int vecbits, 
     A.rsrc16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(d.A16), 0, 0x7fffffff, 0x00020000);
     B.rsrc16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(d.B16), 0, 0x7fffffff, 0x00020000);
     A.vec16 = (vecbits >> 4) & 1; B.vec16 = (vecbits >> 5) & 1;
+    A.s_row16 = (d.a_sk == 1 && d.a16_ld) ? d.a16_ld : d.a_sm; A.s_k16 = (d.a_sk != 1 && d.a16_ld) ? d.a16_ld : d.a_sk;
+    B.s_row16 = (d.b_sk == 1 && d.b16_ld) ? d.b16_ld : d.b_sn; B.s_k16 = (d.b_sk != 1 && d.b16_ld) ? d.b16_ld : d.b_sk;
     B.base = d.B; B.s_row = d.b_sn; B.s_k = d.b_sk; B.rshift = d.b_nshift; B.kshift = d.b_kshift;
     B.rstride = d.b_nstride; B.kstride = d.b_kstride; B.rows = d.N; B.vec = (vecbits >> 1) & 1;
 }
@@ -1213,12 +1217,12 @@ __device__ __forceinline__ void tprep(const XOperand& op, int row0, int tid, TLo
         if (KC) {                            // chunk 4 w + i = rows 32 w + 8 i .. + 7; lane: row l >> 3, slot l & 7
             const int r = 32 * w + 8 * i + (l >> 3);
             const int q = (l & 7) ^ ((r >> 1) & 7);
-            L.o[i] = (uint32_t)((xoff(min(row0 + r, op.rows - 1), op.rshift, op.rstride, op.s_row) + 8 * q) * 2);
+            L.o[i] = (uint32_t)((xoff(min(row0 + r, op.rows - 1), op.rshift, op.rstride, op.s_row16) + 8 * q) * 2);
         } else {                             // chunk 4 w + i = k-rows 16 w + 4 i .. + 3; lane: k-row l >> 4, slot l & 15
             const int k = 16 * w + 4 * i + (l >> 4);
             const int ch = (l & 15) ^ tswz_rc(k);
-            const int64_t ro = xoff(max(0, min(row0 + 8 * ch, op.rows - 8)), op.rshift, op.rstride, 1);
-            L.o[i] = (uint32_t)((ro + (int64_t)k * op.s_k) * 2);
+            const int64_t ro = xoff(max(0, min(row0 + 8 * ch, ((op.rows + 7) & ~7) - 8)), op.rshift, op.rstride, 1);
+            L.o[i] = (uint32_t)((ro + (int64_t)k * op.s_k16) * 2);
         }
     }
 }
@@ -1227,7 +1231,7 @@ __device__ __forceinline__ void tprep(const XOperand& op, int row0, int tid, TLo
 template <bool KC>
 __device__ __forceinline__ void tissue(const XOperand& op, const uint16_t* base16, const TLoad& L, int k0, uint8_t* dst, int wu) {
     const char* gb = t_uniform_ptr(reinterpret_cast<const char*>(base16) +
-                                     2 * xoff(k0, op.kshift, op.kstride, KC ? 1 : op.s_k));
+                                     2 * xoff(k0, op.kshift, op.kstride, KC ? 1 : op.s_k16));
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + L.o[i]),
@@ -1246,7 +1250,7 @@ __device__ __forceinline__ void tfill(const XOperand& op, const uint16_t* base16
             const int r = 32 * w + 8 * i + (l >> 3);
             const int q = (l & 7) ^ ((r >> 1) & 7);
             const int k = k0 + 8 * q;
-            const uint16_t* p = base16 + xoff(min(row0 + r, op.rows - 1), op.rshift, op.rstride, op.s_row) +
+            const uint16_t* p = base16 + xoff(min(row0 + r, op.rows - 1), op.rshift, op.rstride, op.s_row16) +
                                 xoff(k, op.kshift, op.kstride, 1);
             if (k + 7 < kend) v = *reinterpret_cast<const uint4*>(p);
             else if (k < kend) {
@@ -1260,8 +1264,8 @@ __device__ __forceinline__ void tfill(const XOperand& op, const uint16_t* base16
             const int kl = 16 * w + 4 * i + (l >> 4);
             const int ch = (l & 15) ^ tswz_rc(kl);
             if (k0 + kl < kend)
-                v = *reinterpret_cast<const uint4*>(base16 + xoff(max(0, min(row0 + 8 * ch, op.rows - 8)), op.rshift, op.rstride, 1) +
-                                                    xoff(k0 + kl, op.kshift, op.kstride, op.s_k));
+                v = *reinterpret_cast<const uint4*>(base16 + xoff(max(0, min(row0 + 8 * ch, ((op.rows + 7) & ~7) - 8)), op.rshift, op.rstride, 1) +
+                                                    xoff(k0 + kl, op.kshift, op.kstride, op.s_k16));
         }
         *reinterpret_cast<uint4*>(dst + (4 * w + i) * 1024 + l * 16) = v;
     }
@@ -1627,6 +1631,9 @@ static int skg_gemmx_validate(const skg_gemmx_desc& d) {
     if (d.split_k > 1 && (!d.split_ws || d.split_k > 256)) return SKG_E_ARG;
     if ((((uintptr_t)d.C16) & 1u) || (((uintptr_t)d.A16) & 1u) || (((uintptr_t)d.B16) & 1u)) return SKG_E_ALIGN;
     if (((uintptr_t)d.split_ctr) & 3u) return SKG_E_ALIGN;
+    if (d.a16_ld < 0 || d.b16_ld < 0 || (d.b16_ld && (d.b_kshift || d.b_nshift))) return SKG_E_ARG;
+    if (d.a16_ld && d.a16_ld < (d.a_sk == 1 ? d.K : d.M)) return SKG_E_ARG;
+    if (d.b16_ld && d.b16_ld < (d.b_sk == 1 ? d.K : d.N)) return SKG_E_ARG;
     return 0;
 }
 
@@ -1649,6 +1656,15 @@ extern "C" int64_t skg_gemmx_ws_floats(const skg_gemmx_desc* d) {
 static bool xfused_ptrs_ok(const skg_gemmx_fused& f) {
     return skg_aligned16(f.P) && skg_aligned16(f.Q) && skg_aligned16(f.mbias) && skg_aligned16(f.C_raw) &&
            skg_aligned16(f.res) && xmul4(f.ldp) && xmul4(f.ldq) && xmul4(f.ldc_raw) && xmul4(f.ldres);
+}
+
+// launches per main loop since the last reset (statistics for tests and profiles: which products reach the direct-to-LDS kernel)
+static std::atomic<long long> g_path_launches[3];
+extern "C" void skg_gemmx_path_counts(int64_t* out3_host, int reset) {
+    for (int i = 0; i < 3; ++i) {
+        if (out3_host) out3_host[i] = g_path_launches[i].load(std::memory_order_relaxed);
+        if (reset) g_path_launches[i].store(0, std::memory_order_relaxed);
+    }
 }
 
 static bool g_t16_enabled = getenv("SKG_GEMMX_T16") == nullptr || atoi(getenv("SKG_GEMMX_T16")) != 0;   // developer A/B switch
@@ -1685,9 +1701,16 @@ static int skg_gemmx_launch(const skg_gemmx_desc* descs_host, int n, void* strea
             (((uintptr_t)d.C16) & 7u) == 0)
             vec |= 8;
         // bits 4 / 5: the bf16 twin of A / B may feed the fast loop (16-byte pieces of 8 elements)
-        if (bf16 && d.A16 && (vec & 1) && skg_aligned16(d.A16) && (d.a_sk == 1 ? xmul8(d.a_sm) : xmul8(d.a_sk))) vec |= 16;
-        if (bf16 && d.B16 && (vec & 2) && skg_aligned16(d.B16) && (d.b_sk == 1 ? xmul8(d.b_sn) : xmul8(d.b_sk)) &&
-            (d.b_kshift == 0 || xmul8(d.b_kstride)) && (d.b_nshift == 0 || (d.b_nshift >= 3 && xmul8(d.b_nstride))))
+        // (a twin with a leading dimension of its own -- a16_ld / b16_ld: a PADDED copy of an operand whose fp32 rows are not
+        //  16-byte multiples -- does not need bits 0 / 1: only the direct-to-LDS kernel reads it, and it reads nothing else)
+        const int64_t lda16 = d.a16_ld ? d.a16_ld : (d.a_sk == 1 ? d.a_sm : d.a_sk);
+        const int64_t ldb16 = d.b16_ld ? d.b16_ld : (d.b_sk == 1 ? d.b_sn : d.b_sk);
+        if (bf16 && d.A16 && ((vec & 1) || d.a16_ld) && skg_aligned16(d.A16) && xmul8(lda16) &&
+            xfits32((int64_t)(d.a_sk == 1 ? d.M : d.K) * lda16 + 8))
+            vec |= 16;
+        if (bf16 && d.B16 && ((vec & 2) || d.b16_ld) && skg_aligned16(d.B16) && xmul8(ldb16) &&
+            (d.b_kshift == 0 || xmul8(d.b_kstride)) && (d.b_nshift == 0 || (d.b_nshift >= 3 && xmul8(d.b_nstride))) &&
+            (!d.b16_ld || xfits32((int64_t)(d.b_sk == 1 ? d.N : d.K) * ldb16 + 8)))
             vec |= 32;
         if (fused_host && (fused_host[i].kind || fused_host[i].out_rows)) {
             // eval-path epilogues exist in the staged epilogue only, and not behind a split-K reduce
@@ -1717,9 +1740,19 @@ static int skg_gemmx_launch(const skg_gemmx_desc* descs_host, int n, void* strea
     bool t16 = bf16 && g_t16_enabled;
     for (int i = 0; i < g.n && t16; ++i) {
         const skg_gemmx_desc& d = g.d[i];
-        t16 = (g.vec[i] & 48) == 48 && d.K > 0 && (d.a_sk == 1 || ((d.M & 7) == 0 && d.M >= 8)) &&
-              (d.b_sk == 1 || ((d.N & 7) == 0 && d.N >= 8)) && (d.b_kshift == 0 || d.b_kshift >= 6);
+        // row-contiguous twins are staged in 8-row pieces: whole pieces, or a k-stride that leaves room for the last one
+        // (the rows past the end only feed outputs that are never stored)
+        const int64_t lda16 = d.a16_ld ? d.a16_ld : d.a_sk, ldb16 = d.b16_ld ? d.b16_ld : d.b_sk;
+        t16 = (g.vec[i] & 48) == 48 && d.K > 0 && (d.a_sk == 1 || (d.M & 7) == 0 || lda16 >= ((d.M + 7) & ~7)) &&
+              (d.b_sk == 1 || (d.b_nshift == 0 ? ((d.N & 7) == 0 || ldb16 >= ((d.N + 7) & ~7)) : (d.N & 7) == 0)) &&
+              (d.b_kshift == 0 || d.b_kshift >= 6);
     }
+    if (!t16)                                              // the register-staged loops index a twin like its fp32 array
+        for (int i = 0; i < g.n; ++i) {
+            if (g.d[i].a16_ld) g.vec[i] &= ~16;
+            if (g.d[i].b16_ld) g.vec[i] &= ~32;
+        }
+    g_path_launches[t16 ? 2 : (bf16 ? 1 : 0)].fetch_add(1, std::memory_order_relaxed);
     if (t16) hipLaunchKernelGGL(skg_gemmx_t16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     else if (bf16) hipLaunchKernelGGL(skg_gemmx_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(skg_gemmx_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);

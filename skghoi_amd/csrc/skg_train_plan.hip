@@ -42,6 +42,7 @@ static inline Mat cm(const float* p, int r, int c) { return Mat(const_cast<float
 constexpr int BLK_SHIFT = 6;                 // fc_3 weights are stored branch-major [16][1024][64]
 constexpr int64_t BLK_STRIDE = 1024 * 64;
 
+struct Ws;
 struct Ctx {
     const skg_train_plan* P;
     hipStream_t stream;
@@ -51,19 +52,12 @@ struct Ctx {
     int rc;
     double flops;                // 2 M N K over every dense product issued (sizing pass: what the plan WILL issue)
     const float* no_twin;        // workspace buffer whose twin nobody writes (dadj: produced next to dWt, one column wide)
+    const struct Ws* w;          // the workspace layout: where the SIDE twins live (twin_of)
 };
 
-// bf16 twin of a tensor the plan's products read or write, or NULL: activations in the workspace (twin workspace, same
-// offsets), the pair features, the parameter arena.  Caller-owned inputs (pooled features, spatial encodings) have none.
-static uint16_t* twin_of(const Ctx& c, const float* p) {
-    const skg_train_plan* P = c.P;
-    if (!P->ws16 || !p) return nullptr;
-    if (p >= P->ws && p < P->ws + P->ws_floats) return (c.no_twin && p == c.no_twin) ? nullptr : P->ws16 + (p - P->ws);
-    const int64_t npf = (int64_t)(P->Mp > 0 ? P->Mp : 1) * 2048;
-    if (P->pf16 && p >= P->pair_features && p < P->pair_features + npf) return P->pf16 + (p - P->pair_features);
-    if (P->params16 && p >= P->params && p < P->params + P->params_floats) return P->params16 + (p - P->params);
-    return nullptr;
-}
+// bf16 twin of a tensor the plan's products read or write, or NULL (defined behind the workspace layout); *ld receives the
+// twin's pitch where it is a padded copy with a pitch of its own (0: indexed like the fp32 tensor)
+static uint16_t* twin_of(const Ctx& c, const float* p, int64_t* ld);
 
 // announces the twin ranges to the per-row kernels for the duration of one plan call (skg_common.h, skg_tls_twin)
 struct TwinScope {
@@ -172,9 +166,10 @@ static void launch(Ctx& c, skg_gemmx_desc* ops, int n) {
                 if (used_ctr + tiles <= c.P->n_counters) { d.split_ctr = c.P->counters + used_ctr; used_ctr += tiles; }
             }
             if (bf16 && !c.dry) {
-                d.A16 = twin_of(c, d.A); d.B16 = twin_of(c, d.B);
-                uint16_t* c16 = twin_of(c, d.C);
-                d.C16 = (c16 && (d.C < c.P->params || d.C >= c.P->params + c.P->params_floats)) ? c16 : nullptr;
+                d.A16 = twin_of(c, d.A, &d.a16_ld); d.B16 = twin_of(c, d.B, &d.b16_ld);
+                int64_t ldc16 = 0;
+                uint16_t* c16 = twin_of(c, d.C, &ldc16);
+                d.C16 = (c16 && !ldc16 && (d.C < c.P->params || d.C >= c.P->params + c.P->params_floats)) ? c16 : nullptr;
             }
             if (sk > 1) {
                 int64_t need = (int64_t)sk * ((int64_t)d.M * d.N + d.M);
@@ -237,6 +232,32 @@ __global__ __launch_bounds__(1024) void colsum2_kernel(const float* __restrict__
     }
 }
 
+// Gradient of the adjacency Linear(1024 -> 1) (HEAD:644, 897): dw[c] = sum_r dadj[r] Wt[r, c], db = sum_r dadj[r].  As a product
+// of the step (M = 1) it kept its whole launch -- the attention fc_3's dX and dW, 13.4 GFLOP -- off the direct-to-LDS kernel
+// (a row-contiguous twin is read in 8-row pieces); here: partial sums over 64-row chunks (4 x ceil(rows / 64) workgroups, one
+// column per thread), then the chunks in order.  fp32 operands, fixed order.
+__global__ __launch_bounds__(256) void adjw_partial_kernel(const float* __restrict__ dadj, const float* __restrict__ Wt,
+                                                           int rows, float* __restrict__ part) {
+    const int col = (blockIdx.x & 3) * 256 + threadIdx.x, chunk = blockIdx.x >> 2;
+    const int r0 = chunk * 64, r1 = min(rows, r0 + 64);
+    float s = 0.f, sb = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const float d = dadj[r];
+        s += d * Wt[(int64_t)r * 1024 + col];
+        sb += d;
+    }
+    part[(int64_t)chunk * 1028 + col] = s;
+    if (col == 0) part[(int64_t)chunk * 1028 + 1024] = sb;
+}
+__global__ __launch_bounds__(256) void adjw_finish_kernel(const float* __restrict__ part, int chunks, float* __restrict__ dw,
+                                                          float* __restrict__ db) {
+    const int col = blockIdx.x * 256 + threadIdx.x;         // 5 workgroups: columns 0..1023, then the bias
+    if (col > 1024) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += part[(int64_t)k * 1028 + col];
+    if (col < 1024) dw[col] = s; else db[0] = s;
+}
+
 // dF [Mg, 4096] = [attention | obj_to_sub | sub_to_obj | global]: the read-out writes blocks 0 and 3 at the rows of kept pairs;
 // the in-loop stage overwrites blocks 1 and 2 on every row and ADDS to block 0.  What has to be zero beforehand is therefore
 // blocks 0 and 3 of the grid rows WITHOUT a pair (the self pairs, grid_pair < 0: 20 of an image's 400 rows) -- this kernel --
@@ -263,9 +284,23 @@ struct Ws {
     // backward temporaries
     float *dPF, *dTp, *dTg, *dF, *dB1h, *dB1o, *dG1, *dh_node, *dnode, *dHp, *dHm, *dOp, *dOm, *dU, *dV, *dTos, *dTso,
           *da, *dadj, *dWt, *dT, *dA1h, *dA1o, *dC1o, *dC1h, *dS, *ds2, *ds1, *dXhn, *d_enc, *dE1, *db3;
+    // SIDE twins (bf16 step only; only the twin-workspace half of these regions is used): bf16 copies of the operands the
+    // CALLER owns (pooled box features, spatial codes, pooled features['3'], d logits) and PADDED copies of the three weights
+    // whose rows are not 16-byte multiples (fc_head / fc_tail [1024, 1074] -> pitch 1088, spatial_head.0 [128, 46] -> 48),
+    // written by one launch in forward part 0 (d logits: backward stage 0): with them EVERY product of the step has both
+    // twins and runs on the direct-to-LDS kernel (round 4: 7 of 21 launches stayed on the register-staged loop)
+    float *x0t, *sp48t, *gft, *fhw_t, *ftw_t, *sp0w_t, *dlog_t;
+    bool side;                   // the regions above exist (bf16 step, not switched off)
     float* scratch;
     int64_t total;               // floats, scratch excluded
 };
+constexpr int FH_PITCH = 1088, SP0_PITCH = 48;
+
+static bool side_twins_enabled() {                      // developer A/B switch
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SKG_SIDE_TWINS"); on = (e && atoi(e) == 0) ? 0 : 1; }
+    return on != 0;
+}
 
 static void layout_ws(const skg_train_plan* P, float* base, Ws& w) {
     int64_t off = 0;
@@ -294,8 +329,73 @@ static void layout_ws(const skg_train_plan* P, float* base, Ws& w) {
     w.dadj = take(Mg, 1); w.dWt = take(Mg, 1024); w.dT = take(Mg, 1024); w.dA1h = take(Mh, 1024); w.dA1o = take(Mn, 1024);
     w.dC1o = take(Mn, 1024); w.dC1h = take(Mh, 1024); w.dS = take(Mg, 1024); w.ds2 = take(Mg, 256); w.ds1 = take(Mg, 128);
     w.dXhn = take(Mh + Mn, 1088); w.d_enc = take(NA, 1024); w.dE1 = take(NA, 1024); w.db3 = take(4, 1024);
+    w.x0t = w.sp48t = w.gft = w.fhw_t = w.ftw_t = w.sp0w_t = w.dlog_t = nullptr;
+    w.side = P->bf16 && side_twins_enabled();
+    if (w.side) {
+        w.x0t = take(NA, P->x0_k); w.sp48t = take(Mg, SKG_SPATIAL_LD); w.gft = take(Bf, P->Cf);
+        w.fhw_t = take(1024, FH_PITCH); w.ftw_t = take(1024, FH_PITCH); w.sp0w_t = take(128, SP0_PITCH);
+        w.dlog_t = take(Mp, (P->ld_logits + 7) & ~7);      // (pitch of 8: V-COCO's 25 logit columns are stored 28 apart)
+    }
     w.total = off;
     w.scratch = base ? base + off : nullptr;
+}
+
+static uint16_t* twin_of(const Ctx& c, const float* p, int64_t* ld) {
+    const skg_train_plan* P = c.P;
+    *ld = 0;
+    if (!P->ws16 || !p) return nullptr;
+    if (p >= P->ws && p < P->ws + P->ws_floats) return (c.no_twin && p == c.no_twin) ? nullptr : P->ws16 + (p - P->ws);
+    const int64_t npf = (int64_t)(P->Mp > 0 ? P->Mp : 1) * 2048;
+    if (P->pf16 && p >= P->pair_features && p < P->pair_features + npf) return P->pf16 + (p - P->pair_features);
+    const Ws* w = c.w;
+    if (w && w->side && w->x0t) {                          // side twins: caller-owned operands, padded weight copies
+        auto side = [&](const float* region) { return P->ws16 + (region - P->ws); };
+        const float* fh = P->params + P->seg_off[SKG_SEG_FH_W];
+        const float* ft = P->params + P->seg_off[SKG_SEG_FT_W];
+        const float* s0 = P->params + P->seg_off[SKG_SEG_SP0_W];
+        if (p == fh) { *ld = FH_PITCH; return side(w->fhw_t); }
+        if (p == ft) { *ld = FH_PITCH; return side(w->ftw_t); }
+        if (p == s0) { *ld = SP0_PITCH; return side(w->sp0w_t); }
+        if (p >= P->x0 && p < P->x0 + (int64_t)P->NA * P->x0_k) return side(w->x0t) + (p - P->x0);
+        if (p >= P->sp48 && p < P->sp48 + (int64_t)P->Mg * SKG_SPATIAL_LD) return side(w->sp48t) + (p - P->sp48);
+        if (p >= P->gfeat && p < P->gfeat + (int64_t)P->Bf * P->Cf) return side(w->gft) + (p - P->gfeat);
+        if (P->dlogits && P->Mp > 0 && p == P->dlogits) { *ld = (P->ld_logits + 7) & ~7; return side(w->dlog_t); }
+    }
+    if (P->params16 && p >= P->params && p < P->params + P->params_floats) return P->params16 + (p - P->params);
+    return nullptr;
+}
+
+// dst[r, c] = bf16(src[r, c]) for c < cols, 0 up to the twin's pitch: up to 8 segments in one launch (two elements per thread)
+struct TwinSeg { const float* src; uint16_t* dst; int64_t ld_src, ld_dst; int rows, cols; int64_t first; };
+struct TwinSegs { TwinSeg s[8]; int n; int64_t total; };
+__global__ __launch_bounds__(256) void twin_segments_kernel(const TwinSegs g) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < g.total; i += (int64_t)gridDim.x * 256) {
+        int k = 0;
+#pragma unroll
+        for (int t = 1; t < 8; ++t)
+            if (t < g.n && i >= g.s[t].first) k = t;
+        const TwinSeg& sg = g.s[k];
+        const int64_t local = i - sg.first, ppr = sg.ld_dst >> 1;
+        const int64_t row = local / ppr;
+        const int col = (int)(local - row * ppr) * 2;
+        const float* sp = sg.src + row * sg.ld_src + col;
+        const float a = col < sg.cols ? sp[0] : 0.f, b = col + 1 < sg.cols ? sp[1] : 0.f;
+        reinterpret_cast<uint32_t*>(sg.dst)[row * ppr + (col >> 1)] = skg_pack_bf16(a, b);
+    }
+}
+static void twin_segments(Ctx& c, TwinSeg* segs, int n) {
+    if (c.rc || c.dry || n == 0) return;
+    TwinSegs g; g.n = 0; g.total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (segs[i].rows <= 0 || !segs[i].src || !segs[i].dst) continue;
+        segs[i].first = g.total;
+        g.total += (int64_t)segs[i].rows * (segs[i].ld_dst >> 1);
+        g.s[g.n++] = segs[i];
+    }
+    if (!g.n) return;
+    int64_t blocks = (g.total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(twin_segments_kernel, dim3((unsigned)blocks), dim3(256), 0, c.stream, g);
 }
 
 // ---- parameter / gradient segments -------------------------------------------------------------------------------------
@@ -338,6 +438,15 @@ static void forward(Ctx& c, const Ws& w, int part) {
         // step -- the optimizer, load_state_dict, a caller writing p.data -- the products read what the arena holds NOW)
         if (P->bf16 && P->params16 && P->params_floats > 0)
             CK(skg_twin_bf16(P->params, P->params16, P->params_floats & ~(int64_t)3, c.stream));
+        if (w.side && P->ws16 && !c.dry) {
+            auto side = [&](const float* region) { return P->ws16 + (region - P->ws); };
+            TwinSeg sg[6] = {{P->x0, side(w.x0t), kx, kx, NA, kx, 0}, {P->sp48, side(w.sp48t), SKG_SPATIAL_LD, SKG_SPATIAL_LD, Mg, SKG_SPATIAL_LD, 0},
+                             {P->gfeat, side(w.gft), Cf, Cf, Bf, Cf, 0},
+                             {W.at(SKG_SEG_FH_W), side(w.fhw_t), 1074, FH_PITCH, 1024, 1074, 0},
+                             {W.at(SKG_SEG_FT_W), side(w.ftw_t), 1074, FH_PITCH, 1024, 1074, 0},
+                             {W.at(SKG_SEG_SP0_W), side(w.sp0w_t), 46, SP0_PITCH, 128, 46, 0}};
+            twin_segments(c, sg, 6);
+        }
         // ---- box_head (HEAD:812), fc_1 of the global branch (HEAD:971), the first two spatial layers (HEAD:888)
         skg_gemmx_desc l1[2] = {FWD(x0, bh1_w, E1, W.at(SKG_SEG_BH1_B), true),
                                 FWD(sp48, sp0_w, s1, W.at(SKG_SEG_SP0_B), true, -1, 46)};
@@ -495,6 +604,10 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
     for (int st = first; st < last && !c.rc; ++st) switch (st) {
     case 0: {
         // ---- classifier
+        if (w.side && P->ws16 && Mp > 0 && !c.dry) {
+            TwinSeg sg[1] = {{P->dlogits, P->ws16 + (w.dlog_t - P->ws), P->ld_logits, (P->ld_logits + 7) & ~7, Mp, P->ld_logits, 0}};
+            twin_segments(c, sg, 1);
+        }
         Mat clsW(W.at(SKG_SEG_CLS_W), K + 1, 2048), g_clsW(G.at(SKG_SEG_CLS_W), K + 1, 2048);
         skg_gemmx_desc l[2] = {IG(dlogits, clsW, dPF, &PF, false, Mp, 2048, K + 1),
                                WG(dlogits, PF, g_clsW, G.at(SKG_SEG_CLS_B), false, Mp, K + 1, 2048)};
@@ -565,7 +678,21 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
         skg_gemmx_desc l[3] = {IG(dWt, W3[ATT], dT, &T, false, -1, 1024, -1, true),
                                WG(dWt, T, dW3[ATT], db3 + 1024 * ATT, true, -1, -1, -1, true),
                                WG(dadj, Wt, Mat(G.at(SKG_SEG_ADJ_W), 1, 1024), G.at(SKG_SEG_ADJ_B), false)};
-        launch(c, l, 3);
+        if (P->bf16 && w.side) {
+            // the one-row product on two small kernels of its own (partials in the split-K scratch, free between launches)
+            const int chunks = (Mg + 63) / 64;
+            const int64_t need = (int64_t)chunks * 1028;
+            if (need > c.scratch_need) c.scratch_need = need;
+            c.flops += 2.0 * Mg * 1024.0;
+            if (!c.dry && !c.rc) {
+                hipLaunchKernelGGL(adjw_partial_kernel, dim3(4 * chunks), dim3(256), 0, c.stream, w.dadj, w.Wt, Mg, c.scratch);
+                hipLaunchKernelGGL(adjw_finish_kernel, dim3(5), dim3(256), 0, c.stream, c.scratch, chunks,
+                                   G.at(SKG_SEG_ADJ_W), G.at(SKG_SEG_ADJ_B));
+            }
+            launch(c, l, 2);
+        } else {
+            launch(c, l, 3);
+        }
     } break;
     case 5: {
         // ---- in-loop fc_1 * fc_2 products
@@ -644,7 +771,7 @@ int64_t skg_train_ws_floats(const skg_train_plan* P) {
     int rc = check_plan(P);
     if (rc) return rc;
     Ws w; layout_ws(P, nullptr, w);
-    Ctx c{P, nullptr, true, 0, nullptr, 0, 0.0};
+    Ctx c{P, nullptr, true, 0, nullptr, 0, 0.0, nullptr, &w};
     forward(c, w, 0); forward(c, w, 1); backward(c, w, 0, SKG_TRAIN_BWD_STAGES);
     return w.total + c.scratch_need + 4;
 }
@@ -656,10 +783,10 @@ int skg_train_forward_f32(const skg_train_plan* P, int part, void* stream) {
     if (part == 1 && (!P->ent || !P->logits || !P->pair_features)) return SKG_E_ARG;
     Ws w; layout_ws(P, P->ws, w);
     if (w.total > P->ws_floats) return SKG_E_LIMIT;
-    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0, 0.0, w.dadj};
+    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0, 0.0, w.dadj, &w};
     TwinScope twins(P);
     // bound the scratch: the sizing pass told the caller how much the largest launch needs
-    Ctx d{P, nullptr, true, 0, nullptr, 0, 0.0};
+    Ctx d{P, nullptr, true, 0, nullptr, 0, 0.0, nullptr, &w};
     forward(d, w, part);
     if (w.total + d.scratch_need > P->ws_floats) return SKG_E_LIMIT;
     forward(c, w, part);
@@ -676,7 +803,7 @@ static int validate_backward(const skg_train_plan* P, int first_stage, int last_
         first_stage > last_stage)
         return SKG_E_ARG;
     Ws w; layout_ws(P, P->ws, w);
-    Ctx d{P, nullptr, true, 0, nullptr, 0, 0.0};
+    Ctx d{P, nullptr, true, 0, nullptr, 0, 0.0, nullptr, &w};
     backward(d, w, first_stage, last_stage);
     if (w.total + d.scratch_need > P->ws_floats) return SKG_E_LIMIT;
     return 0;
@@ -686,7 +813,7 @@ int skg_train_backward_f32(const skg_train_plan* P, int first_stage, int last_st
     int rc = validate_backward(P, first_stage, last_stage);
     if (rc) return rc;
     Ws w; layout_ws(P, P->ws, w);
-    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0, 0.0, w.dadj};
+    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0, 0.0, w.dadj, &w};
     TwinScope twins(P);
     backward(c, w, first_stage, last_stage);
     if (!c.rc) { hipError_t e = hipGetLastError(); if (e != hipSuccess) c.rc = (int)e; }
@@ -972,7 +1099,7 @@ int skg_train_timer_read(skg_train_timer* t, double* out3_host) {
 double skg_train_flops(const skg_train_plan* P, int which) {
     if (check_plan(P)) return -1.0;
     Ws w; layout_ws(P, nullptr, w);
-    Ctx c{P, nullptr, true, 0, nullptr, 0, 0.0};
+    Ctx c{P, nullptr, true, 0, nullptr, 0, 0.0, nullptr, &w};
     if (which == 0 || which == 2) { forward(c, w, 0); forward(c, w, 1); }
     if (which == 1 || which == 2) backward(c, w, 0, SKG_TRAIN_BWD_STAGES);
     return c.flops;

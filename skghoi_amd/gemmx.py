@@ -21,7 +21,7 @@ class Op:
     """One product.  Set fields directly or through the constructors below."""
     __slots__ = ("A", "a_sm", "a_sk", "B", "b_sn", "b_sk", "b_kshift", "b_kstride", "b_nshift", "b_nstride", "C", "ldc",
                  "c_nshift", "c_nstride", "M", "N", "K", "bias", "relu", "mask", "ldmask", "accumulate", "a_rowsum",
-                 "split_k", "keep", "A16", "B16", "C16")
+                 "split_k", "keep", "A16", "B16", "C16", "a16_ld", "b16_ld")
 
     def __init__(self, **kw):
         self.b_kshift = self.b_nshift = self.c_nshift = 0
@@ -31,6 +31,7 @@ class Op:
         self.relu = self.accumulate = False
         self.split_k = 0                       # 0: chosen by launch()
         self.A16 = self.B16 = self.C16 = None  # bf16 twins (torch.bfloat16 tensors laid out like A / B / C), optional
+        self.a16_ld = self.b16_ld = 0          # pitch of a PADDED twin (0: the fp32 array's)
         self.keep = []
         for k, v in kw.items():
             setattr(self, k, v)
@@ -123,6 +124,13 @@ def counters(device):
     return t
 
 
+def path_counts(reset=False):
+    """Launches since the last reset as (exact fp32, bf16 register-staged, bf16 direct-to-LDS) -- statistics for tests."""
+    out = (C.c_int64 * 3)()
+    _capi.lib().skg_gemmx_path_counts(out, int(reset))
+    return tuple(int(v) for v in out)
+
+
 def launch(ops, bf16=False, inlaunch=None):
     """Enqueues the products (one launch; split products are reduced by their tiles' last workgroups, or -- inlaunch=False,
     or more tiles than counters -- by one more launch).  bf16: operands rounded to bf16 on the way to the matrix core
@@ -145,6 +153,7 @@ def launch(ops, bf16=False, inlaunch=None):
             d.M, d.N, d.K, d.relu = o.M, o.N, o.K, int(bool(o.relu))
             d.bias = _p(o.bias); d.mask = _p(o.mask); d.ldmask = o.ldmask; d.a_rowsum = _p(o.a_rowsum)
             d.A16, d.B16, d.C16 = _p(o.A16), _p(o.B16), _p(o.C16)
+            d.a16_ld, d.b16_ld = o.a16_ld, o.b16_ld
             sk = o.split_k or pick_split(o, bk=bk)
             d.split_k = sk if sk > 1 else 0
             if sk > 1:

@@ -192,3 +192,76 @@ def test_same_products_on_the_register_staged_kernel_agree():
         gemmx.launch([op], bf16=True)
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
+
+
+def _padded(t, pitch):
+    """bf16 twin of a [rows, cols] tensor with rows `pitch` elements apart (cols <= pitch; the pad holds NaN: it must never
+    reach a stored output)."""
+    out = torch.full((t.shape[0], pitch), float("nan"), dtype=torch.bfloat16).cuda()
+    out[:, :t.shape[1]] = t.to(torch.bfloat16)
+    return out
+
+
+@pytest.mark.parametrize("split", [0, 3])
+def test_padded_twins_of_operands_without_16_byte_rows(split):
+    """fc_head / fc_tail are [1024, 1074] (HEAD:694-701): fp32 rows of 4296 bytes, no 16-byte pieces -- their products stayed
+    on the register-staged loop.  With a PADDED twin (pitch 1088: skg_gemmx_desc.a16_ld / b16_ld) all three products of the
+    layer run on the direct-to-LDS kernel: forward (W k-contiguous, K = 1074 ragged), input gradient (W row-contiguous,
+    N = 1074: the last 8-row piece reaches into the pad), weight gradient into the unpadded fp32 gradient (element-wise
+    epilogue: ldc 1074)."""
+    M, N, K = 240, 1024, 1074
+    x, W, b = _rnd(M, 1088, seed=21)[:, :K], _rnd(N, K, seed=22) * 0.05, _rnd(N, seed=23)
+    x16 = torch.full((M, 1088), float("nan"), dtype=torch.bfloat16).cuda(); x16[:, :K] = x.to(torch.bfloat16)
+    W16 = _padded(W, 1088)
+    gemmx.path_counts(reset=True)
+    out = torch.full((M, N), float("nan")).cuda()
+    op = gemmx.forward(x, W, out, bias=b, relu=True, K=K)
+    op.A16, op.B16, op.b16_ld, op.split_k = x16, W16, 1088, split
+    _launch([op])
+    _close(out, torch.relu(_q(x) @ _q(W).t() + b.double()), "forward through a padded weight twin")
+    dz = _rnd(M, N, seed=24)
+    dx = torch.full((M, 1088), float("nan")).cuda()
+    op = gemmx.input_grad(dz, W, dx[:, :K], N_in=K)
+    op.A16, op.B16, op.b16_ld, op.split_k = _tw(dz), W16, 1088, split
+    dW = torch.full((N, K), float("nan")).cuda(); db = torch.full((N,), float("nan")).cuda()
+    op2 = gemmx.weight_grad(dz, x, dW, db=db, k_in=K)
+    op2.A16, op2.B16, op2.split_k = _tw(dz), x16, split
+    _launch([op, op2])
+    _close(dx[:, :K], _q(dz) @ _q(W), "input gradient through a padded weight twin")
+    assert torch.isnan(dx[:, K:]).all()
+    _close(dW, _q(dz).t() @ _q(x), "weight gradient, ragged N")
+    _close(db, _q(dz).sum(0), "bias gradient", tol=1e-5)
+    assert gemmx.path_counts() == (0, 0, 2), "a product left the direct-to-LDS kernel: %r" % (gemmx.path_counts(),)
+
+
+def test_row_contiguous_operand_with_ragged_rows():
+    """dW of the classifier: A(m, k) = dlogits[k][m] with M = 118 rows of a [rows, 120] array (HEAD:410-411: 117 verbs + the
+    suppressor) -- not a multiple of the 8-row pieces a row-contiguous twin is staged in, but the pitch leaves room for the
+    last piece.  Exact integers: any misplaced row shows."""
+    rows, M, N = 3120, 118, 2048
+    dl = _ints(rows, 120, seed=31); dl[:, M:] = 0
+    pf = _ints(rows, N, seed=32)
+    dW = torch.full((M, N), float("nan")).cuda(); db = torch.full((M,), float("nan")).cuda()
+    gemmx.path_counts(reset=True)
+    op = gemmx.weight_grad(dl, pf, dW, db=db, n_out=M)
+    op.A16, op.B16 = _tw(dl), _tw(pf)
+    _launch([op])
+    assert gemmx.path_counts() == (0, 0, 1)
+    assert torch.equal(dW.double(), dl[:, :M].double().t() @ pf.double())
+    assert torch.equal(db.double(), dl[:, :M].double().sum(0))
+    # V-COCO: 25 columns stored 28 apart; the twin is a padded copy with a pitch of 32
+    M2 = 25
+    dl2 = _ints(rows, 28, seed=33); dl2[:, M2:] = 0
+    dW2 = torch.full((M2, N), float("nan")).cuda()
+    op = gemmx.weight_grad(dl2, pf, dW2, n_out=M2)
+    op.A16, op.a16_ld, op.B16 = _padded(dl2, 32), 32, _tw(pf)
+    _launch([op])
+    assert gemmx.path_counts() == (0, 0, 2)
+    assert torch.equal(dW2.double(), dl2[:, :M2].double().t() @ pf.double())
+    dx = torch.full((rows, N), float("nan")).cuda()
+    W = _ints(M2, N, seed=34)
+    op = gemmx.input_grad(dl2, W, dx, K_out=M2)
+    op.A16, op.a16_ld, op.B16 = _padded(dl2, 32), 32, _tw(W)
+    _launch([op])
+    assert gemmx.path_counts() == (0, 0, 3)
+    assert torch.equal(dx.double(), dl2[:, :M2].double() @ W.double())
