@@ -59,6 +59,9 @@ def build_case(name):
     detections (list), feat3 [B,256,h,w], shapes, targets|None, weight_seed, rng_seed, pooled_seed."""
     c = dict(name=name, C=8, p=2, max_human=15, max_object=15, num_iter=2, training=False, targets=None,
              weight_seed=3, rng_seed=1234, pooled_seed=99, box_score_thresh=0.2, box_nms_thresh=0.5)
+    # "<case>@<seed>": the same case with another image seed (developer aid: tools/debug_grad_case.py looks for seeds whose
+    # gradients are reproducible across hosts -- no ReLU input within rounding noise of zero)
+    name, _, alt_seed = name.partition("@")
     cfg = HICO
     small_feat = dict(feat_hw=(6, 9))
     if name == "tiny":
@@ -134,14 +137,18 @@ def build_case(name):
         # BASELINE config 5's TRAINING half: the V-COCO head (K = 24, human_idx = 1: main:73-76, cache.py:165-168) at full
         # width -- the classifier block is 25 columns, every K-dependent shape of the step changes (logit leading dimension,
         # dW of the classifier, the TransH relation tables, the split targets).  Gradient samples from the live reference.
+        # (image seed 1603: of 1600-1604 the best conditioned -- with 1600 and 1601 one fc_2 unit of attention_head sits within
+        #  rounding noise of its ReLU's zero, and whichever side a host's matrix products land on decides 4e-3 of that
+        #  branch's bias gradient: oracle on the GPU box's host vs the reference here, bit-identical losses;
+        #  tools/debug_grad_case.py, tools/case_conditioning.py)
         cfg = VCOCO
-        imgs = _grid_images([(12, 10), (7, 13)], 256, 7, 1, 81, 1600)
+        imgs = _grid_images([(12, 10), (7, 13)], 256, 7, 1, 81, int(alt_seed or 1603))
         c.update(C=256, p=7, weight_seed=0, training=True, n_gt=4)
     elif name == "train_ragged_full":
         # a ragged full-width training batch at the reference's DEFAULT caps (15 / 15): an image over both caps (17 humans
         # + GT, 18 objects: truncation), a SKIPPED image in the middle (no human: the Q9 offset bug at C = 256, p = 7 --
         # HEAD:829-839 -- shifts the pooled rows of everything behind it), a small one and a one-pair image.
-        imgs = _grid_images([(17, 18), (0, 5), (3, 9), (1, 1)], 256, 7, 49, 80, 1700)
+        imgs = _grid_images([(17, 18), (0, 5), (3, 9), (1, 1)], 256, 7, 49, 80, int(alt_seed or 1700))
         c.update(C=256, p=7, weight_seed=0, training=True, n_gt=4)
     else:
         raise KeyError(name)

@@ -68,7 +68,7 @@ def run_reference(case):
     hooks = [gh.adjacency.register_forward_hook(lambda m, i, o: cap["adjacency"].append(o.detach().clone())),
              gh.norm_h.register_forward_hook(lambda m, i, o: cap["norm_h"].append(o.detach().clone())),
              gh.norm_o.register_forward_hook(lambda m, i, o: cap["norm_o"].append(o.detach().clone()))]
-    want_grads = case["name"] in cases.FULL_TRAIN_CASES    # gradient samples from the reference's own autograd
+    want_grads = case["name"].partition("@")[0] in cases.FULL_TRAIN_CASES    # gradient samples from the reference's own autograd
     try:
         with torch.set_grad_enabled(want_grads), StableTies():
             det = head.preprocess(case["detections"], case["targets"], append_gt=case["training"])
@@ -146,7 +146,7 @@ def main(names):
     for name in names:
         case = cases.build_case(name)
         flat = run_reference(case)
-        if name in cases.OUTPUT_ONLY:
+        if name.partition("@")[0] in cases.OUTPUT_ONLY:
             # output-only fixture: drop the bulky intermediates, keep what pins the result
             keep = ("logits_p", "logits_s", "n_results", "n_tables")
             keep += ("hoi_loss", "interactiveness_loss", "transH_loss")
