@@ -134,7 +134,7 @@ def cpu_baseline(budget_s=40.0):
 
 
 def run_train(B, precision, steps, warmup, device, rank, world, dist_on, prefetch=True, force_exchange=False,
-              measure=False):
+              measure=False, probe=None):
     """The data-parallel training step (forward + backward on the HIP GEMMs, AdamW; with a process group: the gradient
     arena exchanged chunk by chunk behind the backward + the fused normaliser all-reduce, over RCCL) on B synthetic 20x20
     images per GPU with ground truth appended.  force_exchange: take the data-parallel route in a process group of ONE rank
@@ -142,6 +142,8 @@ def run_train(B, precision, steps, warmup, device, rank, world, dist_on, prefetc
     dense product (skg_train_timer).  Returns (elapsed seconds of `steps` steps on this rank, last loss dict, info)."""
     from skghoi_amd import synth, trainer
     head = build_head(device).train()
+    if probe is not None:
+        probe["head"] = head                                 # (a watchdog's failure record reads the step's progress off it)
     head.distributed = dist_on
     head.force_collectives = force_exchange
     head.precision = precision
@@ -418,6 +420,108 @@ def launch_ranks(n, argv):
     return rc if rc >= 0 else 128 - rc
 
 
+EXIT_LEG_STUCK = 4        # a rank did not come back from the N > 1 training leg within its deadline
+
+
+class LegGuard:
+    """Guards the N > 1 training leg -- the first code of a run to move gradients between real GPUs -- so that whatever goes
+    wrong in it cannot cost the run its headline line, and cannot pass for success either:
+
+    * an EXCEPTION on any rank becomes `train.bf16.error` on rank 0's line; the rank that raised says so through the process
+      group's store, its peers (who would sit in their next collective until the deadline) see it within a second and leave;
+      exit code 0 -- the run is complete, the leg's failure is in the record;
+    * a leg that is NOT BACK within the deadline (a rank stuck in a collective: a GPU hang) makes rank 0 print the line with
+      the error and every rank's evidence -- rank, backward stages issued, collectives issued, route -- and every rank exit
+      with EXIT_LEG_STUCK: the driver's rc says the run was not clean.
+
+    `out` (the line's dict) is only touched under the guard's lock, by whoever gets there first: the leg's own thread
+    (finish / failed) or the watchdog (bail) -- one line, never two, never a dict printed while it is being built."""
+    KEY = "skg_bench_train_leg_failed"
+
+    def __init__(self, rank, world, out, deadline, evidence=None, emit=None):
+        import threading
+        self.rank, self.world, self.out, self.deadline = rank, world, out, deadline
+        self.evidence = evidence or (lambda: {})
+        self.emit = emit or (lambda o: print(json.dumps(o), flush=True))
+        self.lock = threading.Lock()
+        self.done = threading.Event()
+        self.state = "running"
+        self.store = None
+        try:
+            import torch.distributed as dist
+            if world > 1 and dist.is_initialized():
+                self.store = dist.distributed_c10d._get_default_store()
+        except Exception:                                    # noqa: BLE001
+            self.store = None
+        threading.Thread(target=self._watch, daemon=True).start()
+
+    def _peer_failure(self):
+        if self.store is None:
+            return None
+        try:
+            if self.store.check([self.KEY]):
+                return self.store.get(self.KEY).decode(errors="replace")
+        except Exception:                                    # noqa: BLE001
+            return None
+        return None
+
+    def _watch(self):
+        t_end = time.monotonic() + self.deadline
+        while not self.done.wait(0.5):
+            msg = self._peer_failure()
+            if msg is not None:
+                self._bail("a peer failed in the data-parallel training leg -- " + msg, 0)
+            if time.monotonic() > t_end:
+                self._bail("the data-parallel training leg did not finish within %.0f s" % self.deadline, EXIT_LEG_STUCK)
+
+    def _record(self, error):
+        rec = dict(error=error[:600], rank=self.rank)
+        try:
+            rec["evidence"] = self.evidence()
+        except Exception as e:                               # noqa: BLE001
+            rec["evidence"] = "unavailable: %s" % e
+        return rec
+
+    def _bail(self, error, code):
+        with self.lock:
+            if self.state != "running":
+                return
+            self.state = "bailed"
+            rec = self._record(error)
+            if self.rank == 0:
+                self.out["train"] = dict(bf16=rec)
+                self.out["runtime"] = runtime_info()
+                self.emit(self.out)
+            else:
+                sys.stderr.write("bench.py rank %d: %s\n" % (self.rank, json.dumps(rec)))
+                sys.stderr.flush()
+            os._exit(code)                                   # (with the lock held: the leg's own thread never prints after this)
+
+    def finish(self, train_record):
+        """The leg came back on this rank.  False if the watchdog got there first (the process is on its way out)."""
+        with self.lock:
+            if self.state != "running":
+                return False
+            self.state = "finished"
+            self.out["train"] = train_record
+        self.done.set()
+        return True
+
+    def failed(self, exc):
+        """The leg raised on this rank: tell the peers, record the error."""
+        msg = "rank %d: %s: %s" % (self.rank, type(exc).__name__, exc)
+        peer = self._peer_failure()
+        if peer is not None:         # this rank's error is the echo of a peer's (its collective lost the peer that left)
+            return self.finish(dict(bf16=self._record("a peer failed in the data-parallel training leg -- %s (here, after that: %s)"
+                                                      % (peer, msg))))
+        if self.store is not None:
+            try:
+                self.store.set(self.KEY, msg[:600])
+            except Exception:                                # noqa: BLE001
+                pass
+        return self.finish(dict(bf16=self._record(msg)))
+
+
 def dry_run(args, rank, world):
     """Launcher rehearsal (no GPU, no head): the same rendezvous, barriers, max-over-ranks timing and count gather as the
     real run around an empty step."""
@@ -438,14 +542,35 @@ def dry_run(args, rank, world):
     barrier()
     elapsed = skd.max_over_ranks(time.perf_counter() - t0)
     counts = skd.gather_counts(args.batch * args.steps)
+    out = dict(metric="images/sec through interaction head (20x20 pairs)", value=None, unit="images/s",
+               n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
+               vs_baseline=None, dtype="f32", data="synthetic", dry_run=True,
+               config=dict(workload="launcher rehearsal: no head, empty steps",
+                           images_counted=sum(counts), batch_per_gpu=args.batch),
+               dist=dist_info(world))
+    leg = os.environ.get("SKG_BENCH_DRY_TRAIN_LEG")           # test hook: rehearse the N > 1 training leg's guard --
+    clean = True                                              # "ok" | "raise:<rank>" | "hang:<rank>"
+    if leg and world > 1:
+        guard = LegGuard(rank, world, out, float(os.environ.get("SKG_BENCH_TRAIN_DEADLINE", "300")),
+                         evidence=lambda: dict(route="dry run", stages_issued=0, collectives_issued=0))
+        kind, _, who = leg.partition(":")
+        try:
+            if kind == "raise" and who == str(rank):
+                raise RuntimeError("rehearsed failure of the training leg")
+            if kind == "hang" and who == str(rank):
+                time.sleep(3600)
+            dist.barrier()                                    # (the leg's collective: the peers of a failed rank wait here)
+            guard.finish(dict(bf16=dict(ms_per_step=0.0, rehearsal=True)))
+        except Exception as e:                                # noqa: BLE001
+            clean = False
+            guard.failed(e)
     if rank == 0:
-        print(json.dumps(dict(metric="images/sec through interaction head (20x20 pairs)", value=None, unit="images/s",
-                              n_gpus=world, steps=args.steps, warmup=args.warmup,
-                              ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
-                              vs_baseline=None, dtype="f32", data="synthetic", dry_run=True,
-                              config=dict(workload="launcher rehearsal: no head, empty steps",
-                                          images_counted=sum(counts), batch_per_gpu=args.batch),
-                              dist=dist_info(world))))
+        print(json.dumps(out), flush=True)
+    if not clean:
+        if rank == 0:
+            time.sleep(2.0)          # (rank 0 hosts the store: the peers must get to read this rank's word)
+        os._exit(0)                  # (the peers have left or are leaving: no collective teardown with them)
     if world > 1:
         dist.destroy_process_group()
 
@@ -796,23 +921,35 @@ def main():
         _trainer.limit_host_threads(world)
         ks = 40
         # This leg is the first code to move gradients between real GPUs (a one-GPU box cannot): whatever goes wrong in it
-        # must not cost the run its headline line.  An exception becomes an error record; a leg that does not come back within
-        # the deadline (a rank stuck in a collective) makes rank 0 print the line without it and every rank leave.
-        import threading
-        leg_done = threading.Event()
-        deadline = float(os.environ.get("SKG_BENCH_TRAIN_DEADLINE", "300"))
+        # must not cost the run its headline line, and a hang must show in the exit code (LegGuard): an exception becomes an
+        # error record (rc 0); a leg that is not back within the deadline makes rank 0 print the line with the error and every
+        # rank's evidence, and every rank exit with EXIT_LEG_STUCK.
+        probe = {}
 
-        def bail():
-            if leg_done.wait(deadline):
-                return
-            out["train"] = dict(bf16=dict(error="the data-parallel training leg did not finish within %.0f s" % deadline))
-            out["runtime"] = runtime_info()
-            if rank == 0:
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-        threading.Thread(target=bail, daemon=True).start()
+        def evidence():
+            """What this rank can say about where its step stands (no GPU call, no lock a stuck step could hold)."""
+            ev = dict(rank=rank)
+            head_ = probe.get("head")
+            if head_ is None:
+                return ev
+            from skghoi_amd import _capi
+            ctx = head_.__dict__.get("_train_ctx")
+            if ctx is not None and getattr(ctx, "_h", None):
+                prog = int(_capi.lib().skg_ctx_train_backward_progress(ctx._h))
+                ev.update(backward_stages_issued=prog & 0xff, backward_pending=bool(prog & 0x100))
+            ex = getattr(head_, "grad_exchange", None)
+            if ex is not None:
+                native = getattr(ex, "native", None)
+                ev["route"] = "libskghoi_hip's own RCCL communicator" if native is not None else "torch.distributed"
+                if native is not None:
+                    ev["collectives_issued"] = int(_capi.lib().skg_comm_collectives(native.handle))
+                ev["python_side_collectives"] = getattr(ex, "collectives", None)
+            return ev
+
+        guard = LegGuard(rank, world, out, float(os.environ.get("SKG_BENCH_TRAIN_DEADLINE", "300")), evidence=evidence)
+        leg_ok = True
         try:
-            el_t, losses, inf = run_train(4, "bf16", ks, 10, device, rank, world, True, measure=True)   # (every rank: the steps hold collectives)
+            el_t, losses, inf = run_train(4, "bf16", ks, 10, device, rank, world, True, measure=True, probe=probe)   # (every rank: the steps hold collectives)
             el_t = skd.max_over_ranks(el_t, device=device)
             ms = el_t / ks * 1e3
             rec = dict(ms_per_step=round(ms, 3), images_per_s=round(4 * world * ks / el_t, 2), batch_per_gpu=4, steps=ks,
@@ -821,13 +958,20 @@ def main():
             rec["roofline"] = train_roofline("bf16", ms, inf)
             if inf.get("phases_ms"):
                 rec["phases_ms"] = inf["phases_ms"]
-            out["train"] = dict(bf16=rec, note="data-parallel training step on every rank: fwd + bwd + AdamW at batch 4 per GPU, "
-                                               "gradient arena exchanged in chunks behind the backward + one fused normaliser "
-                                               "all-reduce (RCCL); ms_per_step = max over ranks; roofline of rank 0")
+            guard.finish(dict(bf16=rec, note="data-parallel training step on every rank: fwd + bwd + AdamW at batch 4 per GPU, "
+                                             "gradient arena exchanged in chunks behind the backward + one fused normaliser "
+                                             "all-reduce (RCCL); ms_per_step = max over ranks; roofline of rank 0"))
         except Exception as e:                                   # noqa: BLE001
-            out["train"] = dict(bf16=dict(error=("%s: %s" % (type(e).__name__, e))[:600]))
-        finally:
-            leg_done.set()
+            leg_ok = False
+            guard.failed(e)
+        if not leg_ok:
+            # the peers are leaving through their watchdogs (they saw this rank's word in the store): print and go, without a
+            # collective teardown that would wait for them
+            out["runtime"] = runtime_info()
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+                time.sleep(2.0)                  # (rank 0 hosts the store: the peers must get to read this rank's word)
+            os._exit(0)
         torch.set_num_threads(max(1, host_cpu_share() // world))
     out["runtime"] = runtime_info()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -649,7 +649,11 @@ void skg_context_destroy(skg_context* ctx);       /* waits for a job in flight, 
  * skg_train_backward_f32 would reject (checked HERE, before the job is queued), SKG_E_LIMIT while a job is pending.
  * stage_mask: bit s set = the worker records the context's OWN event for stage s on `stream` right behind that stage (created
  * without timing and with DEVICE-scope release: an event of the default, system-scope kind writes the L2 back and invalidates
- * it at every record -- a dozen of those inside a backward cost 0.09 ms: backward 0.95-0.97 -> 0.86-0.88 ms).  skg_ctx_train_backward_stage_wait(ctx, s)
+ * it at every record -- a dozen of those inside a backward cost 0.09 ms: backward 0.95-0.97 -> 0.86-0.88 ms); bit 31 set = the
+ * chunks behind these stages go to OTHER GPUs (a process group of more than one rank): the events are then of the default,
+ * system-scope kind -- a peer or a registered-buffer transport may read the chunk directly, so the stage's writes must have
+ * left this GPU's L2 (skg_ctx_train_backward_exchange_f32 decides this itself from its communicator's world size).
+ * skg_ctx_train_backward_stage_wait(ctx, s)
  * blocks the HOST until stage s has been enqueued (and its event, if any, recorded) and returns 0, or the job's error if it
  * ended before reaching s; skg_ctx_stream_wait_stage(ctx, s, other_stream) then makes `other_stream` wait for stage s on the
  * DEVICE: a data-parallel caller orders the collective of the gradient-arena prefix stage s completed behind it, while the
@@ -666,6 +670,9 @@ int skg_ctx_train_backward_async_f32(skg_context* ctx, const skg_train_plan* pla
 int skg_ctx_stream_wait_stage(skg_context* ctx, int stage, void* waiting_stream);
 int skg_ctx_train_backward_stage_wait(skg_context* ctx, int stage);
 int skg_ctx_train_backward_join(skg_context* ctx);
+/* Non-blocking: backward stages of the context's current / last job issued so far, | 0x100 while the job is pending.  For
+ * failure records (a rank that does not come back from a step: how far its backward got).                              */
+int skg_ctx_train_backward_progress(skg_context* ctx);
 /* ---- data parallel: the gradient exchange inside the worker's backward (replaces utils.py:202-205, DistributedDataParallel's
  * bucketed NCCL all-reduce, for the head's gradient arena).  skg_comm is an RCCL communicator OF THIS LIBRARY -- RCCL is
  * bound at run time (skg_comm_load: dlopen of `librccl_path`, else of the librccl the process already has; SKG_E_UNSUPPORTED
@@ -712,6 +719,12 @@ int skg_comm_load(const char* librccl_path);
 int skg_comm_unique_id(void* id_out);
 int skg_comm_create(const void* id, int rank, int world, skg_comm** out);
 void skg_comm_destroy(skg_comm* comm);
+/* ncclCommAbort: ends the communicator without its peers' cooperation, so that ranks already waiting in a collective this
+ * rank will never join get an error instead of a hang.  The backward's worker calls it when a stage, an event or a collective
+ * fails between two chunks; callers may after a failed step.  The object stays valid and dead (skg_comm_dead: every later
+ * collective returns SKG_E_COMM) until skg_comm_destroy.                                                               */
+int skg_comm_abort(skg_comm* comm);
+int skg_comm_dead(const skg_comm* comm);
 int skg_comm_world(const skg_comm* comm);
 int skg_comm_rank(const skg_comm* comm);
 int64_t skg_comm_collectives(const skg_comm* comm);                /* all-reduces issued since creation */

@@ -190,6 +190,8 @@ PROTOTYPES = {
     "skg_comm_unique_id": (C.c_int, [_vp]),
     "skg_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "skg_comm_destroy": (None, [_vp]),
+    "skg_comm_abort": (C.c_int, [_vp]),
+    "skg_comm_dead": (C.c_int, [_vp]),
     "skg_comm_world": (C.c_int, [_vp]),
     "skg_comm_rank": (C.c_int, [_vp]),
     "skg_comm_collectives": (_i64, [_vp]),
@@ -201,6 +203,7 @@ PROTOTYPES = {
     "skg_ctx_stream_wait_stage": (C.c_int, [_vp, C.c_int, _vp]),
     "skg_ctx_train_backward_stage_wait": (C.c_int, [_vp, C.c_int]),
     "skg_ctx_train_backward_join": (C.c_int, [_vp]),
+    "skg_ctx_train_backward_progress": (C.c_int, [_vp]),
     "skg_train_ws_offset": (C.c_int64, [C.POINTER(TrainPlan), C.c_int]),
     "skg_train_flops": (C.c_double, [C.POINTER(TrainPlan), C.c_int]),
 }

@@ -59,6 +59,7 @@ struct skg_comm {
     hipEvent_t tail = nullptr;          // scratch: the tail of a caller's stream the exchange stream is ordered behind
     int rank = 0, world = 1, device = 0;
     long collectives = 0;               // issued since creation
+    bool dead = false;                  // aborted (a collective or its ordering failed on this rank): nothing further is issued
 };
 
 extern "C" {
@@ -122,9 +123,26 @@ int skg_comm_create(const void* id_in, int rank, int world, skg_comm** out) {
     return 0;
 }
 
+/* Tears the communicator down without waiting for its peers (ncclCommAbort): a rank whose step failed between two chunk
+ * collectives calls it so that the peers -- already inside the next ncclAllReduce, on a communicator no watchdog looks after
+ * -- get an error instead of waiting for ever.  The object stays valid (dead: every later collective returns SKG_E_COMM)
+ * until skg_comm_destroy. */
+int skg_comm_abort(skg_comm* c) {
+    if (!c) return SKG_E_ARG;
+    if (c->dead) return 0;
+    c->dead = true;
+    if (c->nccl && g_api.comm_abort) {
+        ncclResult_t r = g_api.comm_abort(c->nccl);
+        c->nccl = nullptr;
+        if (r != ncclSuccess) return nccl_fail("ncclCommAbort", r);
+    }
+    return 0;
+}
+int skg_comm_dead(const skg_comm* c) { return c && c->dead ? 1 : 0; }
+
 void skg_comm_destroy(skg_comm* c) {
     if (!c) return;
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream && !c->dead) (void)hipStreamSynchronize(c->stream);
     if (c->nccl && g_api.comm_destroy) (void)g_api.comm_destroy(c->nccl);
     if (c->done) (void)hipEventDestroy(c->done);
     if (c->aux) (void)hipEventDestroy(c->aux);
@@ -143,6 +161,7 @@ int64_t skg_comm_collectives(const skg_comm* c) { return c ? (int64_t)c->collect
 // (a recorded event; NULL: behind nothing), and the close of a step -- `stream` ordered behind every chunk issued so far
 int skg_comm_chunk(skg_comm* c, hipEvent_t after, float* p, int64_t n) {
     if (!c || !p || n < 0) return SKG_E_ARG;
+    if (c->dead) { snprintf(g_err, sizeof(g_err), "the communicator was aborted after an earlier failure"); return SKG_E_COMM; }
     if (n == 0) return 0;
     if (after) {
         hipError_t e = hipStreamWaitEvent(c->stream, after, 0);

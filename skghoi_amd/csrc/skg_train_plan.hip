@@ -841,9 +841,13 @@ struct skg_context {
     int issued = 0;                      // stages [first, issued) of the current / last job are on the stream
     void* stream = nullptr;
     hipEvent_t events[SKG_TRAIN_BWD_STAGES];       // caller's events (measurement), by stage - first
-    hipEvent_t own[SKG_TRAIN_BWD_STAGES];          // the context's own stage events: no timing, DEVICE-scope release
+    hipEvent_t own_dev[SKG_TRAIN_BWD_STAGES];      // the context's own stage events: no timing, DEVICE-scope release
+    hipEvent_t own_sys[SKG_TRAIN_BWD_STAGES];      // ... the same with the default SYSTEM-scope release: what orders a collective
+                                                   // of a world > 1 behind a stage (a peer GPU, or a registered-buffer transport,
+                                                   // may read the chunk directly: the stage's writes must have left this GPU's L2)
+    hipEvent_t* own = own_dev;                     // the set the current job records
     uint32_t own_mask = 0;                         // stages (absolute) behind which own[stage] is recorded
-    bool own_made = false;
+    bool own_made = false, own_sys_made = false;
     bool with_events = false;
     skg_exchange ex = {};                          // the arena chunks this job all-reduces (ex.comm) and / or updates (ex.adamw) itself
     bool has_ex = false;
@@ -905,6 +909,9 @@ struct skg_context {
                     s = e + 1;
                 }
                 if (!r) r = exchange_close((hipStream_t)stream);                 // `stream` behind the last collective / update
+                // a failure between two chunks leaves the peers inside a collective this rank will never join, on a
+                // communicator nobody watches: abort it, so that they get an error instead of a hang
+                if (r && has_ex && ex.comm) (void)skg_comm_abort(ex.comm);
                 lk.lock();
             }
             rc = r; pending = false;
@@ -945,7 +952,9 @@ void skg_context_destroy(skg_context* c) {
     c->cv.notify_all();
     if (c->started && c->worker.joinable()) c->worker.join();
     if (c->own_made)
-        for (int s = 0; s < SKG_TRAIN_BWD_STAGES; ++s) (void)hipEventDestroy(c->own[s]);
+        for (int s = 0; s < SKG_TRAIN_BWD_STAGES; ++s) (void)hipEventDestroy(c->own_dev[s]);
+    if (c->own_sys_made)
+        for (int s = 0; s < SKG_TRAIN_BWD_STAGES; ++s) (void)hipEventDestroy(c->own_sys[s]);
     if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
     if (c->aux_done) (void)hipEventDestroy(c->aux_done);
     delete c;
@@ -978,19 +987,35 @@ static int submit_backward(skg_context* ctx, const skg_train_plan* P, int first_
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
-    if (stage_mask && !a->own_made) {
+    // events with SYSTEM-scope release where the chunk behind a stage goes to OTHER GPUs: the library's communicator of a world
+    // > 1, or a caller that says so (bit 31 of stage_mask: its process group has more than one rank).  World size 1 and the
+    // single-process optimizer chunks keep the device-scope set (measured: a dozen system-scope records cost a backward 0.09 ms).
+    const bool sys_scope = (ex && ex->comm && skg_comm_world(ex->comm) > 1) || (!ex && (stage_mask & 0x80000000u));
+    stage_mask &= 0x7fffffffu;
+    if (stage_mask && sys_scope && !a->own_sys_made) {
+        for (int s = 0; s < SKG_TRAIN_BWD_STAGES; ++s) {
+            e = hipEventCreateWithFlags(&a->own_sys[s], hipEventDisableTiming);
+            if (e != hipSuccess) {
+                for (int t = 0; t < s; ++t) (void)hipEventDestroy(a->own_sys[t]);
+                return (int)e;
+            }
+        }
+        a->own_sys_made = true;
+    }
+    if (stage_mask && !sys_scope && !a->own_made) {
         // DEVICE-scope release: the default (system scope) writes the L2 back and invalidates it at every record -- a dozen
         // of those inside a backward cost its kernels their L2-resident operands (measured: backward 0.95-0.97 ms with them, 0.86-0.88 ms with device-scope events)
         for (int s = 0; s < SKG_TRAIN_BWD_STAGES; ++s) {
-            e = hipEventCreateWithFlags(&a->own[s], hipEventDisableTiming | hipEventReleaseToDevice);
+            e = hipEventCreateWithFlags(&a->own_dev[s], hipEventDisableTiming | hipEventReleaseToDevice);
             if (e != hipSuccess) {
-                for (int t = 0; t < s; ++t) (void)hipEventDestroy(a->own[t]);
+                for (int t = 0; t < s; ++t) (void)hipEventDestroy(a->own_dev[t]);
                 return (int)e;
             }
         }
         a->own_made = true;
     }
     a->own_mask = stage_mask;
+    a->own = sys_scope ? a->own_sys : a->own_dev;
     a->has_ex = ex != nullptr;
     if (ex) a->ex = *ex; else memset(&a->ex, 0, sizeof(a->ex));
     if (ex && !ex->comm && !a->aux) {
@@ -1039,10 +1064,18 @@ int skg_ctx_stream_wait_stage(skg_context* ctx, int stage, void* waiting_stream)
     skg_context* a = ctx_or_default(ctx);
     if (stage < 0 || stage >= SKG_TRAIN_BWD_STAGES) return SKG_E_ARG;
     std::unique_lock<std::mutex> lk(a->m);
-    if (!a->own_made || !((a->own_mask >> stage) & 1u) || a->issued <= stage) return SKG_E_ARG;
+    if (!((a->own_mask >> stage) & 1u) || a->issued <= stage) return SKG_E_ARG;
     hipEvent_t ev = a->own[stage];
     lk.unlock();
     return (int)hipStreamWaitEvent((hipStream_t)waiting_stream, ev, 0);
+}
+
+/* Where the context's current (or last) job stands, without blocking: stages issued so far | 0x100 while a job is pending.
+ * For failure records (a rank stuck in a collective: which stage had gone out). */
+int skg_ctx_train_backward_progress(skg_context* ctx) {
+    skg_context* a = ctx_or_default(ctx);
+    std::unique_lock<std::mutex> lk(a->m);
+    return a->issued | (a->pending ? 0x100 : 0);
 }
 
 int skg_ctx_train_backward_join(skg_context* ctx) {

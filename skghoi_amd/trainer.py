@@ -276,6 +276,10 @@ class ArenaExchange:
         m = 0
         for s_, _ in self.chunk_stages(ends):
             m |= 1 << s_
+        if m and self.world > 1:
+            # the chunk goes to OTHER GPUs: the stage's writes must leave this GPU's L2 before the collective reads them
+            # (bit 31: the context records events with the default system-scope release instead of its device-scope set)
+            m |= 1 << 31
         return m
 
     def native_exchange(self, ga, ends):

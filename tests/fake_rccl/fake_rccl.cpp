@@ -13,6 +13,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -24,6 +25,7 @@ struct Shared {
     std::atomic<int> arrived;                      // sense-reversing barrier
     std::atomic<int> sense;
     std::atomic<int> attached;
+    std::atomic<int> aborted;                      // a rank aborted its communicator: nobody waits for it any more
     long seq[MAX_RANKS];
     long count[MAX_RANKS];
     float slot[MAX_RANKS][PIECE];
@@ -35,6 +37,7 @@ struct Comm {
     char name[64];
 };
 bool barrier(Comm* c) {
+    if (c->sh->aborted.load()) return false;
     c->local_sense ^= 1;
     if (c->sh->arrived.fetch_add(1) + 1 == c->n) {
         c->sh->arrived.store(0);
@@ -44,6 +47,7 @@ bool barrier(Comm* c) {
     const auto t0 = std::chrono::steady_clock::now();
     while (c->sh->sense.load() != c->local_sense) {
         std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if (c->sh->aborted.load()) return false;                                                   // a peer aborted (ncclCommAbort)
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) return false;      // a peer never arrived
     }
     return true;
@@ -88,7 +92,11 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
     delete c;
     return ncclSuccess;
 }
-ncclResult_t ncclCommAbort(ncclComm_t comm) { return ncclCommDestroy(comm); }
+ncclResult_t ncclCommAbort(ncclComm_t comm) {
+    Comm* c = reinterpret_cast<Comm*>(comm);
+    if (c && c->sh) c->sh->aborted.store(1);               // like the real one: the peers' pending collectives end with an error
+    return ncclCommDestroy(comm);
+}
 const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "fake transport error (order / size mismatch or a missing peer)"; }
 
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t comm,
@@ -98,6 +106,12 @@ ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataT
     if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
     // every rank must be in the SAME collective: sequence number and size are compared first
     ++c->seq;
+    {   // failure injection (tests): SKG_FAKE_RCCL_FAIL = "<rank>:<sequence number>" -- that collective fails on that rank
+        // before it meets its peers (what a transport error in the middle of a backward looks like to the caller)
+        const char* f = getenv("SKG_FAKE_RCCL_FAIL");
+        int fr = -1; long fs = -1;
+        if (f && sscanf(f, "%d:%ld", &fr, &fs) == 2 && fr == c->rank && fs == c->seq) return ncclInternalError;
+    }
     c->sh->seq[c->rank] = c->seq; c->sh->count[c->rank] = (long)count;
     if (!barrier(c)) return ncclSystemError;
     bool same = true;

@@ -138,6 +138,39 @@ def test_bench_launcher_propagates_a_rank_failure():
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
+def test_bench_training_leg_guard_exception_is_a_record_and_a_hang_is_an_exit_code():
+    """The guard around bench.py's N > 1 training leg (LegGuard), rehearsed with two gloo ranks and the dry run's stand-in leg:
+    * the leg comes back: one line, rc 0, the leg's record in it;
+    * rank 1 RAISES inside the leg while rank 0 waits in the leg's collective: rank 0 learns of it through the store within
+      a second, prints ONE line whose train.bf16.error names rank 1, rc 0 (the run is complete, the failure is on record);
+    * rank 1 never comes back (a stuck collective): after the deadline rank 0 prints ONE line with the error and its
+      evidence, and the run's exit code is bench.EXIT_LEG_STUCK -- a hang is not a clean run."""
+    import json
+    env = {"SKG_BENCH_BACKEND": "gloo", "SKG_BENCH_TRAIN_DEADLINE": "4"}
+    args = ["--gpus", "2", "--dry-run", "--steps", "2"]
+
+    def line(r):
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, (r.stdout, r.stderr[-1500:])
+        return json.loads(lines[0])
+
+    r = _run_bench(args, dict(env, SKG_BENCH_DRY_TRAIN_LEG="ok"))
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert line(r)["train"]["bf16"]["rehearsal"] is True
+    r = _run_bench(args, dict(env, SKG_BENCH_DRY_TRAIN_LEG="raise:1", SKG_BENCH_TRAIN_DEADLINE="60"))
+    assert r.returncode == 0, r.stderr[-1500:]
+    rec = line(r)["train"]["bf16"]
+    assert "rank 1" in rec["error"] and "rehearsed failure" in rec["error"]
+    r = _run_bench(args, dict(env, SKG_BENCH_DRY_TRAIN_LEG="raise:0", SKG_BENCH_TRAIN_DEADLINE="60"))
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "rank 0" in line(r)["train"]["bf16"]["error"]
+    r = _run_bench(args, dict(env, SKG_BENCH_DRY_TRAIN_LEG="hang:1"))
+    assert r.returncode == 4, (r.returncode, r.stderr[-1500:])
+    rec = line(r)["train"]["bf16"]
+    assert "did not finish within" in rec["error"] and rec["evidence"]["route"] == "dry run" and rec["rank"] == 0
+    assert "bench.py rank 1:" in r.stderr                      # the stuck rank's own watchdog left its evidence too
+
+
 def _exchange_worker(rank, world, port, q):
     """One rank of the data-parallel gradient-exchange test (CPU, gloo): oracle gradients of THIS rank's image under the
     reference's data-parallel loss (sum / (all_reduce_sum(n_p) / world), HEAD:167-172), laid out in the gradient arena,

@@ -145,29 +145,32 @@ def _build_fake_rccl(tmp_path):
     return out
 
 
-def _dp_equiv_worker(rank, world, port, ref_path, q, rccl_lib=None):
-    """One rank of test_two_ranks_through_the_hip_arena_equal_the_unsharded_step: image `rank` of train_tiny through
-    trainer.train_step (fused step, backward on the library's worker thread, arena chunks behind its stage events)."""
+def _dp_equiv_worker(rank, world, port, ref_path, q, rccl_lib=None, case_name="train_tiny", per=1, fail=None):
+    """One rank of test_two_ranks_through_the_hip_arena_equal_the_unsharded_step: images [rank * per, (rank + 1) * per) of the
+    case through trainer.train_step (fused step, backward on the library's worker thread, arena chunks behind its stage
+    events).  fail = "<rank>:<n>": the stand-in transport makes that rank's n-th collective fail (the error test)."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
     from collections import OrderedDict
-    import cases, gpu_run
+    import cases, gpu_run, helpers
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     if rccl_lib:
         os.environ["SKG_RCCL_LIB"] = rccl_lib
+    if fail:
+        os.environ["SKG_FAKE_RCCL_FAIL"] = fail
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     ref = torch.load(ref_path)
-    case = cases.build_case("train_tiny")
+    case = cases.build_case(case_name)
     full = case
     case = dict(case)
     for k in ("detections", "targets", "shapes"):
-        case[k] = full[k][rank:rank + 1]
-    case["feat3"] = full["feat3"][rank:rank + 1]
+        case[k] = full[k][rank * per:(rank + 1) * per]
+    case["feat3"] = full["feat3"][rank * per:(rank + 1) * per]
     head = gpu_run.build_head(case)
     head.distributed = True
-    head.box_roi_pool = _offset_pool(full, ref["n0"] * rank)
+    head.box_roi_pool = _offset_pool(full, ref["first_row"][rank])
     net = trainer.wrap_ddp(head, torch.device("cuda", 0))
     assert net is head and head.grad_exchange is not None
     native = head.grad_exchange.native
@@ -183,6 +186,21 @@ def _dp_equiv_worker(rank, world, port, ref_path, q, rccl_lib=None):
     staged = []
     orig = train_fused.TrainContext.stage_wait
     train_fused.TrainContext.stage_wait = lambda self, s, stream=None: (staged.append(s), orig(self, s, stream))[1]
+    if fail:
+        # the error route: whatever this rank's step returns -- its own collective failed, or its peer aborted the communicator
+        # under it -- it must RETURN (an exception), not wait for a peer that will never come
+        import time
+        t0 = time.time()
+        try:
+            trainer.train_step(net, opt, feats, gpu_run.to_cuda(case["detections"]), case["shapes"],
+                               targets=gpu_run.to_cuda(case["targets"]))
+            outcome = "no error"
+        except Exception as e:                                # noqa: BLE001
+            outcome = "%s: %s" % (type(e).__name__, e)
+        finally:
+            train_fused.TrainContext.stage_wait = orig
+        q.put((rank, outcome, time.time() - t0, int(_capi.lib().skg_comm_dead(native.handle))))
+        os._exit(0)                                           # (no collective teardown over a dead communicator)
     try:
         losses, _ = trainer.train_step(net, opt, feats, gpu_run.to_cuda(case["detections"]), case["shapes"],
                                        targets=gpu_run.to_cuda(case["targets"]))
@@ -201,7 +219,17 @@ def _dp_equiv_worker(rank, world, port, ref_path, q, rccl_lib=None):
             worst_o = max(worst_o, (max(float((g - o).abs().max()) - 1e-9, 0.0) / so, name))
         worst_w = max(worst_w, (float((p.detach().cpu() - ref["weights"][name]).abs().max()), name))
     issued = int(_capi.lib().skg_comm_collectives(native.handle)) - issued0 if native else None
-    q.put((rank, losses, worst_g, worst_o, worst_w, staged, head.grad_exchange.collectives, issued))
+    worst_r = (0.0, "")
+    if ref.get("golden"):
+        # the exchanged gradients against the LIVE REFERENCE's own autograd of the whole batch (the fixture's gradient samples)
+        want = helpers.load_golden(ref["golden"])
+        for name, p in head.named_parameters():
+            if name == "box_pair_head.adjacency.bias":       # exactly zero: rounding noise on every side
+                continue
+            smp = want["grad.%s.sample" % name]; amax = max(float(want["grad.%s.absmax" % name]), 1e-9)
+            got = cases.grad_sample(p.grad.detach().cpu().reshape(-1)).numpy()
+            worst_r = max(worst_r, (float(np.abs(got - smp).max()) / amax, name))
+    q.put((rank, losses, worst_g, worst_o, worst_w, staged, head.grad_exchange.collectives, issued, worst_r))
     dist.barrier()
     if native:
         native.close()
@@ -316,8 +344,9 @@ def test_data_parallel_routes_take_the_same_steps(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case_name,per", [("train_tiny", 1), ("train_full20x4", 2)])
 @pytest.mark.parametrize("transport", ["torch.distributed", "library"])
-def test_two_ranks_through_the_hip_arena_equal_the_unsharded_step(tmp_path, transport):
+def test_two_ranks_through_the_hip_arena_equal_the_unsharded_step(tmp_path, transport, case_name, per):
     """transport = "library": the collectives are issued by libskghoi_hip's worker thread on its own communicator
     (skg_comm, skg_ctx_train_backward_exchange_f32) -- bound, for this test, to tests/fake_rccl instead of RCCL, which
     refuses two ranks on one device: everything of the route but RCCL's own ring runs, between two real ranks.
@@ -326,19 +355,24 @@ def test_two_ranks_through_the_hip_arena_equal_the_unsharded_step(tmp_path, tran
     library's worker thread in one call, the gradient arena leaving chunk by chunk behind its stage events, the fused
     3-element normaliser all-reduce -- against the SAME two images as one batch in a single process: gradients of all 408
     parameters (after the exchange) and the weights after one AdamW step agree, and both agree with the oracle's autograd
-    (main:26-31,175-179; utils.py:202-229).  Two ranks share the one GPU of the test box and talk over gloo."""
+    (main:26-31,175-179; utils.py:202-229).  Two ranks share the one GPU of the test box and talk over gloo.
+
+    train_full20x4, two images per rank: the exchange at FULL WIDTH -- the 29.6 M-float arena in its five chunks of 4.4 / 4.2 /
+    4.5 / 3.6 / 12.9 M floats, the box_head.1 tail that closes the backward -- with the exchanged gradients also held against
+    the live reference's own autograd of the four-image batch (the fixture's gradient samples, <= 1e-4)."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.multiprocessing as mp
     from collections import OrderedDict
     import cases, gpu_run, helpers
-    case = cases.build_case("train_tiny")
+    case = cases.build_case(case_name)
     head = gpu_run.build_head(case)
     net = trainer.wrap_ddp(head, torch.device("cuda", 0))
     opt = trainer.build_optimizer(net, lr=1e-4)
     feats = OrderedDict((k, case["feat3"].cuda()) for k in "0123")
     det, tg = gpu_run.to_cuda(case["detections"]), gpu_run.to_cuda(case["targets"])
-    n0 = int(head.engine().preprocess(det[:1], tg[:1], True, True).sizes[0])      # rows of image 0 in the pooled cache
+    sizes = [int(v) for v in head.engine().preprocess(det, tg, True, True).sizes]   # rows per image in the pooled cache
+    first_row = [sum(sizes[:r * per]) for r in range(2)]
     head.engine().debug = True
     torch.manual_seed(case["rng_seed"])
     state0 = torch.get_rng_state()
@@ -347,31 +381,37 @@ def test_two_ranks_through_the_hip_arena_equal_the_unsharded_step(tmp_path, tran
     # where the generator stood when image 1's tables were drawn: image 0's six table fills + randperm(#negatives) (HEAD:574-580,
     # 939) -- replayed on a copy of the start state
     from skghoi_amd import transh
-    n_pos0 = int(head._last_train["pos_scores"][0].numel())
-    pairs0 = int(results[0]["boxes_h"].shape[0])
+    K = case["cfg"]["K"]
+    n_pos = [int(head._last_train["pos_scores"][i].numel()) for i in range(per)]
+    pairs = [int(results[i]["boxes_h"].shape[0]) for i in range(per)]
     torch.set_rng_state(state0)
-    transh.draw_train(case["cfg"]["K"], [pairs0 * case["cfg"]["K"] - n_pos0], [n_pos0])
+    transh.draw_train(K, [pairs[i] * K - n_pos[i] for i in range(per)], n_pos)      # rank 0's images
     state1 = torch.get_rng_state()
     want, _ = helpers.oracle_train_grads(case)
-    ref = dict(n0=n0, rng_state=[state0, state1], grads={n: p.grad.detach().cpu().clone() for n, p in head.named_parameters()},
+    ref = dict(first_row=first_row, rng_state=[state0, state1],
+               grads={n: p.grad.detach().cpu().clone() for n, p in head.named_parameters()},
                weights={n: p.detach().cpu().clone() for n, p in head.named_parameters()},
-               oracle={n: torch.from_numpy(np.ascontiguousarray(g)) for n, g in want.items()})
+               oracle={n: torch.from_numpy(np.ascontiguousarray(g)) for n, g in want.items()},
+               golden=case_name if case_name in cases.FULL_TRAIN_CASES else None)
     path = str(tmp_path / "unsharded.pt")
     torch.save(ref, path)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     fake = _build_fake_rccl(tmp_path) if transport == "library" else None
-    procs = [ctx.Process(target=_dp_equiv_worker, args=(r, 2, port, path, q, fake)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_equiv_worker, args=(r, 2, port, path, q, fake, case_name, per)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(_gather(procs, q, 2, 300), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    for rank, losses, worst_g, worst_o, worst_w, staged, k, issued in res:
-        assert worst_g[0] <= 1e-5, (rank, worst_g, worst_o, worst_w)    # exchanged arena == un-sharded arena (summation order)
-        assert worst_o[0] <= 1e-4, (rank, worst_o)          # ... == oracle autograd of the two-image batch
+    for rank, losses, worst_g, worst_o, worst_w, staged, k, issued, worst_r in res:
+        # exchanged arena == un-sharded arena up to the summation order (two half-batch sums added across ranks instead of one
+        # sum over the whole batch: at 3200 grid rows a few 1e-5 on the cancellation-heavy tensors)
+        assert worst_g[0] <= (1e-5 if per == 1 else 5e-5), (rank, worst_g, worst_o, worst_w)
+        assert worst_o[0] <= 1e-4, (rank, worst_o)          # ... == oracle autograd of the whole batch
+        assert worst_r[0] <= 1e-4, (rank, worst_r)          # ... == the live reference's autograd (full-width fixture)
         # the replicas took the un-sharded step (the reference's lr, main:109; AdamW's first update lr * g / (|g| + eps) turns
         # the summation-order noise of near-zero gradient entries into at most a few 1e-7 of weight)
         assert worst_w[0] <= 1e-6, (rank, worst_w)
@@ -385,6 +425,44 @@ def test_two_ranks_through_the_hip_arena_equal_the_unsharded_step(tmp_path, tran
     for key in ("hoi_loss", "interactiveness_loss"):
         mean = 0.5 * (res[0][1][key] + res[1][1][key])
         assert abs(mean - single[key]) <= 1e-5 * max(1.0, abs(single[key])), key
+
+
+@pytest.mark.gpu
+def test_a_failed_collective_on_one_rank_ends_the_peers_step_with_an_error_not_a_hang(tmp_path):
+    """Advisor finding (round 4): when the backward's worker fails between two chunk collectives it used to stop there, while
+    its peers waited inside the next ncclAllReduce on the library's own communicator -- which no watchdog looks after -- for
+    ever.  Now the worker ABORTS the communicator (skg_comm_abort -> ncclCommAbort): rank 1's second collective fails (injected
+    in the stand-in transport), rank 1's step raises, and rank 0 -- already waiting for rank 1 in that collective -- gets an
+    error within seconds as well; both communicators end dead, nothing hangs."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.multiprocessing as mp
+    import cases, gpu_run
+    case = cases.build_case("train_tiny")
+    head = gpu_run.build_head(case)
+    det, tg = gpu_run.to_cuda(case["detections"]), gpu_run.to_cuda(case["targets"])
+    sizes = [int(v) for v in head.engine().preprocess(det, tg, True, True).sizes]
+    state = torch.get_rng_state()
+    path = str(tmp_path / "ref.pt")
+    torch.save(dict(first_row=[0, sizes[0]], rng_state=[state, state]), path)
+    fake = _build_fake_rccl(tmp_path)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_equiv_worker, args=(r, 2, port, path, q, fake, "train_tiny", 1, "1:2")) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted(q.get(timeout=120) for _ in range(2))
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    for rank, outcome, seconds, dead in res:
+        assert "SkgError" in outcome, (rank, outcome)                  # an error on BOTH ranks ...
+        assert seconds < 45, (rank, seconds)                           # ... well inside the stand-in's own 60 s peer timeout
+    assert res[1][3] == 1                                              # the failing rank aborted its communicator
 
 
 @pytest.mark.gpu
