@@ -228,17 +228,17 @@ int skg_gemm_group_f32(const skg_gemm_desc* descs_host, int n, void* stream);
  * tiles a member may carry split_k > 1 (epilogues BIAS / BIAS_RELU / BIAS_RES_RELU): one more launch then reduces all
  * split members in slice order.  SKG_EPI_RELU_DOT members write 2 * ceil(N / (64 * scale)) dot_partial slabs.       */
 int skg_gemm_group_tile(const skg_gemm_desc* descs_host, int n);
-/* Developer switch: which 64 x 64 main loop the small launches take (3 = 64-k steps, register staged: the default;
- * 1 = 16-k steps, DMA staged).  Returns the previous setting; other values only query.                              */
-int skg_gemm_small_mode(int mode);
-/* Developer switch: a launch / group takes the 64 x 64 tiles below this many 128 x 128 tiles (default 384); returns the
- * previous bound, tiles <= 0 only queries.                                                                          */
-int skg_gemm_small_tiles(int tiles);
-/* Launches (and grouped launches) that are "small" by the rule above but have at least this many 128 x 128 tiles (split-K
- * slices counted) run on skg_gemmx_f32's register-pipelined 128 x 128 loop, their fused epilogue included -- the regime
- * of 2-8 images, where it beats both eval loops (csrc/skg_gemm.hip, g_route_tiles).  Returns the previous value;
- * tiles <= 0 only reads it.  A developer switch (SKG_ROUTE_TILES); a very large value turns the routing off.           */
-int skg_gemm_route_tiles(int tiles);
+/* Tuning switches of the eval GEMM (developer A/B knobs; 0 = the library's default).  They live in a CONTEXT the caller creates
+ * (skg_context, below) and apply to the skg_gemm_* calls of the threads that made that context current
+ * (skg_ctx_make_current) -- the library keeps no process-wide tuning state.
+ *   small_mode   which 64 x 64 main loop the small launches take: 3 = 64-k steps, register staged (default); 1 = 16-k steps,
+ *                DMA staged; 4 = 64-k steps staged straight into LDS; 5 / 6 = the eight-wave loop (all / up to khalves_blocks
+ *                workgroups)
+ *   small_tiles  a launch / group takes the 64 x 64 tiles below this many 128 x 128 tiles (default 384)
+ *   route_tiles  "small" launches with at least this many 128 x 128 tiles (split-K slices counted) run on skg_gemmx_f32's
+ *                register-pipelined 128 x 128 loop, fused epilogue included -- the regime of 2-8 images (default 200; a very
+ *                large value turns the routing off)                                                                       */
+typedef struct { int32_t small_mode, small_tiles, route_tiles, khalves_blocks; } skg_tuning;
 
 /* ---------------------------------------------------------------------------------------------------------------
  * fc_head / fc_tail input rows (HEAD:884-885): out[r] = [ enc[enc_row[r], 0:1024] | ent[ent_img[r], ent_row[r], 0:50]
@@ -624,6 +624,9 @@ typedef struct {
      * plan's split-K products are then reduced inside their own launch (skg_gemmx_desc.split_ctr) instead of by a second
      * launch each -- 16 launches less per batch-4 step.  Products whose tiles do not fit keep the reduce launch.       */
     uint32_t* counters; int64_t n_counters;
+    /* split-K of the plan's products (developer knobs; 0 = the measured defaults: ~500 workgroups per product on the exact
+     * fp32 loop, ~160 on the bf16 loops, at most 64 slices)                                                              */
+    int32_t split_target, split_max;
 } skg_train_plan;
 /* Floats of workspace the plan needs (activations kept for the backward, backward temporaries, split-K scratch);
  * < 0: rejected plan.  Only the sizes, bf16 and params (non-null) are read.                                              */
@@ -644,6 +647,13 @@ int skg_train_backward_f32(const skg_train_plan* plan_host, int first_stage, int
 typedef struct skg_context skg_context;
 skg_context* skg_context_create(void);
 void skg_context_destroy(skg_context* ctx);       /* waits for a job in flight, stops and joins the worker */
+/* The context's tuning switches (skg_tuning above): set copies *t (SKG_E_ARG for an unknown small_mode), get reads them back.
+ * skg_ctx_make_current makes `ctx` (NULL: none -- the defaults) the CALLING THREAD's current context and returns the previous
+ * one: the skg_gemm_* calls of that thread then read its switches.  A context must not be destroyed while it is current on
+ * another thread.                                                                                                        */
+int skg_ctx_set_tuning(skg_context* ctx, const skg_tuning* t);
+int skg_ctx_get_tuning(skg_context* ctx, skg_tuning* out);
+skg_context* skg_ctx_make_current(skg_context* ctx);
 /* skg_train_backward_f32 issued from the context's worker thread (one job at a time per context; the plan is copied, the
  * worker selects the caller's current device): returns at once -- 0, SKG_E_* for a plan / stage range / workspace that
  * skg_train_backward_f32 would reject (checked HERE, before the job is queued), SKG_E_LIMIT while a job is pending.

@@ -72,6 +72,11 @@ class Exchange(C.Structure):
                                                                           "bias1", "bias2")]
 
 
+class Tuning(C.Structure):
+    """Mirror of skg_tuning: the eval GEMM's developer switches, kept in a context (0 = the library's default)."""
+    _fields_ = [(n, _i32) for n in ("small_mode", "small_tiles", "route_tiles", "khalves_blocks")]
+
+
 class TrainPlan(C.Structure):
     """Mirror of skg_train_plan."""
     _fields_ = [(n, _i32) for n in ("NA", "Mg", "Mp", "Mh", "Mn", "A", "K", "Bf", "Cf", "x0_k", "bf16", "ld_logits")] + \
@@ -82,7 +87,7 @@ class TrainPlan(C.Structure):
                                    "node_of")] + \
                [("ws", _vp), ("ws_floats", _i64), ("pair_features", _vp), ("logits", _vp), ("dlogits", _vp),
                 ("dx0", _vp), ("dgfeat", _vp), ("timer", _vp), ("ws16", _vp), ("params16", _vp), ("pf16", _vp),
-                ("params_floats", _i64), ("counters", _vp), ("n_counters", _i64)]
+                ("params_floats", _i64), ("counters", _vp), ("n_counters", _i64), ("split_target", _i32), ("split_max", _i32)]
 
 
 LAYOUT_SLICES = ("meta", "node_img", "hum_img", "node_enc_row", "hum_enc_row", "node_ent_row", "hum_ent_row", "enc_row_hn",
@@ -126,9 +131,9 @@ PROTOTYPES = {
     "skg_gemm_group_tile": (C.c_int, [C.POINTER(GemmDesc), C.c_int]),
     "skg_row_exponents_f32": (C.c_int, [_vp, C.c_int64, _vp, C.c_int, C.c_int, _vp, _vp]),
     "skg_adamw_f32": (C.c_int, [_vp, C.c_int] + [C.c_double] * 7 + [_vp, C.c_int, _vp]),
-    "skg_gemm_small_mode": (C.c_int, [C.c_int]),
-    "skg_gemm_small_tiles": (C.c_int, [C.c_int]),
-    "skg_gemm_route_tiles": (C.c_int, [C.c_int]),
+    "skg_ctx_set_tuning": (C.c_int, [_vp, C.POINTER(Tuning)]),
+    "skg_ctx_get_tuning": (C.c_int, [_vp, C.POINTER(Tuning)]),
+    "skg_ctx_make_current": (_vp, [_vp]),
     "skg_gemmx_ws_floats": (C.c_int64, [C.POINTER(GemmXDesc)]),
     "skg_gemmx_f32": (C.c_int, [C.POINTER(GemmXDesc), C.c_int, _vp]),
     "skg_gemmx_bf16": (C.c_int, [C.POINTER(GemmXDesc), C.c_int, _vp]),
@@ -232,14 +237,42 @@ def lib():
         raise SkgError("skg_exchange is %d bytes in libskghoi_hip.so, %d in the binding" % (l.skg_sizeof_exchange(), C.sizeof(Exchange)))
     if l.skg_abi_version() != ABI_VERSION:
         raise SkgError("libskghoi_hip.so ABI %d != binding ABI %d" % (l.skg_abi_version(), ABI_VERSION))
-    if os.environ.get("SKG_SMALL_MODE"):                 # developer switch: 64 x 64 main loop of the small launches
-        l.skg_gemm_small_mode(int(os.environ["SKG_SMALL_MODE"]))
-    if os.environ.get("SKG_SMALL_TILES"):                # developer switch: bound of the 64 x 64-tile launches
-        l.skg_gemm_small_tiles(int(os.environ["SKG_SMALL_TILES"]))
-    if os.environ.get("SKG_ROUTE_TILES"):                # developer switch: mid-size launches on the free-layout GEMM from here up
-        l.skg_gemm_route_tiles(int(os.environ["SKG_ROUTE_TILES"]))
     _LIB = l
+    # developer switches of the eval GEMM from the environment (SKG_SMALL_MODE: 64 x 64 main loop of the small launches,
+    # SKG_SMALL_TILES: bound of the 64 x 64-tile launches, SKG_ROUTE_TILES: mid-size launches on the free-layout GEMM from
+    # here up, SKG_KHALVES_BLOCKS): they go into a context of THIS module, current on the loading thread -- the library
+    # itself has no process-wide switch any more
+    env = {k: int(os.environ[e]) for k, e in (("small_mode", "SKG_SMALL_MODE"), ("small_tiles", "SKG_SMALL_TILES"),
+                                              ("route_tiles", "SKG_ROUTE_TILES"), ("khalves_blocks", "SKG_KHALVES_BLOCKS"))
+           if os.environ.get(e)}
+    if env:
+        set_tuning(**env)
     return l
+
+
+_TUNE_CTX = None
+
+
+def set_tuning(**kw):
+    """Developer switches of the eval GEMM (skg_tuning fields; 0 = the library's default) for the CALLING THREAD: they are
+    written to a context owned by this module, which is made the thread's current context.  Returns the previous values, so
+    that `old = set_tuning(route_tiles=1 << 30); ...; set_tuning(**old)` restores them."""
+    global _TUNE_CTX
+    l = lib()
+    if _TUNE_CTX is None:
+        _TUNE_CTX = l.skg_context_create()
+        if not _TUNE_CTX:
+            raise SkgError("skg_context_create failed")
+    t = Tuning()
+    check(l.skg_ctx_get_tuning(_TUNE_CTX, C.byref(t)), "skg_ctx_get_tuning")
+    old = {n: int(getattr(t, n)) for n, _ in Tuning._fields_}
+    for k, v in kw.items():
+        if k not in old:
+            raise TypeError("unknown tuning switch %r" % k)
+        setattr(t, k, int(v))
+    check(l.skg_ctx_set_tuning(_TUNE_CTX, C.byref(t)), "skg_ctx_set_tuning")
+    l.skg_ctx_make_current(_TUNE_CTX)
+    return old
 
 
 _ERR = {-1: "SKG_E_ARG (bad argument)", -2: "SKG_E_ALIGN (pointer / leading dimension not 16-byte aligned)",

@@ -38,6 +38,15 @@ __device__ __forceinline__ float skg_block_sum256(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---- tuning of the calling thread's CURRENT context (include/skghoi.h: skg_tuning, skg_ctx_make_current).  The library
+// itself keeps no process-wide tuning state: every switch below lives in a context the caller created and is read through
+// this thread-local pointer (NULL: the built-in defaults, constants).
+extern thread_local const skg_tuning* skg_tls_tuning;
+static inline int skg_tune_small_mode() { const skg_tuning* t = skg_tls_tuning; return t && t->small_mode > 0 ? t->small_mode : 3; }
+static inline int skg_tune_small_tiles() { const skg_tuning* t = skg_tls_tuning; return t && t->small_tiles > 0 ? t->small_tiles : 384; }
+static inline int skg_tune_route_tiles() { const skg_tuning* t = skg_tls_tuning; return t && t->route_tiles > 0 ? t->route_tiles : 200; }
+static inline int skg_tune_khalves_blocks() { const skg_tuning* t = skg_tls_tuning; return t && t->khalves_blocks > 0 ? t->khalves_blocks : 320; }
+
 // ---- bf16 twins of fp32 tensors (skg_gemmx_desc.A16 / B16: what the direct-to-LDS GEMM of the bf16 training step reads).
 // The training plan (skg_train_plan.hip) keeps, beside its fp32 workspace, a twin workspace with the SAME element indexing
 // and announces both for the duration of one of its calls in this thread-local map; the per-row kernels it launches look

@@ -1194,21 +1194,11 @@ extern "C" int skg_row_exponents_f32(const float* A, int64_t lda, const int32_t*
 // group 76 against 64 us (its 96 KiB ring leaves one workgroup per CU), B = 1 0.517 against 0.498 ms.  A step of this tile is
 // a chain of 32 dependent fp32 MFMAs (0.93 us) plus a ~0.4 us bubble at the barrier whatever stages the tile: the launch is
 // bound by that chain at one wave per SIMD, not by the staging.  Mode 3 stays the default; 4 is selectable.
-static int g_small_mode = 3;
-static int64_t g_khalves_blocks = getenv("SKG_KHALVES_BLOCKS") ? atoll(getenv("SKG_KHALVES_BLOCKS")) : 320;   // mode 6: launches up to this many workgroups take the eight-wave loop
-extern "C" int skg_gemm_small_mode(int mode) {
-    const int old = g_small_mode;
-    if (mode == 1 || mode == 3 || mode == 4 || mode == 5 || mode == 6) g_small_mode = mode;
-    return old;
-}
-
-// A launch (or group) counts as small -- 64 x 64 tiles -- below this many 128 x 128 tiles (split-K slices included).
-static int g_small_tiles = 384;
-extern "C" int skg_gemm_small_tiles(int tiles) {
-    const int old = g_small_tiles;
-    if (tiles > 0) g_small_tiles = tiles;
-    return old;
-}
+// (round 5: the switches live in the calling thread's current context -- skg_tuning, skg_common.h -- not in the library)
+#define g_small_mode skg_tune_small_mode()
+#define g_khalves_blocks skg_tune_khalves_blocks()
+// A launch (or group) counts as small -- 64 x 64 tiles -- below this many 128 x 128 tiles (split-K slices included): 384.
+#define g_small_tiles skg_tune_small_tiles()
 
 // 64 x 64 tiles when the 128 x 128 grid would leave most CUs idle (small M: low-batch inference); needs the DMA path.
 static int skg_gemm_tile_scale(const skg_gemm_desc* d) {
@@ -1256,12 +1246,7 @@ static int skg_gemm_validate(const skg_gemm_desc& d) {
 // goes there when it has at least g_route_tiles tiles of 128 x 128 (split slices counted) but is still "small", carries
 // no weight twin / row gather / dot epilogue, and its fused epilogue can run in the staged epilogue (skg_gemmx_can_fuse).
 // The summation order over k differs from the eval loops (as theirs do from each other): results agree to rounding.
-static int g_route_tiles = 200;
-extern "C" int skg_gemm_route_tiles(int tiles) {
-    const int old = g_route_tiles;
-    if (tiles > 0) g_route_tiles = tiles;
-    return old;
-}
+#define g_route_tiles skg_tune_route_tiles()
 
 static bool skg_route_desc(const skg_gemm_desc& d, skg_gemmx_desc& x, skg_gemmx_fused& f) {
     if (d.w_split || d.a_rows || d.a_exp || d.epilogue == SKG_EPI_RELU_DOT) return false;

@@ -122,25 +122,15 @@ static skg_gemmx_desc WG(const Mat& dz, const Mat& x, const Mat& dW, float* db, 
 // fp32 300 / 500 / 750 / 1000 / 1400 -> 2.676 / 2.672 / 2.703 / 2.696 / 2.81 ms.
 // End of round 4 (direct-to-LDS kernel on most launches): bf16 64 / 96 / 128 / 160 / 208 / 256 / 320 -> 1.332 / 1.260 / 1.274 /
 // 1.258 / 1.279 (other box) / 1.265 / 1.378 ms; fp32 350 / 500 / 700 level (2.49 / 2.48 / 2.49).
-static int split_target(int bk) {
-    static int t16 = 0, t32 = 0;
-    if (!t16) {
-        const char* a = getenv("SKG_SPLIT_TARGET_F32"); const char* b = getenv("SKG_SPLIT_TARGET_BF16");    // developer knobs
-        t16 = a && atoi(a) > 0 ? atoi(a) : 500;
-        t32 = b && atoi(b) > 0 ? atoi(b) : 160;
-    }
-    return bk == 16 ? t16 : t32;
-}
-static int pick_split(const skg_gemmx_desc& o, int bk) {
+// (the knobs travel in the plan -- skg_train_plan.split_target / split_max -- not in the library: no process-wide state)
+static int pick_split(const skg_train_plan* P, const skg_gemmx_desc& o, int bk) {
     int64_t tiles = (int64_t)((o.M + 127) / 128) * ((o.N + 127) / 128);
     int kt = (o.K + bk - 1) / bk;
-    int target = split_target(bk);
-    int cap = kt * bk / 128; if (cap > 64) cap = 64;
+    const int target = P->split_target > 0 ? P->split_target : (bk == 16 ? 500 : 160);
+    const int smax = P->split_max > 0 ? P->split_max : 64;
+    int cap = kt * bk / 128; if (cap > smax) cap = smax;
     if (tiles == 0 || cap < 2) return 1;
     int sk = (int)((double)target / (double)tiles + 0.5);
-    static int smax = -1;
-    if (smax < 0) { const char* e = getenv("SKG_SPLIT_MAX"); smax = e && atoi(e) > 0 ? atoi(e) : 64; }    // developer knob
-    if (cap > smax) cap = smax;
     if (sk > cap) sk = cap;
     return sk < 1 ? 1 : sk;
 }
@@ -158,7 +148,7 @@ static void launch(Ctx& c, skg_gemmx_desc* ops, int n) {
         int64_t used = 0, used_ctr = 0;
         for (int i = 0; i < cnt; ++i) {
             skg_gemmx_desc& d = live[i0 + i];
-            int sk = pick_split(d, bk);
+            int sk = pick_split(c.P, d, bk);
             d.split_k = sk > 1 ? sk : 0;
             d.split_ctr = nullptr;
             if (sk > 1 && c.P->counters) {                 // reduced inside the product launch: one counter per tile
@@ -849,6 +839,7 @@ struct skg_context {
     uint32_t own_mask = 0;                         // stages (absolute) behind which own[stage] is recorded
     bool own_made = false, own_sys_made = false;
     bool with_events = false;
+    skg_tuning tuning = {0, 0, 0, 0};              // the eval GEMM's switches for the threads this context is current on
     skg_exchange ex = {};                          // the arena chunks this job all-reduces (ex.comm) and / or updates (ex.adamw) itself
     bool has_ex = false;
     hipStream_t aux = nullptr;                     // single process + optimizer inside the backward: the updates' stream
@@ -889,6 +880,7 @@ struct skg_context {
             if (quit && !pending) return;
             lk.unlock();
             int r = (int)hipSetDevice(device);
+            (void)skg_ctx_make_current(this);              // the eval GEMM's switches of THIS context (fp32 plan: the fc_2 products)
             if (!with_events) {
                 if (!r) r = skg_train_backward_f32(&plan, first, last, stream);
                 lk.lock();
@@ -942,8 +934,30 @@ extern "C" {
 
 skg_context* skg_context_create(void) { return new (std::nothrow) skg_context; }
 
+int skg_ctx_set_tuning(skg_context* c, const skg_tuning* t) {
+    if (!c || !t) return SKG_E_ARG;
+    if (t->small_mode != 0 && t->small_mode != 1 && (t->small_mode < 3 || t->small_mode > 6)) return SKG_E_ARG;
+    std::unique_lock<std::mutex> lk(c->m);
+    c->tuning = *t;
+    return 0;
+}
+int skg_ctx_get_tuning(skg_context* c, skg_tuning* out) {
+    if (!c || !out) return SKG_E_ARG;
+    std::unique_lock<std::mutex> lk(c->m);
+    *out = c->tuning;
+    return 0;
+}
+static thread_local skg_context* tls_current_ctx = nullptr;
+skg_context* skg_ctx_make_current(skg_context* c) {
+    skg_context* old = tls_current_ctx;
+    tls_current_ctx = c;
+    skg_tls_tuning = c ? &c->tuning : nullptr;
+    return old;
+}
+
 void skg_context_destroy(skg_context* c) {
     if (!c) return;
+    if (tls_current_ctx == c) (void)skg_ctx_make_current(nullptr);
     {
         std::unique_lock<std::mutex> lk(c->m);
         c->cv.wait(lk, [&] { return !c->pending; });           // a job in flight finishes issuing first

@@ -127,6 +127,7 @@ int skg_adamw_slice(const skg_adamw_chunk* chunks, int first, int last, const sk
 
 // ------------------------------------------------------------------------------------------------ bf16 twins
 thread_local skg_twin_map skg_tls_twin = {{nullptr, nullptr}, {nullptr, nullptr}, {0, 0}};
+thread_local const skg_tuning* skg_tls_tuning = nullptr;     // the calling thread's current context's switches (skg_ctx_make_current)
 
 // dst[i] = bf16(src[i]) (round to nearest even): the twin of a whole fp32 buffer in one pass (the parameter arena of the
 // bf16 training step: 118 MB read, 59 MB written, ~30 us).

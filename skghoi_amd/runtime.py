@@ -20,6 +20,7 @@ import os
 import warnings
 
 DEFAULT_HW_QUEUES = 3
+_MARK = "SKG_HW_QUEUES_SET_BY_SKGHOI"      # carries the value this module exported: a child process can tell it from the user's
 _STATE = dict(configured=False, effective=None, source=None)
 
 
@@ -40,8 +41,13 @@ def configure(hw_queues=None):
         env = os.environ.get("SKG_HW_QUEUES")
         hw_queues = int(env) if env not in (None, "") else DEFAULT_HW_QUEUES
     user = os.environ.get("GPU_MAX_HW_QUEUES")
-    if _STATE["configured"] and _STATE["source"] == "skghoi_amd.runtime.configure":
+    if _STATE["configured"] and _STATE["source"].startswith("skghoi_amd.runtime.configure"):
         user = None                                     # (our own earlier setting is not the user's)
+    inherited = False
+    if user is not None and os.environ.get(_MARK) == user:
+        # set by THIS module in a parent process (bench.py --gpus N starts its ranks, the world-size-1 RCCL child): our own
+        # choice travelling through the environment, not the user's -- the record must say so
+        user, inherited = None, True
     if user is not None:
         _STATE.update(configured=True, effective=user, source="environment (GPU_MAX_HW_QUEUES exported by the user)")
     elif _hip_started():
@@ -50,8 +56,12 @@ def configure(hw_queues=None):
         _STATE.update(configured=True, effective=None, source="too late: HIP runtime already initialised")
     elif hw_queues:
         os.environ["GPU_MAX_HW_QUEUES"] = str(int(hw_queues))
-        _STATE.update(configured=True, effective=str(int(hw_queues)), source="skghoi_amd.runtime.configure")
+        os.environ[_MARK] = str(int(hw_queues))         # (child processes: this value is ours, see above)
+        _STATE.update(configured=True, effective=str(int(hw_queues)),
+                      source="skghoi_amd.runtime.configure" + (" (in the launching process)" if inherited else ""))
     else:
+        if inherited:
+            os.environ.pop("GPU_MAX_HW_QUEUES", None); os.environ.pop(_MARK, None)
         _STATE.update(configured=True, effective=None, source="runtime default (configure(hw_queues=0))")
     return info()
 

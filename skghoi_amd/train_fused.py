@@ -685,6 +685,11 @@ class NativeJob(TrainJob):
             setattr(pl, k, S[k].data_ptr())
         pl.pair_img, pl.hum_of, pl.node_of = self.pair_img.data_ptr(), self.hum_of.data_ptr(), self.node_of.data_ptr()
         pl.timer = self.head.__dict__.get("_train_timer")      # measurement aid (bench.py): events around every gemmx launch
+        tgt = os.environ.get("SKG_SPLIT_TARGET_BF16" if self.bf16 else "SKG_SPLIT_TARGET_F32")     # developer knobs: they travel
+        if tgt:                                                                                    # in the plan, not in the library
+            pl.split_target = int(tgt)
+        if os.environ.get("SKG_SPLIT_MAX"):
+            pl.split_max = int(os.environ["SKG_SPLIT_MAX"])
         if INLAUNCH_SPLIT_REDUCE:
             ctr = st.counters()                                # split-K reduced inside the product launches (skg_gemmx_desc.split_ctr)
             pl.counters, pl.n_counters = ctr.data_ptr(), ctr.numel()

@@ -309,11 +309,11 @@ def test_mid_size_launches_on_the_free_layout_kernel_agree_with_the_eval_loops()
         return out
 
     routed = run()
-    old = lib.skg_gemm_route_tiles(1 << 30)
+    old = _capi.set_tuning(route_tiles=1 << 30)
     try:
         plain = run()
     finally:
-        lib.skg_gemm_route_tiles(old)
+        _capi.set_tuning(**old)
     keep = orow >= 0
     mul = torch.relu(v * (P[pi.long()] + Q[qi.long()] + mb).double()).float()
     ref_mul = torch.zeros(M, N, device="cuda"); ref_mul[orow[keep].long()] = mul[keep]
@@ -631,9 +631,9 @@ def test_gemm_bf16_random():
 def direct_lds_small_loop():
     """skg_gemm_small_mode(4): the 64 x 64 launches take the direct-to-LDS latency loop (opt-in since round 4)."""
     lib = _capi.lib()
-    old = lib.skg_gemm_small_mode(4)
+    old = _capi.set_tuning(small_mode=4)
     yield
-    lib.skg_gemm_small_mode(old)
+    _capi.set_tuning(**old)
 
 
 @pytest.mark.parametrize("M,N,K,S", [(800, 1024, 1024, 0), (40, 1024, 12544, 16), (1, 1024, 256, 0), (513, 256, 128, 0),
@@ -654,9 +654,9 @@ def test_direct_lds_latency_loop_matches_the_register_staged_one(M, N, K, S, dir
     got = run()
     _close(got[:, :N], ref, 2e-5)
     assert torch.all(got[:, N:] == 7.0)
-    assert lib.skg_gemm_small_mode(3) == 4
+    assert _capi.set_tuning(small_mode=3)["small_mode"] == 4
     want = run()
-    lib.skg_gemm_small_mode(4)
+    _capi.set_tuning(small_mode=4)
     assert torch.equal(got, want)
 
 
@@ -664,9 +664,9 @@ def test_direct_lds_latency_loop_matches_the_register_staged_one(M, N, K, S, dir
 def eight_wave_small_loop():
     """skg_gemm_small_mode(5): every 64 x 64 launch takes the eight-wave latency loop (two k-halves per 32 x 32 sub-tile)."""
     lib = _capi.lib()
-    old = lib.skg_gemm_small_mode(5)
+    old = _capi.set_tuning(small_mode=5)
     yield
-    lib.skg_gemm_small_mode(old)
+    _capi.set_tuning(**old)
 
 
 @pytest.mark.parametrize("M,N,K,S", [(400, 1024, 1024, 0), (40, 1024, 12544, 16), (1, 1024, 256, 0), (513, 256, 128, 0),

@@ -9,7 +9,7 @@ from skghoi_amd.engine import gemm
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 N = 1024
 if os.environ.get("SKG_SMALL_MODE"):
-    _capi.lib().skg_gemm_small_mode(int(os.environ["SKG_SMALL_MODE"]))
+    _capi.set_tuning(small_mode=int(os.environ["SKG_SMALL_MODE"]))
 g = torch.Generator().manual_seed(0)
 res = {}
 for K in (1024, 4096):

@@ -11,7 +11,7 @@ import bench
 from skghoi_amd import _capi, transh
 
 if os.environ.get("SKG_SMALL_MODE"):
-    _capi.lib().skg_gemm_small_mode(int(os.environ["SKG_SMALL_MODE"]))
+    _capi.set_tuning(small_mode=int(os.environ["SKG_SMALL_MODE"]))
 B = int(os.environ.get("BIG", "256"))
 dev = torch.device("cuda", 0)
 head = bench.build_head(dev)

@@ -16,7 +16,7 @@ prof = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 dev = torch.device("cuda", 0)
 if os.environ.get("SKG_SMALL_MODE"):
     from skghoi_amd import _capi
-    _capi.lib().skg_gemm_small_mode(int(os.environ["SKG_SMALL_MODE"]))
+    _capi.set_tuning(small_mode=int(os.environ["SKG_SMALL_MODE"]))
 head = bench.build_head(dev)
 head.precision = prec
 dets, pooled, feats, shapes = bench.make_inputs(B, 0, dev)
