@@ -57,6 +57,7 @@ struct skg_comm {
     hipEvent_t done = nullptr;          // behind the last collective of a step (timing enabled: exposed-wait measurement)
     hipEvent_t aux = nullptr;           // behind a collective outside the step's chunk sequence (begin / end pair)
     hipEvent_t tail = nullptr;          // scratch: the tail of a caller's stream the exchange stream is ordered behind
+    hipEvent_t joined = nullptr;        // scratch: the exchange stream's tail a caller's stream is ordered behind (in-stream chunk)
     int rank = 0, world = 1, device = 0;
     long collectives = 0;               // issued since creation
     bool dead = false;                  // aborted (a collective or its ordering failed on this rank): nothing further is issued
@@ -114,6 +115,7 @@ int skg_comm_create(const void* id_in, int rank, int world, skg_comm** out) {
     if (e == hipSuccess) e = hipEventCreate(&c->done);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->aux, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->tail, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->joined, hipEventDisableTiming);
     if (e != hipSuccess) { int rc = hip_fail("skg_comm_create", e); skg_comm_destroy(c); return rc; }
     ncclUniqueId id;
     memcpy(&id, id_in, sizeof(id));
@@ -147,6 +149,7 @@ void skg_comm_destroy(skg_comm* c) {
     if (c->done) (void)hipEventDestroy(c->done);
     if (c->aux) (void)hipEventDestroy(c->aux);
     if (c->tail) (void)hipEventDestroy(c->tail);
+    if (c->joined) (void)hipEventDestroy(c->joined);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -173,6 +176,26 @@ int skg_comm_chunk(skg_comm* c, hipEvent_t after, float* p, int64_t n) {
     return 0;
 }
 
+// The LAST chunk of a step, on the step's own stream: nothing is left to overlap it with (the backward has ended), so the
+// collective goes where the optimizer waits anyway -- no event on the backward's queue in front of it, no cross-queue hop
+// behind it (measured at world size 1: the two hops at the tail were most of what the data-parallel route cost).  `stream` is
+// first ordered behind the exchange stream's tail (the earlier chunks: normally long finished); `done` is recorded behind
+// the collective for skg_comm_exposed_ms.
+int skg_comm_chunk_in_stream(skg_comm* c, hipStream_t stream, float* p, int64_t n) {
+    if (!c || !p || n < 0) return SKG_E_ARG;
+    if (c->dead) { snprintf(g_err, sizeof(g_err), "the communicator was aborted after an earlier failure"); return SKG_E_COMM; }
+    hipError_t e = hipEventRecord(c->joined, c->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(stream, c->joined, 0);
+    if (e != hipSuccess) return hip_fail("skg_comm_chunk_in_stream", e);
+    if (n > 0) {
+        ncclResult_t r = g_api.all_reduce(p, p, (size_t)n, ncclFloat32, ncclSum, c->nccl, stream);
+        if (r != ncclSuccess) return nccl_fail("ncclAllReduce", r);
+        ++c->collectives;
+    }
+    e = hipEventRecord(c->done, stream);
+    return e == hipSuccess ? 0 : hip_fail("skg_comm_chunk_in_stream", e);
+}
+
 hipStream_t skg_comm_stream(skg_comm* c) { return c ? c->stream : nullptr; }
 
 int skg_comm_close_step(skg_comm* c, hipStream_t stream) {
@@ -196,10 +219,10 @@ int skg_comm_all_reduce_chunks_f32(skg_comm* c, float* arena, const int64_t* end
     int rc = e == hipSuccess ? 0 : hip_fail("hipEventRecord", e);
     done = 0;
     for (int i = 0; i < n_chunks && !rc; ++i) {
-        rc = skg_comm_chunk(c, i == 0 ? c->tail : nullptr, arena + done, ends_host[i] - done);
+        if (i == n_chunks - 1) rc = skg_comm_chunk_in_stream(c, (hipStream_t)stream, arena + done, ends_host[i] - done);
+        else rc = skg_comm_chunk(c, i == 0 ? c->tail : nullptr, arena + done, ends_host[i] - done);
         done = ends_host[i];
     }
-    if (!rc) rc = skg_comm_close_step(c, (hipStream_t)stream);
     return rc;
 }
 

@@ -131,6 +131,7 @@ int skg_layernorm_bwd_multi(const skg_layernorm_bwd_args* calls, int n, void* st
 // skg_comm_close_step: `stream` ordered behind every collective issued so far.
 int skg_comm_chunk(skg_comm* c, hipEvent_t after, float* p, int64_t n);
 int skg_comm_close_step(skg_comm* c, hipStream_t stream);
+int skg_comm_chunk_in_stream(skg_comm* c, hipStream_t stream, float* p, int64_t n);   // a step's LAST chunk, on the step's stream
 hipStream_t skg_comm_stream(skg_comm* c);
 // skg_util.hip: entries [first, last) of an AdamW chunk table with the factors carried by an skg_exchange
 int skg_adamw_slice(const skg_adamw_chunk* chunks, int first, int last, const skg_exchange& x, bool with_steps, hipStream_t stream);

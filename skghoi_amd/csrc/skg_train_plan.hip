@@ -854,9 +854,13 @@ struct skg_context {
             while (ex.adamw && fi < ex.n_chunks - 1 && ex.adamw_first[fi + 1] <= ex.adamw_first[fi]) ++fi;
             if (!ex.comm && i == ex.n_chunks - 1)      // no collective to wait for: the last update follows its stage in-stream
                 return skg_adamw_slice(ex.adamw, ex.adamw_first[i], ex.adamw_first[i + 1], ex, i == fi, stream);
-            hipStream_t xs = ex.comm ? skg_comm_stream(ex.comm) : aux;
+            // the step's last chunk has nothing left to hide behind: its collective (and its update) go on the step's own stream
+            const bool in_stream = ex.comm && i == ex.n_chunks - 1;
+            hipStream_t xs = in_stream ? stream : (ex.comm ? skg_comm_stream(ex.comm) : aux);
             int r = 0;
-            if (ex.comm)
+            if (in_stream)
+                r = skg_comm_chunk_in_stream(ex.comm, stream, ex.arena + (i ? ex.end[i - 1] : 0), ex.end[i] - (i ? ex.end[i - 1] : 0));
+            else if (ex.comm)
                 r = skg_comm_chunk(ex.comm, own[e], ex.arena + (i ? ex.end[i - 1] : 0), ex.end[i] - (i ? ex.end[i - 1] : 0));
             else
                 r = (int)hipStreamWaitEvent(xs, own[e], 0);
@@ -868,7 +872,7 @@ struct skg_context {
     // `stream` behind everything the exchange stream holds for this job
     int exchange_close(hipStream_t stream) {
         if (!has_ex) return 0;
-        if (ex.comm) return skg_comm_close_step(ex.comm, stream);
+        if (ex.comm) return 0;                       // (the last chunk ran on `stream` itself, behind the exchange stream's tail)
         hipError_t err = hipEventRecord(aux_done, aux);
         if (err == hipSuccess) err = hipStreamWaitEvent(stream, aux_done, 0);
         return (int)err;
@@ -992,7 +996,7 @@ static int submit_backward(skg_context* ctx, const skg_train_plan* P, int first_
             if (ex->stage[i] < first_stage || ex->stage[i] >= last_stage || (i && ex->stage[i] <= ex->stage[i - 1]) ||
                 ex->end[i] < (i ? ex->end[i - 1] : 0))
                 return SKG_E_ARG;
-            if (ex->comm || i + 1 < ex->n_chunks) stage_mask |= 1u << ex->stage[i];      // (no event behind a chunk updated in-stream)
+            if (i + 1 < ex->n_chunks) stage_mask |= 1u << ex->stage[i];      // (no event behind the last chunk: it stays in-stream)
         }
     }
     skg_context* a = ctx_or_default(ctx);

@@ -226,7 +226,7 @@ class ArenaExchange:
     where a parameter has none -- DDP's find_unused_parameters semantics) through the same chunk sequence.  (A batch without
     a single pair cannot complete a step on either side: the reference's torch.cat over its empty score lists raises.)"""
 
-    def __init__(self, head, group=None, min_chunk=1 << 22, native=None):
+    def __init__(self, head, group=None, min_chunk=1 << 23, native=None):
         self.head, self.group, self.min_chunk = head, group, int(_os.environ.get("SKG_DP_MIN_CHUNK") or min_chunk)
         self.n_stages = 12                    # (_capi.TRAIN_BWD_STAGES: the arena's milestones)
         self.native = native                  # NativeComm: the library's worker thread issues the collectives itself

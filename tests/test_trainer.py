@@ -211,6 +211,11 @@ def _dp_equiv_worker(rank, world, port, ref_path, q, rccl_lib=None, case_name="t
     for name, p in head.named_parameters():
         g = p.grad.detach().cpu()
         w = ref["grads"][name]
+        if name == "box_pair_head.adjacency.bias":
+            # shifts every logit of a softmax alike: the exact gradient is zero, every implementation returns the rounding noise
+            # of thousands of cancelling terms (a few 1e-10 at train_tiny, ~1e-9 at 3200 grid rows)
+            assert float(g.abs().max()) < 1e-7 and float(w.abs().max()) < 1e-7
+            continue
         scale = max(float(w.abs().max()), 1e-6)
         worst_g = max(worst_g, (max(float((g - w).abs().max()) - 1e-9, 0.0) / scale, name))
         if name in ref["oracle"]:
