@@ -160,6 +160,17 @@ int64_t skg_comm_collectives(const skg_comm* c) { return c ? (int64_t)c->collect
 
 }  // extern "C"
 
+// A collective that fails on this rank leaves the peers inside it: whoever issued it (the backward's worker, the preparation's
+// normaliser all-reduce on the caller's thread), the communicator is aborted on the spot so that they get an error too.
+static int collective_failed(skg_comm* c, ncclResult_t r) {
+    const int rc = nccl_fail("ncclAllReduce", r);
+    char keep[sizeof(g_err)];
+    memcpy(keep, g_err, sizeof(keep));
+    (void)skg_comm_abort(c);
+    memcpy(g_err, keep, sizeof(keep));                 // (the text of the failure, not of the abort)
+    return rc;
+}
+
 // ---- what the backward's worker thread calls (skg_train_plan.hip): the collective of ONE arena chunk behind `after`
 // (a recorded event; NULL: behind nothing), and the close of a step -- `stream` ordered behind every chunk issued so far
 int skg_comm_chunk(skg_comm* c, hipEvent_t after, float* p, int64_t n) {
@@ -171,7 +182,7 @@ int skg_comm_chunk(skg_comm* c, hipEvent_t after, float* p, int64_t n) {
         if (e != hipSuccess) return hip_fail("hipStreamWaitEvent(exchange stream)", e);
     }
     ncclResult_t r = g_api.all_reduce(p, p, (size_t)n, ncclFloat32, ncclSum, c->nccl, c->stream);
-    if (r != ncclSuccess) return nccl_fail("ncclAllReduce", r);
+    if (r != ncclSuccess) return collective_failed(c, r);
     ++c->collectives;
     return 0;
 }
@@ -189,7 +200,7 @@ int skg_comm_chunk_in_stream(skg_comm* c, hipStream_t stream, float* p, int64_t 
     if (e != hipSuccess) return hip_fail("skg_comm_chunk_in_stream", e);
     if (n > 0) {
         ncclResult_t r = g_api.all_reduce(p, p, (size_t)n, ncclFloat32, ncclSum, c->nccl, stream);
-        if (r != ncclSuccess) return nccl_fail("ncclAllReduce", r);
+        if (r != ncclSuccess) return collective_failed(c, r);
         ++c->collectives;
     }
     e = hipEventRecord(c->done, stream);

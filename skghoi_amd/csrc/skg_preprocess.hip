@@ -15,6 +15,12 @@ __device__ __forceinline__ uint32_t skg_orderable(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // monotone: a < b  <=>  ord(a) < ord(b)
 }
 
+// the label of a candidate from its staged int32 copy; a label that did not fit is re-read (it multiplies the NMS offset
+// exactly as the reference's int64 would)
+__device__ __forceinline__ int64_t labels64_of(int staged, const int64_t* __restrict__ labels, int64_t at) {
+    return staged != -2147483647 - 1 ? (int64_t)staged : labels[at];
+}
+
 __global__ __launch_bounds__(PRE_THREADS) void skg_preprocess_kernel(
     const float* __restrict__ boxes, const float* __restrict__ scores, const int64_t* __restrict__ labels,
     const int32_t* __restrict__ det_off, int human_idx, float score_thresh, float nms_thresh, int max_human,
@@ -28,6 +34,14 @@ __global__ __launch_bounds__(PRE_THREADS) void skg_preprocess_kernel(
     __shared__ float sred[PRE_THREADS / 64];
     __shared__ int ssel[SKG_MAX_NODES];
     __shared__ int sact;
+    // the image's raw candidates, read ONCE: boxes, scores, labels and the verb counts of the classes all leave in one round
+    // trip (independent loads), every later phase -- sorted-order boxes, the counts at the end -- reads these copies.  The
+    // kernel is a chain of dependent phases on one workgroup: each trip to global memory it does not make is ~2 us of a
+    // single-image forward (it made six; now two: the offsets, then everything else).
+    __shared__ float4 rbox[SKG_MAX_DET_PER_IMAGE];
+    __shared__ float rscore[SKG_MAX_DET_PER_IMAGE];
+    __shared__ int rlab[SKG_MAX_DET_PER_IMAGE];
+    __shared__ int snv[256];                           // nverbs of classes 0..255 (more classes: read from global)
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -51,13 +65,18 @@ __global__ __launch_bounds__(PRE_THREADS) void skg_preprocess_kernel(
     // ---- keys: descending score, ties by ascending input index; inactive (score < thresh or NaN) sort last
     float lmax = -INFINITY;
     int lact = 0;
+    for (int t = tid; t < 256 && t < num_obj_classes; t += PRE_THREADS) snv[t] = nverbs[t];
     for (int i = tid; i < npow; i += PRE_THREADS) {
         unsigned long long key = ~0ull;
         if (i < n0) {
             const float s = scores[base + i];
+            const float4 bx = *reinterpret_cast<const float4*>(boxes + 4 * (int64_t)(base + i));
+            const int64_t lab64 = labels[base + i];
+            rscore[i] = s; rbox[i] = bx;
+            // (labels outside int32 cannot name a class: they keep "no verbs" and never equal human_idx below)
+            rlab[i] = (lab64 >= -2147483647LL && lab64 <= 2147483647LL) ? (int)lab64 : -2147483647 - 1;
             if (s >= score_thresh) {
                 key = ((unsigned long long)(~skg_orderable(s)) << 32) | (unsigned)i;
-                const float4 bx = *reinterpret_cast<const float4*>(boxes + 4 * (int64_t)(base + i));
                 lmax = fmaxf(lmax, fmaxf(fmaxf(bx.x, bx.y), fmaxf(bx.z, bx.w)));
                 ++lact;
             }
@@ -95,8 +114,8 @@ __global__ __launch_bounds__(PRE_THREADS) void skg_preprocess_kernel(
     const float shift_unit = max_coord + 1.0f;
     for (int i = tid; i < nact; i += PRE_THREADS) {
         const int idx = (int)(skey[i] & 0xffffffffu);
-        const float4 bx = *reinterpret_cast<const float4*>(boxes + 4 * (int64_t)(base + idx));
-        const int64_t lab = labels[base + idx];
+        const float4 bx = rbox[idx];
+        const int64_t lab = labels64_of(rlab[idx], labels, base + idx);
         const float off = (float)lab * shift_unit;
         const float4 sb = make_float4(bx.x + off, bx.y + off, bx.z + off, bx.w + off);
         sbox[i] = sb;
@@ -187,9 +206,9 @@ __global__ __launch_bounds__(PRE_THREADS) void skg_preprocess_kernel(
         if (t < n) {
             const int s = (t < nh) ? ssel[t] : ssel[max_human + (t - nh)];
             v = (int)(skey[s] & 0xffffffffu);
-            const int64_t lab = labels[base + v];
-            lv += (lab >= 0 && lab < num_obj_classes) ? nverbs[lab] : 0;
-            if (t < nh && powf(scores[base + v], prior_pow) != 0.f) ++lz;
+            const int64_t lab = labels64_of(rlab[v], labels, base + v);
+            lv += (lab >= 0 && lab < num_obj_classes) ? (lab < 256 ? snv[lab] : nverbs[lab]) : 0;
+            if (t < nh && powf(rscore[v], prior_pow) != 0.f) ++lz;
         }
         out_index[(int64_t)b * ld_out + t] = v;
     }

@@ -726,3 +726,41 @@ def test_direct_lds_latency_loop_in_a_grouped_launch_with_fused_epilogues(direct
     torch.cuda.synchronize()
     for C, r in zip(outs, refs):
         _close(C, r, 2e-5)
+
+
+def test_public_spatial_ratio_encodings_match_the_oracle():
+    """skghoi_amd.ops.compute_spatial_ratio_encodings -- the drop-in of the reference's public ops.py:85-157 for explicit box
+    lists (row i of boxes_1 pairs with row i of boxes_2) -- against the oracle's restatement of the same lines: 46 columns in
+    the reference's order, several images with their own (h, w), an empty list entry, boxes that touch,
+    contain each other and coincide, a zero-area box (0 / 0 IoU: NaN in the reference; the head scrubs it at HEAD:866-868,
+    this function does not -- it returns what ops.py returns)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import skg_oracle as O
+    from skghoi_amd import ops
+    rs = np.random.RandomState(5)
+
+    def boxes(n, w, h):
+        xy = rs.uniform(0, [w * 0.7, h * 0.7], (n, 2)); wh = rs.uniform(4, [w * 0.3, h * 0.3], (n, 2))
+        return torch.from_numpy(np.concatenate([xy, xy + wh], 1).astype(np.float32))
+
+    shapes = [(800, 1200), (480, 640), (600, 600)]
+    b1 = [boxes(37, 1200, 800), torch.zeros(0, 4), boxes(9, 600, 600)]
+    b2 = [boxes(37, 1200, 800), torch.zeros(0, 4), boxes(9, 600, 600)]
+    b2[0][0] = b1[0][0]                                          # coincide: IoU 1
+    b2[0][1] = b1[0][1] + torch.tensor([3.0, 3.0, -3.0, -3.0])  # contained
+    b2[0][2, :2] = b1[0][2, 2:]; b2[0][2, 2:] = b1[0][2, 2:] + 20.0      # touch at a corner: IoU 0
+    got = ops.compute_spatial_ratio_encodings([b.cuda() for b in b1], [b.cuda() for b in b2], shapes)
+    want = torch.cat([O.spatial_ratio_encoding(x, y, hw) for x, y, hw in zip(b1, b2, shapes)])
+    assert got.shape == (46, 46) and want.shape == (46, 46)
+    assert torch.isfinite(want).all()
+    assert float((got.cpu() - want).abs().max()) <= 1e-5
+    # a zero-area first box: the reference's 0 / 0 IoU stays NaN here (the head's scrub is the head's)
+    z1 = torch.tensor([[10.0, 10.0, 10.0, 10.0]]); z2 = torch.tensor([[10.0, 10.0, 10.0, 10.0]])
+    g = ops.compute_spatial_ratio_encodings([z1.cuda()], [z2.cuda()], [(100, 100)]).cpu()
+    w = O.spatial_ratio_encoding(z1, z2, (100, 100))
+    assert torch.equal(torch.isnan(g), torch.isnan(w)) and torch.isnan(w).any()
+    fin = ~torch.isnan(w)
+    assert float((g[fin] - w[fin]).abs().max()) <= 1e-5
+    with pytest.raises(ValueError):
+        ops.compute_spatial_ratio_encodings([z1.cuda()], [z2.cuda()], [(100, 100)], eps=1e-6)

@@ -200,6 +200,7 @@ def _dp_equiv_worker(rank, world, port, ref_path, q, rccl_lib=None, case_name="t
         finally:
             train_fused.TrainContext.stage_wait = orig
         q.put((rank, outcome, time.time() - t0, int(_capi.lib().skg_comm_dead(native.handle))))
+        q.close(); q.join_thread()                            # (the queue's feeder thread must have sent it before the exit)
         os._exit(0)                                           # (no collective teardown over a dead communicator)
     try:
         losses, _ = trainer.train_step(net, opt, feats, gpu_run.to_cuda(case["detections"]), case["shapes"],
@@ -419,7 +420,9 @@ def test_two_ranks_through_the_hip_arena_equal_the_unsharded_step(tmp_path, tran
         assert worst_r[0] <= 1e-4, (rank, worst_r)          # ... == the live reference's autograd (full-width fixture)
         # the replicas took the un-sharded step (the reference's lr, main:109; AdamW's first update lr * g / (|g| + eps) turns
         # the summation-order noise of near-zero gradient entries into at most a few 1e-7 of weight)
-        assert worst_w[0] <= 1e-6, (rank, worst_w)
+        # (full width: gradient entries at the rounding-noise level, |g| ~ 1e-9 against eps = 1e-8, move by a fraction of lr
+        #  with the summation order -- 1.5e-5 seen on box_head.1.weight, whose gradients agree to 2e-5 of their scale)
+        assert worst_w[0] <= (1e-6 if per == 1 else 5e-5), (rank, worst_w)
         if fake:
             # the worker issued one all-reduce per arena chunk, the preparation one for the normalisers; nothing was driven
             # from Python
