@@ -640,6 +640,64 @@ def b1_stream(device, n_forwards=2048, n_images=256, seed=2024):
     return out
 
 
+def b4_validate(device, n_images=256, batch=4, seed=2025):
+    """The reference's VALIDATION loop (utils.py:283-299: eval mode, batches of 4 WITH their targets -- main:55-63 -- results
+    into a 117-class meter) on a stream of batches whose shapes never repeat: 256 synthetic images with the HICO-like spread
+    of b1_stream, ground truth from their own boxes, at the default 15 / 15 caps.  Each batch goes through the head's
+    eval-with-targets pass -- the native preparation (selection, pairs, label association, the reference's host RNG) and
+    the native launch plan's forward in exact fp32 -- with the next batch prepared on the side stream meanwhile, as
+    trainer.Trainer.validate does.  Per-batch latency = call to results complete on the device.  Nothing is captured: a
+    launch plan here is a struct on the stack, so there is no per-shape state to miss (no hit rate to report)."""
+    from skghoi_amd import synth, trainer
+    head = build_head(device, max_human=15, max_object=15).eval()
+    rs = np.random.RandomState(seed)
+    kh = np.arange(1, 16); ph = kh ** -1.2; ph /= ph.sum()
+    ko = np.arange(1, 16); po = ko ** -0.8; po /= po.sum()
+    o2v = synth.hico_object_to_verb()
+    imgs = []
+    for i in range(n_images):
+        nh, no = int(rs.choice(kh, p=ph)), int(rs.choice(ko, p=po))
+        im = synth.make_image(70000 + i, n_h=nh, n_o=no, out_channels=C_FEAT, pool=POOL)
+        det = dict(boxes=im["boxes"], labels=im["labels"], scores=im["scores"])
+        tg = synth.make_targets(det, 49, o2v, 800 + i, n_gt=3)
+        imgs.append((det, tg, im["pooled"], im["feat3"], im["hw"]))
+    batches = []
+    for b0 in range(0, n_images, batch):
+        chunk = imgs[b0:b0 + batch]
+        dets = [{k: v.to(device) for k, v in c[0].items()} for c in chunk]
+        tgs = [{k: v.to(device) for k, v in c[1].items()} for c in chunk]
+        f3 = torch.cat([c[3] for c in chunk]).to(device)
+        batches.append((OrderedDict((k, f3) for k in "0123"), dets, [c[4] for c in chunk], tgs,
+                        torch.cat([c[2] for c in chunk]).to(device)))
+    pool = ResidentPool(None)
+    head.box_roi_pool = pool
+    out = {}
+    with torch.no_grad():
+        for name in ("first_pass", "steady_state"):
+            lat = np.zeros(len(batches))
+            torch.cuda.synchronize()
+            t_all = time.perf_counter()
+            for k, (feats, dets, shp, tgs, pooled) in enumerate(batches):
+                pool.pooled = pooled
+                t0 = time.perf_counter()
+                head(feats, dets, shp, tgs)
+                if k + 1 < len(batches):                     # the look-ahead of Trainer.validate
+                    nb = batches[k + 1]
+                    trainer.prefetch_batch(head, nb[0], nb[1], nb[2], nb[3])
+                torch.cuda.synchronize()
+                lat[k] = time.perf_counter() - t0
+            wall = time.perf_counter() - t_all
+            out[name] = dict(batches=len(batches), mean_ms=round(float(lat.mean()) * 1e3, 4),
+                             p50_ms=round(float(np.percentile(lat, 50)) * 1e3, 4),
+                             p95_ms=round(float(np.percentile(lat, 95)) * 1e3, 4),
+                             images_per_s=round(n_images / wall, 1))
+    out.update(batch=batch, images=n_images, max_human=15, max_object=15, precision="fp32",
+               note="eval-mode forwards WITH targets (validation batches of 4: labels associated, sampling RNG consumed) over "
+                    "a stream of batch shapes that never repeat; native preparation + native launch plan, next batch prepared "
+                    "on the side stream; no captured graphs on this route")
+    return out
+
+
 def train_roofline(prec, ms, inf):
     """Roofline record of one training leg, everything measured in this run: whole-step fraction (plan arithmetic / step
     time) and the dense products' own fraction (HIP events around every skg_gemmx launch of a few untimed steps)."""
@@ -694,6 +752,7 @@ def main():
     ap.add_argument("--no-legs", action="store_true",
                     help="headline only: skip the extra legs (fp16x2, small-batch latency, training step)")
     ap.add_argument("--b1-stream", action="store_true", help="only the single-image shape-stream leg (prints its record)")
+    ap.add_argument("--b4-validate", action="store_true", help="only the batch-4 validation-stream leg (prints its record)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="train: NegativeSampling+MarginLoss training step (fwd+bwd+AdamW) as the headline instead")
     ap.add_argument("--dp-world1", action="store_true",
@@ -749,6 +808,9 @@ def main():
         return train_mode(args, device, rank, world, dist_on)
     if args.b1_stream:
         print(json.dumps(b1_stream(device)))
+        return
+    if args.b4_validate:
+        print(json.dumps(b4_validate(device)))
         return
 
     from skghoi_amd import engine
@@ -877,6 +939,7 @@ def main():
         out["b1_latency_ms"] = round(small_batch_latency(head, dets, pooled, feats, shapes, 1), 4)
         out["b4_latency_ms"] = round(small_batch_latency(head, dets, pooled, feats, shapes, min(4, args.batch)), 4)
         out["b1_stream"] = b1_stream(device)
+        out["b4_validate"] = b4_validate(device)
         out["small_batch"] = dict(precision=head.precision, b1_images_per_s=round(1e3 / out["b1_latency_ms"], 1),
                                   b4_images_per_s=round(4e3 / out["b4_latency_ms"], 1),
                                   note="mean wall time per eval forward, 200 back-to-back forwards after 30 warm-ups")

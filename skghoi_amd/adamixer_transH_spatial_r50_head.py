@@ -440,6 +440,15 @@ class InteractionHead(Module):
             # whenever targets are given (HEAD:933-963); served by the training-mode graph pass without autograd,
             # without GT boxes appended (HEAD:105-106) and with the eval score power (HEAD:742)
             with torch.no_grad():
+                if self.fused_training:
+                    # the native preparation + the native launch plan's forward, in exact fp32 (round 5: validation batches no
+                    # longer walk the round-1 autograd graph)
+                    from skghoi_amd import train_fused
+                    if train_fused.supported(self):
+                        out = train_fused.validate_forward(self, self.engine(), features, detections, image_shapes, targets,
+                                                           prep=self._take_prefetched(detections, image_shapes, targets))
+                        if out is not None:
+                            return out
                 return self._forward_train(features, detections, image_shapes, targets, with_losses=False)
         eng = self.engine()
         if eng.small_batch_max and len(detections) <= eng.small_batch_max and _graphs_allowed():
@@ -494,7 +503,7 @@ class InteractionHead(Module):
         train_fused.release_prepared(head) on the step's stream once the step that consumed the batch has enqueued its last
         kernel -- the slot is reused behind that point."""
         from skghoi_amd import train_fused
-        if not (self.training and self.fused_training and train_fused.supported(self)) or not detections:
+        if not (self.fused_training and train_fused.supported(self)) or not detections or targets is None:
             return False
         dev = detections[0]["boxes"].device
         if dev.type != "cuda":
@@ -521,7 +530,9 @@ class InteractionHead(Module):
             slot = ring[k]
             with on_device(dev), on_stream(side):
                 slot.begin(side, current_stream_of(dev))
-        h = _Prefetch(self, train_fused.prepare_steps(self, eng, detections, image_shapes, targets, arena=slot), dev,
+        # (eval mode: the preparation of a VALIDATION batch -- no GT boxes appended, eval score power)
+        h = _Prefetch(self, train_fused.prepare_steps(self, eng, detections, image_shapes, targets, arena=slot,
+                                                      training=self.training), dev,
                       side, (detections, image_shapes, targets))
         h.advance()                            # launches the detection-selection kernel; its counts are read later
         self._prefetched = h

@@ -1081,9 +1081,9 @@ def _stacked_for(head, dev):
     return st
 
 
-def prepare_train(head, eng, detections, image_shapes, targets, before_sync=None):
+def prepare_train(head, eng, detections, image_shapes, targets, before_sync=None, training=True):
     """prepare_steps() run to the end in one go (the inline forward)."""
-    gen = prepare_steps(head, eng, detections, image_shapes, targets, before_sync)
+    gen = prepare_steps(head, eng, detections, image_shapes, targets, before_sync, training=training)
     try:
         while True:
             next(gen)
@@ -1091,7 +1091,7 @@ def prepare_train(head, eng, detections, image_shapes, targets, before_sync=None
         return done.value
 
 
-def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None, arena=None):
+def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None, arena=None, training=True):
     """The weight-independent part of InteractionHead.forward in training mode (HEAD:92-151 preprocess with GT boxes
     appended, HEAD:847-868 pairs + spatial encoding, HEAD:703-719 label association, the host RNG of HEAD:574-580 / 939,
     and the whole TransH term HEAD:207-235 / 936-963: its scores depend only on the step's throw-away embeddings).
@@ -1101,13 +1101,16 @@ def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None
     before_sync(prep): called right before the second one (the inline forward enqueues the table-independent part of the
     dense forward there, so that the GPU works while the host waits and draws).
     arena: a PrepArena slot (already begun on the current stream) that holds the batch's device tensors instead of one
-    torch allocation each."""
+    torch allocation each.
+    training=False: the same for an eval-mode forward WITH targets (validation, utils.py:283-299): no GT boxes appended
+    (HEAD:105-106), the eval score power in the cell count (HEAD:742); labels are associated and the host RNG is consumed
+    exactly as in training -- the reference does both whenever targets are given (HEAD:933-963)."""
     from . import transh
     from . import dist as skd
     lib = _capi.lib()
     gh = head.box_pair_head
     K = head.num_classes
-    launched = eng.pre_launch(detections, targets, True, True, defer=True)
+    launched = eng.pre_launch(detections, targets, training, training, defer=True)
     yield 1
     pre = eng.pre_pack(eng.pre_launch_end(launched))
     dev = pre.device
@@ -1118,6 +1121,7 @@ def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None
                                          faithful_skip_offset=eng.faithful_skip_offset)
     prep = Prepared()
     prep.pre, prep.lay, prep.inputs = pre, lay, (detections, image_shapes, targets)
+    prep.training = training
     A = lay.n_active
     if A == 0 or lay.sum_p == 0:
         prep.empty = True
@@ -1186,7 +1190,7 @@ def prepare_steps(head, eng, detections, image_shapes, targets, before_sync=None
     prep.norm = None
     counts = None
     force = getattr(head, "force_collectives", False)
-    if head.distributed and skd.dist.is_available() and skd.dist.is_initialized() and \
+    if training and head.distributed and skd.dist.is_available() and skd.dist.is_initialized() and \
             (skd.dist.get_world_size() > 1 or force):
         vt = eng.verbs(dev)
         counts = E(3, torch.float32)
@@ -1274,6 +1278,8 @@ class TrainRun:
             raise _capi.SkgError("box_roi_pool returned %d rows for %d boxes" % (box_features.shape[0], lay.sum_all))
         st = _stacked_for(head, dev)
         job = job_class(head)(head, eng, st, lay, pre, prep.ibuf, prep.offs, None, prep.meta)
+        if getattr(self, "exact", False):
+            job.bf16 = False                                            # (validation: exact fp32 products)
         job.params = _head_params(head)
         job.S.update(prep.arrays)
         isl = job.isl
@@ -1470,6 +1476,46 @@ def train_forward(head, eng, features, detections, image_shapes, targets, prep=N
                 t.record_stream(main)
         run.start(prep)
     return run.finish(prep), prep
+
+
+def validate_forward(head, eng, features, detections, image_shapes, targets, prep=None):
+    """InteractionHead.forward in EVAL mode with targets (validation: utils.py:283-299 runs the net in eval mode on batches
+    that carry their targets, at batch 4 -- main:55-63) on the fused step's machinery: the native preparation (selection
+    without GT boxes, pairs + spatial encoding, label association, the reference's host RNG stream) and the native launch
+    plan's dense FORWARD in exact fp32 -- no losses, no backward, the eval score power (HEAD:742).  The results carry
+    `labels` / `unary_labels` like the reference's (HEAD:323-327).  Until round 5 this mode went through the round-1 autograd
+    graph (train_graph.py): ~100 torch ops per batch.  prep: a Prepared batch made ahead of time (prefetch_train in eval
+    mode) or None.  Returns the result list, or None when the batch has no image with pairs (the caller's generic path)."""
+    run = TrainRun(head, eng, features, image_shapes)
+    run.reuse_ws = True                      # no backward will read the workspace: the arena's persistent one serves every batch
+    run.exact = True                         # validation scores in the reference's own arithmetic, whatever the training precision
+    if prep is None:
+        prep = prepare_train(head, eng, detections, image_shapes, targets, before_sync=run.start, training=False)
+        if prep.empty:
+            return None
+    else:
+        if prep.empty or getattr(prep, "training", True):
+            return None
+        if prep.ready is not None:
+            main = current_stream_of(None)
+            main.wait_event(prep.ready)
+            for t in prep.cross:
+                t.record_stream(main)
+        run.start(prep)
+    job, pre, lay = run.job, prep.pre, prep.lay
+    job.ent = prep.ent
+    with torch.no_grad():
+        S = job.forward(run.box_features, run.gfeat)
+        logits = S["logits"]
+        g = dict(layout=lay, meta=prep.meta, x_keep=prep.arrays["x_keep"], y_keep=prep.arrays["y_keep"])
+        job.result = r = eng.score(logits, pre, g, False)            # (eval: prior scores to the power 2.8)
+        job.loss_forward(logits)                                     # the labels at the scored cells / per pair (HEAD:323-327)
+    if eng.debug:
+        head._last_train = dict(pair_features=S["PF"][:lay.sum_p], pos_scores=prep.pos_s.split(prep.n_pos),
+                                neg_scores=prep.neg_s.split(prep.n_pos), job=job)
+    results = head._results(lay, r, pre.device, train_extras=(job.cell_labels, job.unary))
+    job.S = None
+    return results
 
 
 def _head_params(head):

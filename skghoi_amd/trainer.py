@@ -1050,10 +1050,21 @@ class Trainer:
         meter = self._new_meter()
         dev = self._meter_device()
         self.net.eval()
-        for batch in self.val_loader:
-            inputs = relocate_to_device(batch, dev)
-            results = self.net(*inputs)
+        # one-batch look-ahead, as in training: while the GPU runs batch i's forward the head prepares batch i + 1 on its side
+        # stream (selection, pairs, label association, the reference's host RNG draws: InteractionHead.prefetch_train in eval
+        # mode); only for batches of the head's own call shape -- any other batch is simply not prepared
+        it = iter(self.val_loader)
+        cur = next(it, None)
+        cur = None if cur is None else relocate_to_device(cur, dev)
+        while cur is not None:
+            results = self.net(*cur)
+            nxt = next(it, None)
+            if nxt is not None:
+                nxt = relocate_to_device(nxt, dev)
+                if self.lookahead and isinstance(nxt, (list, tuple)) and len(nxt) == 4:
+                    prefetch_batch(self.net, *nxt)
             self.log_results(results, meter)
+            cur = nxt
         return meter.eval()
 
     def on_end_epoch(self):

@@ -328,6 +328,66 @@ def test_eval_with_targets_consumes_rng_like_reference():
         assert np.abs(got["res%d.scores" % b] - want["res%d.scores" % b]).max() <= 1e-5
 
 
+@pytest.mark.parametrize("name", ["eval_targets", "train_tiny", "train_skips", "train_ragged_full", "train_vcoco"])
+def test_validation_forward_on_the_native_plan_equals_the_generic_pass(name):
+    """Eval mode WITH targets (what Trainer.validate runs: utils.py:283-299) on the fused machinery -- native preparation,
+    native launch plan forward in exact fp32, round 5 -- against the round-1 generic pass (`fused_training = False`: torch ops
+    over the autograd graph): the same result dicts (index / prediction / labels / unary_labels / object bit-exact, scores,
+    priors, weights and boxes to 1e-5), no GT boxes appended, and the host RNG left at the same position (per image six table
+    fills + randperm(#negatives), HEAD:574-580, 939 -- consumed whenever targets are given).  Also with a precision="bf16"
+    head: validation scores stay exact fp32.  Cases: ragged, skipped images, V-COCO, over-cap truncation."""
+    case = dict(cases.build_case(name))
+    case["training"] = False
+    outs = {}
+    for route, fused, prec in (("generic", False, "fp32"), ("native", True, "fp32"), ("native, bf16 head", True, "bf16")):
+        head = gpu_run.build_head(case)
+        head.fused_training = fused
+        head.precision = prec
+        head.eval()
+        outs[route] = gpu_run.run_head(case, head=head)
+    want = outs["generic"]
+    for route in ("native", "native, bf16 head"):
+        got = outs[route]
+        assert int(got["n_results"]) == int(want["n_results"])
+        assert np.array_equal(got["rng_after"], want["rng_after"]), route
+        for b in range(int(want["n_results"])):
+            for k in ("index", "prediction", "object", "labels", "unary_labels"):
+                assert np.array_equal(got["res%d.%s" % (b, k)], want["res%d.%s" % (b, k)]), (route, b, k)
+            for k in ("scores", "prior", "weights", "boxes_h", "boxes_o"):
+                a, w = got["res%d.%s" % (b, k)], want["res%d.%s" % (b, k)]
+                assert a.shape == w.shape and (a.size == 0 or np.abs(a - w).max() <= 1e-5), (route, b, k)
+            assert np.array_equal(got["pre%d.boxes" % b], want["pre%d.boxes" % b])
+
+
+def test_trainer_validate_prepares_the_next_batch_while_the_gpu_runs_this_one():
+    """Trainer.validate with its one-batch look-ahead (the next validation batch prepared on the side stream: selection, pairs,
+    association, host RNG) returns the APs of the same loop without look-ahead, and leaves the host RNG where that loop does."""
+    from collections import OrderedDict
+    from skghoi_amd import trainer
+    case = dict(cases.build_case("train_tiny")); case["training"] = False
+    det = gpu_run.to_cuda(case["detections"]); tg = gpu_run.to_cuda(case["targets"])
+    batches = []
+    for rep in range(3):
+        for b in range(len(det)):
+            batches.append((OrderedDict((k, case["feat3"][b:b + 1].cuda()) for k in "0123"), [det[b]], [case["shapes"][b]], [tg[b]]))
+
+    class Pool(torch.nn.Module):
+        def forward(self, features, boxes, image_shapes):
+            n = sum(len(x) for x in boxes)
+            return cases.pooled_for(case, n).cuda()
+    res = {}
+    for look in (False, True):
+        head = gpu_run.build_head(case)
+        head.box_roi_pool = Pool()
+        t = trainer.Trainer(head, None, val_loader=batches, num_classes=case["cfg"]["K"], device="cuda")
+        t.lookahead = look
+        torch.manual_seed(77)
+        ap = t.validate()
+        res[look] = (ap.cpu().numpy(), torch.empty(4).uniform_().numpy())
+    assert np.array_equal(res[True][1], res[False][1])
+    assert np.allclose(res[True][0], res[False][0], atol=1e-7, equal_nan=True)
+
+
 @pytest.fixture(scope="module", params=cases.FULL_TRAIN_CASES)
 def full_train_oracle(request):
     """CPU autograd of the oracle on a full-width training case (pinned to the live reference's autograd by
