@@ -627,6 +627,13 @@ typedef struct {
     /* split-K of the plan's products (developer knobs; 0 = the measured defaults: ~500 workgroups per product on the exact
      * fp32 loop, ~160 on the bf16 loops, at most 64 slices)                                                              */
     int32_t split_target, split_max;
+    /* 1: two-branch schedule (bf16 step): the NODE chain of the step -- fc_head / fc_tail and the fc_1 projections in the
+     * forward; from backward stage 6 on the fc_1 / fc_head / box_head gradients -- runs on a second stream beside the SPATIAL
+     * chain on the grid rows (fc_2 of all four MBFs, the spatial head), which it shares nothing with; every call returns
+     * with the caller's stream ordered behind both.  The second stream and its two events belong to a CONTEXT: honoured by
+     * skg_ctx_train_forward_f32 and by backwards issued through a context; skg_train_ws_floats then asks for a second
+     * split-K scratch region.  0: one stream (and always so for the context-free entry points).                        */
+    int32_t two_branch, reserved2;
 } skg_train_plan;
 /* Floats of workspace the plan needs (activations kept for the backward, backward temporaries, split-K scratch);
  * < 0: rejected plan.  Only the sizes, bf16 and params (non-null) are read.                                              */
@@ -677,6 +684,8 @@ skg_context* skg_ctx_make_current(skg_context* ctx);
  * calls).                                                                                                              */
 int skg_ctx_train_backward_async_f32(skg_context* ctx, const skg_train_plan* plan_host, int first_stage, int last_stage,
                                      void* stream, void* const* stage_events_host, uint32_t stage_mask);
+/* skg_train_forward_f32 with the context's second branch at hand (plan.two_branch; the calling thread issues both branches). */
+int skg_ctx_train_forward_f32(skg_context* ctx, const skg_train_plan* plan_host, int part, void* stream);
 int skg_ctx_stream_wait_stage(skg_context* ctx, int stage, void* waiting_stream);
 int skg_ctx_train_backward_stage_wait(skg_context* ctx, int stage);
 int skg_ctx_train_backward_join(skg_context* ctx);

@@ -87,7 +87,8 @@ class TrainPlan(C.Structure):
                                    "node_of")] + \
                [("ws", _vp), ("ws_floats", _i64), ("pair_features", _vp), ("logits", _vp), ("dlogits", _vp),
                 ("dx0", _vp), ("dgfeat", _vp), ("timer", _vp), ("ws16", _vp), ("params16", _vp), ("pf16", _vp),
-                ("params_floats", _i64), ("counters", _vp), ("n_counters", _i64), ("split_target", _i32), ("split_max", _i32)]
+                ("params_floats", _i64), ("counters", _vp), ("n_counters", _i64), ("split_target", _i32), ("split_max", _i32),
+                ("two_branch", _i32), ("reserved2", _i32)]
 
 
 LAYOUT_SLICES = ("meta", "node_img", "hum_img", "node_enc_row", "hum_enc_row", "node_ent_row", "hum_ent_row", "enc_row_hn",
@@ -189,6 +190,7 @@ PROTOTYPES = {
     "skg_context_create": (_vp, []),
     "skg_context_destroy": (None, [_vp]),
     "skg_ctx_train_backward_async_f32": (C.c_int, [_vp, C.POINTER(TrainPlan), C.c_int, C.c_int, _vp, _vp, C.c_uint32]),
+    "skg_ctx_train_forward_f32": (C.c_int, [_vp, C.POINTER(TrainPlan), C.c_int, _vp]),
     "skg_ctx_train_backward_exchange_f32": (C.c_int, [_vp, C.POINTER(TrainPlan), C.c_int, C.c_int, _vp, _vp, C.POINTER(Exchange)]),
     "skg_sizeof_exchange": (C.c_int, []),
     "skg_comm_load": (C.c_int, [C.c_char_p]),

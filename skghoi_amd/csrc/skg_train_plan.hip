@@ -53,6 +53,19 @@ struct Ctx {
     double flops;                // 2 M N K over every dense product issued (sizing pass: what the plan WILL issue)
     const float* no_twin;        // workspace buffer whose twin nobody writes (dadj: produced next to dWt, one column wide)
     const struct Ws* w;          // the workspace layout: where the SIDE twins live (twin_of)
+    // second branch (skg_branch: a stream, two events, a split-K scratch region of its own) or NULL: one stream
+    const struct skg_branch* br;
+};
+// What a two-branch plan call needs besides the caller's stream; owned by a context (skg_ctx_train_forward_f32 / the worker).
+struct skg_branch {
+    hipStream_t stream;
+    hipEvent_t fork, join;       // no timing, device-scope release
+};
+// Runs the launches of its scope on the branch's stream with the branch's scratch region.
+struct OnBranch {
+    Ctx& c; hipStream_t s0; float* sc0;
+    OnBranch(Ctx& c_, float* scratch2) : c(c_), s0(c_.stream), sc0(c_.scratch) { c.stream = c.br->stream; c.scratch = scratch2; }
+    ~OnBranch() { c.stream = s0; c.scratch = sc0; }
 };
 
 // bf16 twin of a tensor the plan's products read or write, or NULL (defined behind the workspace layout); *ld receives the
@@ -282,6 +295,7 @@ struct Ws {
     float *x0t, *sp48t, *gft, *fhw_t, *ftw_t, *sp0w_t, *dlog_t;
     bool side;                   // the regions above exist (bf16 step, not switched off)
     float* scratch;
+    float* scratch2;             // the second branch's split-K scratch (set by the entry points: scratch + the sizing pass's need)
     int64_t total;               // floats, scratch excluded
 };
 constexpr int FH_PITCH = 1088, SP0_PITCH = 48;
@@ -328,6 +342,7 @@ static void layout_ws(const skg_train_plan* P, float* base, Ws& w) {
     }
     w.total = off;
     w.scratch = base ? base + off : nullptr;
+    w.scratch2 = nullptr;
 }
 
 static uint16_t* twin_of(const Ctx& c, const float* p, int64_t* ld) {
@@ -450,28 +465,52 @@ static void forward(Ctx& c, const Ws& w, int part) {
     const int Mp1 = Mp > 0 ? Mp : 1;
     // ---- fc_head / fc_tail on unique node rows (HEAD:884-885)
     Mat Xhn(w.Xhn, Mh + Mn, 1088), GH(w.GH, Mh, 1024), GO(w.GO, Mn, 1024), Sp(w.Sp, Mg, 1024);
-    CK(skg_concat_entity_f32(w.enc, 1024, P->enc_row_hn, P->ent, P->img_hn, P->ent_row_hn, Mh + Mn, w.Xhn, 1088, c.stream));
     Mat fh_w(W.at(SKG_SEG_FH_W), 1024, 1074), ft_w(W.at(SKG_SEG_FT_W), 1024, 1074);
-    {
-        skg_gemmx_desc l[3] = {FWD(Xhn.row_range(0, Mh), fh_w, GH, W.at(SKG_SEG_FH_B), true, -1, 1074),
-                               FWD(Xhn.row_range(Mh, Mn), ft_w, GO, W.at(SKG_SEG_FT_B), true, -1, 1074),
-                               FWD(s2, sp4_w, Sp, W.at(SKG_SEG_SP4_B), true)};           // + the last spatial layer
-        launch(c, l, 3);
-    }
-    // ---- fc_1 projections on node rows (HEAD:894-896 separable over [human | object]; HEAD:514, 524)
     Mat A1h(w.A1h, Mh, 1024), A1o(w.A1o, Mn, 1024), C1o(w.C1o, Mn, 1024), C1h(w.C1h, Mh, 1024);
     Mat Wa1 = W1[ATT];
-    {
-        skg_gemmx_desc l[4] = {FWD(GH, Wa1, A1h, nullptr, false, -1, 1024), FWD(GO, Wa1.from_col(1024), A1o, nullptr, false, -1, 1024),
-                               FWD(GO, W1[OS], C1o, b1[OS], false), FWD(GH, W1[SO], C1h, b1[SO], false)};
-        launch(c, l, 4);
-    }
-    // ---- fc_2 on the grid rows; the raw fc_2 output F = [F2 | F_os | F_so | F_g] (ld 4096) is kept for the backward
     Mat F(w.F, Mg, 4096), T(w.T, Mg, 1024), Tos(w.Tos, Mg, 1024), Tso(w.Tso, Mg, 1024), Tg(w.Tg, Mp1, 1024);
     const float* W2 = W.at(SKG_SEG_W2); const float* b2 = W.at(SKG_SEG_B2);
+    // The NODE chain (entity rows -> fc_head / fc_tail -> the four fc_1 projections: a few hundred rows, launches bound by
+    // their latency) shares nothing with the SPATIAL chain (last spatial layer -> fc_2 of all four MBFs on the grid rows:
+    // the step's largest forward product) until the fc_1 * fc_2 products.  With a second branch (bf16 step) the node chain
+    // runs there, beside the spatial chain on the caller's stream, and joins in front of the products.
+    auto node_chain = [&]() {
+        CK(skg_concat_entity_f32(w.enc, 1024, P->enc_row_hn, P->ent, P->img_hn, P->ent_row_hn, Mh + Mn, w.Xhn, 1088, c.stream));
+        skg_gemmx_desc l[2] = {FWD(Xhn.row_range(0, Mh), fh_w, GH, W.at(SKG_SEG_FH_B), true, -1, 1074),
+                               FWD(Xhn.row_range(Mh, Mn), ft_w, GO, W.at(SKG_SEG_FT_B), true, -1, 1074)};
+        launch(c, l, 2);
+        // fc_1 projections on node rows (HEAD:894-896 separable over [human | object]; HEAD:514, 524)
+        skg_gemmx_desc l4[4] = {FWD(GH, Wa1, A1h, nullptr, false, -1, 1024), FWD(GO, Wa1.from_col(1024), A1o, nullptr, false, -1, 1024),
+                                FWD(GO, W1[OS], C1o, b1[OS], false), FWD(GH, W1[SO], C1h, b1[SO], false)};
+        launch(c, l4, 4);
+    };
+    const bool two = c.br != nullptr && P->bf16 && !c.dry;
+    if (two) {
+        CK((int)hipEventRecord(c.br->fork, c.stream));
+        CK((int)hipStreamWaitEvent(c.br->stream, c.br->fork, 0));
+        {
+            OnBranch on(c, w.scratch2);
+            node_chain();
+            CK((int)hipEventRecord(c.br->join, c.stream));
+        }
+        skg_gemmx_desc l[1] = {FWD(s2, sp4_w, Sp, W.at(SKG_SEG_SP4_B), true)};           // the last spatial layer
+        launch(c, l, 1);
+    } else {
+        // (one stream; the sizing pass walks this form: the same products, the scratch high-water mark is per launch)
+        CK(skg_concat_entity_f32(w.enc, 1024, P->enc_row_hn, P->ent, P->img_hn, P->ent_row_hn, Mh + Mn, w.Xhn, 1088, c.stream));
+        skg_gemmx_desc l[3] = {FWD(Xhn.row_range(0, Mh), fh_w, GH, W.at(SKG_SEG_FH_B), true, -1, 1074),
+                               FWD(Xhn.row_range(Mh, Mn), ft_w, GO, W.at(SKG_SEG_FT_B), true, -1, 1074),
+                               FWD(s2, sp4_w, Sp, W.at(SKG_SEG_SP4_B), true)};
+        launch(c, l, 3);
+        skg_gemmx_desc l4[4] = {FWD(GH, Wa1, A1h, nullptr, false, -1, 1024), FWD(GO, Wa1.from_col(1024), A1o, nullptr, false, -1, 1024),
+                                FWD(GO, W1[OS], C1o, b1[OS], false), FWD(GH, W1[SO], C1h, b1[SO], false)};
+        launch(c, l4, 4);
+    }
+    // ---- fc_2 on the grid rows; the raw fc_2 output F = [F2 | F_os | F_so | F_g] (ld 4096) is kept for the backward
     if (P->bf16) {
         skg_gemmx_desc l[1] = {FWD(Sp, cm(W2, 4096, 1024), F, b2, false)};            // all four fc_2 as ONE N = 4096 product
         launch(c, l, 1);
+        if (two) CK((int)hipStreamWaitEvent(c.stream, c.br->join, 0));                 // the node chain's fc_1 tables
         {   // the four fc_1 * fc_2 -> ReLU products as one launch
             skg_rows_mul_args m[4] = {
                 {w.A1h, P->grid_h, 1024, w.A1o, P->grid_o, 1024, b1[ATT], w.F, nullptr, 4096, Mg, 1024, w.T, 1024},
@@ -591,6 +630,16 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
     Mat E1(w.E1, NA, 1024), dE1(w.dE1, NA, 1024), d_enc(w.d_enc, NA, 1024);
     Mat bh1_w(W.at(SKG_SEG_BH1_W), 1024, kx), bh3_w(W.at(SKG_SEG_BH3_W), 1024, 1024);
     Mat g_bh1(G.at(SKG_SEG_BH1_W), 1024, kx), g_bh3(G.at(SKG_SEG_BH3_W), 1024, 1024);
+    // Behind stage 5 the backward is two chains that share nothing: the SPATIAL chain on the grid rows (fc_2 of all four MBFs
+    // -- the step's largest product --, then the spatial head) and the NODE chain on a few hundred rows (the fc_1 projections,
+    // fc_head / fc_tail, box_head: launches bound by their latency).  With a second branch (bf16 step) the node chain runs
+    // there from stage 6 on, beside the spatial chain on the caller's stream; the call joins them before it returns.
+    const bool two = c.br != nullptr && P->bf16 && !c.dry && first <= 6 && last >= 8;
+    bool forked = false;
+    auto on_node = [&](auto&& fn) {
+        if (two && forked) { OnBranch on(c, w.scratch2); fn(); }
+        else fn();
+    };
     for (int st = first; st < last && !c.rc; ++st) switch (st) {
     case 0: {
         // ---- classifier
@@ -703,6 +752,11 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
             hipLaunchKernelGGL(colsum2_kernel, dim3(16), dim3(1024), 0, c.stream, w.dA1h, Mh, w.dB1h, Mh, db1[ATT]);
     } break;
     case 6: {
+        if (two) {                                         // the node chain's stream behind everything issued so far
+            CK((int)hipEventRecord(c.br->fork, c.stream));
+            CK((int)hipStreamWaitEvent(c.br->stream, c.br->fork, 0));
+            forked = !c.rc;
+        }
         // ---- fc_2 of all four MBFs: ONE product for the input gradient (K = 4096), one for the weights
         Mat W2(W.at(SKG_SEG_W2), 4096, 1024), g_W2(G.at(SKG_SEG_W2), 4096, 1024);
         skg_gemmx_desc l[2] = {IG(dF, W2, dS, &Sp, false, -1, 1024), WG(dF, Sp, g_W2, G.at(SKG_SEG_B2), false)};
@@ -714,13 +768,15 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
                                WG(dA1h, GH, dWa1, nullptr, true, -1, -1, 1024),
                                WG(dA1o, GO, dWa1.from_col(1024), nullptr, true, -1, -1, 1024),
                                IG(dS, sp4_w, ds2, &s2, false), WG(dS, s2, g_sp4, G.at(SKG_SEG_SP4_B), false)};
-        launch(c, l, 6);
+        if (two && forked) { on_node([&] { launch(c, l, 4); }); launch(c, l + 4, 2); }
+        else launch(c, l, 6);
     } break;
     case 8: {
         skg_gemmx_desc l[6] = {IG(dC1h, W1[SO], dHp, &GH, true), IG(dC1o, W1[OS], dOp, &GO, true),
                                WG(dC1h, GH, dW1[SO], db1[SO], false), WG(dC1o, GO, dW1[OS], db1[OS], false),
                                IG(ds2, sp2_w, ds1, &s1, false), WG(ds2, s1, g_sp2, G.at(SKG_SEG_SP2_B), false)};
-        launch(c, l, 6);
+        if (two && forked) { on_node([&] { launch(c, l, 4); }); launch(c, l + 4, 2); }
+        else launch(c, l, 6);
     } break;
     case 9: {
         // ---- fc_head / fc_tail, the first spatial layer and the global branch's fc_1 (HEAD:971)
@@ -732,24 +788,37 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
                                WG(dG1, gfeat, dW1[GL], db1[GL], false), skg_gemmx_desc()};
         int n = 6;
         if (P->dgfeat || c.dry) l[n++] = IG(dG1, W1[GL], Mat(P->dgfeat, Bf, Cf), nullptr, false);   // (sizing: assume it)
-        launch(c, l, n);
-        CK(skg_entity_rows_bwd_f32(w.dXhn, 1088, P->hum_of, P->node_of, Mh, NA, w.enc, w.d_enc, c.stream));
+        if (two && forked) {
+            on_node([&] {
+                launch(c, l, 4);
+                CK(skg_entity_rows_bwd_f32(w.dXhn, 1088, P->hum_of, P->node_of, Mh, NA, w.enc, w.d_enc, c.stream));
+            });
+            launch(c, l + 4, n - 4);
+        } else {
+            launch(c, l, n);
+            CK(skg_entity_rows_bwd_f32(w.dXhn, 1088, P->hum_of, P->node_of, Mh, NA, w.enc, w.d_enc, c.stream));
+        }
     } break;
     case 10: {
         // ---- box_head layer 2
         skg_gemmx_desc l[2] = {IG(d_enc, bh3_w, dE1, &E1, false), WG(d_enc, E1, g_bh3, G.at(SKG_SEG_BH3_B), false)};
-        launch(c, l, 2);
+        on_node([&] { launch(c, l, 2); });
     } break;
     case 11: {
         // ---- box_head layer 1; every fc_3 branch gets its MBF's bias gradient (the bias is added once per row)
         skg_gemmx_desc l[2] = {WG(dE1, x0, g_bh1, G.at(SKG_SEG_BH1_B), false), skg_gemmx_desc()};
         int n = 1;
         if (P->dx0 || c.dry) l[n++] = IG(dE1, bh1_w, Mat(P->dx0, NA, kx), nullptr, false);
-        launch(c, l, n);
+        on_node([&] { launch(c, l, n); });
         if (!c.dry)
             hipLaunchKernelGGL(b3bcast_kernel, dim3(256), dim3(256), 0, c.stream, w.db3, G.at(SKG_SEG_B3));
     } break;
     default: break;
+    }
+    if (forked) {                                          // the caller's stream behind the node chain: the call returns joined
+        hipError_t e = hipEventRecord(c.br->join, c.br->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c.stream, c.br->join, 0);
+        if (e != hipSuccess && !c.rc) c.rc = (int)e;
     }
 }
 
@@ -761,28 +830,45 @@ int64_t skg_train_ws_floats(const skg_train_plan* P) {
     int rc = check_plan(P);
     if (rc) return rc;
     Ws w; layout_ws(P, nullptr, w);
-    Ctx c{P, nullptr, true, 0, nullptr, 0, 0.0, nullptr, &w};
+    Ctx c{P, nullptr, true, 0, nullptr, 0, 0.0, nullptr, &w, nullptr};
     forward(c, w, 0); forward(c, w, 1); backward(c, w, 0, SKG_TRAIN_BWD_STAGES);
-    return w.total + c.scratch_need + 4;
+    // (twice the split-K scratch: a two-branch call gives each branch a region of its own)
+    return w.total + (P->two_branch ? 2 : 1) * c.scratch_need + 4;
 }
 
-int skg_train_forward_f32(const skg_train_plan* P, int part, void* stream) {
+}  // extern "C"
+
+namespace {
+// a branch is used when the plan asks for one, the caller's context supplied it and the workspace holds a second scratch region
+static const skg_branch* usable_branch(const skg_train_plan* P, const skg_branch* br, Ws& w, int64_t scratch_need) {
+    if (!br || !P->two_branch || !P->bf16 || P->counters) return nullptr;      // (tile counters are per stream: one branch only)
+    if (w.total + 2 * scratch_need > P->ws_floats) return nullptr;
+    w.scratch2 = w.scratch + scratch_need;
+    return br;
+}
+
+int forward_entry(const skg_train_plan* P, int part, void* stream, const skg_branch* br) {
     int rc = check_plan(P);
     if (rc) return rc;
     if (!P->ws || !P->x0 || !P->gfeat || !P->sp48 || part < 0 || part > 1) return SKG_E_ARG;
     if (part == 1 && (!P->ent || !P->logits || !P->pair_features)) return SKG_E_ARG;
     Ws w; layout_ws(P, P->ws, w);
     if (w.total > P->ws_floats) return SKG_E_LIMIT;
-    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0, 0.0, w.dadj, &w};
-    TwinScope twins(P);
     // bound the scratch: the sizing pass told the caller how much the largest launch needs
-    Ctx d{P, nullptr, true, 0, nullptr, 0, 0.0, nullptr, &w};
+    Ctx d{P, nullptr, true, 0, nullptr, 0, 0.0, nullptr, &w, nullptr};
     forward(d, w, part);
     if (w.total + d.scratch_need > P->ws_floats) return SKG_E_LIMIT;
+    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0, 0.0, w.dadj, &w, usable_branch(P, br, w, d.scratch_need)};
+    TwinScope twins(P);
     forward(c, w, part);
     if (!c.rc) { hipError_t e = hipGetLastError(); if (e != hipSuccess) c.rc = (int)e; }
     return c.rc;
 }
+}  // namespace
+
+extern "C" {
+
+int skg_train_forward_f32(const skg_train_plan* P, int part, void* stream) { return forward_entry(P, part, stream, nullptr); }
 
 // what both the direct and the worker-thread entry check BEFORE anything is enqueued or queued: arguments, stage range and
 // the workspace bound (a sizing pass over the requested stages)
@@ -793,21 +879,31 @@ static int validate_backward(const skg_train_plan* P, int first_stage, int last_
         first_stage > last_stage)
         return SKG_E_ARG;
     Ws w; layout_ws(P, P->ws, w);
-    Ctx d{P, nullptr, true, 0, nullptr, 0, 0.0, nullptr, &w};
+    Ctx d{P, nullptr, true, 0, nullptr, 0, 0.0, nullptr, &w, nullptr};
     backward(d, w, first_stage, last_stage);
     if (w.total + d.scratch_need > P->ws_floats) return SKG_E_LIMIT;
     return 0;
 }
 
-int skg_train_backward_f32(const skg_train_plan* P, int first_stage, int last_stage, void* stream) {
+static int backward_entry(const skg_train_plan* P, int first_stage, int last_stage, void* stream, const skg_branch* br) {
     int rc = validate_backward(P, first_stage, last_stage);
     if (rc) return rc;
     Ws w; layout_ws(P, P->ws, w);
-    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0, 0.0, w.dadj, &w};
+    int64_t need = 0;
+    if (br && P->two_branch) {
+        Ctx d{P, nullptr, true, 0, nullptr, 0, 0.0, nullptr, &w, nullptr};
+        backward(d, w, first_stage, last_stage);
+        need = d.scratch_need;
+    }
+    Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0, 0.0, w.dadj, &w, usable_branch(P, br, w, need)};
     TwinScope twins(P);
     backward(c, w, first_stage, last_stage);
     if (!c.rc) { hipError_t e = hipGetLastError(); if (e != hipSuccess) c.rc = (int)e; }
     return c.rc;
+}
+
+int skg_train_backward_f32(const skg_train_plan* P, int first_stage, int last_stage, void* stream) {
+    return backward_entry(P, first_stage, last_stage, stream, nullptr);
 }
 
 }  // extern "C"
@@ -840,6 +936,17 @@ struct skg_context {
     bool own_made = false, own_sys_made = false;
     bool with_events = false;
     skg_tuning tuning = {0, 0, 0, 0};              // the eval GEMM's switches for the threads this context is current on
+    skg_branch branch = {nullptr, nullptr, nullptr};   // second branch of two-branch plan calls (stream + fork / join events)
+    bool branch_made = false;
+    const skg_branch* get_branch() {                // (the submitting / calling thread's device is current)
+        if (branch_made) return &branch;
+        hipError_t e = hipStreamCreateWithFlags(&branch.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&branch.fork, hipEventDisableTiming | hipEventReleaseToDevice);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&branch.join, hipEventDisableTiming | hipEventReleaseToDevice);
+        if (e != hipSuccess) return nullptr;
+        branch_made = true;
+        return &branch;
+    }
     skg_exchange ex = {};                          // the arena chunks this job all-reduces (ex.comm) and / or updates (ex.adamw) itself
     bool has_ex = false;
     hipStream_t aux = nullptr;                     // single process + optimizer inside the backward: the updates' stream
@@ -886,7 +993,7 @@ struct skg_context {
             int r = (int)hipSetDevice(device);
             (void)skg_ctx_make_current(this);              // the eval GEMM's switches of THIS context (fp32 plan: the fc_2 products)
             if (!with_events) {
-                if (!r) r = skg_train_backward_f32(&plan, first, last, stream);
+                if (!r) r = backward_entry(&plan, first, last, stream, plan.two_branch ? get_branch() : nullptr);
                 lk.lock();
                 issued = last;
             } else {
@@ -895,7 +1002,7 @@ struct skg_context {
                 while (s < last && !r) {
                     int e = s;
                     while (e + 1 < last && !events[e - first] && !((own_mask >> e) & 1u)) ++e;
-                    r = skg_train_backward_f32(&plan, s, e + 1, stream);
+                    r = backward_entry(&plan, s, e + 1, stream, plan.two_branch ? get_branch() : nullptr);
                     if (!r && events[e - first]) r = (int)hipEventRecord(events[e - first], (hipStream_t)stream);
                     if (!r && ((own_mask >> e) & 1u)) r = (int)hipEventRecord(own[e], (hipStream_t)stream);
                     if (!r) r = exchange_after(e, (hipStream_t)stream);
@@ -973,6 +1080,10 @@ void skg_context_destroy(skg_context* c) {
         for (int s = 0; s < SKG_TRAIN_BWD_STAGES; ++s) (void)hipEventDestroy(c->own_dev[s]);
     if (c->own_sys_made)
         for (int s = 0; s < SKG_TRAIN_BWD_STAGES; ++s) (void)hipEventDestroy(c->own_sys[s]);
+    if (c->branch_made) {
+        (void)hipStreamSynchronize(c->branch.stream); (void)hipStreamDestroy(c->branch.stream);
+        (void)hipEventDestroy(c->branch.fork); (void)hipEventDestroy(c->branch.join);
+    }
     if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
     if (c->aux_done) (void)hipEventDestroy(c->aux_done);
     delete c;
@@ -1055,6 +1166,16 @@ static int submit_backward(skg_context* ctx, const skg_train_plan* P, int first_
     lk.unlock();
     a->cv.notify_all();
     return 0;
+}
+
+int skg_ctx_train_forward_f32(skg_context* ctx, const skg_train_plan* P, int part, void* stream) {
+    skg_context* a = ctx_or_default(ctx);
+    const skg_branch* br = nullptr;
+    if (P && P->two_branch) {
+        std::unique_lock<std::mutex> lk(a->m);
+        br = a->get_branch();
+    }
+    return forward_entry(P, part, stream, br);
 }
 
 int skg_ctx_train_backward_async_f32(skg_context* ctx, const skg_train_plan* P, int first_stage, int last_stage,
@@ -1150,7 +1271,7 @@ int skg_train_timer_read(skg_train_timer* t, double* out3_host) {
 double skg_train_flops(const skg_train_plan* P, int which) {
     if (check_plan(P)) return -1.0;
     Ws w; layout_ws(P, nullptr, w);
-    Ctx c{P, nullptr, true, 0, nullptr, 0, 0.0, nullptr, &w};
+    Ctx c{P, nullptr, true, 0, nullptr, 0, 0.0, nullptr, &w, nullptr};
     if (which == 0 || which == 2) { forward(c, w, 0); forward(c, w, 1); }
     if (which == 1 || which == 2) backward(c, w, 0, SKG_TRAIN_BWD_STAGES);
     return c.flops;

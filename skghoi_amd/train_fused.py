@@ -43,6 +43,8 @@ EPS_LN = 1e-5
 # while the reduce launch it replaces costs ~5 us and back-to-back launches of one stream leave no gap between them:
 # bf16 step 1.26 -> 1.37 ms, fp32 2.47 -> 2.59.  Opt-in.
 INLAUNCH_SPLIT_REDUCE = os.environ.get("SKG_INLAUNCH_REDUCE", "0") == "1"
+# SKG_TWO_BRANCH=0: the training plan on ONE stream (developer A/B switch; same kernels, same results)
+TWO_BRANCH = os.environ.get("SKG_TWO_BRANCH", "1") != "0"
 
 
 def _check(rc, what):
@@ -690,6 +692,9 @@ class NativeJob(TrainJob):
             pl.split_target = int(tgt)
         if os.environ.get("SKG_SPLIT_MAX"):
             pl.split_max = int(os.environ["SKG_SPLIT_MAX"])
+        # the step's node chain on a second stream beside the spatial chain (skg_train_plan.two_branch; bf16 step, single
+        # process: a staged data-parallel backward issues its stages in runs that end at the chunk events)
+        pl.two_branch = 1 if (self.bf16 and TWO_BRANCH) else 0
         if INLAUNCH_SPLIT_REDUCE:
             ctr = st.counters()                                # split-K reduced inside the product launches (skg_gemmx_desc.split_ctr)
             pl.counters, pl.n_counters = ctr.data_ptr(), ctr.numel()
@@ -733,7 +738,7 @@ class NativeJob(TrainJob):
             pl.pf16 = self.PF16.data_ptr()
         self.logits_full = torch.zeros(Mp1, pl.ld_logits, device=dev, dtype=torch.float32)
         pl.pair_features, pl.logits = self.PF.data_ptr(), self.logits_full.data_ptr()
-        _check(lib.skg_train_forward_f32(C.byref(pl), 0, _stream()), "skg_train_forward_f32[0]")
+        _check(lib.skg_ctx_train_forward_f32(context_for(self.head).handle(), C.byref(pl), 0, _stream()), "skg_train_forward_f32[0]")
         self.part_a_done = True
 
     def forward(self, x0, gfeat):
@@ -741,7 +746,8 @@ class NativeJob(TrainJob):
             self.forward_a(x0, gfeat)
         pl = self.plan
         pl.ent = self.ent.data_ptr()
-        _check(_capi.lib().skg_train_forward_f32(C.byref(pl), 1, _stream()), "skg_train_forward_f32[1]")
+        _check(_capi.lib().skg_ctx_train_forward_f32(context_for(self.head).handle(), C.byref(pl), 1, _stream()),
+               "skg_train_forward_f32[1]")
         self.S.update(PF=self.PF, logits=self.logits_full[:self.lay.sum_p])
         return self.S
 
