@@ -54,12 +54,14 @@ struct Ctx {
     const float* no_twin;        // workspace buffer whose twin nobody writes (dadj: produced next to dWt, one column wide)
     const struct Ws* w;          // the workspace layout: where the SIDE twins live (twin_of)
     // second branch (skg_branch: a stream, two events, a split-K scratch region of its own) or NULL: one stream
-    const struct skg_branch* br;
+    struct skg_branch* br;
 };
 // What a two-branch plan call needs besides the caller's stream; owned by a context (skg_ctx_train_forward_f32 / the worker).
 struct skg_branch {
     hipStream_t stream;
     hipEvent_t fork, join;       // no timing, device-scope release
+    bool forked;                 // a backward's node chain is out on the branch, not joined yet: a staged (data-parallel) backward
+                                 // forks in the call that holds stage 6 and joins in the one that completes the next arena chunk
 };
 // Runs the launches of its scope on the branch's stream with the branch's scratch region.
 struct OnBranch {
@@ -237,28 +239,47 @@ __global__ __launch_bounds__(1024) void colsum2_kernel(const float* __restrict__
 
 // Gradient of the adjacency Linear(1024 -> 1) (HEAD:644, 897): dw[c] = sum_r dadj[r] Wt[r, c], db = sum_r dadj[r].  As a product
 // of the step (M = 1) it kept its whole launch -- the attention fc_3's dX and dW, 13.4 GFLOP -- off the direct-to-LDS kernel
-// (a row-contiguous twin is read in 8-row pieces); here: partial sums over 64-row chunks (4 x ceil(rows / 64) workgroups, one
-// column per thread), then the chunks in order.  fp32 operands, fixed order.
+// (a row-contiguous twin is read in 8-row pieces); here: partial sums over 16-row chunks (4 x ceil(rows / 16) workgroups, one
+// column per thread), then the chunks in a fixed order.  fp32 operands, fixed order.
+#define ADJW_ROWS 16                         // rows per partial chunk: 16 independent loads per thread (64 made the kernel a
+                                             // chain of load latencies: 17.9 us for 13 MB; the finish summed 50 chunks serially: 15 us)
 __global__ __launch_bounds__(256) void adjw_partial_kernel(const float* __restrict__ dadj, const float* __restrict__ Wt,
                                                            int rows, float* __restrict__ part) {
     const int col = (blockIdx.x & 3) * 256 + threadIdx.x, chunk = blockIdx.x >> 2;
-    const int r0 = chunk * 64, r1 = min(rows, r0 + 64);
+    const int r0 = chunk * ADJW_ROWS;
     float s = 0.f, sb = 0.f;
-    for (int r = r0; r < r1; ++r) {
-        const float d = dadj[r];
-        s += d * Wt[(int64_t)r * 1024 + col];
-        sb += d;
+    if (r0 + ADJW_ROWS <= rows) {
+        float d[ADJW_ROWS], v[ADJW_ROWS];
+#pragma unroll
+        for (int i = 0; i < ADJW_ROWS; ++i) { d[i] = dadj[r0 + i]; v[i] = Wt[(int64_t)(r0 + i) * 1024 + col]; }
+#pragma unroll
+        for (int i = 0; i < ADJW_ROWS; ++i) { s += d[i] * v[i]; sb += d[i]; }
+    } else {
+        for (int r = r0; r < rows; ++r) {
+            const float d = dadj[r];
+            s += d * Wt[(int64_t)r * 1024 + col];
+            sb += d;
+        }
     }
     part[(int64_t)chunk * 1028 + col] = s;
     if (col == 0) part[(int64_t)chunk * 1028 + 1024] = sb;
 }
-__global__ __launch_bounds__(256) void adjw_finish_kernel(const float* __restrict__ part, int chunks, float* __restrict__ dw,
-                                                          float* __restrict__ db) {
-    const int col = blockIdx.x * 256 + threadIdx.x;         // 5 workgroups: columns 0..1023, then the bias
-    if (col > 1024) return;
+// out[col] = sum over the chunks in a FIXED order: sixteen chunk groups per workgroup (chunks g, g + 16, ...), then the groups
+__global__ __launch_bounds__(1024) void adjw_finish_kernel(const float* __restrict__ part, int chunks, float* __restrict__ dw,
+                                                           float* __restrict__ db) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, col = blockIdx.x * 64 + lane;   // 17 workgroups: 1024 columns + the bias
     float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += part[(int64_t)k * 1028 + col];
-    if (col < 1024) dw[col] = s; else db[0] = s;
+    if (col <= 1024)
+        for (int k = g; k < chunks; k += 16) s += part[(int64_t)k * 1028 + col];
+    red[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && col <= 1024) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) a += (red[q][lane] + red[q + 1][lane]) + (red[q + 2][lane] + red[q + 3][lane]);
+        if (col < 1024) dw[col] = a; else db[0] = a;
+    }
 }
 
 // dF [Mg, 4096] = [attention | obj_to_sub | sub_to_obj | global]: the read-out writes blocks 0 and 3 at the rows of kept pairs;
@@ -373,6 +394,8 @@ static uint16_t* twin_of(const Ctx& c, const float* p, int64_t* ld) {
 // dst[r, c] = bf16(src[r, c]) for c < cols, 0 up to the twin's pitch: up to 8 segments in one launch (two elements per thread)
 struct TwinSeg { const float* src; uint16_t* dst; int64_t ld_src, ld_dst; int rows, cols; int64_t first; };
 struct TwinSegs { TwinSeg s[8]; int n; int64_t total; };
+// (work items of FOUR elements: a 16-byte load where the source row allows it -- pitch and base multiples of 4 floats, the
+//  quad inside the row --, scalar loads otherwise; the twin's pitch is a multiple of 4 by construction)
 __global__ __launch_bounds__(256) void twin_segments_kernel(const TwinSegs g) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < g.total; i += (int64_t)gridDim.x * 256) {
         int k = 0;
@@ -380,12 +403,19 @@ __global__ __launch_bounds__(256) void twin_segments_kernel(const TwinSegs g) {
         for (int t = 1; t < 8; ++t)
             if (t < g.n && i >= g.s[t].first) k = t;
         const TwinSeg& sg = g.s[k];
-        const int64_t local = i - sg.first, ppr = sg.ld_dst >> 1;
-        const int64_t row = local / ppr;
-        const int col = (int)(local - row * ppr) * 2;
+        const int64_t local = i - sg.first, qpr = sg.ld_dst >> 2;
+        const int64_t row = local / qpr;
+        const int col = (int)(local - row * qpr) * 4;
         const float* sp = sg.src + row * sg.ld_src + col;
-        const float a = col < sg.cols ? sp[0] : 0.f, b = col + 1 < sg.cols ? sp[1] : 0.f;
-        reinterpret_cast<uint32_t*>(sg.dst)[row * ppr + (col >> 1)] = skg_pack_bf16(a, b);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col + 3 < sg.cols && (sg.ld_src & 3) == 0 && skg_aligned16_dev(sg.src)) v = *reinterpret_cast<const float4*>(sp);
+        else {
+            if (col < sg.cols) v.x = sp[0];
+            if (col + 1 < sg.cols) v.y = sp[1];
+            if (col + 2 < sg.cols) v.z = sp[2];
+            if (col + 3 < sg.cols) v.w = sp[3];
+        }
+        skg_store_twin4(sg.dst + row * sg.ld_dst + col, v);
     }
 }
 static void twin_segments(Ctx& c, TwinSeg* segs, int n) {
@@ -394,7 +424,7 @@ static void twin_segments(Ctx& c, TwinSeg* segs, int n) {
     for (int i = 0; i < n; ++i) {
         if (segs[i].rows <= 0 || !segs[i].src || !segs[i].dst) continue;
         segs[i].first = g.total;
-        g.total += (int64_t)segs[i].rows * (segs[i].ld_dst >> 1);
+        g.total += (int64_t)segs[i].rows * (segs[i].ld_dst >> 2);
         g.s[g.n++] = segs[i];
     }
     if (!g.n) return;
@@ -634,8 +664,12 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
     // -- the step's largest product --, then the spatial head) and the NODE chain on a few hundred rows (the fc_1 projections,
     // fc_head / fc_tail, box_head: launches bound by their latency).  With a second branch (bf16 step) the node chain runs
     // there from stage 6 on, beside the spatial chain on the caller's stream; the call joins them before it returns.
-    const bool two = c.br != nullptr && P->bf16 && !c.dry && first <= 6 && last >= 8;
-    bool forked = false;
+    // A staged backward (data parallel: one call per run of stages up to the next arena chunk) forks in the call that holds
+    // stage 6 -- the chunk that stage completes is all spatial-chain and earlier output, its event needs no join -- and joins
+    // at the end of the first call that ran node-chain stages, in front of that call's chunk event.
+    const bool two = c.br != nullptr && P->bf16 && !c.dry;
+    bool no_branch = false;
+    bool& forked = two ? c.br->forked : no_branch;
     auto on_node = [&](auto&& fn) {
         if (two && forked) { OnBranch on(c, w.scratch2); fn(); }
         else fn();
@@ -719,13 +753,13 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
                                WG(dadj, Wt, Mat(G.at(SKG_SEG_ADJ_W), 1, 1024), G.at(SKG_SEG_ADJ_B), false)};
         if (P->bf16 && w.side) {
             // the one-row product on two small kernels of its own (partials in the split-K scratch, free between launches)
-            const int chunks = (Mg + 63) / 64;
+            const int chunks = (Mg + ADJW_ROWS - 1) / ADJW_ROWS;
             const int64_t need = (int64_t)chunks * 1028;
             if (need > c.scratch_need) c.scratch_need = need;
             c.flops += 2.0 * Mg * 1024.0;
             if (!c.dry && !c.rc) {
                 hipLaunchKernelGGL(adjw_partial_kernel, dim3(4 * chunks), dim3(256), 0, c.stream, w.dadj, w.Wt, Mg, c.scratch);
-                hipLaunchKernelGGL(adjw_finish_kernel, dim3(5), dim3(256), 0, c.stream, c.scratch, chunks,
+                hipLaunchKernelGGL(adjw_finish_kernel, dim3(17), dim3(1024), 0, c.stream, c.scratch, chunks,
                                    G.at(SKG_SEG_ADJ_W), G.at(SKG_SEG_ADJ_B));
             }
             launch(c, l, 2);
@@ -752,7 +786,7 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
             hipLaunchKernelGGL(colsum2_kernel, dim3(16), dim3(1024), 0, c.stream, w.dA1h, Mh, w.dB1h, Mh, db1[ATT]);
     } break;
     case 6: {
-        if (two) {                                         // the node chain's stream behind everything issued so far
+        if (two && !forked) {                              // the node chain's stream behind everything issued so far
             CK((int)hipEventRecord(c.br->fork, c.stream));
             CK((int)hipStreamWaitEvent(c.br->stream, c.br->fork, 0));
             forked = !c.rc;
@@ -815,10 +849,11 @@ static void backward(Ctx& c, const Ws& w, int first, int last) {
     } break;
     default: break;
     }
-    if (forked) {                                          // the caller's stream behind the node chain: the call returns joined
+    if (forked && last >= 8) {                             // node-chain stages ran: the caller's stream behind the branch
         hipError_t e = hipEventRecord(c.br->join, c.br->stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(c.stream, c.br->join, 0);
         if (e != hipSuccess && !c.rc) c.rc = (int)e;
+        forked = false;
     }
 }
 
@@ -840,14 +875,14 @@ int64_t skg_train_ws_floats(const skg_train_plan* P) {
 
 namespace {
 // a branch is used when the plan asks for one, the caller's context supplied it and the workspace holds a second scratch region
-static const skg_branch* usable_branch(const skg_train_plan* P, const skg_branch* br, Ws& w, int64_t scratch_need) {
+static skg_branch* usable_branch(const skg_train_plan* P, skg_branch* br, Ws& w, int64_t scratch_need) {
     if (!br || !P->two_branch || !P->bf16 || P->counters) return nullptr;      // (tile counters are per stream: one branch only)
     if (w.total + 2 * scratch_need > P->ws_floats) return nullptr;
     w.scratch2 = w.scratch + scratch_need;
     return br;
 }
 
-int forward_entry(const skg_train_plan* P, int part, void* stream, const skg_branch* br) {
+int forward_entry(const skg_train_plan* P, int part, void* stream, skg_branch* br) {
     int rc = check_plan(P);
     if (rc) return rc;
     if (!P->ws || !P->x0 || !P->gfeat || !P->sp48 || part < 0 || part > 1) return SKG_E_ARG;
@@ -885,14 +920,14 @@ static int validate_backward(const skg_train_plan* P, int first_stage, int last_
     return 0;
 }
 
-static int backward_entry(const skg_train_plan* P, int first_stage, int last_stage, void* stream, const skg_branch* br) {
+static int backward_entry(const skg_train_plan* P, int first_stage, int last_stage, void* stream, skg_branch* br) {
     int rc = validate_backward(P, first_stage, last_stage);
     if (rc) return rc;
     Ws w; layout_ws(P, P->ws, w);
     int64_t need = 0;
-    if (br && P->two_branch) {
+    if (br && P->two_branch) {                             // (over ALL stages: the calls of a staged backward agree on scratch2)
         Ctx d{P, nullptr, true, 0, nullptr, 0, 0.0, nullptr, &w, nullptr};
-        backward(d, w, first_stage, last_stage);
+        backward(d, w, 0, SKG_TRAIN_BWD_STAGES);
         need = d.scratch_need;
     }
     Ctx c{P, (hipStream_t)stream, false, 0, w.scratch, 0, 0.0, w.dadj, &w, usable_branch(P, br, w, need)};
@@ -936,9 +971,9 @@ struct skg_context {
     bool own_made = false, own_sys_made = false;
     bool with_events = false;
     skg_tuning tuning = {0, 0, 0, 0};              // the eval GEMM's switches for the threads this context is current on
-    skg_branch branch = {nullptr, nullptr, nullptr};   // second branch of two-branch plan calls (stream + fork / join events)
+    skg_branch branch = {nullptr, nullptr, nullptr, false};   // second branch of two-branch plan calls (stream + fork / join events)
     bool branch_made = false;
-    const skg_branch* get_branch() {                // (the submitting / calling thread's device is current)
+    skg_branch* get_branch() {                // (the submitting / calling thread's device is current)
         if (branch_made) return &branch;
         hipError_t e = hipStreamCreateWithFlags(&branch.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&branch.fork, hipEventDisableTiming | hipEventReleaseToDevice);
@@ -1152,6 +1187,7 @@ static int submit_backward(skg_context* ctx, const skg_train_plan* P, int first_
         if (e == hipSuccess) e = hipEventCreateWithFlags(&a->aux_done, hipEventDisableTiming);
         if (e != hipSuccess) return (int)e;
     }
+    a->branch.forked = false;
     a->plan = *P; a->first = first_stage; a->last = last_stage; a->stream = stream; a->device = dev; a->rc = 0;
     a->issued = first_stage;
     a->with_events = stage_events_host != nullptr || stage_mask != 0 || ex != nullptr;
@@ -1170,7 +1206,7 @@ static int submit_backward(skg_context* ctx, const skg_train_plan* P, int first_
 
 int skg_ctx_train_forward_f32(skg_context* ctx, const skg_train_plan* P, int part, void* stream) {
     skg_context* a = ctx_or_default(ctx);
-    const skg_branch* br = nullptr;
+    skg_branch* br = nullptr;
     if (P && P->two_branch) {
         std::unique_lock<std::mutex> lk(a->m);
         br = a->get_branch();
