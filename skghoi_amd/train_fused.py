@@ -43,8 +43,13 @@ EPS_LN = 1e-5
 # while the reduce launch it replaces costs ~5 us and back-to-back launches of one stream leave no gap between them:
 # bf16 step 1.26 -> 1.37 ms, fp32 2.47 -> 2.59.  Opt-in.
 INLAUNCH_SPLIT_REDUCE = os.environ.get("SKG_INLAUNCH_REDUCE", "0") == "1"
-# SKG_TWO_BRANCH=0: the training plan on ONE stream (developer A/B switch; same kernels, same results)
-TWO_BRANCH = os.environ.get("SKG_TWO_BRANCH", "1") != "0"
+# SKG_TWO_BRANCH=1: the bf16 plan's node chain (fc_head / fc_tail, fc_1 projections; from backward stage 6 on their gradients
+# and box_head's) on a second stream beside the spatial chain (skg_train_plan.two_branch).  Same kernels, same results -- and
+# no faster on MI355X (round 5, profiles/r05_two_branch_*): the chains do overlap, but the spatial chain's products fill every
+# CU (456-800 workgroups at two per CU), so a node-chain launch beside them waits for CUs to drain (stage 7's node products:
+# 105 us beside stage 6 instead of 20 alone) and the big products stretch (61 vs 49 us) -- what the overlap hides, contention
+# and seven more launches give back: 1.24-1.25 vs 1.22-1.27 ms.  Opt-in.
+TWO_BRANCH = os.environ.get("SKG_TWO_BRANCH", "0") == "1"
 
 
 def _check(rc, what):
