@@ -371,6 +371,30 @@ def test_two_ranks_through_the_hip_arena_equal_the_unsharded_step(tmp_path, tran
     import torch.multiprocessing as mp
     from collections import OrderedDict
     import cases, gpu_run, helpers
+    path, single = _UNSHARDED.get((case_name, per), (None, None))       # (both transports check against the same un-sharded step)
+    if path is None:
+        path, single = _unsharded_reference(case_name, per)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    fake = _build_fake_rccl(tmp_path) if transport == "library" else None
+    procs = [ctx.Process(target=_dp_equiv_worker, args=(r, 2, port, path, q, fake, case_name, per)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(_gather(procs, q, 2, 300), key=lambda t: t[0])
+    _check_two_rank_results(res, procs, per, fake, single)
+
+
+_UNSHARDED = {}
+
+
+def _unsharded_reference(case_name, per):
+    """The two-rank test's yardstick, made once per case: the same images as ONE batch in this process (gradients, weights after
+    one AdamW step, the generator positions each rank starts from) + the oracle's autograd, saved for the rank processes."""
+    import sys, tempfile
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from collections import OrderedDict
+    import cases, gpu_run, helpers
     case = cases.build_case(case_name)
     head = gpu_run.build_head(case)
     net = trainer.wrap_ddp(head, torch.device("cuda", 0))
@@ -399,16 +423,13 @@ def test_two_ranks_through_the_hip_arena_equal_the_unsharded_step(tmp_path, tran
                weights={n: p.detach().cpu().clone() for n, p in head.named_parameters()},
                oracle={n: torch.from_numpy(np.ascontiguousarray(g)) for n, g in want.items()},
                golden=case_name if case_name in cases.FULL_TRAIN_CASES else None)
-    path = str(tmp_path / "unsharded.pt")
+    path = os.path.join(tempfile.mkdtemp(prefix="skg_unsharded_"), "unsharded.pt")
     torch.save(ref, path)
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    fake = _build_fake_rccl(tmp_path) if transport == "library" else None
-    procs = [ctx.Process(target=_dp_equiv_worker, args=(r, 2, port, path, q, fake, case_name, per)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(_gather(procs, q, 2, 300), key=lambda t: t[0])
+    _UNSHARDED[(case_name, per)] = (path, single)
+    return path, single
+
+
+def _check_two_rank_results(res, procs, per, fake, single):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
