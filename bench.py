@@ -591,7 +591,9 @@ def b1_stream(device, n_forwards=2048, n_images=256, seed=2024):
     max_object = 15): n_h in 1..15 with P ~ 1 / k^1.2, objects in 1..15 with P ~ 1 / k^0.8 (many small graphs, a tail of
     large ones), ~150 distinct shapes.  Two passes over the same stream: the first pays the plan captures (one per shape
     BUCKET, skghoi_amd/small.py), the second is the steady state.  Per-forward latency = call to results complete on
-    the device (synchronised per forward, like a loop that consumes each result)."""
+    the device (synchronised per forward, like a loop that consumes each result).  The loop is trainer.test's: it knows its
+    next image and hands that image's detections to the head once the current forward is enqueued (look-ahead); a third
+    pass without it is reported as steady_state_plain."""
     from skghoi_amd import synth
     head = build_head(device, max_human=15, max_object=15)
     rs = np.random.RandomState(seed)
@@ -610,8 +612,13 @@ def b1_stream(device, n_forwards=2048, n_images=256, seed=2024):
     order = rs.randint(0, n_images, n_forwards)
     runner = None
     out = {}
+    resident = torch.cuda.Event(); resident.record()          # the images are on the device: nothing for a look-ahead to wait for
     with torch.no_grad():
-        for name in ("first_pass", "steady_state"):
+        # first_pass / steady_state: the loop of trainer.test -- once forward i is enqueued, image i + 1's detections go to the
+        # head (InteractionHead.prefetch_eval: selection, count read-back and table draw beside the forward in flight);
+        # steady_state_plain: the same stream with every forward preparing for itself, as a caller without look-ahead sees it
+        for name in ("first_pass", "steady_state", "steady_state_plain"):
+            ahead = name != "steady_state_plain"
             lat = np.zeros(n_forwards)
             torch.cuda.synchronize()
             t_all = time.perf_counter()
@@ -620,6 +627,8 @@ def b1_stream(device, n_forwards=2048, n_images=256, seed=2024):
                 pool.pooled = pooled
                 t0 = time.perf_counter()
                 head(feats, det, shp)
+                if ahead and k + 1 < n_forwards:
+                    head.prefetch_eval(imgs[int(order[k + 1])][0], after=resident)
                 torch.cuda.synchronize()
                 lat[k] = time.perf_counter() - t0
             wall = time.perf_counter() - t_all
@@ -631,7 +640,8 @@ def b1_stream(device, n_forwards=2048, n_images=256, seed=2024):
                              p95_ms=round(float(np.percentile(lat, 95)) * 1e3, 4),
                              max_ms=round(float(lat.max()) * 1e3, 3), images_per_s=round(n_forwards / wall, 1),
                              plan_hit_rate=round((st["hits"] - prev["hits"]) / max(calls, 1), 4),
-                             captures=st["captures"] - prev["captures"], evictions=st["evictions"] - prev["evictions"])
+                             captures=st["captures"] - prev["captures"], evictions=st["evictions"] - prev["evictions"],
+                             look_ahead_hits=st["look_ahead_hits"] - prev.get("look_ahead_hits", 0))
             runner = st
     out.update(distinct_shapes=len(shapes_seen), plans=runner["plans"], max_human=15, max_object=15, precision=head.precision,
                note="single-image eval forwards over %d synthetic images with a HICO-like spread of graph sizes; one "
@@ -939,7 +949,8 @@ def main():
         out["b1_latency_ms"] = round(small_batch_latency(head, dets, pooled, feats, shapes, 1), 4)
         out["b4_latency_ms"] = round(small_batch_latency(head, dets, pooled, feats, shapes, min(4, args.batch)), 4)
         out["b1_stream"] = b1_stream(device)
-        out["b4_validate"] = b4_validate(device)
+        if "b4_validate" not in os.environ.get("SKG_BENCH_SKIP", ""):        # (developer aid: legs to leave out)
+            out["b4_validate"] = b4_validate(device)
         out["small_batch"] = dict(precision=head.precision, b1_images_per_s=round(1e3 / out["b1_latency_ms"], 1),
                                   b4_images_per_s=round(4e3 / out["b4_latency_ms"], 1),
                                   note="mean wall time per eval forward, 200 back-to-back forwards after 30 warm-ups")
@@ -958,6 +969,8 @@ def main():
             rec["roofline"] = train_roofline(prec, ms, inf)
             if inf.get("phases_ms"):
                 rec["phases_ms"] = inf["phases_ms"]
+            if inf.get("product_launches_per_step"):
+                rec["product_launches_per_step"] = inf["product_launches_per_step"]     # which GEMM loop the step's products ran on
             train[prec] = rec
         # (d) the DATA-PARALLEL route of the bf16 step on this one GPU: RCCL process group of world size 1, arena exchange
         # installed, in a child process (RCCL's queues stay out of this one)

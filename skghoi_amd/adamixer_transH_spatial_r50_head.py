@@ -432,6 +432,8 @@ class InteractionHead(Module):
             return self._forward(features, detections, image_shapes, targets)
 
     def _forward(self, features, detections, image_shapes, targets):
+        if self.training or targets is not None:
+            self._drop_eval_look_ahead()
         if self.training:
             assert targets is not None, "Targets should be passed during training"
             return self._forward_train(features, detections, image_shapes, targets)
@@ -459,6 +461,7 @@ class InteractionHead(Module):
                 eng._small = SmallBatchRunner(eng)
             if eng._small.eligible(self, detections, targets):
                 return eng._small.forward(self, features, detections, image_shapes)
+        self._drop_eval_look_ahead()
         pre = eng.preprocess(detections, targets, False, False, check_weights=True)
         return self._forward_eager(pre, features, image_shapes)
 
@@ -482,6 +485,34 @@ class InteractionHead(Module):
         return self._results(lay, r, dev)
 
     # ------------------------------------------------------------------------------------------ prefetch
+    def prefetch_eval(self, detections: List[dict], after=None) -> bool:
+        """The reference's test loop (utils.py:157-167) calls the network once per image; a loop that knows its NEXT image
+        can hand that image's detections over as soon as the current forward is enqueued: detection selection (HEAD:92-151),
+        the read-back of its counts and the image's TransH table draw (HEAD:574-580) then run on the side stream beside
+        the forward in flight, and the next `forward(features, detections, image_shapes)` called with this same list starts
+        at its launch plan.  Single images in eval mode only (anything else returns False and does nothing); results and
+        the position of the global CPU generator are those of the loop without look-ahead, also when the next call turns out
+        to be for other detections (skghoi_amd/small.py, SmallBatchRunner.look_ahead; `after`: see there).
+        `trainer.test` drives it."""
+        if self.training or not detections or len(detections) != 1:
+            return False
+        dev = detections[0]["boxes"].device
+        if dev.type != "cuda":
+            raise _capi.SkgError("the interaction head runs on a HIP device only (detections on %s)" % dev)
+        eng = self.engine()
+        if not (eng.small_batch_max and _graphs_allowed()):
+            return False
+        from skghoi_amd.small import SmallBatchRunner
+        if eng._small is None:
+            eng._small = SmallBatchRunner(eng)
+        with on_device(dev):
+            return eng._small.look_ahead(self, detections, after=after)
+
+    def _drop_eval_look_ahead(self):
+        small = getattr(self.__dict__.get("_engine"), "_small", None)
+        if small is not None:
+            small.drop_look_ahead()
+
     def prefetch_train(self, detections: List[dict], image_shapes: List[Tuple[int, int]], targets: List[dict],
                        after=None, arena=False) -> bool:
         """Prepares the NEXT training batch while the GPU is busy with the current step: detection selection (HEAD:92-151),

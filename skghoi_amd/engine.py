@@ -587,6 +587,10 @@ class HeadEngine:
         self.plan_epoch = 0
         self._ck_events = None
         self.small_two_branches = os.environ.get("SKG_SMALL_ONE_BRANCH") != "1"    # captured plans: spatial chain beside the box_head chain
+        # single-image batches: the global branch's fc_1 as a launch of its own that opens the captured plan's side chain (the
+        # eager path issues the same two launches: the paths stay bit-identical).  From two images up the grouped launch is
+        # the faster one (B = 4: 0.898 vs 0.954 ms, same box).  SKG_G1_ON_SIDE=0: grouped at every batch size, as until round 4
+        self.g1_on_side_branch = os.environ.get("SKG_G1_ON_SIDE", "1") != "0"
         self.small_batch_max = 8    # eval batches of up to this many images replay a captured hipGraph (skghoi_amd/small.py); 0: off
         self.small_batch_buckets = True   # single images share one plan per BUCKET of (humans, nodes) instead of one per shape
         self.small_capture_after = 2      # an exact-shape plan is captured at the shape's 2nd sighting (eager until then; 1: at once)
@@ -845,6 +849,10 @@ class HeadEngine:
         with self._split_ctx(pw):
             return self._classify(pair_features, pw)
 
+    def g1_on_side(self, n_images):
+        """Whether fc_1 of the global branch is launched apart from box_head layer 2 (captured AND eager path alike)."""
+        return self.g1_on_side_branch and int(n_images) == 1
+
     def _graph(self, feat3, image_shapes, pooled, pre, training, tables, want_scores, pw):
         """GraphHead.forward (HEAD:769-993) for the batch.  Returns a dict of packed device tensors + layout.
 
@@ -885,8 +893,12 @@ class HeadEngine:
             gemm(x0, pw.bh1_w, pw.bh1_b, enc1, NA, 1024, x0.shape[1], _capi.EPI_BIAS_RELU, split_k=sk, split_ws=ws)
         # box_head layer 2 and fc_1(global features) are independent: one launch (the same call the captured small-batch
         # plan makes, skghoi_amd/small.py -- the two paths stay bit-identical)
-        gemm_group([((enc1, pw.bh3_w, pw.bh3_b, enc, NA, 1024, 1024, _capi.EPI_BIAS_RELU), {}),
-                    ((gfeat, pw.att_g["w1"], pw.att_g["b1"], G1, Bf, 1024, Cf, _capi.EPI_BIAS), {})])
+        bh3 = ((enc1, pw.bh3_w, pw.bh3_b, enc, NA, 1024, 1024, _capi.EPI_BIAS_RELU), {})
+        g1 = ((gfeat, pw.att_g["w1"], pw.att_g["b1"], G1, Bf, 1024, Cf, _capi.EPI_BIAS), {})
+        if self.g1_on_side(Bf):             # (two launches, as the captured plan issues them: see small.py)
+            gemm_group([g1]); gemm_group([bh3])
+        else:
+            gemm_group([bh3, g1])
         out["enc"] = enc[:NA]
         out["gfeat"] = gfeat
         if A == 0:

@@ -79,6 +79,9 @@ class SmallBatchRunner:
         self.captures = self.evictions = 0
         self._ent_stage = None             # one image's entity table, drawn ahead of the count synchronisation
         self._predrawn = None              # generator state from before that draw, while the draw is still unclaimed
+        self._ahead = None                 # the NEXT image's selection, launched beside the current forward (look_ahead)
+        self._ahead_stage = None
+        self.ahead_hits = 0
 
     def _retire(self, plans):
         self.retired.extend(plans)
@@ -86,10 +89,12 @@ class SmallBatchRunner:
     def stats(self):
         n = self.hits + self.misses
         return dict(calls=n, hits=self.hits, misses=self.misses, hit_rate=(self.hits / n if n else None),
-                    captures=self.captures, evictions=self.evictions, plans=len(self.plans), deferred=self.deferred)
+                    captures=self.captures, evictions=self.evictions, plans=len(self.plans), deferred=self.deferred,
+                    look_ahead_hits=self.ahead_hits)
 
     def close(self):
         """Drops every plan through the idle-device path (engine replaced, head torn down, tests)."""
+        self.drop_look_ahead()
         self._retire(self.plans.values())
         self.plans.clear()
         self._bury_retired()
@@ -191,19 +196,36 @@ class SmallBatchRunner:
             x_keep = torch.empty(max(Mp, 1), device=dev, dtype=torch.int64); y_keep = torch.empty_like(x_keep)
             PF = torch.empty(max(Mp, 1), 2048, **f32)
             fork = torch.cuda.Event(); fork.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(fork)
-                cx = eng._chunk_phase_a(p.ch, pw, p.pre, None, x_keep, y_keep, PF, ibuf=p.ibuf, offs=p.offs,
-                                        meta=p.meta_dev, caps=p.caps)
-                s_ready = torch.cuda.Event(); s_ready.record(side)
-            # box_head layer 2 (HEAD:812) and attention_head_g's fc_1 on the global features (HEAD:971): independent
-            gemm_group([((p.enc1, pw.bh3_w, pw.bh3_b, enc, NA, 1024, 1024, _capi.EPI_BIAS_RELU), {}),
-                        ((p.gfeat, pw.att_g["w1"], pw.att_g["b1"], G1, Bf, 1024, Cf, _capi.EPI_BIAS), {})])
-            g1_ready = torch.cuda.Event(); g1_ready.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(g1_ready)
-                eng._chunk_phase_a2(cx, pw, p.pre, G1, PF)
-                g_done = torch.cuda.Event(); g_done.record(side)
+            bh3 = ((p.enc1, pw.bh3_w, pw.bh3_b, enc, NA, 1024, 1024, _capi.EPI_BIAS_RELU), {})       # box_head layer 2 (HEAD:812)
+            g1 = ((p.gfeat, pw.att_g["w1"], pw.att_g["b1"], G1, Bf, 1024, Cf, _capi.EPI_BIAS), {})   # attention_head_g fc_1 (HEAD:971)
+            if eng.g1_on_side(Bf):
+                # The graph forks ONCE, at its root: the global branch's fc_1 opens the side chain instead of riding in the main
+                # chain's first launch.  Grouped with box_head layer 2 it gave that launch two successors -- the main chain's
+                # entity rows and the side chain's read-out -- and the replayed graph continued BOTH on other queues: a
+                # cross-queue hand-over of 15-20 us in the middle of the critical chain (round 5, r05_b1_eval_timeline*.txt).
+                with torch.cuda.stream(side):
+                    side.wait_event(fork)
+                    gemm_group([g1])
+                    cx = eng._chunk_phase_a(p.ch, pw, p.pre, None, x_keep, y_keep, PF, ibuf=p.ibuf, offs=p.offs,
+                                            meta=p.meta_dev, caps=p.caps)
+                    s_ready = torch.cuda.Event(); s_ready.record(side)
+                    eng._chunk_phase_a2(cx, pw, p.pre, G1, PF)
+                    g_done = torch.cuda.Event(); g_done.record(side)
+                gemm_group([bh3])
+                g1_ready = fork
+            else:
+                with torch.cuda.stream(side):
+                    side.wait_event(fork)
+                    cx = eng._chunk_phase_a(p.ch, pw, p.pre, None, x_keep, y_keep, PF, ibuf=p.ibuf, offs=p.offs,
+                                            meta=p.meta_dev, caps=p.caps)
+                    s_ready = torch.cuda.Event(); s_ready.record(side)
+                # box_head layer 2 and attention_head_g's fc_1 on the global features: independent, one launch
+                gemm_group([bh3, g1])
+                g1_ready = torch.cuda.Event(); g1_ready.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(g1_ready)
+                    eng._chunk_phase_a2(cx, pw, p.pre, G1, PF)
+                    g_done = torch.cuda.Event(); g_done.record(side)
             eng._chunk_phase_b(cx, (p.ent_dev, None, None), pw, p.pre, enc, PF, None, None,
                                need_S=lambda: main.wait_event(s_ready), need_Tg=lambda: main.wait_event(g_done))
             main.wait_event(g_done)
@@ -247,11 +269,77 @@ class SmallBatchRunner:
         return (not head.training and targets is None and 0 < len(detections) <= eng.small_batch_max
                 and not eng.debug)
 
+    def look_ahead(self, head, detections, after=None):
+        """The selection of the NEXT single image (score filter, class-wise NMS, top-k: HEAD:92-151), its count read-back, the
+        parameter checksum and its TransH entity-table draw, started NOW on the head's side stream -- beside the forward
+        that was enqueued a moment ago -- instead of at the top of the next forward, where the GPU would sit idle for the
+        selection kernel plus one device -> host round trip (~50 us of a 0.45 ms forward).  The next `forward` called
+        with this same `detections` object picks the result up; any other call puts the global CPU generator back where
+        it stood and starts over, so results and RNG position are those of a loop without look-ahead.
+
+        after: an event recorded behind whatever produced `detections` (a loader's uploads).  The side stream waits for it
+        and for nothing else; None = everything the current stream holds right now, which is always safe but puts the
+        selection BEHIND the forward in flight.  The parameters must not change between this call and that forward (the
+        checksum that notices a changed weight is taken here)."""
+        eng = self.eng
+        self.drop_look_ahead()
+        if len(detections) != 1 or not self.eligible(head, detections, None):
+            return False
+        dev = detections[0]["boxes"].device
+        side = head._prefetch_stream(dev)
+        if after is None:
+            after = torch.cuda.Event()
+            after.record(current_stream_of(dev))
+        side.wait_event(after)
+        for t in detections[0].values():
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(side)
+        from .engine import on_stream
+        with on_stream(side):
+            st = eng.pre_launch(detections, None, False, False, check_weights=True, defer=True)
+        state = torch.get_rng_state()
+        if self._ahead_stage is None:
+            self._ahead_stage = torch.empty(1, _capi.TRANSH_ENT, _capi.TRANSH_DIM)
+        transh.draw_batch(eng.K, 1, need_relations=False, out=(self._ahead_stage, None, None))
+        self._ahead = (detections, detections[0], st, state, side)
+        return True
+
+    def drop_look_ahead(self):
+        """An unclaimed look-ahead is abandoned: the generator goes back to where it stood before its table draw."""
+        if self._ahead is not None:
+            torch.set_rng_state(self._ahead[3])
+            self._ahead = None
+
+    def _claim_look_ahead(self, detections):
+        a = self._ahead
+        if a is None:
+            return None
+        if a[0] is not detections or len(detections) != 1 or detections[0] is not a[1]:
+            self.drop_look_ahead()
+            return None
+        self._ahead = None
+        st, state = a[2], a[3]
+        main = current_stream_of(st["dev"])
+        kind, _host, ev = st["pending"]
+        if ev is not None:
+            main.wait_event(ev)                    # the selection's outputs were written on the side stream ...
+        else:
+            main.wait_stream(a[4])                 # (blocking-copy mode: no event of its own)
+        for t in (st["index"], st["countx"], st["raw"][3]):
+            t.record_stream(main)                  # ... into blocks of ITS pool, which this stream's launches now read
+        self.ahead_hits += 1
+        return st, state
+
     def forward(self, head, features, detections, image_shapes):
         """Returns the list of result dicts, or None when this batch has to take the eager path."""
         eng = self.eng
         predrawn = None
-        if len(detections) == 1:
+        ahead = self._claim_look_ahead(detections)
+        if ahead is not None:
+            st, predrawn = ahead
+            self._ent_stage, self._ahead_stage = self._ahead_stage, self._ent_stage      # the table drawn with the look-ahead
+            pre = eng.pre_launch_end(st)
+        elif len(detections) == 1:
             # one image (the reference's evaluation mode): its TransH entity table (HEAD:574-580: ~4 000 normal draws from the
             # global CPU generator, ~20 us) is drawn while the selection kernel runs, not after the counts have arrived with
             # the GPU idle.  Same generator, same order -- unless the image turns out to have no pairs or the call leaves for

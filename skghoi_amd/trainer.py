@@ -984,6 +984,58 @@ def _with_lookahead(loader, enabled=True):
         cur = nxt
 
 
+@torch.no_grad()
+def test(net, test_loader, evaluator, device=None, lookahead=True):
+    """utils.py:148-198 (`test`): eval mode, ONE image per forward (`assert len(output) == 1`), every result associated
+    with the image's ground-truth pairs and logged into the 600-class 11-point meter; returns `evaluator.summary()`
+    (`ap` per class, `full`, and `rare` / `non_rare` when the evaluator knows the training counts).
+
+    test_loader yields batches whose LAST element is the list of targets ({boxes_h, boxes_o, hoi}) and whose other
+    elements are the network's arguments -- for the bare interaction head (inference from cached features / detections):
+    (features, detections, image_shapes, targets).  evaluator: evaluate.DeviceHOIEvaluator (results stay on the device) or
+    evaluate.HOIEvaluator (the host restatement).
+
+    lookahead: the loop runs one image ahead of the network -- image i + 1 is uploaded BEFORE forward i is enqueued and its
+    detection selection, count read-back and TransH table draw run beside forward i on the head's side stream
+    (InteractionHead.prefetch_eval), so forward i + 1 begins at its launch plan.  Same results, same RNG stream."""
+    from .evaluate import DeviceHOIEvaluator
+    mod = net.module if isinstance(net, nn.parallel.DistributedDataParallel) else net
+    if device is None:
+        p = next(mod.parameters(), None)
+        device = p.device if p is not None else torch.device("cpu")
+    device = torch.device(device)
+    net.eval()
+    ahead = getattr(mod, "prefetch_eval", None) if (lookahead and device.type == "cuda") else None
+    batched = isinstance(evaluator, DeviceHOIEvaluator)
+    it = iter(test_loader)
+    cur = next(it, None)
+    inputs = None if cur is None else relocate_to_device(cur[:-1], device)
+    while cur is not None:
+        nxt = next(it, None)
+        nxt_inputs, uploaded = None, None
+        if nxt is not None:
+            nxt_inputs = relocate_to_device(nxt[:-1], device)
+            if ahead is not None:
+                from .engine import current_stream_of
+                uploaded = torch.cuda.Event()
+                uploaded.record(current_stream_of(device))           # behind image i + 1's uploads, in front of forward i
+        output = net(*inputs)
+        if ahead is not None and nxt_inputs is not None and len(nxt_inputs) >= 2 and isinstance(nxt_inputs[1], list) \
+                and len(nxt_inputs[1]) == 1 and isinstance(nxt_inputs[1][0], dict) \
+                and torch.is_tensor(nxt_inputs[1][0].get("boxes")) and nxt_inputs[1][0]["boxes"].is_cuda:
+            ahead(nxt_inputs[1], after=uploaded)
+        if output is not None:
+            assert len(output) == 1, "Batch size is not 1"           # utils.py:166-167
+            target = cur[-1][0]
+            if batched:
+                evaluator.add(output, [target])
+            else:
+                # (blocking copies: pocket.ops.relocate_to_cpu, utils.py:169 -- the host evaluator reads them at once)
+                evaluator.add({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in output[0].items()}, target)
+        cur, inputs = nxt, nxt_inputs
+    return evaluator.summary()
+
+
 # ---------------------------------------------------------------------------------------------------- engine
 class Trainer:
     """The training loop of the reference's CustomisedDLE / pocket DistributedLearningEngine, reduced to what the head's

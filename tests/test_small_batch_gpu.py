@@ -317,3 +317,141 @@ def test_bucket_plans_reproduce_the_reference_goldens(name, precision):
     K = case["cfg"]["K"]
     # (nanbox: the scrubbed +-FLT_MAX features drive the logits to ~1e9; the bar is relative there)
     assert np.abs(gl[:, :K].cpu().numpy() - g["logits_p"]).max() <= 1e-4 * max(1.0, np.abs(g["logits_p"]).max())
+
+
+class _StreamPool(torch.nn.Module):
+    pooled = None
+
+    def forward(self, features, boxes, image_shapes):
+        assert sum(len(b) for b in boxes) == self.pooled.shape[0]
+        return self.pooled
+
+
+def _image_stream(case, shapes, base):
+    out = []
+    for i, (nh, no) in enumerate(shapes):
+        det, pooled, feat3 = _single_image(base + i, nh, no, case["C"], case["p"])
+        out.append((det, pooled, OrderedDict((k, feat3) for k in "0123")))
+    return out
+
+
+def _loop(head, imgs, seed, ahead, order=None, decoys=None):
+    """The test loop of utils.py:157-167 over `imgs`; ahead: hand image i + 1 to the head once forward i is enqueued."""
+    eng = head.engine()
+    eng.debug = False
+    eng.small_batch_max, eng.small_batch_buckets, eng.small_capture_after = 8, True, 1
+    uploaded = torch.cuda.Event(); uploaded.record()
+    res = []
+    with torch.no_grad():
+        torch.manual_seed(seed)
+        for k, (det, pooled, feats) in enumerate(imgs):
+            head.box_roi_pool.pooled = pooled
+            res.append(head(feats, det, [(800, 1200)]))
+            if ahead and k + 1 < len(imgs):
+                nxt = imgs[k + 1][0] if decoys is None else decoys[k]
+                assert head.prefetch_eval(nxt, after=uploaded) is True
+        tail = torch.empty(3).uniform_()
+    return res, tail
+
+
+def test_look_ahead_selection_gives_the_plain_loops_results():
+    """InteractionHead.prefetch_eval: the next image's selection / count read-back / TransH table draw beside the forward in
+    flight.  Results are bit-identical to the loop without look-ahead (same plans, same kernels, same tables), the global
+    CPU generator ends at the same position, and every forward but the first claimed its look-ahead."""
+    case = cases.build_case("tiny")
+    head = gpu_run.build_head(case).eval()
+    head.box_roi_pool = _StreamPool()
+    shapes = [(5, 8), (2, 3), (6, 9), (1, 4), (5, 7), (3, 3), (6, 6), (1, 1), (4, 9)]
+    imgs = _image_stream(case, shapes, 400)
+    want, wt = _loop(head, imgs, 31, ahead=False)
+    st0 = dict(head.engine()._small.stats())
+    got, gt = _loop(head, imgs, 31, ahead=True)
+    for a, b in zip(got, want):
+        _same(a, b)
+    assert torch.equal(gt, wt)
+    st = head.engine()._small.stats()
+    assert st["look_ahead_hits"] - st0["look_ahead_hits"] == len(imgs) - 1, st
+    assert st["captures"] == st0["captures"]                 # the second pass replayed the first pass's plans
+
+
+def test_an_unclaimed_look_ahead_leaves_no_trace():
+    """A look-ahead for detections the next forward is NOT called with (a loop that skips an image, an interleaved training
+    step, an eager-size batch) is dropped: the generator goes back to where it stood, the forward prepares for itself."""
+    case = cases.build_case("tiny")
+    head = gpu_run.build_head(case).eval()
+    head.box_roi_pool = _StreamPool()
+    imgs = _image_stream(case, [(5, 8), (2, 3), (6, 9), (3, 4)], 500)
+    decoys = [d for d, _, _ in _image_stream(case, [(4, 4), (1, 2), (2, 2)], 600)]
+    want, wt = _loop(head, imgs, 32, ahead=False)
+    got, gt = _loop(head, imgs, 32, ahead=True, decoys=decoys)
+    for a, b in zip(got, want):
+        _same(a, b)
+    assert torch.equal(gt, wt)
+    assert head.engine()._small.stats()["look_ahead_hits"] == 0
+    # training mode / batches of several images: nothing to look ahead for
+    assert head.prefetch_eval(imgs[0][0] + imgs[1][0]) is False
+    head.train()
+    assert head.prefetch_eval(imgs[0][0]) is False
+    head.eval()
+    # ... and a pending look-ahead is dropped by a forward of another kind (here: the eager path of a larger batch size cap)
+    torch.manual_seed(5)
+    assert head.prefetch_eval(imgs[0][0]) is True
+    head.engine().small_batch_max = 0
+    head.box_roi_pool.pooled = imgs[1][1]
+    with torch.no_grad():
+        r1 = head(imgs[1][2], imgs[1][0], [(800, 1200)])
+    t1 = torch.empty(2).uniform_()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        r2 = head(imgs[1][2], imgs[1][0], [(800, 1200)])
+    t2 = torch.empty(2).uniform_()
+    _same(r1, r2)
+    assert torch.equal(t1, t2)
+
+
+def test_trainer_test_loop_with_and_without_look_ahead():
+    """trainer.test (utils.py:148-198) over a loader of single cached images: the device evaluator and the host restatement
+    agree, with the one-image look-ahead and without."""
+    from skghoi_amd import evaluate, trainer
+    case = dict(cases.build_case("tiny"))
+    case["o2v"] = synth.hico_object_to_verb()               # HICO-DET's valid (object, verb) pairs: every scored cell is an HOI
+    head = gpu_run.build_head(case).eval()
+    shapes = [(5, 8), (2, 3), (6, 9), (1, 4), (3, 3), (4, 6)]
+    lut = evaluate.hico_object_n_verb_to_interaction()
+    raw = []
+    for i, (nh, no) in enumerate(shapes):
+        im = synth.make_image(7400 + i, n_h=nh, n_o=no, out_channels=case["C"], pool=case["p"])
+        det = dict(boxes=im["boxes"], labels=im["labels"], scores=im["scores"])
+        tg = synth.make_targets(det, 49, synth.hico_object_to_verb(), 900 + i, n_gt=3)
+        hoi = lut[tg["object"], tg["labels"]]
+        keep = hoi >= 0
+        target = dict(boxes_h=tg["boxes_h"][keep], boxes_o=tg["boxes_o"][keep], hoi=hoi[keep].long())
+        raw.append((im, det, target))
+    num_gt = [0] * 600
+    for _, _, t in raw:
+        for h in t["hoi"].tolist():
+            num_gt[h] += 1
+
+    class Loader:
+        def __iter__(self):
+            for im, det, target in raw:
+                # (the pooled rows ride with the batch; a pool module that looks them up by identity of the feature map)
+                yield (OrderedDict((k, im["feat3"]) for k in "0123"), [det], [im["hw"]], [target])
+
+    class Pool(torch.nn.Module):
+        def forward(self, features, boxes, image_shapes):
+            f = features["3"]
+            for im, _, _ in raw:
+                if f.shape == im["feat3"].shape and torch.equal(f.cpu(), im["feat3"]):
+                    return im["pooled"].cuda()
+            raise AssertionError("unknown image")
+
+    head.box_roi_pool = Pool()
+    summaries = []
+    for look, dev_eval in ((False, False), (True, True), (True, False), (False, True)):
+        ev = evaluate.DeviceHOIEvaluator(num_gt, lut) if dev_eval else evaluate.HOIEvaluator(num_gt, lut)
+        torch.manual_seed(77)
+        summaries.append(trainer.test(head, Loader(), ev, device="cuda", lookahead=look))
+    for s in summaries[1:]:
+        assert torch.allclose(s["ap"].double(), summaries[0]["ap"].double(), atol=1e-9)
+    assert head.engine()._small.stats()["look_ahead_hits"] == 2 * (len(shapes) - 1)
