@@ -203,6 +203,10 @@ class SmallBatchRunner:
                 # chain's first launch.  Grouped with box_head layer 2 it gave that launch two successors -- the main chain's
                 # entity rows and the side chain's read-out -- and the replayed graph continued BOTH on other queues: a
                 # cross-queue hand-over of 15-20 us in the middle of the critical chain (round 5, r05_b1_eval_timeline*.txt).
+                # (capture ORDER matters too: hipGraphLaunch enqueues a graph chain by chain, the chain of the root captured
+                # first going out first.  With box_head layer 2 captured first the main chain starts 55 us earlier and the side
+                # chain 38 us later; the three-product group then runs beside the global branch's two products, all of them
+                # slower for it -- 0.480-0.488 against 0.471-0.473 ms, profiles/r05_b1_eval_capture_order.txt.)
                 with torch.cuda.stream(side):
                     side.wait_event(fork)
                     gemm_group([g1])
