@@ -150,6 +150,27 @@ def build_case(name):
         # HEAD:829-839 -- shifts the pooled rows of everything behind it), a small one and a one-pair image.
         imgs = _grid_images([(17, 18), (0, 5), (3, 9), (1, 1)], 256, 7, 49, 80, int(alt_seed or 1700))
         c.update(C=256, p=7, weight_seed=0, training=True, n_gt=4)
+    elif name == "train_no_positive":
+        # humans only: pairs exist (human-human) but there is no ground truth, hence no positive pair in the whole batch --
+        # the reference's TransH term raises (HEAD:207-235: an empty score vector viewed as [-1, 0])
+        imgs = _grid_images([(3, 0), (2, 0)], 8, 2, 49, 80, 330)
+        c.update(training=True)
+    elif name == "train_random":
+        # "train_random@<seed>": a seeded random training batch at test width -- 2 to 5 images with 0..5 humans and 0..6
+        # objects each (images without a human are SKIPPED: Q9; an image of one human and nothing else has no pair either),
+        # 1..5 ground-truth pairs per image, V-COCO's head every third seed.  No fixture: the GPU step is compared with the
+        # oracle's autograd on the same host (tests/test_random_parity_gpu.py).
+        seed = int(alt_seed or 0)
+        rs = np.random.RandomState(77000 + seed)
+        vcoco = seed % 3 == 2
+        if vcoco:
+            cfg = VCOCO
+        while True:
+            shapes = [(int(rs.randint(0, 6)), int(rs.randint(0, 7))) for _ in range(int(rs.randint(2, 6)))]
+            if any(h >= 1 and o >= 1 for h, o in shapes):          # (a batch without a positive pair raises, HEAD:207-235)
+                break
+        imgs = _grid_images(shapes, 8, 2, 1 if vcoco else 49, 81 if vcoco else 80, 78000 + 10 * seed)
+        c.update(training=True, n_gt=int(rs.randint(1, 6)), rng_seed=4000 + seed, weight_seed=3 + seed % 2)
     else:
         raise KeyError(name)
     c["cfg"] = cfg

@@ -82,3 +82,56 @@ def test_random_graphs_full_head_vs_oracle(seed, precision):
     for b in range(int(want["n_results"])):
         if want["res%d.scores" % b].size:
             assert np.abs(got["res%d.scores" % b] - want["res%d.scores" % b]).max() <= 1e-5
+
+
+# seeds of cases.build_case("train_random@<seed>") whose gradients are well conditioned as a cross-device comparison (no
+# ReLU input within rounding noise of zero: tools/case_conditioning.py reports <= 3.3e-5 for these, 5e-3 for seed 2)
+TRAIN_SEEDS = [4, 5, 6, 8, 9, 10]
+
+
+@pytest.mark.parametrize("seed", TRAIN_SEEDS)
+def test_random_training_batches_match_oracle_autograd(seed):
+    """Seeded random training batches (2-5 images of 0..5 humans / 0..6 objects, images without a human or without ground
+    truth, HICO-DET's and V-COCO's head): association labels and result indices bit-exact, the three losses to 1e-5, the
+    gradients of all 408 parameters against CPU autograd of the oracle -- the trainer's route (gradients written straight
+    into the arena, no autograd engine) on even seeds, the autograd-backed fused step on odd ones."""
+    case = cases.build_case("train_random@%d" % seed)
+    mode = "direct" if seed % 2 == 0 else True
+    flat, grads = gpu_run.run_train_with_grads(case, fused=mode)
+    want, losses, oflat = helpers.oracle_train_grads(case, with_flat=True)
+    for k in ("hoi_loss", "interactiveness_loss", "transH_loss"):
+        assert abs(float(flat[k]) - losses[k]) <= 1e-5 * max(1.0, abs(losses[k])), (k, float(flat[k]), losses[k])
+    assert int(flat["n_results"]) == int(oflat["n_results"])
+    for b in range(int(oflat["n_results"])):
+        for k in ("index", "prediction", "object", "labels", "unary_labels"):
+            assert np.array_equal(flat["res%d.%s" % (b, k)], oflat["res%d.%s" % (b, k)]), (b, k)
+        assert np.abs(flat["res%d.scores" % b] - oflat["res%d.scores" % b]).max(initial=0.0) <= 1e-5
+    assert set(want) == set(grads), set(want) ^ set(grads)
+    worst = (0.0, "")
+    for k, w in want.items():
+        scale = max(np.abs(w).max(), 1e-6)
+        err = max(np.abs(grads[k] - w).max() - 1e-9, 0.0) / scale
+        worst = max(worst, (err, k))
+        # the adjacency weight's gradient is a sum of large cancelling terms at this width: a few ulp on the pooled features
+        # move it by up to 3e-5 of its scale under the oracle itself (same tool), hence the wider bar for that one tensor
+        bar = 3e-4 if k == "box_pair_head.adjacency.weight" else 1e-4
+        assert err <= bar, "%s: rel err %.3e (|grad| max %.3e)" % (k, err, scale)
+    print("seed %d: max relative gradient error %.3e (%s)" % (seed, worst[0], worst[1]))
+
+
+def test_training_batch_without_a_positive_pair_ends_like_the_reference():
+    """No positive pair in the whole batch (here: humans only, so no ground truth): the reference divides both focal terms by
+    n_p = 0 (HEAD:165, 192-200) -- its training loop then stops at the NaN guard (utils.py:219) -- and the TransH term, in
+    the semantics the oracle restates, views an empty score vector as [-1, 0] and raises RuntimeError.  The
+    head must end the same way on every training route: RuntimeError, or losses that are not finite -- never a fault, a
+    hang or a finite loss."""
+    case = cases.build_case("train_no_positive")
+    with pytest.raises(RuntimeError):
+        helpers.oracle_train_grads(case)
+    for mode in ("direct", True, False):
+        try:
+            flat, _ = gpu_run.run_train_with_grads(cases.build_case("train_no_positive"), fused=mode)
+        except RuntimeError:
+            continue
+        assert not np.isfinite(float(flat["hoi_loss"])), (mode, float(flat["hoi_loss"]))
+    torch.cuda.synchronize()
