@@ -282,7 +282,13 @@ def train_mode(args, device, rank, world, dist_on):
 
 def runtime_info():
     from skghoi_amd import runtime
-    return runtime.info()
+    rec = runtime.info()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # the three-queue default was chosen from single-GPU A/Bs (profiles/r05_hw_queues_full_bench.txt); RCCL's own
+        # streams share those queues on a multi-rank run and no multi-GPU box has been available to compare against
+        rec = dict(rec, note="hardware-queue count measured at world size 1 only; unmeasured for world > 1 "
+                             "(SKG_HW_QUEUES=0 keeps the HIP runtime's default)")
+    return rec
 
 
 def dp_world1_child(precision, steps, warmup):
