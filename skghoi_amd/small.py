@@ -48,8 +48,56 @@ from .engine import Preprocessed, current_stream_of, enqueue_row_exponents, gemm
 META_WORDS = layout.META_DTYPE.itemsize // 4
 
 
+# ---- lifetime of the captured graphs
+# A hipGraphExec is destroyed HERE and nowhere else: `reap()`, on an idle device, before anything of a new capture exists.
+# A plan only borrows its graph.  Plans die whenever Python says so -- by reference count when a test drops its head, by the
+# cyclic collector at any allocation (engine <-> runner is a cycle), i.e. possibly between another plan's capture and its
+# first replay -- and the HIP runtime has crashed in hipGraphLaunch next to such a teardown (once more
+# in round 5: gpurun_out/r5y, a full test run, the replay right behind a fresh capture).  So the graph and the events its
+# capture recorded are held by this table; a dying plan merely marks its entry.
+_KEPT = {}                 # token -> (CUDAGraph, events of the capture)
+_DEAD = []                 # tokens whose plan is gone or retired: destroyed by the next reap()
+_NEXT = [0]
+
+
+def keep_graph(graph, events):
+    _NEXT[0] += 1
+    _KEPT[_NEXT[0]] = (graph, events)
+    return _NEXT[0]
+
+
+def release_graph(token):
+    """The graph will not be launched again; its destruction waits for reap()."""
+    if token is not None and token in _KEPT and token not in _DEAD:
+        _DEAD.append(token)
+
+
+def reap():
+    """Destroys every released graph -- with the device idle, on the calling thread, now.  Returns how many."""
+    if not _DEAD:
+        return 0
+    torch.cuda.synchronize()
+    gone = [_KEPT.pop(t, None) for t in _DEAD]
+    del _DEAD[:]
+    n = len(gone)
+    del gone               # hipGraphExecDestroy / hipGraphDestroy / hipEventDestroy run here
+    return n
+
+
 class _Plan:
     caps = None            # (grid rows, pair rows) the image owns when the plan serves a bucket of shapes
+    token = None           # entry of the graph table above
+
+    @property
+    def graph(self):       # borrowed: None before the capture and once the graph has been reaped
+        ent = _KEPT.get(self.token)
+        return ent[0] if ent is not None else None
+
+    def __del__(self):     # (whenever: reference count, cyclic GC, interpreter exit -- never destroys a graph itself)
+        try:
+            release_graph(self.token)
+        except Exception:  # noqa: BLE001  (module globals already torn down at exit)
+            pass
 
 
 def capacity(v, limit):
@@ -84,6 +132,9 @@ class SmallBatchRunner:
         self.ahead_hits = 0
 
     def _retire(self, plans):
+        plans = list(plans)
+        for p in plans:
+            release_graph(getattr(p, "token", None))
         self.retired.extend(plans)
 
     def stats(self):
@@ -103,11 +154,13 @@ class SmallBatchRunner:
         """Destroys dropped plans (their hipGraphExec, pool blocks, events, pinned staging) -- with the device idle and
         before anything of a new capture exists.  Tearing graphs down while the next one is being captured or replayed
         on the same streams and pool is where the runtime has crashed (rarely) in hipGraphLaunch."""
-        if self.retired:
-            torch.cuda.synchronize()
-            self.retired.clear()
+        if self.retired or _DEAD:
             import gc
-            gc.collect()                   # dead cycles holding graphs / events go now, not in the middle of a capture
+            self.retired.clear()
+            gc.collect()                   # dead cycles (engine <-> runner <-> plans of heads long dropped) mark their graphs
+            if not _DEAD:
+                torch.cuda.synchronize()   # (plans without a graph yet: still the idle point their buffers are freed at)
+            reap()                         # ... and every released graph of the process is destroyed here, device idle
 
     # ------------------------------------------------------------------------------------------------ plan
     def _build_plan(self, key, pre, lay, pw, feat3, pooled):
@@ -168,7 +221,6 @@ class SmallBatchRunner:
         p.r = dict(index=i64[:Lmax], prediction=i64[Lmax:2 * Lmax], object=i64[2 * Lmax:],
                    scores=f[:Lmax], prior=f[Lmax:3 * Lmax], weights=f[3 * Lmax:3 * Lmax + Mq],
                    boxes_h=f[3 * Lmax + Mq:3 * Lmax + 5 * Mq].view(Mq, 4), boxes_o=f[3 * Lmax + 5 * Mq:].view(Mq, 4))
-        p.graph = None
         p.out = None
         return p
 
@@ -264,7 +316,7 @@ class SmallBatchRunner:
             _engine.AMAX_CAPTURE_KEEP = None
             if gc_on:
                 gc.enable()
-        p.graph = g
+        p.token = keep_graph(g, p.out.get("_events") if isinstance(p.out, dict) else None)
         self.captures += 1
 
     # ------------------------------------------------------------------------------------------------ forward
@@ -506,7 +558,10 @@ class SmallBatchRunner:
             eng.last = dict(p.out, layout=call_lay, plan=p, logits=p.out["logits"][:Mp],
                             pair_features=p.out["pair_features"][:Mp], x_keep=p.out["x_keep"][:Mp],
                             y_keep=p.out["y_keep"][:Mp], enc=p.out["enc"][:n_act])
-            return head._results(call_lay, r, dev)
+            # one active image, nothing skipped: the views above ARE its result dict (HEAD:317-322) -- what
+            # head._results(call_lay, r, dev) returns after re-slicing and splitting each of the eight arrays once more
+            return [dict(boxes_h=r["boxes_h"], boxes_o=r["boxes_o"], index=r["index"], prediction=r["prediction"],
+                         scores=r["scores"], object=r["object"], prior=r["prior"], weights=r["weights"])]
         call_lay = copy.copy(lay)
         cells = np.zeros(lay.n_active, np.int64); cells[:] = L
         call_lay.cells_per_image = cells

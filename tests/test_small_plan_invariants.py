@@ -119,3 +119,52 @@ def test_close_and_eviction_route_plans_through_the_idle_teardown(fake_cuda):
     assert not r.plans and not r.retired and ("device_synchronize", None) in log
     st = r.stats()
     assert st["plans"] == 0 and st["hit_rate"] is None
+
+
+def test_a_graph_is_destroyed_only_by_reap_never_by_its_plans_death(fake_cuda, monkeypatch):
+    """Round 5 (gpurun_out/r5y: segfault in hipGraphLaunch right behind a fresh capture, in a full test run): plans die whenever
+    Python says so -- reference count, cyclic GC (engine <-> runner is a cycle) -- and must not take their hipGraphExec with
+    them at that moment.  The graph and the capture's events live in small._KEPT; a dying or retired plan marks its entry;
+    small.reap() destroys the marked ones behind a device synchronisation, and the next capture starts with it."""
+    import weakref
+    log = fake_cuda
+
+    class Graph:
+        def replay(self):
+            pass
+
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", Graph)
+    small.reap()
+    r = _runner(log)
+    p = small._Plan()
+    r._capture(p)
+    g = weakref.ref(p.graph)
+    tok = p.token
+    assert tok in small._KEPT and small._KEPT[tok][1] == ("fork", "s_ready", "g1_ready", "g_done")
+    # (1) the plan dies by reference count: the graph object survives, its entry is marked
+    del p
+    gc.collect()
+    assert g() is not None and tok in small._DEAD
+    # (2) reap: synchronise, then destroy
+    del log[:]
+    assert small.reap() == 1
+    assert log[0][0] == "device_synchronize" and g() is None and tok not in small._KEPT and not small._DEAD
+    # (3) a retired plan that somebody still holds (engine.last does) keeps no graph once the runner has buried it, and the
+    #     next capture reaps whatever died in the meantime before its own body runs
+    p2 = small._Plan(); r._capture(p2)
+    g2 = weakref.ref(p2.graph)
+    r.plans["k"] = p2
+    r.close()
+    assert p2.graph is None and g2() is None
+    p3 = small._Plan(); r._capture(p3)
+    g3 = weakref.ref(p3.graph)
+    tok3 = p3.token
+    del p3
+    gc.collect()
+    assert g3() is not None
+    del log[:]
+    r._capture(small._Plan())
+    kinds = [k for k, _ in log]
+    assert g3() is None and tok3 not in small._KEPT
+    assert kinds.index("device_synchronize") < kinds.index("body")
+    small.reap()
