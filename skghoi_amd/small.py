@@ -161,6 +161,10 @@ class SmallBatchRunner:
             if not _DEAD:
                 torch.cuda.synchronize()   # (plans without a graph yet: still the idle point their buffers are freed at)
             reap()                         # ... and every released graph of the process is destroyed here, device idle
+            if self.pool is not None and not any(q.graph is not None for q in self.plans.values()):
+                # the last graph of this runner's memory pool is gone (weights changed, engine closed): torch retires a graph
+                # pool with its last graph -- the next capture starts a new one
+                self.pool = None
 
     # ------------------------------------------------------------------------------------------------ plan
     def _build_plan(self, key, pre, lay, pw, feat3, pooled):
