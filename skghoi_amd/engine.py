@@ -587,10 +587,13 @@ class HeadEngine:
         self.plan_epoch = 0
         self._ck_events = None
         self.small_two_branches = os.environ.get("SKG_SMALL_ONE_BRANCH") != "1"    # captured plans: spatial chain beside the box_head chain
-        # single-image batches: the global branch's fc_1 as a launch of its own that opens the captured plan's side chain (the
-        # eager path issues the same two launches: the paths stay bit-identical).  From two images up the grouped launch is
-        # the faster one (B = 4: 0.898 vs 0.954 ms, same box).  SKG_G1_ON_SIDE=0: grouped at every batch size, as until round 4
-        self.g1_on_side_branch = os.environ.get("SKG_G1_ON_SIDE", "1") != "0"
+        # OPT-IN (SKG_G1_ON_SIDE=1), single-image batches only: the global branch's fc_1 as a launch of its own that opens the
+        # captured plan's side chain (the eager path then issues the same two launches: the paths stay bit-identical).  It
+        # takes a cross-queue hand-over out of the replayed graph (B = 1: 0.465 against 0.485 ms) -- but both full GPU test
+        # runs made with it ended in a segmentation fault inside hipGraphLaunch, at the first replay of a plan captured
+        # after another plan's graph had been destroyed (gpurun_out/r5y, r5z2), where the grouped form
+        # has run clean in every full run of rounds 3-5.  The grouped launch stays the default.
+        self.g1_on_side_branch = os.environ.get("SKG_G1_ON_SIDE", "0") == "1"
         self.small_batch_max = 8    # eval batches of up to this many images replay a captured hipGraph (skghoi_amd/small.py); 0: off
         self.small_batch_buckets = True   # single images share one plan per BUCKET of (humans, nodes) instead of one per shape
         self.small_capture_after = 2      # an exact-shape plan is captured at the shape's 2nd sighting (eager until then; 1: at once)
