@@ -498,7 +498,7 @@ class InteractionHead(Module):
             return False
         dev = detections[0]["boxes"].device
         if dev.type != "cuda":
-            raise _capi.SkgError("the interaction head runs on a HIP device only (detections on %s)" % dev)
+            return False                       # (the forward reports it, from where a loop without look-ahead sees it)
         eng = self.engine()
         if not (eng.small_batch_max and _graphs_allowed()):
             return False

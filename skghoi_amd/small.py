@@ -355,8 +355,14 @@ class SmallBatchRunner:
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(side)
         from .engine import on_stream
-        with on_stream(side):
-            st = eng.pre_launch(detections, None, False, False, check_weights=True, defer=True)
+        try:
+            with on_stream(side):
+                st = eng.pre_launch(detections, None, False, False, check_weights=True, defer=True)
+        except Exception:                          # noqa: BLE001
+            # whatever is wrong with these detections (too many of them, a tensor on another device) is the NEXT forward's to
+            # report, from the place a loop without look-ahead sees it -- not this call's, which runs while the results of
+            # the forward before are still on their way to the caller
+            return False
         state = torch.get_rng_state()
         if self._ahead_stage is None:
             self._ahead_stage = torch.empty(1, _capi.TRANSH_ENT, _capi.TRANSH_DIM)

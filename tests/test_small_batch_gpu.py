@@ -390,6 +390,14 @@ def test_an_unclaimed_look_ahead_leaves_no_trace():
     assert head.engine()._small.stats()["look_ahead_hits"] == 0
     # training mode / batches of several images: nothing to look ahead for
     assert head.prefetch_eval(imgs[0][0] + imgs[1][0]) is False
+    # detections the forward will refuse: the look-ahead declines quietly, the forward raises from its usual place
+    big = [dict(boxes=torch.rand(1100, 4).cuda() * 100, labels=torch.full((1100,), 49).cuda(), scores=torch.rand(1100).cuda())]
+    assert head.prefetch_eval(big) is False
+    assert head.prefetch_eval([{k: v.cpu() for k, v in imgs[0][0][0].items()}]) is False
+    from skghoi_amd import _capi
+    with pytest.raises(_capi.SkgError):
+        with torch.no_grad():
+            head(imgs[0][2], big, [(800, 1200)])
     head.train()
     assert head.prefetch_eval(imgs[0][0]) is False
     head.eval()
