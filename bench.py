@@ -498,6 +498,10 @@ class LegGuard:
                 self.out["train"] = dict(bf16=rec)
                 self.out["runtime"] = runtime_info()
                 self.emit(self.out)
+                if code == EXIT_LEG_STUCK and self.world > 1:
+                    # the peers' watchdogs run on the same deadline with a 0.5 s poll: give them the time to leave their own
+                    # evidence on stderr before this rank's exit makes the launcher end them
+                    time.sleep(1.5)
             else:
                 sys.stderr.write("bench.py rank %d: %s\n" % (self.rank, json.dumps(rec)))
                 sys.stderr.flush()
