@@ -261,7 +261,20 @@ class ArenaExchange:
             self.collectives += 1
 
     def chunk_stages(self, ends):
-        """[(stage, end)]: the stages of the backward behind which an arena chunk goes out (prefixes coalesced to min_chunk)."""
+        """[(stage, end)]: the stages of the backward behind which an arena chunk goes out (prefixes coalesced to min_chunk).
+        The same milestone list comes back every step: the answer is kept (three walks per step otherwise, on the host
+        thread, between the loss and the backward's submission -- where the GPU is waiting for this thread)."""
+        key = (tuple(ends), self.min_chunk, self.n_stages)
+        c = self.__dict__.get("_chunks_cache")
+        if c is not None and c[0] == key:
+            return c[1]
+        out = self._chunk_stages(ends)
+        self._chunks_cache = (key, out)
+        self.__dict__.pop("_mask_cache", None)
+        self.__dict__.pop("_ex_cache", None)
+        return out
+
+    def _chunk_stages(self, ends):
         out, done, n = [], 0, len(ends)
         for s_, end in enumerate(ends):
             last = s_ == n - 1
@@ -273,25 +286,36 @@ class ArenaExchange:
     def stage_mask(self, ends):
         """Bit mask of chunk_stages() for skg_ctx_train_backward_async_f32: the worker records the context's own (device-
         scope) event behind exactly these stages."""
+        chunks = self.chunk_stages(ends)
+        c = self.__dict__.get("_mask_cache")
+        if c is not None and c[0] is chunks and c[1] == self.world:
+            return c[2]
         m = 0
-        for s_, _ in self.chunk_stages(ends):
+        for s_, _ in chunks:
             m |= 1 << s_
         if m and self.world > 1:
             # the chunk goes to OTHER GPUs: the stage's writes must leave this GPU's L2 before the collective reads them
             # (bit 31: the context records events with the default system-scope release instead of its device-scope set)
             m |= 1 << 31
+        self._mask_cache = (chunks, self.world, m)
         return m
 
     def native_exchange(self, ga, ends):
         """skg_exchange of this step for skg_ctx_train_backward_exchange_f32: the chunk table of chunk_stages(), the arena
         padding behind the last milestone included in the last chunk (as finish() sends it on the torch route)."""
         from . import _capi
-        ex = _capi.Exchange()
         chunks = self.chunk_stages(ends)
-        ex.comm, ex.arena, ex.n_chunks = self.native.handle, ga.data_ptr(), len(chunks)
-        for i, (s_, end) in enumerate(chunks):
-            ex.stage[i], ex.end[i] = s_, end
-        ex.end[len(chunks) - 1] = max(int(ex.end[len(chunks) - 1]), ga.numel())
+        c = self.__dict__.get("_ex_cache")
+        if c is not None and c[0] is chunks and c[1] == (ga.data_ptr(), ga.numel(), self.native.handle):
+            ex = c[2]                        # the gradient arena is handed out again from step to step: the same table
+            ex.adamw = None                  # (the caller fills the optimizer's part per step, or leaves it off)
+        else:
+            ex = _capi.Exchange()
+            ex.comm, ex.arena, ex.n_chunks = self.native.handle, ga.data_ptr(), len(chunks)
+            for i, (s_, end) in enumerate(chunks):
+                ex.stage[i], ex.end[i] = s_, end
+            ex.end[len(chunks) - 1] = max(int(ex.end[len(chunks) - 1]), ga.numel())
+            self._ex_cache = (chunks, (ga.data_ptr(), ga.numel(), self.native.handle), ex)
         self.done = ga.numel()
         self.collectives = len(chunks)
         return ex
