@@ -84,6 +84,22 @@ def reap():
     return n
 
 
+def _at_exit():
+    """Interpreter exit: the graphs go while the HIP runtime is still up (atexit runs before module globals are torn down)."""
+    try:
+        _DEAD[:] = list(_KEPT)
+        if _DEAD and torch.cuda.is_initialized():
+            reap()
+        else:
+            _KEPT.clear(); del _DEAD[:]
+    except Exception:      # noqa: BLE001
+        pass
+
+
+import atexit  # noqa: E402
+atexit.register(_at_exit)
+
+
 class _Plan:
     caps = None            # (grid rows, pair rows) the image owns when the plan serves a bucket of shapes
     token = None           # entry of the graph table above
@@ -156,11 +172,10 @@ class SmallBatchRunner:
         on the same streams and pool is where the runtime has crashed (rarely) in hipGraphLaunch."""
         if self.retired or _DEAD:
             import gc
+            torch.cuda.synchronize()       # the idle point: the dropped plans' buffers go first ...
             self.retired.clear()
-            gc.collect()                   # dead cycles (engine <-> runner <-> plans of heads long dropped) mark their graphs
-            if not _DEAD:
-                torch.cuda.synchronize()   # (plans without a graph yet: still the idle point their buffers are freed at)
-            reap()                         # ... and every released graph of the process is destroyed here, device idle
+            gc.collect()                   # ... dead cycles (engine <-> runner <-> plans of heads long dropped) mark their graphs
+            reap()                         # ... and every released graph of the process is destroyed here
             if self.pool is not None and not any(q.graph is not None for q in self.plans.values()):
                 # the last graph of this runner's memory pool is gone (weights changed, engine closed): torch retires a graph
                 # pool with its last graph -- the next capture starts a new one
