@@ -178,8 +178,10 @@ def run_train(B, precision, steps, warmup, device, rank, world, dist_on, prefetc
     # -- falls inside the timed region except the first step's, which the last warm-up step prepared (and the last timed
     # step prepares one batch nobody runs: the counts balance).
     nxt = (feats, dets, shapes, targets) if prefetch else None
+    # ... and the batch after that (trainer.Trainer's default: a two-batch look-ahead); SKG_BENCH_LOOKAHEAD=1: one batch
+    nxt2 = nxt if os.environ.get("SKG_BENCH_LOOKAHEAD", "2") != "1" else None
     for _ in range(warmup):
-        losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=nxt)
+        losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=nxt, prefetch2=nxt2)
     torch.cuda.synchronize()
     if dist_on:
         torch.distributed.barrier()
@@ -188,7 +190,7 @@ def run_train(B, precision, steps, warmup, device, rank, world, dist_on, prefetc
     _gemmx.path_counts(reset=True)
     t0 = time.perf_counter()
     for _ in range(steps):
-        losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=nxt)
+        losses, _ = trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=nxt, prefetch2=nxt2)
     torch.cuda.synchronize()
     if dist_on:
         torch.distributed.barrier()
@@ -210,7 +212,7 @@ def run_train(B, precision, steps, warmup, device, rank, world, dist_on, prefetc
         exs[0].timing = True
         waits = []
         for _ in range(5):
-            trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=nxt)
+            trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=nxt, prefetch2=nxt2)
             waits.append(exs[0].read_timing())
         native = exs[0].native is not None
         info["grad_exchange"] = dict(collectives_per_step=exs[0].collectives + 1,
@@ -234,7 +236,7 @@ def run_train(B, precision, steps, warmup, device, rank, world, dist_on, prefetc
         head._train_timer = tm
         try:
             for _ in range(n_meas):
-                trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=nxt)
+                trainer.train_step(net, opt, feats, dets, shapes, targets=targets, lazy=True, prefetch=nxt, prefetch2=nxt2)
             torch.cuda.synchronize()
             out3 = (ctypes.c_double * 3)()
             _capi.check(lib.skg_train_timer_read(tm, out3), "skg_train_timer_read")

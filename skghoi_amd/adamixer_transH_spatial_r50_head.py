@@ -358,7 +358,8 @@ class InteractionHead(Module):
 
     # run-time caches (engine with its streams / captured plans, parameter arena bookkeeping, prefetch state): never part of
     # a copy or a pickle of the module -- they are rebuilt on first use
-    _RUNTIME = ("_engine", "_stacked", "_pf_stream", "_prefetched", "_last_train", "_last_train_plan", "_train_params")
+    _RUNTIME = ("_engine", "_stacked", "_pf_stream", "_prefetched", "_prefetched2", "_last_train", "_last_train_plan",
+                "_train_params")
 
     def __getstate__(self):
         state = dict(self.__dict__)
@@ -514,7 +515,7 @@ class InteractionHead(Module):
             small.drop_look_ahead()
 
     def prefetch_train(self, detections: List[dict], image_shapes: List[Tuple[int, int]], targets: List[dict],
-                       after=None, arena=False) -> bool:
+                       after=None, arena=False, deep=False) -> bool:
         """Prepares the NEXT training batch while the GPU is busy with the current step: detection selection (HEAD:92-151),
         pairs + spatial encoding, label association and the host RNG draws of the forward (TransH tables, negative
         permutations) run now, on a high-priority side stream; the next `forward(features, detections, image_shapes,
@@ -532,7 +533,10 @@ class InteractionHead(Module):
         arena=True (trainer.train_step only): the batch's device tensors are carved out of a reusable block
         (train_fused.PrepArena, three slots in rotation) instead of one allocation each; the caller MUST call
         train_fused.release_prepared(head) on the step's stream once the step that consumed the batch has enqueued its last
-        kernel -- the slot is reused behind that point."""
+        kernel -- the slot is reused behind that point.
+        deep=True (trainer.train_step's two-batch look-ahead): the batch AFTER the next one.  Its handle waits in a second
+        place (`promote_prefetched` moves it up one step later) and nothing of it touches the host RNG until it has been
+        promoted and finished -- the draws stay in batch order."""
         from skghoi_amd import train_fused
         if not (self.fused_training and train_fused.supported(self)) or not detections or targets is None:
             return False
@@ -566,8 +570,29 @@ class InteractionHead(Module):
                                                       training=self.training), dev,
                       side, (detections, image_shapes, targets))
         h.advance()                            # launches the detection-selection kernel; its counts are read later
-        self._prefetched = h
+        if deep:
+            old = self.__dict__.get("_prefetched2")
+            if old is not None:
+                old.abandon()
+            self._prefetched2 = h
+        else:
+            self._prefetched = h
         return h
+
+    def promote_prefetched(self, detections, targets):
+        """The preparation started one step ago with prefetch_train(deep=True) becomes the NEXT batch's, if it was made from
+        exactly these objects; returns its handle (advance() / finish()), else None (a stale one is abandoned: it has not
+        drawn from the host RNG yet)."""
+        h = self.__dict__.get("_prefetched2")
+        self._prefetched2 = None
+        if h is None:
+            return None
+        d, _s, t = h.inputs
+        if d is detections and t is targets and getattr(self, "_prefetched", None) is None:
+            self._prefetched = h
+            return h
+        h.abandon()
+        return None
 
     def fused_step(self, features, detections, image_shapes, targets, after_forward=None, defer_backward=False,
                    adamw=None):

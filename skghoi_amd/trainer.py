@@ -578,7 +578,7 @@ def _accepts(fn, name):
     return _ACCEPTS[key]
 
 
-def prefetch_batch(net, *batch, after=None, arena=False):
+def prefetch_batch(net, *batch, after=None, arena=False, deep=False):
     """Hands the NEXT batch to the head for preparation on its side stream (InteractionHead.prefetch_train) while the GPU
     works on the step just enqueued; returns the handle of the preparation in progress (advance() / finish()) or None.
     Only when `net` IS the interaction head (training from cached detections / features) and the batch has the head's own
@@ -599,10 +599,23 @@ def prefetch_batch(net, *batch, after=None, arena=False):
         kw["after"] = after
     if arena and _accepts(fn, "arena"):
         kw["arena"] = True
+    if deep:
+        if not _accepts(fn, "deep"):
+            return None
+        kw["deep"] = True
     return fn(detections, image_shapes, targets, **kw) or None
 
 
-def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
+def _promote_prefetched(net, batch):
+    """The preparation `train_step(prefetch2=batch)` started one step ago, now the next batch's (None if there is none)."""
+    mod = net.module if isinstance(net, nn.parallel.DistributedDataParallel) else net
+    fn = getattr(mod, "promote_prefetched", None)
+    if fn is None or batch is None or len(batch) != 4:
+        return None
+    return fn(batch[1], batch[3])
+
+
+def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None, prefetch2=None):
     """utils.py:213-229: zero_grad -> forward -> NaN guard -> sum of the loss dict -> backward -> step.  Returns the loss
     dict (detached floats) and the per-image results.
 
@@ -614,6 +627,14 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
     prefetch = the NEXT batch (features, detections, image_shapes, targets), or None: once this step is enqueued the
     head prepares that batch on a side stream (selection, pairs, labels, host RNG draws), so that the next call starts
     its dense forward at once instead of paying two host synchronisations with an idle GPU (`prefetch_batch`).
+
+    prefetch2 = the batch AFTER that one, or None (round 5).  With one batch of look-ahead the preparation's last part -- the
+    read-back of the positive counts, ~0.16 ms of reference RNG draws on this thread, the uploads, the TransH term -- sits
+    between this step's optimizer launch and the next step's forward, and it takes longer than AdamW runs: the GPU idles
+    ~85 us at every step boundary (profiles/r05_train_bf16_b4_step_timeline.txt).  With two, batch i + 2's preparation is
+    STARTED during step i (selection, pairs, association: device work on the side stream) and FINISHED during step i + 1,
+    right behind the submission of that step's backward, where this thread would otherwise wait for the worker; the next
+    step's forward then follows the optimizer launch at once.  Same batches, same order of host RNG draws, same results.
 
     lazy=True keeps the host off the GPU's heels: the losses come back as detached DEVICE tensors and the NaN guard is
     left to whoever reads them (Trainer does, at its print interval / end of epoch) -- the reference's per-iteration
@@ -631,9 +652,27 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
         entry = torch.cuda.Event()
         entry.record(current_stream_of(None))
 
+    ahead2 = [None]
+    promoted = [False]
+    if prefetch2 is not None and exchanges(net):
+        # data parallel: one batch of look-ahead.  Finishing a preparation in the middle of the backward puts its fused
+        # normaliser all-reduce (torch's communicator) beside the arena chunks' collectives (the library's): measured at world
+        # size 1 the step got SLOWER with two (1.424 against 1.333 ms), where the single-process step gains 3 %
+        prefetch2 = None
+
     def look_ahead():
         if prefetch is not None and ahead[0] is None:
-            ahead[0] = prefetch_batch(net, *prefetch, after=entry, arena=True)      # selection kernel launched
+            h = _promote_prefetched(net, prefetch) if _cuda_here() else None
+            if h is not None:
+                # started a step ago (prefetch2 of the previous call): its device work is long done -- finish it NOW (counts,
+                # host RNG draws, uploads, TransH term), behind this step's submitted backward instead of behind its optimizer
+                ahead[0] = h
+                promoted[0] = True
+                h.finish()
+            else:
+                ahead[0] = prefetch_batch(net, *prefetch, after=entry, arena=True)      # selection kernel launched
+        if prefetch2 is not None and ahead2[0] is None and ahead[0] is not None and entry is not None:
+            ahead2[0] = prefetch_batch(net, *prefetch2, after=entry, arena=True, deep=True)     # its selection kernel
     out = None
     fused = getattr(net, "fused_step", None)            # the bare interaction head: forward + backward without the autograd
     try:
@@ -659,7 +698,9 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
             # data parallel: handing out the chunks blocks this thread until the worker has enqueued the backward's last stage
             # (~0.4 ms) -- the look-ahead's first half (counts read, pairs + association launched) goes in front of that wait,
             # not behind it, or the next batch's preparation and this step's optimizer both start late
-            ahead[0].advance()
+            h = ahead2[0] if promoted[0] else ahead[0]       # (the batch whose preparation began in THIS call)
+            if h is not None:
+                h.advance()
             advanced = True
         if fused_ran:
             _drive_exchanges()           # data parallel: the arena chunks go out behind the stages the worker is issuing
@@ -671,7 +712,10 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
             total = sum(loss for loss in loss_dict.values())
             total.backward()
         if ahead[0] is not None and not advanced:
-            ahead[0].advance()           # counts read (ready by now), pairs + association launched
+            # counts read (ready by now), pairs + association launched -- for the batch whose preparation began in this call
+            h = ahead2[0] if promoted[0] else ahead[0]
+            if h is not None:
+                h.advance()
         for ex in exchanges(net):        # data parallel: a rank whose batch bypassed the fused node joins its peers here
             ex.after_backward()
     finally:
@@ -689,7 +733,7 @@ def train_step(net, optimizer, *inputs, targets, lazy=False, prefetch=None):
     if spans and "o1" not in spans[-1]:
         spans[-1]["o1"] = torch.cuda.Event(enable_timing=True)
         spans[-1]["o1"].record()
-    if ahead[0] is not None:
+    if ahead[0] is not None and not promoted[0]:
         ahead[0].finish()                # positive counts read, host RNG draws, uploads, TransH term
     if lazy:
         return {k: v.detach() for k, v in loss_dict.items()}, out
@@ -986,26 +1030,23 @@ def relocate_to_device(x, device):
     return x
 
 
-def _with_lookahead(loader, enabled=True):
-    """(batch, next batch or None) pairs; the loader is advanced one batch ahead of the step (nothing else changes: same
-    batches, same order)."""
+def _with_lookahead(loader, enabled=True, depth=1):
+    """(batch, next batch or None) pairs -- with depth=2 (batch, next, the one after) triples; the loader is advanced `depth`
+    batches ahead of the step (nothing else changes: same batches, same order)."""
     it = iter(loader)
-    try:
-        cur = next(it)
-    except StopIteration:
+    if not enabled:
+        for cur in it:
+            yield (cur, None) if depth == 1 else (cur, None, None)
         return
-    while True:
-        nxt = next(it, None) if enabled else None
-        if not enabled:
-            yield cur, None
-            cur = next(it, None)
-            if cur is None:
-                return
-            continue
-        yield cur, nxt
-        if nxt is None:
-            return
-        cur = nxt
+    window = []
+    for b in it:
+        window.append(b)
+        if len(window) == depth + 1:
+            yield tuple(window)
+            window.pop(0)
+    while window:
+        yield tuple(window) + (None,) * (depth + 1 - len(window))
+        window.pop(0)
 
 
 @torch.no_grad()
@@ -1091,8 +1132,8 @@ class Trainer:
         # the default step takes a one-batch look-ahead and lets the head prepare it while this step runs on the GPU
         # (prefetch_batch: only for batches of the head's own call shape; any other batch shape is simply not prepared)
         self.lookahead = step_fn is None
-        self.step_fn = step_fn or (lambda n, o, b, nxt=None: train_step(n, o, *b[:-1], targets=b[-1], lazy=lazy_losses,
-                                                                        prefetch=nxt))
+        self.step_fn = step_fn or (lambda n, o, b, nxt=None, nxt2=None: train_step(
+            n, o, *b[:-1], targets=b[-1], lazy=lazy_losses, prefetch=nxt, prefetch2=nxt2))
         self.history = []
         # the training-mAP meter of the reference's engine (utils.py:208, 229): on when there is a validation loader (the
         # end-of-epoch report needs it) unless switched explicitly
@@ -1198,8 +1239,10 @@ class Trainer:
         self.net.train()
         if self.train_meter and self.meter is None:
             self.meter = self._new_meter()
-        for batch, nxt in _with_lookahead(self.train_loader, self.lookahead):
-            losses, results = self.step_fn(self.net, self.optimizer, batch, nxt) if self.lookahead else \
+        # the default step looks TWO batches ahead (train_step: prefetch / prefetch2): batch i + 2's preparation starts
+        # during step i and ends during step i + 1, off the step boundary
+        for batch, nxt, nxt2 in _with_lookahead(self.train_loader, self.lookahead, depth=2):
+            losses, results = self.step_fn(self.net, self.optimizer, batch, nxt, nxt2) if self.lookahead else \
                 self.step_fn(self.net, self.optimizer, batch)
             if self.meter is not None:
                 self.log_results(results, self.meter)

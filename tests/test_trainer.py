@@ -1199,11 +1199,13 @@ def test_prefetched_steps_equal_inline_steps_bit_for_bit(precision):
     case = cases.build_case("train_tiny")
     case2 = cases.build_case("train_skips")
     batches = []
-    for c in (case, case2, case, case2):
+    for c in (case, case2, case, case2, case2, case):
         batches.append((OrderedDict((k, c["feat3"].cuda()) for k in "0123"), gpu_run.to_cuda(c["detections"]),
                         c["shapes"], gpu_run.to_cuda(c["targets"]), c))
+    decoy = (OrderedDict((k, case["feat3"].cuda()) for k in "0123"), gpu_run.to_cuda(case["detections"]), case["shapes"],
+             gpu_run.to_cuda(case["targets"]))
 
-    def run(prefetch):
+    def run(depth, stale_at=None):
         head = gpu_run.build_head(case)
         head.precision = precision
         net = trainer.wrap_ddp(head, torch.device("cuda", 0))
@@ -1212,17 +1214,28 @@ def test_prefetched_steps_equal_inline_steps_bit_for_bit(precision):
         losses = []
         for i, (f, d, s, t, c) in enumerate(batches):
             head.box_roi_pool = gpu_run.CachedPool(c)
-            nxt = batches[i + 1][:4] if prefetch and i + 1 < len(batches) else None
-            l, _ = trainer.train_step(net, opt, f, d, s, targets=t, lazy=True, prefetch=nxt)
+            nxt = batches[i + 1][:4] if depth >= 1 and i + 1 < len(batches) else None
+            nxt2 = batches[i + 2][:4] if depth >= 2 and i + 2 < len(batches) else None
+            if stale_at == i:
+                nxt2 = decoy                  # a look-ahead for a batch that never comes: dropped one step later, untouched RNG
+            l, _ = trainer.train_step(net, opt, f, d, s, targets=t, lazy=True, prefetch=nxt, prefetch2=nxt2)
             losses.append(trainer.read_losses(l))
         return head, losses, torch.empty(3).uniform_()
 
-    h0, l0, r0 = run(False)
-    h1, l1, r1 = run(True)
+    h0, l0, r0 = run(0)
+    h1, l1, r1 = run(1)
     assert l0 == l1
     assert torch.equal(r0, r1)                                      # the host generator ends at the same position
     for (k, a), (_, b) in zip(h0.state_dict().items(), h1.state_dict().items()):
         assert torch.equal(a, b), k
+    # two batches of look-ahead (round 5: batch i + 2's preparation starts during step i and ends during step i + 1), and the
+    # same with one look-ahead gone stale in the middle of the run
+    for depth, stale in ((2, None), (2, 2)):
+        h2, l2, r2 = run(depth, stale)
+        assert l0 == l2, (depth, stale)
+        assert torch.equal(r0, r2)
+        for (k, a), (_, b) in zip(h0.state_dict().items(), h2.state_dict().items()):
+            assert torch.equal(a, b), (k, depth, stale)
     st = h1._stacked
     assert st.adoptions == 1 and st.aliased()
     lo, hi = st.buf.data_ptr(), st.buf.data_ptr() + 4 * st.total
