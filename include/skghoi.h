@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SKG_ABI_VERSION 17
+#define SKG_ABI_VERSION 18
 #define SKG_E_ARG   (-1)   /* null pointer / negative size / unsupported shape            */
 #define SKG_E_ALIGN (-2)   /* pointer or leading dimension not 16-byte aligned            */
 #define SKG_E_LIMIT (-3)   /* exceeds a compiled-in limit (boxes per image, verbs, ...)   */
@@ -288,6 +288,11 @@ int skg_graph_aggregate_f32(const float* dot_partial, int n_partial, int64_t par
 /* out = LayerNorm(x) * gamma + beta over `cols` (= 1024) columns, eps 1e-5 (HEAD:658-659, 912-914, 923-925). */
 int skg_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, int rows, int cols,
                       float eps, float* out, int64_t ldo, void* stream);
+/* ... the two of a graph pass (norm_h over the human rows, norm_o over the node rows) in ONE launch; per row bit-identical
+ * to skg_layernorm_f32 (round 5: one launch and one graph node less per forward).                                   */
+int skg_layernorm2_f32(const float* x0, int64_t ldx0, const float* gamma0, const float* beta0, int rows0, float* out0,
+                       int64_t ldo0, const float* x1, int64_t ldx1, const float* gamma1, const float* beta1, int rows1,
+                       float* out1, int64_t ldo1, int cols, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * compute_prior_scores (HEAD:721-767) + InteractionHead.postprocess (HEAD:237-337), table driven.

@@ -12,7 +12,7 @@ MAX_NODES = 160
 SPATIAL_LD = 48
 TRANSH_DIM = 50
 TRANSH_ENT = 80
-ABI_VERSION = 17
+ABI_VERSION = 18
 GEMM_GROUP_MAX = 4
 CHECKSUM_PARTIALS = 1024
 LOSS_CHUNKS = 64
@@ -148,6 +148,8 @@ PROTOTYPES = {
     "skg_graph_aggregate_f32": (C.c_int, [_vp, C.c_int, _i64, _f32, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp,
                                           _vp, _i64, C.c_int, _vp, _vp, _i64, _vp, _vp]),
     "skg_layernorm_f32": (C.c_int, [_vp, _i64, _vp, _vp, C.c_int, C.c_int, _f32, _vp, _i64, _vp]),
+    "skg_layernorm2_f32": (C.c_int, [_vp, _i64, _vp, _vp, C.c_int, _vp, _i64, _vp, _i64, _vp, _vp, C.c_int, _vp, _i64,
+                                     C.c_int, _f32, _vp]),
     "skg_postprocess_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int,
                                       _f32, _i64, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "skg_associate_f32": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _f32, _vp, _vp, _vp]),

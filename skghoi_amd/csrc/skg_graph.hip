@@ -143,6 +143,48 @@ __global__ __launch_bounds__(256) void skg_layernorm_kernel(const float* __restr
     }
 }
 
+// Two LayerNorms in one launch (norm_h on the human rows, norm_o on the node rows: HEAD:912-914, 923-925): workgroups
+// [0, rows0) take the first, the rest the second; per row the same arithmetic as skg_layernorm_kernel, bit for bit.
+struct skg_ln_seg { const float* x; int64_t ldx; const float* gamma; const float* beta; float* out; int64_t ldo; int rows; };
+
+__global__ __launch_bounds__(256) void skg_layernorm2_kernel(const skg_ln_seg a, const skg_ln_seg b, int cols, float eps) {
+    __shared__ float sred[4];
+    const bool first = (int)blockIdx.x < a.rows;
+    const skg_ln_seg& g = first ? a : b;
+    const int r = first ? (int)blockIdx.x : (int)blockIdx.x - a.rows;
+    const int c = threadIdx.x * 4;
+    const bool in = c < cols;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in) v = *reinterpret_cast<const float4*>(g.x + (int64_t)r * g.ldx + c);
+    const float mean = skg_block_sum256((v.x + v.y) + (v.z + v.w), sred) / (float)cols;
+    float4 dlt = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+    float sq = in ? (dlt.x * dlt.x + dlt.y * dlt.y) + (dlt.z * dlt.z + dlt.w * dlt.w) : 0.f;
+    const float var = skg_block_sum256(sq, sred) / (float)cols;
+    const float rstd = 1.f / sqrtf(var + eps);
+    if (in) {
+        const float4 gm = *reinterpret_cast<const float4*>(g.gamma + c);
+        const float4 bb = *reinterpret_cast<const float4*>(g.beta + c);
+        *reinterpret_cast<float4*>(g.out + (int64_t)r * g.ldo + c) =
+            make_float4(dlt.x * rstd * gm.x + bb.x, dlt.y * rstd * gm.y + bb.y, dlt.z * rstd * gm.z + bb.z,
+                        dlt.w * rstd * gm.w + bb.w);
+    }
+}
+
+extern "C" int skg_layernorm2_f32(const float* x0, int64_t ldx0, const float* gamma0, const float* beta0, int rows0,
+                                  float* out0, int64_t ldo0, const float* x1, int64_t ldx1, const float* gamma1,
+                                  const float* beta1, int rows1, float* out1, int64_t ldo1, int cols, float eps,
+                                  void* stream) {
+    if (rows0 < 0 || rows1 < 0 || cols <= 0 || cols > 1024 || (cols & 3)) return SKG_E_ARG;
+    if (rows0 + rows1 == 0) return 0;
+    if ((rows0 && (!x0 || !gamma0 || !beta0 || !out0)) || (rows1 && (!x1 || !gamma1 || !beta1 || !out1))) return SKG_E_ARG;
+    if ((ldx0 & 3) || (ldo0 & 3) || (ldx1 & 3) || (ldo1 & 3)) return SKG_E_ALIGN;
+    if (rows0 && (!skg_aligned16(x0) || !skg_aligned16(out0) || !skg_aligned16(gamma0) || !skg_aligned16(beta0))) return SKG_E_ALIGN;
+    if (rows1 && (!skg_aligned16(x1) || !skg_aligned16(out1) || !skg_aligned16(gamma1) || !skg_aligned16(beta1))) return SKG_E_ALIGN;
+    const skg_ln_seg a{x0, ldx0, gamma0, beta0, out0, ldo0, rows0}, b{x1, ldx1, gamma1, beta1, out1, ldo1, rows1};
+    hipLaunchKernelGGL(skg_layernorm2_kernel, dim3(rows0 + rows1), dim3(256), 0, (hipStream_t)stream, a, b, cols, eps);
+    return skg_launch_status();
+}
+
 extern "C" int skg_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, int rows,
                                  int cols, float eps, float* out, int64_t ldo, void* stream) {
     if (rows < 0 || cols <= 0 || cols > 1024 || (cols & 3)) return SKG_E_ARG;

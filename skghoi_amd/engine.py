@@ -1108,10 +1108,11 @@ class HeadEngine:
                         ((V, pw.so["w3"], pw.so["b3"], Op, Mn, 1024, 1024, _capi.EPI_BIAS_RES_RELU),
                          dict(res=GO, ldres=1024))])
             h_node = torch.empty(Mh, 1024, **f32); node = torch.empty(Mn, 1024, **f32)
-            _capi.check(lib.skg_layernorm_f32(Hp.data_ptr(), 1024, pw.nh_g.data_ptr(), pw.nh_b.data_ptr(), Mh, 1024,
-                                              EPS_LN, h_node.data_ptr(), 1024, st), "skg_layernorm_f32")
-            _capi.check(lib.skg_layernorm_f32(Op.data_ptr(), 1024, pw.no_g.data_ptr(), pw.no_b.data_ptr(), Mn, 1024,
-                                              EPS_LN, node.data_ptr(), 1024, st), "skg_layernorm_f32")
+            # norm_h and norm_o (HEAD:912-914, 923-925) as one launch
+            _capi.check(lib.skg_layernorm2_f32(Hp.data_ptr(), 1024, pw.nh_g.data_ptr(), pw.nh_b.data_ptr(), Mh,
+                                               h_node.data_ptr(), 1024, Op.data_ptr(), 1024, pw.no_g.data_ptr(),
+                                               pw.no_b.data_ptr(), Mn, node.data_ptr(), 1024, 1024, EPS_LN, st),
+                        "skg_layernorm2_f32")
         else:
             # num_iter == 0: the raw box_head encodings reach the read-out (HEAD:843-845)
             if need_S is not None:

@@ -103,6 +103,9 @@ def test_argument_validation_without_gpu(lib):
     assert lib.skg_preprocess_f32(16, 16, 16, 16, 2, 49, 0.2, 0.5, 100, 100, 16, 80, 2.8, 16, 16, None) == -3
     assert lib.skg_global_avgpool_f32(None, 0, 256, 10, None, None) == 0
     assert lib.skg_layernorm_f32(16, 1024, 16, 16, 3, 2048, 1e-5, 16, 1024, None) == -1
+    assert lib.skg_layernorm2_f32(16, 1024, 16, 16, 3, 16, 1024, 16, 1024, 16, 16, 2, 16, 1024, 2048, 1e-5, None) == -1
+    assert lib.skg_layernorm2_f32(16, 1024, 16, 16, -1, 16, 1024, 16, 1024, 16, 16, 2, 16, 1024, 1024, 1e-5, None) == -1
+    assert lib.skg_layernorm2_f32(None, 1024, 16, 16, 0, 16, 1024, None, 1024, 16, 16, 0, 16, 1024, 1024, 1e-5, None) == 0
     # fp16x2 weight twins: size query is pure host code; the scale must be a positive power of two
     assert lib.skg_split_weights_bytes(1024, 1024) == 32 * 64 * 2048
     assert lib.skg_split_weights_bytes(118, 2048) == 4 * 128 * 2048

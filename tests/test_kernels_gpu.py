@@ -351,6 +351,18 @@ def test_layernorm_avgpool_rowsmul():
     _capi.check(lib.skg_layernorm_f32(x.data_ptr(), 1024, g.data_ptr(), b.data_ptr(), 37, 1024, 1e-5, out.data_ptr(),
                                       1024, _stream()), "ln")
     _close(out, torch.nn.functional.layer_norm(x, (1024,), g, b), 1e-5)
+    # the two LayerNorms of a graph pass in one launch: per row bit-identical to the single launches, also with an empty half
+    y = _rand(11, 1024, seed=11) * 0.5; g2 = _rand(1024, seed=12); b2 = _rand(1024, seed=13)
+    want_y = torch.empty_like(y)
+    _capi.check(lib.skg_layernorm_f32(y.data_ptr(), 1024, g2.data_ptr(), b2.data_ptr(), 11, 1024, 1e-5, want_y.data_ptr(),
+                                      1024, _stream()), "ln")
+    for r0, r1 in ((37, 11), (37, 0), (0, 11)):
+        o0 = torch.full_like(x, 7.0); o1 = torch.full_like(y, 7.0)
+        _capi.check(lib.skg_layernorm2_f32(x.data_ptr(), 1024, g.data_ptr(), b.data_ptr(), r0, o0.data_ptr(), 1024,
+                                           y.data_ptr(), 1024, g2.data_ptr(), b2.data_ptr(), r1, o1.data_ptr(), 1024, 1024,
+                                           1e-5, _stream()), "ln2")
+        assert torch.equal(o0[:r0], out[:r0]) and torch.equal(o1[:r1], want_y[:r1])
+        assert bool((o0[r0:] == 7.0).all()) and bool((o1[r1:] == 7.0).all())
     f = _rand(3, 256, 25, 38, seed=4)
     o = torch.empty(3, 256, device="cuda")
     _capi.check(lib.skg_global_avgpool_f32(f.data_ptr(), 3, 256, 25 * 38, o.data_ptr(), _stream()), "pool")
