@@ -996,6 +996,66 @@ def test_trainer_default_step_takes_four_tuple_batches_and_only_prefetches_devic
     assert net.prefetched == [(dets, [(8, 8)], ["t"])]
 
 
+def test_lookahead_windows_and_the_two_deep_step_arguments():
+    """_with_lookahead: the loader advanced one or two batches ahead of the step, same batches in the same order, None where
+    the epoch ends; a deep look-ahead is only asked of a module that offers it (prefetch_batch(deep=True) declines otherwise)."""
+    w = trainer._with_lookahead
+    assert list(w([1, 2, 3])) == [(1, 2), (2, 3), (3, None)]
+    assert list(w([1, 2, 3, 4], depth=2)) == [(1, 2, 3), (2, 3, 4), (3, 4, None), (4, None, None)]
+    assert list(w([1], depth=2)) == [(1, None, None)] and list(w([], depth=2)) == []
+    assert list(w([1, 2], enabled=False, depth=2)) == [(1, None, None), (2, None, None)]
+    assert list(w(iter([1, 2]), depth=2)) == [(1, 2, None), (2, None, None)]
+    net = _HeadLike(3)                                               # its prefetch_train has no `deep` keyword
+
+    class _OnDevice:
+        is_cuda = True
+    import unittest.mock as mock
+    with mock.patch.object(torch, "is_tensor", lambda t: isinstance(t, _OnDevice) or isinstance(t, torch.Tensor)):
+        dets = [dict(boxes=_OnDevice())]
+        assert trainer.prefetch_batch(net, "features", dets, [(8, 8)], ["t"], deep=True) is None
+    assert net.prefetched == []
+    assert trainer._promote_prefetched(net, ("f", dets, [(8, 8)], ["t"])) is None      # nothing to promote, nothing raised
+
+
+def test_test_loop_feeds_one_image_per_forward_into_the_evaluator():
+    """trainer.test (utils.py:148-198) on the CPU with a stand-in network: one image per forward, `None` outputs skipped, a
+    batch of two refused like the reference's assert, the evaluator's summary returned; no look-ahead off the GPU."""
+    from skghoi_amd import evaluate
+    lut = evaluate.hico_object_n_verb_to_interaction()
+    obj, verb = [(o, v) for o in range(lut.shape[0]) for v in range(lut.shape[1]) if int(lut[o, v]) >= 0][5]
+    hoi = int(lut[obj, verb])
+    box = torch.tensor([[10.0, 10.0, 50.0, 60.0]])
+    calls = []
+
+    class Net(nn.Module):
+        def __init__(self, per_call=1):
+            super().__init__()
+            self.lin = nn.Linear(1, 1)
+            self.per_call = per_call
+
+        def forward(self, features, detections, image_shapes):
+            calls.append(len(detections))
+            if features is None:
+                return None
+            r = dict(boxes_h=box.clone(), boxes_o=box.clone() + 100, index=torch.zeros(1, dtype=torch.int64),
+                     prediction=torch.tensor([verb]), scores=torch.tensor([0.9]), object=torch.tensor([obj]))
+            return [r] * self.per_call
+
+    target = dict(boxes_h=box.clone(), boxes_o=box.clone() + 100, hoi=torch.tensor([hoi]))
+    miss = dict(boxes_h=box.clone() + 500, boxes_o=box.clone() + 700, hoi=torch.tensor([hoi]))
+    loader = [("f", [dict(boxes=box)], [(100, 100)], [target]), (None, [dict(boxes=box)], [(100, 100)], [target]),
+              ("f", [dict(boxes=box)], [(100, 100)], [miss])]
+    num_gt = [0] * 600
+    num_gt[hoi] = 2
+    net = Net()
+    summ = trainer.test(net, loader, evaluate.HOIEvaluator(num_gt, lut), device="cpu")
+    assert calls == [1, 1, 1] and not net.training
+    ap = summ["ap"]
+    assert ap.shape[0] == 600 and float(ap[hoi]) > 0 and float(ap.sum()) == float(ap[hoi])     # one hit of two GT pairs
+    with pytest.raises(AssertionError, match="Batch size is not 1"):
+        trainer.test(Net(per_call=2), loader, evaluate.HOIEvaluator(num_gt, lut), device="cpu")
+
+
 class _ValNet(_HeadLike):
     """_HeadLike whose forward also returns per-image result dicts with labels (training mode, or eval with targets)."""
 
