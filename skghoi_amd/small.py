@@ -36,6 +36,7 @@ new tuple takes the eager path, so a stream whose tuples never repeat never pays
 Reference path replaced: heads/adamixer_transH_spatial_r50_head.py:341-429 (InteractionHead.forward, eval mode).
 """
 import copy
+import threading
 import ctypes as C
 from collections import OrderedDict
 
@@ -58,27 +59,33 @@ META_WORDS = layout.META_DTYPE.itemsize // 4
 _KEPT = {}                 # token -> (CUDAGraph, events of the capture)
 _DEAD = []                 # tokens whose plan is gone or retired: destroyed by the next reap()
 _NEXT = [0]
+_LOCK = threading.RLock()  # (a plan's __del__ may run on any thread, also inside reap(): re-entrant)
 
 
 def keep_graph(graph, events):
-    _NEXT[0] += 1
-    _KEPT[_NEXT[0]] = (graph, events)
-    return _NEXT[0]
+    with _LOCK:
+        _NEXT[0] += 1
+        _KEPT[_NEXT[0]] = (graph, events)
+        return _NEXT[0]
 
 
 def release_graph(token):
     """The graph will not be launched again; its destruction waits for reap()."""
-    if token is not None and token in _KEPT and token not in _DEAD:
-        _DEAD.append(token)
+    with _LOCK:
+        if token is not None and token in _KEPT and token not in _DEAD:
+            _DEAD.append(token)
 
 
 def reap():
     """Destroys every released graph -- with the device idle, on the calling thread, now.  Returns how many."""
-    if not _DEAD:
-        return 0
+    with _LOCK:
+        if not _DEAD:
+            return 0
+        dead = list(_DEAD)
+        del _DEAD[:]
     torch.cuda.synchronize()
-    gone = [_KEPT.pop(t, None) for t in _DEAD]
-    del _DEAD[:]
+    with _LOCK:
+        gone = [_KEPT.pop(t, None) for t in dead]
     n = len(gone)
     del gone               # hipGraphExecDestroy / hipGraphDestroy / hipEventDestroy run here
     return n
@@ -87,7 +94,8 @@ def reap():
 def _at_exit():
     """Interpreter exit: the graphs go while the HIP runtime is still up (atexit runs before module globals are torn down)."""
     try:
-        _DEAD[:] = list(_KEPT)
+        with _LOCK:
+            _DEAD[:] = list(_KEPT)
         if _DEAD and torch.cuda.is_initialized():
             reap()
         else:
