@@ -703,9 +703,11 @@ def b4_validate(device, n_images=256, batch=4, seed=2025):
                 pool.pooled = pooled
                 t0 = time.perf_counter()
                 head(feats, dets, shp, tgs)
-                if k + 1 < len(batches):                     # the look-ahead of Trainer.validate
-                    nb = batches[k + 1]
-                    trainer.prefetch_batch(head, nb[0], nb[1], nb[2], nb[3])
+                if k + 1 < len(batches):                     # the look-ahead of Trainer.validate: the next batch's whole
+                    nb = batches[k + 1]                      # preparation while the GPU runs this batch's forward
+                    h = trainer.prefetch_batch(head, nb[0], nb[1], nb[2], nb[3])
+                    if h is not None and os.environ.get("SKG_BENCH_VALIDATE_FINISH", "1") != "0":
+                        h.finish()
                 torch.cuda.synchronize()
                 lat[k] = time.perf_counter() - t0
             wall = time.perf_counter() - t_all
