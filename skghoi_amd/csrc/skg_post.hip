@@ -89,16 +89,27 @@ __global__ __launch_bounds__(256) void skg_postprocess_kernel(
     for (int k = 0; k < wv; ++k) wbase += swave[k];
     const int64_t o0 = (int64_t)mt.out_off + sbase + wbase + (inc - cnt);
     if (cnt > 0) {
+        // four cells per trip: the verb ids, then the four logits, are in flight together (one cell per trip was two
+        // dependent round trips to memory per verb: ~1.5 us each, 15 us for a pair row of ten verbs)
         const int v0 = verb_off[cls];
-        for (int t = 0; t < cnt; ++t) {
-            const int v = verb_list[v0 + t];
-            const int64_t o = o0 + t;
-            out_index[o] = pl;
-            out_pred[o] = v;
-            out_prior[o] = ph;
-            out_prior[L_total + o] = po;
-            const float s = skg_sigmoid(logits[gp * ld_logits + v]);
-            out_scores[o] = s * (ph * po) * wgt;
+        for (int t = 0; t < cnt; t += 4) {
+            int v[4];
+            float lg[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (t + u < cnt) ? verb_list[v0 + t + u] : 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) lg[u] = (t + u < cnt) ? logits[gp * ld_logits + v[u]] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (t + u >= cnt) continue;
+                const int64_t o = o0 + t + u;
+                out_index[o] = pl;
+                out_pred[o] = v[u];
+                out_prior[o] = ph;
+                out_prior[L_total + o] = po;
+                const float s = skg_sigmoid(lg[u]);
+                out_scores[o] = s * (ph * po) * wgt;
+            }
         }
     }
 }
